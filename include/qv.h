@@ -1,0 +1,175 @@
+/*
+ * qv.h — C ABI of libqv, the MI355X (gfx950) similarity-search hot path for Quiver.
+ *
+ * This is the drop-in boundary: the entry points below are exactly what a cgo
+ * binding for the reference's flat-scan / neighbour-distance path would bind
+ * (INTEGRATION.md shows the Go side).  No torch types, no C++ types: plain
+ * pointers and sizes.  Each entry point cites the reference interface it
+ * replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns QV_OK (0) or a negative qv_status; it never aborts.
+ *     qv_last_error() returns a thread-local message whose wording follows the
+ *     reference's error strings (pkg/hybrid/exact.go:45,49,101,105).
+ *   - the device sees dense uint32 row numbers (the analogue of
+ *     hnsw.Node.VectorIndex, pkg/hnsw/hnsw.go:94); string ids stay in the host
+ *     language.
+ *   - vectors are COPIED on add (copy-on-insert, pkg/hybrid/exact.go:53-56); no
+ *     caller pointer is retained after a call returns (cgo pointer rule).
+ *   - result ordering: distance ascending, ties by row ascending.  The reference
+ *     leaves tie order unspecified (Go map iteration + unstable sort,
+ *     pkg/hybrid/exact.go:115,124); this is a deterministic refinement of it.
+ *   - qv_index_search*, qv_distance_rows* are thread-safe and may run
+ *     concurrently (the reference runs Index.Search under a read lock,
+ *     pkg/core/collection.go:647); add / remove / reserve / destroy need external
+ *     exclusion (the reference holds c.Lock there, pkg/core/collection.go:139).
+ *   - "_device" variants take device pointers and a hipStream_t (passed as
+ *     void*), enqueue work and return without synchronising, so a caller can keep
+ *     queries and results resident in HBM and time with HIP events.
+ */
+#ifndef QV_H
+#define QV_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QV_ABI_VERSION 1
+
+typedef struct qv_index qv_index; /* opaque; owns device memory */
+
+/* Distance metrics.  0..4 restate pkg/vectortypes/distances.go:12-104 (float64
+ * accumulation, one rounding to float32; SquaredEuclidean is all-float32).
+ * 5..7 restate pkg/hnsw/adapter.go:105-167 (float32 sequential accumulation),
+ * the functions a reloaded collection uses (pkg/core/db.go:181-188). */
+typedef enum qv_metric {
+    QV_COSINE      = 0, /* vectortypes.CosineDistance            distances.go:12-40  */
+    QV_L2          = 1, /* vectortypes.EuclideanDistance         distances.go:43-55  */
+    QV_L2SQ        = 2, /* vectortypes.SquaredEuclideanDistance  distances.go:60-72  */
+    QV_DOT         = 3, /* vectortypes.DotProductDistance        distances.go:77-90  */
+    QV_L1          = 4, /* vectortypes.ManhattanDistance         distances.go:93-104 */
+    QV_COSINE_F32  = 5, /* hnsw.CosineDistanceFunc               adapter.go:105-136  */
+    QV_L2_F32      = 6, /* hnsw.EuclideanDistanceFunc            adapter.go:139-151  */
+    QV_DOT_F32     = 7, /* hnsw.DotProductDistanceFunc           adapter.go:154-165  */
+    QV_METRIC_COUNT = 8
+} qv_metric;
+
+typedef enum qv_status {
+    QV_OK                 =  0,
+    QV_ERR_INVALID_ARG    = -1,
+    QV_ERR_DIM_MISMATCH   = -2, /* "vector dimension mismatch" / "query dimension mismatch" */
+    QV_ERR_K_NOT_POSITIVE = -3, /* "k must be positive" (exact.go:104-106; adapter.go:42-44) */
+    QV_ERR_OUT_OF_RANGE   = -4, /* row id >= size */
+    QV_ERR_NO_DEVICE      = -5, /* no HIP device / HIP runtime failure at create time */
+    QV_ERR_DEVICE         = -6, /* HIP error during a call (message carries hipGetErrorString) */
+    QV_ERR_OOM            = -7,
+    QV_ERR_UNSUPPORTED    = -8
+} qv_status;
+
+/* flags for qv_index_create */
+#define QV_FLAG_NONE        0ull
+#define QV_FLAG_ROWMAJOR    1ull /* also keep a row-major copy: fast single-row gathers for
+                                    qv_distance_rows / HNSW traversal (hnsw.go:536-563) */
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+
+/* Replaces hybrid.NewExactIndex(distFunc) (pkg/hybrid/exact.go:29-35) plus the
+ * dimension lock-in of the first Insert (exact.go:43-47): dim is fixed here.
+ * device = HIP device ordinal the index lives on (one index = one GPU = one shard). */
+int qv_index_create(qv_index** out, uint32_t dim, qv_metric metric, int device, uint64_t flags);
+void qv_index_destroy(qv_index* idx);
+
+/* Pre-size device storage for `rows` rows (amortises growth; optional). */
+int qv_index_reserve(qv_index* idx, uint64_t rows);
+
+/* ---- mutation ------------------------------------------------------------------- */
+
+/* Replaces ExactIndex.Insert / HybridIndex.InsertBatch data movement
+ * (exact.go:38-58; hybrid_index.go:132-242): append n host rows [n][dim] (row-major
+ * float32), copied to the device.  *first_row_out = row number of rows[0]; the
+ * others follow contiguously. */
+int qv_index_add(qv_index* idx, const float* rows, uint32_t n, uint32_t* first_row_out);
+
+/* Same, rows already on the device (Arrow IPC values buffer -> device path,
+ * index/arrow_hnsw.go:222-225).  Synchronous w.r.t. `stream`. */
+int qv_index_add_device(qv_index* idx, const float* d_rows, uint32_t n, uint32_t* first_row_out, void* stream);
+
+/* Append n synthetic unit rows generated on the device by the counter-based
+ * generator of oracle/qv_oracle.c (qvo_gen_rows); global row number of the first
+ * generated row is `gen_row0` (so shards of one corpus agree).  Benchmark/test
+ * helper: keeps 30 GB corpora off PCIe. */
+int qv_index_add_synthetic(qv_index* idx, uint64_t seed, uint64_t gen_row0, uint32_t n, uint32_t* first_row_out);
+
+/* Replaces ExactIndex.Delete (exact.go:61-70) / HNSW tombstoning (hnsw.go:829):
+ * rows are tombstoned, never renumbered.  Removing a dead row is not an error
+ * (exact.go:65 never errors). */
+int qv_index_remove(qv_index* idx, const uint32_t* rows, uint32_t n);
+
+/* Overwrite one live or dead row in place and mark it live (Collection.Update
+ * path, pkg/core/collection.go:~400: delete + insert under one lock). */
+int qv_index_update(qv_index* idx, uint32_t row, const float* vec);
+
+/* ---- queries -------------------------------------------------------------------- */
+
+/* Number of rows ever added (dead rows included) and number of live rows
+ * (= ExactIndex.Size, exact.go:136-141). */
+uint32_t qv_index_rows(const qv_index* idx);
+uint32_t qv_index_size(const qv_index* idx);
+uint32_t qv_index_dim(const qv_index* idx);
+int      qv_index_metric(const qv_index* idx);
+
+/* Replaces ExactIndex.Search (exact.go:92-133) for nq queries at once
+ * (HybridIndex.BatchSearch, hybrid_index.go:677-811, is nq independent searches).
+ *   queries  [nq][dim] host float32
+ *   k        > 0; clamped to the live size (exact.go:109-111); may equal the size
+ *            (filtered search asks for a full ranking, collection.go:679-682)
+ *   rows_out [nq][k], dist_out [nq][k]  caller-allocated; entries past count are
+ *            row = 0xFFFFFFFF, dist = +inf
+ *   count_out[nq] = min(k, live size); empty index -> 0 results, QV_OK (exact.go:96-98)
+ * Order of checks follows exact.go:96-106: empty -> ok; then k <= 0 -> error. */
+int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                    uint32_t* rows_out, float* dist_out, uint32_t* count_out);
+
+/* Same with device-resident queries/results; enqueues on `stream`, no sync. */
+int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
+                           uint32_t* d_rows_out, float* d_dist_out, void* stream);
+
+/* Batched-query path: approximate scores by fp32 MFMA GEMM with fused per-tile
+ * candidate selection, then exact re-scoring of the candidates with the same
+ * arithmetic as qv_index_search, so results are identical to it.  Same
+ * arguments as qv_index_search. */
+int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                            uint32_t* rows_out, float* dist_out, uint32_t* count_out);
+
+/* Replaces the neighbour loop of HNSW.searchLayer (hnsw.go:536-563) and the
+ * re-rank loops (hybrid_index.go:536-546; adapter.go:387-415): distance of one
+ * query to n listed rows.  dist_out[i] = distance(query, row rows[i]); dead rows
+ * are still evaluated (the reference skips nil nodes before calling). */
+int qv_distance_rows(qv_index* idx, const float* query, const uint32_t* rows, uint32_t n, float* dist_out);
+int qv_distance_rows_device(qv_index* idx, const float* d_query, const uint32_t* d_rows, uint32_t n,
+                            float* d_dist_out, void* stream);
+
+/* Replaces a vectortypes.DistanceFunc call (pkg/vectortypes/surface.go:8) for n
+ * independent pairs a[i], b[i] (each [dim]); computed on the device `device`. */
+int qv_distance_pairs(qv_metric metric, const float* a, const float* b, uint32_t n, uint32_t dim,
+                      float* dist_out, int device);
+
+/* Copy row `row` back to the host (ExactIndex keeps vectors readable,
+ * hybrid_index.go:537 reads idx.vectors[id] for the re-rank). */
+int qv_index_get_row(qv_index* idx, uint32_t row, float* vec_out);
+
+/* ---- misc ----------------------------------------------------------------------- */
+const char* qv_last_error(void);          /* thread-local */
+int         qv_abi_version(void);
+int         qv_device_count(void);
+/* Timing of the last qv_index_search_device-style launch is the caller's business
+ * (HIP events on its stream); this returns static facts for reports. */
+int         qv_device_info(int device, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QV_H */

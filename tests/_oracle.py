@@ -1,0 +1,227 @@
+"""ctypes binding of oracle/libqvoracle.so — TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never
+by quiver_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "libqvoracle.so")
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    lib.qvo_distance.restype = C.c_float
+    lib.qvo_distance.argtypes = [C.c_int, _f32p, _f32p, C.c_uint32]
+    lib.qvo_gen_rows.restype = None
+    lib.qvo_gen_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _f32p]
+    lib.qvo_exact_search.restype = C.c_int64
+    lib.qvo_exact_search.argtypes = [C.c_int, _f32p, C.c_void_p, C.c_uint32, C.c_uint32, _f32p, C.c_uint32, _u32p, _f32p]
+    lib.qvo_all_distances.restype = None
+    lib.qvo_all_distances.argtypes = [C.c_int, _f32p, C.c_uint32, C.c_uint32, _f32p, _f32p]
+    lib.qvo_exact_search_negative.restype = C.c_int64
+    lib.qvo_exact_search_negative.argtypes = [C.c_int, _f32p, C.c_void_p, C.c_uint32, C.c_uint32, _f32p, _f32p, C.c_float,
+                                              C.c_uint32, C.c_void_p, _u32p, _f32p]
+    lib.qvo_faithful_create.restype = C.c_void_p
+    lib.qvo_faithful_create.argtypes = [C.c_int, C.c_uint32]
+    lib.qvo_faithful_destroy.argtypes = [C.c_void_p]
+    lib.qvo_faithful_insert.argtypes = [C.c_void_p, C.c_char_p, _f32p]
+    lib.qvo_faithful_size.restype = C.c_uint32
+    lib.qvo_faithful_size.argtypes = [C.c_void_p]
+    lib.qvo_faithful_search.restype = C.c_int64
+    lib.qvo_faithful_search.argtypes = [C.c_void_p, _f32p, C.c_uint32, C.POINTER(C.c_char_p), _f32p]
+    lib.qvo_hnsw_create.restype = C.c_void_p
+    lib.qvo_hnsw_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
+    lib.qvo_hnsw_destroy.argtypes = [C.c_void_p]
+    lib.qvo_hnsw_insert.restype = C.c_int64
+    lib.qvo_hnsw_insert.argtypes = [C.c_void_p, _f32p]
+    lib.qvo_hnsw_delete.argtypes = [C.c_void_p, C.c_uint32]
+    lib.qvo_hnsw_search.restype = C.c_int64
+    lib.qvo_hnsw_search.argtypes = [C.c_void_p, _f32p, C.c_uint32, _u32p, _f32p, C.POINTER(C.c_uint64)]
+    lib.qvo_hnsw_set_ef_search.argtypes = [C.c_void_p, C.c_int]
+    lib.qvo_hnsw_size.restype = C.c_uint32
+    lib.qvo_hnsw_size.argtypes = [C.c_void_p]
+    lib.qvo_hnsw_nodes.restype = C.c_uint32
+    lib.qvo_hnsw_nodes.argtypes = [C.c_void_p]
+    lib.qvo_hnsw_entry_point.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    lib.qvo_hnsw_node_level.argtypes = [C.c_void_p, C.c_uint32]
+    lib.qvo_hnsw_links.argtypes = [C.c_void_p, C.c_uint32, C.c_int, _u32p, C.c_uint32]
+    lib.qvo_hnsw_random_level.argtypes = [C.c_void_p]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def distance(metric: int, a, b) -> np.float32:
+    a, b = _f32(a), _f32(b)
+    if a.shape != b.shape:
+        raise ValueError("vectors must have the same length")
+    return np.float32(lib().qvo_distance(metric, a, b, a.size))
+
+
+def gen_rows(seed: int, row0: int, n: int, dim: int) -> np.ndarray:
+    out = np.empty((n, dim), dtype=np.float32)
+    lib().qvo_gen_rows(seed, row0, n, dim, out)
+    return out
+
+
+def all_distances(metric: int, rows, query) -> np.ndarray:
+    rows, query = _f32(rows), _f32(query)
+    out = np.empty(rows.shape[0], dtype=np.float32)
+    lib().qvo_all_distances(metric, rows, rows.shape[0], rows.shape[1], query, out)
+    return out
+
+
+def exact_search(metric: int, rows, query, k: int, alive=None):
+    rows, query = _f32(rows), _f32(query)
+    n, dim = rows.shape if rows.ndim == 2 else (0, query.size)
+    if n and query.size != dim:
+        raise ValueError(f"query dimension mismatch: expected {dim}, got {query.size}")
+    ro = np.empty(max(k, 1), dtype=np.uint32)
+    do = np.empty(max(k, 1), dtype=np.float32)
+    ap = None
+    if alive is not None:
+        alive = np.ascontiguousarray(alive, dtype=np.uint8)
+        ap = alive.ctypes.data_as(C.c_void_p)
+    if n == 0:
+        return ro[:0], do[:0]
+    got = lib().qvo_exact_search(metric, rows, ap, n, dim, query, max(k, 0), ro, do)
+    if got < 0:
+        raise ValueError("k must be positive")
+    return ro[:got].copy(), do[:got].copy()
+
+
+def exact_search_negative(metric: int, rows, query, negative, weight: float, k: int, alive=None, id_rank=None):
+    rows, query, negative = _f32(rows), _f32(query), _f32(negative)
+    n, dim = rows.shape
+    cap = max(2 * k, 30)
+    ro = np.empty(cap, dtype=np.uint32)
+    do = np.empty(cap, dtype=np.float32)
+    ap = None
+    if alive is not None:
+        alive = np.ascontiguousarray(alive, dtype=np.uint8)
+        ap = alive.ctypes.data_as(C.c_void_p)
+    rp = None
+    if id_rank is not None:
+        id_rank = np.ascontiguousarray(id_rank, dtype=np.uint32)
+        rp = id_rank.ctypes.data_as(C.c_void_p)
+    got = lib().qvo_exact_search_negative(metric, rows, ap, n, dim, query, negative, weight, k, rp, ro, do)
+    if got < 0:
+        raise ValueError("k must be positive")
+    return ro[:got].copy(), do[:got].copy()
+
+
+class Faithful:
+    """reference-faithful ExactIndex (CPU baseline)"""
+
+    def __init__(self, metric: int, dim: int):
+        self._h = lib().qvo_faithful_create(metric, dim)
+        self.dim = dim
+
+    def insert(self, id_: str, vec) -> None:
+        if lib().qvo_faithful_insert(self._h, id_.encode(), _f32(vec)) != 0:
+            raise ValueError(f"vector with ID {id_} already exists")
+
+    def size(self) -> int:
+        return lib().qvo_faithful_size(self._h)
+
+    def search(self, query, k: int):
+        ids = (C.c_char_p * max(k, 1))()
+        do = np.empty(max(k, 1), dtype=np.float32)
+        got = lib().qvo_faithful_search(self._h, _f32(query), k, ids, do)
+        if got < 0:
+            raise ValueError("k must be positive")
+        return [ids[i].decode() for i in range(got)], do[:got].copy()
+
+    def __del__(self):
+        try:
+            lib().qvo_faithful_destroy(self._h)
+        except Exception:
+            pass
+
+
+class HNSW:
+    """oracle restatement of pkg/hnsw/hnsw.go"""
+
+    def __init__(self, metric: int, dim: int, M=16, maxM0=0, efConstruction=200, efSearch=100, maxLevel=16, seed=1):
+        self._h = lib().qvo_hnsw_create(metric, dim, M, maxM0, efConstruction, efSearch, maxLevel, seed)
+        self.dim = dim
+
+    def insert(self, vec) -> int:
+        return int(lib().qvo_hnsw_insert(self._h, _f32(vec)))
+
+    def delete(self, node: int) -> int:
+        return lib().qvo_hnsw_delete(self._h, node)
+
+    def set_ef_search(self, ef: int):
+        lib().qvo_hnsw_set_ef_search(self._h, ef)
+
+    def search(self, query, k: int, with_evals=False):
+        ro = np.empty(max(k, 1), dtype=np.uint32)
+        do = np.empty(max(k, 1), dtype=np.float32)
+        ne = C.c_uint64(0)
+        got = lib().qvo_hnsw_search(self._h, _f32(query), max(k, 0), ro, do, C.byref(ne))
+        if got == -1:
+            raise ValueError("k must be positive")
+        if got < 0:
+            raise RuntimeError("search failed")
+        if with_evals:
+            return ro[:got].copy(), do[:got].copy(), int(ne.value)
+        return ro[:got].copy(), do[:got].copy()
+
+    def size(self) -> int:
+        return lib().qvo_hnsw_size(self._h)
+
+    def nodes(self) -> int:
+        return lib().qvo_hnsw_nodes(self._h)
+
+    def entry_point(self):
+        ep, lv = C.c_uint32(0), C.c_int(0)
+        lib().qvo_hnsw_entry_point(self._h, C.byref(ep), C.byref(lv))
+        return int(ep.value), int(lv.value)
+
+    def node_level(self, node: int) -> int:
+        return lib().qvo_hnsw_node_level(self._h, node)
+
+    def links(self, node: int, level: int) -> np.ndarray:
+        out = np.empty(4096, dtype=np.uint32)
+        n = lib().qvo_hnsw_links(self._h, node, level, out, out.size)
+        if n < 0:
+            return out[:0]
+        return out[:n].copy()
+
+    def random_level(self) -> int:
+        return lib().qvo_hnsw_random_level(self._h)
+
+    def __del__(self):
+        try:
+            lib().qvo_hnsw_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,47 @@
+"""pytest configuration: registers the `gpu` marker and builds the CPU oracle once.
+
+`-m "not gpu"` tests run in the GPU-less authoring container: oracle vs the
+reference's known-answer tests, host logic, and that the C-ABI library loads and
+exports every symbol include/qv.h declares.  `-m gpu` tests are the parity tests
+proper: they call the HIP path through the C ABI and compare with the oracle.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running CPU test")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    so = os.path.join(ROOT, "oracle", "libqvoracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("qv_oracle.c", "qv_oracle_hnsw.c", "qv_oracle.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    yield

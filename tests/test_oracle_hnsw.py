@@ -1,0 +1,162 @@
+"""Properties the reference asserts for pkg/hnsw (its seeded-random tests cannot be
+regenerated without Go), checked on the oracle restatement, plus the
+literal tables of tests/golden/ref_kats.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+KATS = json.load(open(os.path.join(O.ROOT, "tests", "golden", "ref_kats.json")))
+
+
+def _build(metric, rows, seed=1, **kw):
+    h = O.HNSW(metric, rows.shape[1], seed=seed, **kw)
+    for r in rows:
+        assert h.insert(r) >= 0
+    return h
+
+
+@pytest.mark.parametrize("kat", KATS["hnsw_properties"], ids=lambda k: k["src"])
+def test_hnsw_kats(kat):
+    """The reference's level RNG is wall-clock seeded (hnsw.go:248), so its own test
+    must pass for whatever levels get drawn.  It does not quite: when two nodes draw
+    level >= 1 the later one keeps only self-links at level 0 (hnsw.go:463-467) and a
+    level-0 search entered through it returns just that node, so the reference's
+    'exact match is rank 0' test is itself flaky (a few % of wall-clock seeds).  The
+    restatement must reproduce exactly that: strict when every node is level 0,
+    and failing only with the self-link signature otherwise."""
+    rows = np.array(kat["rows"], dtype=np.float32)
+    orders = kat.get("orders", [list(range(len(rows)))])
+    total = ok = 0
+    for seed in range(40):
+        for order in orders:
+            h = O.HNSW(kat["metric"], rows.shape[1], seed=seed)
+            for i in order:
+                h.insert(rows[i])
+            levels = [h.node_level(n) for n in range(len(order))]
+            r, d = h.search(kat["query"], kat["k"])
+            assert 0 < len(r) <= kat["k"]
+            assert all(d[i] <= d[i + 1] for i in range(len(d) - 1))
+            got_rows = [order[i] for i in r]
+            good = True
+            if "want_first_row" in kat:
+                good &= got_rows[0] == kat["want_first_row"] and d[0] == kat["want_first_dist"]
+            if "must_contain_row" in kat:
+                good &= kat["must_contain_row"] in got_rows
+            total += 1
+            ok += good
+            if not good:
+                assert max(levels) >= 1
+                first = int(r[0])
+                assert levels[first] >= 1 and set(h.links(first, 0).tolist()) <= {first}
+    assert ok / total >= 0.85
+
+
+def test_empty_and_k_errors():
+    h = O.HNSW(6, 3)
+    r, d = h.search([1, 2, 3], 5)               # hnsw.go:606-608
+    assert len(r) == 0
+    h.insert([1, 2, 3])
+    with pytest.raises(ValueError):
+        h.search([1, 2, 3], 0)                  # hnsw.go:610-612
+    r, d = h.search([1, 2, 3], 10)              # k clamped, hnsw.go:615-617
+    assert list(r) == [0] and d[0] == 0.0
+
+
+def test_self_retrieval_small():                # hnsw_property_test.go:15-77: k = min(10, n), n <= 10 -> must be found
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 5, 10):
+        for seed in range(8):
+            rows = rng.standard_normal((n, 3)).astype(np.float32)
+            h = _build(6, rows, seed=seed, efSearch=50)
+            for i in range(n):
+                r, d = h.search(rows[i], min(10, n))
+                assert i in r.tolist()              # graph search under-fills -> exact top-up (hnsw.go:676-710)
+                assert len(r) == n
+
+
+def test_results_sorted_and_bounded_and_match_recomputed_distance():
+    rows = O.gen_rows(11, 0, 2000, 32)
+    h = _build(0, rows, seed=5)
+    qs = O.gen_rows(12, 0, 20, 32)
+    for q in qs:
+        r, d, ne = h.search(q, 10, with_evals=True)
+        assert len(r) == 10 and len(set(r.tolist())) == 10
+        assert all(d[i] <= d[i + 1] for i in range(9))
+        assert ne > 0
+        for i, row in enumerate(r):
+            assert d[i] == O.distance(0, q, rows[row])
+
+
+def test_recall_against_exact_is_reasonable():
+    rows = O.gen_rows(21, 0, 3000, 24)
+    h = _build(0, rows, seed=9, efSearch=128)
+    qs = O.gen_rows(22, 0, 50, 24)
+    hit = 0
+    for q in qs:
+        r, _ = h.search(q, 10)
+        e, _ = O.exact_search(0, rows, q, 10)
+        hit += len(set(r.tolist()) & set(e.tolist()))
+    assert hit / 500 > 0.5                      # the reference asserts no recall; sanity only
+
+
+def test_level_law():                           # hnsw.go:716-738: p=0.25 per extra level, <= min(MaxLevel,10) draws
+    h = O.HNSW(6, 2, maxLevel=16, seed=123)
+    lv = np.array([h.random_level() for _ in range(40000)])
+    assert lv.max() <= 10
+    assert abs((lv >= 1).mean() - 0.25) < 0.01
+    assert abs((lv >= 2).mean() - 0.0625) < 0.005
+    h2 = O.HNSW(6, 2, maxLevel=2, seed=123)
+    assert max(h2.random_level() for _ in range(5000)) <= 1
+
+
+def test_multi_level_nodes_self_link_quirk():   # hnsw.go:463-467 (documented in qv_oracle_hnsw.c)
+    rows = O.gen_rows(31, 0, 400, 16)
+    h = _build(6, rows, seed=2)
+    seen = 0
+    for n in range(1, 400):
+        if h.node_level(n) >= 1:
+            l0 = h.links(n, 0)
+            if n in l0.tolist():
+                seen += 1
+    assert seen > 0
+
+
+def test_delete_then_search_tops_up():          # hnsw.go:676-710; hnsw_property_test.go delete-removes
+    rows = O.gen_rows(41, 0, 200, 8)
+    h = _build(6, rows, seed=4)
+    for n in range(0, 200, 2):
+        assert h.delete(n) == 0
+    assert h.delete(0) != 0                     # already deleted -> error (hnsw.go:745-749)
+    assert h.size() == 100 and h.nodes() == 200
+    for q in O.gen_rows(42, 0, 10, 8):
+        r, d = h.search(q, 100)
+        assert len(r) == 100                    # under-filled graph search is topped up to k
+        assert all(x % 2 == 1 for x in r.tolist())
+        assert all(d[i] <= d[i + 1] for i in range(len(d) - 1))
+        e, ed = O.exact_search(6, rows, q, 100, alive=(np.arange(200) % 2 == 1))
+        assert set(r.tolist()) == set(e.tolist())
+
+
+def test_delete_all_then_reinsert():
+    h = O.HNSW(6, 3, seed=1)
+    a = h.insert([1, 0, 0])
+    assert h.delete(a) == 0
+    r, _ = h.search([1, 0, 0], 1)
+    assert len(r) == 0                          # hnsw.go:632-634
+    b = h.insert([0, 1, 0])
+    r, d = h.search([0, 1, 0], 1)
+    assert list(r) == [b] and d[0] == 0.0
+
+
+def test_same_seed_same_graph_different_seed_may_differ():
+    rows = O.gen_rows(51, 0, 300, 16)
+    h1, h2 = _build(0, rows, seed=77), _build(0, rows, seed=77)
+    for n in range(300):
+        assert h1.node_level(n) == h2.node_level(n)
+        for l in range(h1.node_level(n) + 1):
+            assert np.array_equal(h1.links(n, l), h2.links(n, l))
+    assert h1.entry_point() == h2.entry_point()
