@@ -98,7 +98,7 @@ int qv_index_add(qv_index* idx, const float* rows, uint32_t n, uint32_t* first_r
 int qv_index_add_device(qv_index* idx, const float* d_rows, uint32_t n, uint32_t* first_row_out, void* stream);
 
 /* Append n synthetic unit rows generated on the device by the counter-based
- * generator of oracle/qv_oracle.c (qvo_gen_rows); global row number of the first
+ * generator documented in DESIGN.md (synthetic corpus); global row number of the first
  * generated row is `gen_row0` (so shards of one corpus agree).  Benchmark/test
  * helper: keeps 30 GB corpora off PCIe. */
 int qv_index_add_synthetic(qv_index* idx, uint64_t seed, uint64_t gen_row0, uint32_t n, uint32_t* first_row_out);
@@ -156,6 +156,21 @@ int qv_distance_rows_device(qv_index* idx, const float* d_query, const uint32_t*
  * independent pairs a[i], b[i] (each [dim]); computed on the device `device`. */
 int qv_distance_pairs(qv_metric metric, const float* a, const float* b, uint32_t n, uint32_t dim,
                       float* dist_out, int device);
+
+/* Deterministic merge of per-shard top-k lists (the exchange step of the sharded flat
+ * scan: every rank all-gathers its k (distance, global row) pairs over RCCL, then
+ * merges).  d_dist_lists / d_row_lists are [n_lists][k] device arrays, each list
+ * sorted or not; output = the k smallest by (distance, row).  n_lists * k <= 65536.
+ * No reference counterpart: the reference is single-process. */
+int qv_merge_topk_device(const float* d_dist_lists, const uint32_t* d_row_lists, uint32_t n_lists, uint32_t k,
+                         uint32_t* d_rows_out, float* d_dist_out, void* stream);
+
+/* Measurement aid: when enabled, every flat-scan kernel launched through
+ * qv_index_search_device is bracketed by HIP events on the caller's stream;
+ * qv_index_profile_read synchronises those events and returns the summed kernel
+ * time and the number of launches since the last read.  Off by default. */
+int qv_index_profile(qv_index* idx, int enable);
+int qv_index_profile_read(qv_index* idx, double* scan_ms_sum_out, uint64_t* launches_out);
 
 /* Copy row `row` back to the host (ExactIndex keeps vectors readable,
  * hybrid_index.go:537 reads idx.vectors[id] for the re-rank). */

@@ -1,0 +1,590 @@
+// qv_api.cpp — the C ABI of include/qv.h over the gfx950 kernels of qv_device.hip.
+//
+// Host-side responsibilities only: argument checks in the reference's order and
+// wording, device-memory ownership (tile storage sized for 288 GB HBM3E: one
+// allocation per array, geometric growth, explicit reserve), a pool of per-call
+// search contexts (stream + pinned staging + workspace) so concurrent searches do
+// not serialise, and per-stream workspaces for the *_device entry points.
+// There is NO CPU compute path here: every distance and every selection runs in
+// a HIP kernel, and a missing/failed HIP runtime is a loud error, never a fallback.
+#include "../../include/qv.h"
+#include "qv_device.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Buf {            // growable device buffer
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return QV_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(bytes, (size_t)4096);
+        HIPCHK(hipMalloc(&p, want));
+        cap = want; return QV_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct PinBuf {         // growable pinned host buffer
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return QV_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(bytes, (size_t)4096);
+        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want; return QV_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct Workspace { Buf ws; };
+
+struct SearchCtx {
+    hipStream_t stream = nullptr;
+    Buf d_q, d_rows, d_dist, d_ids, ws;
+    PinBuf h_q, h_rows, h_dist, h_ids;
+    void release() {
+        d_q.release(); d_rows.release(); d_dist.release(); d_ids.release(); ws.release();
+        h_q.release(); h_rows.release(); h_dist.release(); h_ids.release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
+}  // namespace
+
+struct qv_index {
+    int device = 0;
+    int cus = 256;
+    uint32_t dim = 0, dim4 = 0;
+    int metric = QV_COSINE;
+    uint64_t flags = 0;
+    uint32_t n_rows = 0, n_live = 0;
+    uint64_t cap_tiles = 0;
+    float* d_tiles = nullptr;
+    double* d_rnorm = nullptr;
+    uint64_t* d_alive = nullptr;
+    float* d_rowmaj = nullptr;
+    std::vector<uint64_t> alive_host;          // mirror of d_alive, for size bookkeeping and validation
+
+    std::mutex ctx_mu;
+    std::vector<SearchCtx*> free_ctx;
+    std::vector<SearchCtx*> all_ctx;
+    bool profiling = false;                    // qv_index_profile: event pairs around scan kernels
+    std::mutex prof_mu;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::mutex ws_mu;
+    std::map<hipStream_t, Workspace*> stream_ws;   // workspaces of the *_device entry points, one per caller stream
+
+    qv::IndexView view() const {
+        qv::IndexView v;
+        v.tiles = d_tiles; v.rnorm = d_rnorm; v.alive = d_alive; v.rowmaj = d_rowmaj;
+        v.dim = dim; v.dim4 = dim4; v.n_rows = n_rows; v.n_tiles = (n_rows + 63) / 64; v.metric = metric;
+        return v;
+    }
+    size_t tile_bytes() const { return (size_t)dim4 * 64 * 16; }
+};
+
+namespace {
+
+int acquire_ctx(qv_index* idx, SearchCtx** out) {
+    {
+        std::lock_guard<std::mutex> g(idx->ctx_mu);
+        if (!idx->free_ctx.empty()) { *out = idx->free_ctx.back(); idx->free_ctx.pop_back(); return QV_OK; }
+    }
+    SearchCtx* c = new (std::nothrow) SearchCtx();
+    if (!c) return fail(QV_ERR_OOM, "out of host memory");
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(QV_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    std::lock_guard<std::mutex> g(idx->ctx_mu);
+    idx->all_ctx.push_back(c);
+    *out = c;
+    return QV_OK;
+}
+void release_ctx(qv_index* idx, SearchCtx* c) {
+    std::lock_guard<std::mutex> g(idx->ctx_mu);
+    idx->free_ctx.push_back(c);
+}
+struct CtxGuard {
+    qv_index* idx; SearchCtx* c;
+    ~CtxGuard() { if (c) release_ctx(idx, c); }
+};
+
+int stream_workspace(qv_index* idx, hipStream_t s, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> g(idx->ws_mu);
+    Workspace*& w = idx->stream_ws[s];
+    if (!w) w = new (std::nothrow) Workspace();
+    if (!w) return fail(QV_ERR_OOM, "out of host memory");
+    if (bytes > w->ws.cap) {
+        // a larger workspace replaces one the stream may still be using: drain first
+        HIPCHK(hipStreamSynchronize(s));
+        int rc = w->ws.ensure(bytes + bytes / 2);
+        if (rc != QV_OK) return rc;
+    }
+    *out = w->ws.p;
+    return QV_OK;
+}
+
+// grow device storage to hold `rows` rows (whole tiles), preserving contents
+int ensure_rows(qv_index* idx, uint64_t rows, bool exact) {
+    uint64_t need_tiles = (rows + 63) / 64;
+    if (need_tiles <= idx->cap_tiles) return QV_OK;
+    if (rows > 0xFFFFFFF0ull) return fail(QV_ERR_INVALID_ARG, "row count %llu exceeds the uint32 row space", (unsigned long long)rows);
+    uint64_t new_tiles = exact ? need_tiles : std::max<uint64_t>(need_tiles, idx->cap_tiles + idx->cap_tiles / 2 + 16);
+    const size_t tb = idx->tile_bytes();
+    float* nt = nullptr; double* nn = nullptr; uint64_t* na = nullptr; float* nr = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&nt), new_tiles * tb));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nn), new_tiles * 64 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&na), new_tiles * sizeof(uint64_t));
+    if (e == hipSuccess && (idx->flags & QV_FLAG_ROWMAJOR)) e = hipMalloc(reinterpret_cast<void**>(&nr), new_tiles * 64 * (size_t)idx->dim * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(nt); (void)hipFree(nn); (void)hipFree(na); (void)hipFree(nr);
+        return fail(QV_ERR_OOM, "device allocation for %llu rows failed: %s", (unsigned long long)(new_tiles * 64), hipGetErrorString(e));
+    }
+    const uint64_t used_tiles = (idx->n_rows + 63) / 64;
+    // zero the new part (pad rows must be finite; alive bits must start clear), copy the used part
+    HIPCHK(hipMemset(reinterpret_cast<char*>(nt) + used_tiles * tb, 0, (new_tiles - used_tiles) * tb));
+    HIPCHK(hipMemset(nn + used_tiles * 64, 0, (new_tiles - used_tiles) * 64 * sizeof(double)));
+    HIPCHK(hipMemset(na + used_tiles, 0, (new_tiles - used_tiles) * sizeof(uint64_t)));
+    if (used_tiles) {
+        HIPCHK(hipMemcpy(nt, idx->d_tiles, used_tiles * tb, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nn, idx->d_rnorm, used_tiles * 64 * sizeof(double), hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(na, idx->d_alive, used_tiles * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+        if (nr) HIPCHK(hipMemcpy(nr, idx->d_rowmaj, (size_t)idx->n_rows * idx->dim * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rowmaj);
+    idx->d_tiles = nt; idx->d_rnorm = nn; idx->d_alive = na; idx->d_rowmaj = nr;
+    idx->cap_tiles = new_tiles;
+    return QV_OK;
+}
+
+void mark_alive_host(qv_index* idx, uint32_t row0, uint32_t n) {
+    idx->alive_host.resize(((size_t)row0 + n + 63) / 64, 0);
+    for (uint32_t r = row0; r < row0 + n; r++) idx->alive_host[r >> 6] |= 1ull << (r & 63);
+}
+
+// undo a partially applied add: counters back, alive words of every tile from the
+// first touched one re-uploaded from the host mirror (the scan masks by alive bits only)
+void rollback_rows(qv_index* idx, uint32_t base_rows, uint32_t base_live) {
+    idx->n_rows = base_rows; idx->n_live = base_live;
+    const size_t t0 = base_rows / 64;
+    std::vector<uint64_t> words(idx->cap_tiles - t0, 0);
+    if (t0 < idx->alive_host.size()) {
+        idx->alive_host.resize((base_rows + 63) / 64);
+        if (base_rows & 63) idx->alive_host[t0] &= (1ull << (base_rows & 63)) - 1;
+        if (t0 < idx->alive_host.size()) words[0] = idx->alive_host[t0];
+    }
+    if (!words.empty()) (void)hipMemcpy(idx->d_alive + t0, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+}
+
+size_t lds_limit_dim() { return 16384; }   // f64 query staging: 16384 * 8 B = 128 KiB of the CU's 160 KiB
+
+}  // namespace
+
+extern "C" {
+
+const char* qv_last_error(void) { return g_err; }
+int qv_abi_version(void) { return QV_ABI_VERSION; }
+
+int qv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int qv_device_info(int device, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (name_out && name_cap) { snprintf(name_out, name_cap, "%s (%s)", p.name, p.gcnArchName); }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    return QV_OK;
+}
+
+int qv_index_create(qv_index** out, uint32_t dim, qv_metric metric, int device, uint64_t flags) {
+    if (!out) return fail(QV_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (dim == 0) return fail(QV_ERR_INVALID_ARG, "dimension must be positive");
+    if (dim > lds_limit_dim()) return fail(QV_ERR_UNSUPPORTED, "dimension %u exceeds the supported maximum %zu", dim, lds_limit_dim());
+    if ((int)metric < 0 || (int)metric >= QV_METRIC_COUNT) return fail(QV_ERR_INVALID_ARG, "unknown metric %d", (int)metric);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(QV_ERR_NO_DEVICE, "no HIP device available (%s); libqv has no CPU path", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(QV_ERR_INVALID_ARG, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    qv_index* idx = new (std::nothrow) qv_index();
+    if (!idx) return fail(QV_ERR_OOM, "out of host memory");
+    idx->device = device; idx->cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    idx->dim = dim; idx->dim4 = (dim + 3) / 4; idx->metric = (int)metric; idx->flags = flags;
+    *out = idx;
+    return QV_OK;
+}
+
+void qv_index_destroy(qv_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    (void)hipDeviceSynchronize();
+    for (SearchCtx* c : idx->all_ctx) { c->release(); delete c; }
+    for (auto& kv : idx->stream_ws) { kv.second->ws.release(); delete kv.second; }
+    (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rowmaj);
+    delete idx;
+}
+
+int qv_index_reserve(qv_index* idx, uint64_t rows) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    HIPCHK(hipSetDevice(idx->device));
+    return ensure_rows(idx, rows, true);
+}
+
+uint32_t qv_index_rows(const qv_index* idx) { return idx ? idx->n_rows : 0; }
+uint32_t qv_index_size(const qv_index* idx) { return idx ? idx->n_live : 0; }
+uint32_t qv_index_dim(const qv_index* idx) { return idx ? idx->dim : 0; }
+int qv_index_metric(const qv_index* idx) { return idx ? idx->metric : -1; }
+
+int qv_index_add_device(qv_index* idx, const float* d_rows, uint32_t n, uint32_t* first_row_out, void* stream) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (first_row_out) *first_row_out = idx->n_rows;
+    if (n == 0) return QV_OK;
+    if (!d_rows) return fail(QV_ERR_INVALID_ARG, "rows is null");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = ensure_rows(idx, (uint64_t)idx->n_rows + n, false);
+    if (rc != QV_OK) return rc;
+    const uint32_t row0 = idx->n_rows;
+    idx->n_rows += n;                                   // view() must cover the new rows
+    hipError_t e = qv::launch_ingest(idx->view(), d_rows, row0, n, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { idx->n_rows = row0; return fail(QV_ERR_DEVICE, "ingest failed: %s", hipGetErrorString(e)); }
+    idx->n_live += n;
+    mark_alive_host(idx, row0, n);
+    return QV_OK;
+}
+
+int qv_index_add(qv_index* idx, const float* rows, uint32_t n, uint32_t* first_row_out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (first_row_out) *first_row_out = idx->n_rows;
+    if (n == 0) return QV_OK;
+    if (!rows) return fail(QV_ERR_INVALID_ARG, "rows is null");
+    HIPCHK(hipSetDevice(idx->device));
+    int rc = ensure_rows(idx, (uint64_t)idx->n_rows + n, false);
+    if (rc != QV_OK) return rc;
+    // stage in chunks of <= 256 MiB so a 30 GB corpus never needs a second full-size buffer
+    const size_t row_bytes = (size_t)idx->dim * sizeof(float);
+    const uint32_t chunk_rows = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, ((size_t)256 << 20) / row_bytes));
+    float* d_stage = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_stage), (size_t)chunk_rows * row_bytes));
+    uint32_t done = 0;
+    const uint32_t base_rows = idx->n_rows, base_live = idx->n_live;
+    while (done < n) {
+        uint32_t m = std::min(chunk_rows, n - done);
+        hipError_t e = hipMemcpy(d_stage, rows + (size_t)done * idx->dim, (size_t)m * row_bytes, hipMemcpyHostToDevice);
+        rc = e == hipSuccess ? QV_OK : fail(QV_ERR_DEVICE, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
+        uint32_t fr = 0;
+        if (rc == QV_OK) rc = qv_index_add_device(idx, d_stage, m, &fr, nullptr);
+        if (rc != QV_OK) {                      // all-or-nothing (InsertBatch rolls back, hybrid_index.go:175-216)
+            (void)hipFree(d_stage);
+            rollback_rows(idx, base_rows, base_live);
+            return rc;
+        }
+        done += m;
+    }
+    (void)hipFree(d_stage);
+    if (first_row_out) *first_row_out = base_rows;
+    return QV_OK;
+}
+
+int qv_index_add_synthetic(qv_index* idx, uint64_t seed, uint64_t gen_row0, uint32_t n, uint32_t* first_row_out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (first_row_out) *first_row_out = idx->n_rows;
+    if (n == 0) return QV_OK;
+    HIPCHK(hipSetDevice(idx->device));
+    int rc = ensure_rows(idx, (uint64_t)idx->n_rows + n, false);
+    if (rc != QV_OK) return rc;
+    const uint32_t row0 = idx->n_rows;
+    idx->n_rows += n;
+    hipError_t e = qv::launch_generate(idx->view(), seed, gen_row0, row0, n, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) { idx->n_rows = row0; return fail(QV_ERR_DEVICE, "generate failed: %s", hipGetErrorString(e)); }
+    idx->n_live += n;
+    mark_alive_host(idx, row0, n);
+    return QV_OK;
+}
+
+int qv_index_remove(qv_index* idx, const uint32_t* rows, uint32_t n) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (n == 0) return QV_OK;
+    if (!rows) return fail(QV_ERR_INVALID_ARG, "rows is null");
+    for (uint32_t i = 0; i < n; i++)
+        if (rows[i] >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", rows[i], idx->n_rows);
+    HIPCHK(hipSetDevice(idx->device));
+    uint32_t* d = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * sizeof(uint32_t)));
+    hipError_t e = hipMemcpy(d, rows, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = qv::launch_set_alive(idx->view(), d, n, 0, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "remove failed: %s", hipGetErrorString(e));
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t bit = 1ull << (rows[i] & 63);
+        if (idx->alive_host[rows[i] >> 6] & bit) { idx->alive_host[rows[i] >> 6] &= ~bit; idx->n_live--; }
+    }
+    return QV_OK;
+}
+
+int qv_index_update(qv_index* idx, uint32_t row, const float* vec) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (!vec) return fail(QV_ERR_INVALID_ARG, "vector is null");
+    if (row >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", row, idx->n_rows);
+    HIPCHK(hipSetDevice(idx->device));
+    float* d = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)idx->dim * sizeof(float)));
+    hipError_t e = hipMemcpy(d, vec, (size_t)idx->dim * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = qv::launch_ingest(idx->view(), d, row, 1, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "update failed: %s", hipGetErrorString(e));
+    uint64_t bit = 1ull << (row & 63);
+    if (!(idx->alive_host[row >> 6] & bit)) { idx->alive_host[row >> 6] |= bit; idx->n_live++; }
+    return QV_OK;
+}
+
+int qv_index_get_row(qv_index* idx, uint32_t row, float* vec_out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (!vec_out) return fail(QV_ERR_INVALID_ARG, "vec_out is null");
+    if (row >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", row, idx->n_rows);
+    HIPCHK(hipSetDevice(idx->device));
+    float* d = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)idx->dim * sizeof(float)));
+    hipError_t e = qv::launch_fetch_row(idx->view(), row, d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(vec_out, d, (size_t)idx->dim * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "get_row failed: %s", hipGetErrorString(e));
+    return QV_OK;
+}
+
+// shared by the host and device entry points: enqueue nq searches of list length kk
+// (kk = min(k, live)), results written with row stride k_stride
+static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                          void* ws, size_t ws_bytes, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    const qv::IndexView v = idx->view();
+    const qv::ScanPlan plan = qv::plan_scan(v.n_tiles, idx->cus);
+    (void)ws_bytes;
+    if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride) {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (idx->profiling) {
+            if (hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {
+                std::lock_guard<std::mutex> g(idx->prof_mu);
+                idx->prof_events.emplace_back(ev0, ev1);
+            } else { ev0 = ev1 = nullptr; }
+        }
+        hipError_t e = qv::launch_flat_topk(v, plan, d_queries, nq, kk, ws, d_rows_out, d_dist_out, s, ev0, ev1);
+        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "flat scan launch failed: %s", hipGetErrorString(e));
+        return QV_OK;
+    }
+    // full-ranking path (k > 64, e.g. filtered search asking for k = N, collection.go:679-682),
+    // also used when the output stride differs from the list length
+    for (uint32_t q = 0; q < nq; q++) {
+        hipError_t e = qv::launch_flat_fullsort(v, plan, d_queries + (size_t)q * idx->dim, k_stride, ws,
+                                                d_rows_out + (size_t)q * k_stride, d_dist_out + (size_t)q * k_stride, s);
+        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "full-sort launch failed: %s", hipGetErrorString(e));
+    }
+    return QV_OK;
+}
+
+static size_t search_ws_bytes(const qv_index* idx, uint32_t nq, uint32_t kk, uint32_t k_stride) {
+    const uint32_t n_tiles = (idx->n_rows + 63) / 64;
+    const qv::ScanPlan plan = qv::plan_scan(n_tiles, idx->cus);
+    if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride) return qv::scan_workspace_bytes(plan, nq, kk);
+    return qv::full_sort_workspace_bytes(n_tiles);
+}
+
+int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                    uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (nq == 0) return QV_OK;
+    if (!queries || !count_out) return fail(QV_ERR_INVALID_ARG, "queries/count_out is null");
+    if (idx->n_live == 0) {                                           // exact.go:96-98: empty index -> empty result, nil error
+        for (uint32_t q = 0; q < nq; q++) count_out[q] = 0;
+        return QV_OK;
+    }
+    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");        // exact.go:104-106
+    if (!rows_out || !dist_out) return fail(QV_ERR_INVALID_ARG, "rows_out/dist_out is null");
+    const uint32_t kk = std::min(k, idx->n_live);                                // exact.go:109-111
+    HIPCHK(hipSetDevice(idx->device));
+    SearchCtx* c = nullptr;
+    int rc = acquire_ctx(idx, &c);
+    if (rc != QV_OK) return rc;
+    CtxGuard guard{idx, c};
+    const size_t qbytes = (size_t)nq * idx->dim * sizeof(float);
+    const size_t obytes = (size_t)nq * kk * sizeof(uint32_t);
+    if ((rc = c->d_q.ensure(qbytes)) || (rc = c->h_q.ensure(qbytes)) || (rc = c->d_rows.ensure(obytes)) || (rc = c->d_dist.ensure(obytes)) ||
+        (rc = c->h_rows.ensure(obytes)) || (rc = c->h_dist.ensure(obytes)) || (rc = c->ws.ensure(search_ws_bytes(idx, nq, kk, kk))))
+        return rc;
+    memcpy(c->h_q.p, queries, qbytes);
+    HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_search(idx, static_cast<const float*>(c->d_q.p), nq, kk, kk, c->ws.p, c->ws.cap,
+                        static_cast<uint32_t*>(c->d_rows.p), static_cast<float*>(c->d_dist.p), c->stream);
+    if (rc != QV_OK) return rc;
+    HIPCHK(hipMemcpyAsync(c->h_rows.p, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t* hr = static_cast<const uint32_t*>(c->h_rows.p);
+    const float* hd = static_cast<const float*>(c->h_dist.p);
+    for (uint32_t q = 0; q < nq; q++) {
+        memcpy(rows_out + (size_t)q * k, hr + (size_t)q * kk, (size_t)kk * sizeof(uint32_t));
+        memcpy(dist_out + (size_t)q * k, hd + (size_t)q * kk, (size_t)kk * sizeof(float));
+        for (uint32_t i = kk; i < k; i++) { rows_out[(size_t)q * k + i] = 0xFFFFFFFFu; dist_out[(size_t)q * k + i] = __builtin_inff(); }
+        count_out[q] = kk;
+    }
+    return QV_OK;
+}
+
+int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
+                           uint32_t* d_rows_out, float* d_dist_out, void* stream) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (nq == 0) return QV_OK;
+    if (!d_queries || !d_rows_out || !d_dist_out) return fail(QV_ERR_INVALID_ARG, "null device pointer");
+    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (idx->n_live == 0) {                                           // pad everything: no results
+        HIPCHK(hipMemsetAsync(d_rows_out, 0xFF, (size_t)nq * k * sizeof(uint32_t), s));
+        std::vector<float> inf((size_t)nq * k, __builtin_inff());
+        HIPCHK(hipMemcpyAsync(d_dist_out, inf.data(), inf.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return QV_OK;
+    }
+    const uint32_t kk = std::min(k, idx->n_live);
+    void* ws = nullptr;
+    int rc = stream_workspace(idx, s, search_ws_bytes(idx, nq, kk, k), &ws);
+    if (rc != QV_OK) return rc;
+    return enqueue_search(idx, d_queries, nq, kk, k, ws, 0, d_rows_out, d_dist_out, s);
+}
+
+int qv_merge_topk_device(const float* d_dist_lists, const uint32_t* d_row_lists, uint32_t n_lists, uint32_t k,
+                         uint32_t* d_rows_out, float* d_dist_out, void* stream) {
+    if (!d_dist_lists || !d_row_lists || !d_rows_out || !d_dist_out) return fail(QV_ERR_INVALID_ARG, "null device pointer");
+    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");
+    if (k > (uint32_t)qv::kMaxFusedK || n_lists == 0 || (uint64_t)n_lists * k > 65536) return fail(QV_ERR_UNSUPPORTED, "merge supports k <= %d and n_lists*k <= 65536", qv::kMaxFusedK);
+    hipError_t e = qv::launch_merge_pairs(d_dist_lists, d_row_lists, n_lists, k, d_rows_out, d_dist_out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "merge launch failed: %s", hipGetErrorString(e));
+    return QV_OK;
+}
+
+int qv_index_profile(qv_index* idx, int enable) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    idx->profiling = enable != 0;
+    return QV_OK;
+}
+
+int qv_index_profile_read(qv_index* idx, double* scan_ms_sum_out, uint64_t* launches_out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    HIPCHK(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> g(idx->prof_mu);
+    double sum = 0.0; uint64_t n = 0;
+    for (auto& pr : idx->prof_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { sum += ms; n++; }
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    idx->prof_events.clear();
+    if (scan_ms_sum_out) *scan_ms_sum_out = sum;
+    if (launches_out) *launches_out = n;
+    return QV_OK;
+}
+
+int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                            uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
+    // the MFMA pre-filter is not built yet; the exact scan gives the identical result
+    return qv_index_search(idx, queries, nq, k, rows_out, dist_out, count_out);
+}
+
+int qv_distance_rows_device(qv_index* idx, const float* d_query, const uint32_t* d_rows, uint32_t n,
+                            float* d_dist_out, void* stream) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (n == 0) return QV_OK;
+    if (!d_query || !d_rows || !d_dist_out) return fail(QV_ERR_INVALID_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(idx->device));
+    hipError_t e = qv::launch_distance_rows(idx->view(), d_query, d_rows, n, d_dist_out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_rows launch failed: %s", hipGetErrorString(e));
+    return QV_OK;
+}
+
+int qv_distance_rows(qv_index* idx, const float* query, const uint32_t* rows, uint32_t n, float* dist_out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (n == 0) return QV_OK;
+    if (!query || !rows || !dist_out) return fail(QV_ERR_INVALID_ARG, "query/rows/dist_out is null");
+    for (uint32_t i = 0; i < n; i++)
+        if (rows[i] >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", rows[i], idx->n_rows);
+    HIPCHK(hipSetDevice(idx->device));
+    SearchCtx* c = nullptr;
+    int rc = acquire_ctx(idx, &c);
+    if (rc != QV_OK) return rc;
+    CtxGuard guard{idx, c};
+    const size_t qbytes = (size_t)idx->dim * sizeof(float), ibytes = (size_t)n * sizeof(uint32_t), obytes = (size_t)n * sizeof(float);
+    if ((rc = c->d_q.ensure(qbytes)) || (rc = c->h_q.ensure(qbytes)) || (rc = c->d_ids.ensure(ibytes)) || (rc = c->h_ids.ensure(ibytes)) ||
+        (rc = c->d_dist.ensure(obytes)) || (rc = c->h_dist.ensure(obytes)))
+        return rc;
+    memcpy(c->h_q.p, query, qbytes);
+    memcpy(c->h_ids.p, rows, ibytes);
+    HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_ids.p, c->h_ids.p, ibytes, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = qv::launch_distance_rows(idx->view(), static_cast<const float*>(c->d_q.p), static_cast<const uint32_t*>(c->d_ids.p), n,
+                                            static_cast<float*>(c->d_dist.p), c->stream);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_rows launch failed: %s", hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(dist_out, c->h_dist.p, obytes);
+    return QV_OK;
+}
+
+int qv_distance_pairs(qv_metric metric, const float* a, const float* b, uint32_t n, uint32_t dim, float* dist_out, int device) {
+    if ((int)metric < 0 || (int)metric >= QV_METRIC_COUNT) return fail(QV_ERR_INVALID_ARG, "unknown metric %d", (int)metric);
+    if (n == 0) return QV_OK;
+    if (!a || !b || !dist_out) return fail(QV_ERR_INVALID_ARG, "a/b/dist_out is null");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(QV_ERR_NO_DEVICE, "no HIP device available; libqv has no CPU path");
+    if (device < 0 || device >= ndev) return fail(QV_ERR_INVALID_ARG, "device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    const size_t bytes = (size_t)n * dim * sizeof(float);
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&da), std::max<size_t>(bytes, 16));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&db), std::max<size_t>(bytes, 16));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), (size_t)n * sizeof(float));
+    if (e == hipSuccess && bytes) e = hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && bytes) e = hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = qv::launch_distance_pairs((int)metric, da, db, n, dim, dout, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(dist_out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_pairs failed: %s", hipGetErrorString(e));
+    return QV_OK;
+}
+
+}  // extern "C"

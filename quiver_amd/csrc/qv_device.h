@@ -1,0 +1,86 @@
+// qv_device.h — internal interface between the C-ABI layer (qv_api.cpp) and the
+// gfx950 kernels (qv_device.hip).  Not installed; include/qv.h is the public ABI.
+//
+// HBM layout of an index ("row tiles", the SoA layout of DESIGN.md §3):
+//   tiles   float  [n_tiles][dim4][64][4]   tile t holds rows 64t..64t+63; within a
+//                                            tile, 16-byte chunk c (dims 4c..4c+3) of
+//                                            row r sits at ((t*dim4 + c)*64 + r)*16 B.
+//                                            One wave-wide dwordx4 load = one contiguous
+//                                            KiB; lane == row, so a lane accumulates its
+//                                            row's distance over dims 0..D-1 in exactly
+//                                            the reference's element order.
+//   rnorm   double [n_tiles*64]              per-row sqrt(sum b_i^2) in the metric's
+//                                            precision (cosine metrics only)
+//   alive   u64    [n_tiles]                 bit r of word t = row 64t+r is live
+//   rowmaj  float  [rows][dim]               optional row-major copy (QV_FLAG_ROWMAJOR)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qv {
+
+constexpr int kTileRows = 64;          // one wavefront
+constexpr int kMaxFusedK = 64;         // wave-resident top-k list: one key per lane
+constexpr uint64_t kDeadKey = ~0ull;
+
+struct IndexView {
+    float*    tiles;
+    double*   rnorm;
+    uint64_t* alive;
+    float*    rowmaj;     // may be null
+    uint32_t  dim;
+    uint32_t  dim4;       // ceil(dim/4)
+    uint32_t  n_rows;     // rows ever added
+    uint32_t  n_tiles;    // ceil(n_rows/64)
+    int       metric;
+};
+
+struct ScanPlan {
+    uint32_t grid;        // workgroups
+    uint32_t block;       // threads (multiple of 64)
+    uint32_t n_lists;     // partial lists the scan writes (= grid)
+};
+
+// how many workgroups a scan over n_tiles uses on a device with `cus` CUs
+ScanPlan plan_scan(uint32_t n_tiles, int cus);
+
+// bytes of workspace for nq queries at list length k (partial lists)
+size_t scan_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k);
+
+// --- ingest ---------------------------------------------------------------------
+// d_rows [n][dim] row-major on device -> tiles at rows [row0, row0+n); computes rnorm;
+// sets alive bits; also fills rowmaj if present.
+hipError_t launch_ingest(const IndexView& v, const float* d_rows, uint32_t row0, uint32_t n, hipStream_t s);
+// synthetic rows straight into tile layout (the synthetic-corpus generator of DESIGN.md)
+hipError_t launch_generate(const IndexView& v, uint64_t seed, uint64_t gen_row0, uint32_t row0, uint32_t n, hipStream_t s);
+// tombstone / revive
+hipError_t launch_set_alive(const IndexView& v, const uint32_t* d_rows, uint32_t n, int alive, hipStream_t s);
+// tile layout -> row-major (one row)
+hipError_t launch_fetch_row(const IndexView& v, uint32_t row, float* d_out, hipStream_t s);
+
+// --- search ---------------------------------------------------------------------
+// Flat scan + fused top-k for k <= kMaxFusedK.  d_queries [nq][dim] float32 on device.
+// d_ws: workspace of scan_workspace_bytes().  Writes d_rows_out/d_dist_out [nq][k]
+// (padded with 0xFFFFFFFF / +inf).
+// ev0/ev1 (optional): recorded immediately before/after the scan kernel on `s`.
+hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
+                            void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
+                            hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// merge n_lists lists of k (dist, row) pairs -> k best by (dist, row)
+hipError_t launch_merge_pairs(const float* d_dist, const uint32_t* d_rows, uint32_t n_lists, uint32_t k,
+                              uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
+
+// Full ranking path (any k): all distances -> 64-bit keys -> stable radix sort -> first k.
+// d_keys_a/d_keys_b: two buffers of n_tiles*64 u64; d_hist: radix histogram workspace.
+size_t  full_sort_workspace_bytes(uint32_t n_tiles);
+hipError_t launch_flat_fullsort(const IndexView& v, const ScanPlan& p, const float* d_query, uint32_t k,
+                                void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
+
+// distance of one query to n listed rows (lane == listed row, sequential accumulation)
+hipError_t launch_distance_rows(const IndexView& v, const float* d_query, const uint32_t* d_rows, uint32_t n,
+                                float* d_dist_out, hipStream_t s);
+// n independent pairs a[i], b[i] (row-major [n][dim])
+hipError_t launch_distance_pairs(int metric, const float* d_a, const float* d_b, uint32_t n, uint32_t dim,
+                                 float* d_out, hipStream_t s);
+
+}  // namespace qv

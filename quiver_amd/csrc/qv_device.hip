@@ -1,0 +1,733 @@
+// qv_device.hip — gfx950 (MI355X, CDNA4) kernels of the similarity-search hot path.
+//
+// What the kernels replace in the reference (paths relative to the reference tree):
+//   k_flat_scan     ExactIndex.Search's distance loop + sort.Sort + truncate
+//                   (pkg/hybrid/exact.go:115-129) with vectortypes' distance
+//                   arithmetic fused in (pkg/vectortypes/distances.go:12-104,
+//                   pkg/hnsw/adapter.go:105-167)
+//   k_merge_lists   the tail of the same sort: merge of per-workgroup top-k lists
+//   k_distance_rows the neighbour loop of HNSW.searchLayer (pkg/hnsw/hnsw.go:536-563)
+//                   and the re-rank loops (pkg/hybrid/hybrid_index.go:536-546)
+//   k_distance_pairs one vectortypes.DistanceFunc call per pair (surface.go:8)
+//   k_ingest / k_generate   copy-on-insert (exact.go:53-56) into the tile layout
+//
+// Arithmetic contract: every distance is computed by ONE lane walking its row's
+// dimensions 0..D-1 in order, in the precision the reference uses (float64
+// accumulation of exact float32 products, or float32 unfused for the *_F32 metrics),
+// so results are bit-identical to the reference's scalar Go loops — there is no
+// cross-lane partial-sum reduction to reorder the additions.  Cross-lane work
+// (ballot / readlane / wave shifts) is used only for top-k selection on 64-bit
+// (distance, row) keys, which is exact integer work.
+//
+// Built with -ffp-contract=off: float32 paths must NOT be fused; float64 paths use
+// explicit fma(), which is bit-identical to mul+add there because the products of
+// float32-valued doubles are exact.
+#include "qv_device.h"
+#include "../../include/qv.h"
+
+namespace qv {
+
+typedef float f4 __attribute__((ext_vector_type(4)));   // native vector: lets the nontemporal builtin emit global_load_dwordx4 nt
+
+// ---------------------------------------------------------------- wave helpers -----
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, uint32_t src /*uniform*/) {
+    uint32_t lo = __builtin_amdgcn_readlane((uint32_t)x, src);
+    uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+// lane i <- lane i-1 (lane 0 keeps its value); full-wave shift right by one
+__device__ __forceinline__ uint64_t wave_shr1(uint64_t x) {
+    // DPP wave_shr:1 (0x138) is a gfx9-family control; bound_ctrl=0 keeps lane 0's old value
+    uint32_t lo = __builtin_amdgcn_update_dpp((uint32_t)x, (uint32_t)x, 0x138, 0xf, 0xf, false);
+    uint32_t hi = __builtin_amdgcn_update_dpp((uint32_t)(x >> 32), (uint32_t)(x >> 32), 0x138, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// float32 -> uint32 whose unsigned order is the float order; NaN sorts after +inf
+__device__ __forceinline__ uint32_t ord_f32(float f) {
+    if (f != f) return 0xFFFFFFFEu;                  // canonical NaN key (below the dead sentinel)
+    if (f == 0.0f) f = 0.0f;                         // -0 -> +0 (Go compares them equal)
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(uint32_t k) {
+    if (k == 0xFFFFFFFEu) return __uint_as_float(0x7FC00000u);
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t make_key(float dist, uint32_t row) { return ((uint64_t)ord_f32(dist) << 32) | row; }
+
+// Sorted wave-resident list: lane i holds the i-th smallest key seen so far
+// (kDeadKey = empty).  Inserts every lane's `key` that beats the current k-th key.
+__device__ __forceinline__ void list_insert(uint64_t& list, uint64_t& thr, uint64_t key, uint32_t kth_lane, uint32_t lane) {
+    uint64_t mask = __ballot(key < thr);
+    while (mask) {
+        uint32_t src = (uint32_t)__builtin_ctzll(mask);
+        mask &= mask - 1;
+        uint64_t c = readlane64(key, src);
+        if (c >= thr) continue;                      // threshold tightened since the ballot
+        uint32_t pos = (uint32_t)__builtin_popcountll(__ballot(list < c));
+        uint64_t up = wave_shr1(list);
+        list = lane > pos ? up : (lane == pos ? c : list);
+        thr = readlane64(list, kth_lane);
+    }
+}
+
+// ---------------------------------------------------------------- metric traits ----
+template <int M> struct MT;
+// f64-accumulating metrics take the query as double, the rest as float
+template <> struct MT<QV_COSINE>     { using Q = double; using A = double; static constexpr bool needs_rnorm = true;  };
+template <> struct MT<QV_L2>         { using Q = float;  using A = double; static constexpr bool needs_rnorm = false; };
+template <> struct MT<QV_L2SQ>       { using Q = float;  using A = float;  static constexpr bool needs_rnorm = false; };
+template <> struct MT<QV_DOT>        { using Q = double; using A = double; static constexpr bool needs_rnorm = false; };
+template <> struct MT<QV_L1>         { using Q = float;  using A = double; static constexpr bool needs_rnorm = false; };
+template <> struct MT<QV_COSINE_F32> { using Q = float;  using A = float;  static constexpr bool needs_rnorm = true;  };
+template <> struct MT<QV_L2_F32>     { using Q = float;  using A = float;  static constexpr bool needs_rnorm = false; };
+template <> struct MT<QV_DOT_F32>    { using Q = float;  using A = float;  static constexpr bool needs_rnorm = false; };
+
+// one element: a = query element (already in the metric's Q type), b = row element
+template <int M> __device__ __forceinline__ void acc1(typename MT<M>::A& acc, typename MT<M>::Q a, float b) {
+    if constexpr (M == QV_COSINE || M == QV_DOT) {
+        acc = __builtin_fma(a, (double)b, acc);                       // distances.go:19 / :84
+    } else if constexpr (M == QV_L2) {
+        double d = (double)(a - b);                                   // float32 subtract, widen (distances.go:50)
+        acc = __builtin_fma(d, d, acc);
+    } else if constexpr (M == QV_L1) {
+        acc = acc + __builtin_fabs((double)(a - b));                  // distances.go:100
+    } else if constexpr (M == QV_L2SQ || M == QV_L2_F32) {
+        float d = a - b; float sq = d * d; acc = acc + sq;            // distances.go:67-68 / adapter.go:146-147 (unfused)
+    } else {                                                          // QV_COSINE_F32, QV_DOT_F32
+        float p = a * b; acc = acc + p;                               // adapter.go:117 / :161 (unfused)
+    }
+}
+
+// per-query constants: for cosine metrics the query's own norm, computed once per
+// wave in the reference's element order (distances.go:20: magnitudeA += a*a)
+struct QConst { double qn; float qn32; };
+
+template <int M> __device__ __forceinline__ QConst query_const(const typename MT<M>::Q* q, uint32_t dim) {
+    QConst c; c.qn = 0.0; c.qn32 = 0.0f;
+    if constexpr (M == QV_COSINE) {
+        double ma = 0.0;
+        for (uint32_t i = 0; i < dim; i++) ma = __builtin_fma(q[i], q[i], ma);
+        c.qn = __builtin_sqrt(ma);                                    // sqrt(ma) == 0  <=>  ma == 0
+    } else if constexpr (M == QV_COSINE_F32) {
+        float na = 0.0f;
+        for (uint32_t i = 0; i < dim; i++) { float p = q[i] * q[i]; na = na + p; }
+        c.qn32 = (float)__builtin_sqrt((double)na);                   // adapter.go:128
+        c.qn = (double)na;                                            // zero test is on na itself (adapter.go:122)
+    }
+    return c;
+}
+
+// rn = stored per-row norm (see k_ingest): sqrt(mb) for COSINE; for COSINE_F32 the
+// float32 value float32(sqrt(float64(nb))) widened, negative if nb == 0 cannot occur,
+// so rn == 0 <=> nb == 0 only when the sqrt underflows; we store nb's zero-ness in the sign bit
+template <int M> __device__ __forceinline__ float finalize(typename MT<M>::A acc, const QConst& qc, double rn) {
+    if constexpr (M == QV_COSINE) {
+        if (qc.qn == 0.0 || rn == 0.0) return 1.0f;                   // distances.go:25-27
+        double sim = acc / (qc.qn * rn);                              // :30
+        if (sim > 1.0) sim = 1.0; else if (sim < -1.0) sim = -1.0;    // :32-36
+        return (float)(1.0 - sim);                                    // :39
+    } else if constexpr (M == QV_L2) {
+        return (float)__builtin_sqrt(acc);                            // :54
+    } else if constexpr (M == QV_DOT) {
+        return (float)(1.0 - acc);                                    // :89
+    } else if constexpr (M == QV_L1) {
+        return (float)acc;                                            // :103
+    } else if constexpr (M == QV_L2SQ) {
+        return acc;                                                   // :71
+    } else if constexpr (M == QV_COSINE_F32) {
+        if (qc.qn == 0.0 || rn < 0.0) return 1.0f;                    // adapter.go:122-124 (rn < 0 encodes nb == 0)
+        float den = qc.qn32 * (float)rn;                              // :128
+        float sim = acc / den;
+        if (sim > 1.0f) sim = 1.0f; else if (sim < -1.0f) sim = -1.0f;
+        return 1.0f - sim;                                            // :135
+    } else if constexpr (M == QV_L2_F32) {
+        return (float)__builtin_sqrt((double)acc);                    // adapter.go:150
+    } else {
+        return 1.0f - acc;                                            // adapter.go:164
+    }
+}
+
+// stage the query into LDS in the metric's Q type, zero-padded to dim4*4
+template <int M> __device__ __forceinline__ void stage_query(typename MT<M>::Q* q_lds, const float* q, uint32_t dim, uint32_t dim4) {
+    for (uint32_t i = threadIdx.x; i < dim4 * 4; i += blockDim.x) q_lds[i] = i < dim ? (typename MT<M>::Q)q[i] : (typename MT<M>::Q)0;
+}
+
+// distance of the query (in LDS) to the row whose chunk c lives at p[c * stride4]
+template <int M, int U>
+__device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict__ p, uint32_t stride4,
+                                                            const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4) {
+    using Q = typename MT<M>::Q;
+    typename MT<M>::A acc = 0;
+    uint32_t c0 = 0;
+    for (; c0 + U <= dim4; c0 += U) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * stride4]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const Q* qq = q_lds + (size_t)(c0 + u) * 4;
+            acc1<M>(acc, qq[0], v[u].x); acc1<M>(acc, qq[1], v[u].y);
+            acc1<M>(acc, qq[2], v[u].z); acc1<M>(acc, qq[3], v[u].w);
+        }
+    }
+    for (; c0 < dim4; c0++) {
+        f4 v = __builtin_nontemporal_load(&p[(size_t)c0 * stride4]);
+        const Q* qq = q_lds + (size_t)c0 * 4;
+        acc1<M>(acc, qq[0], v.x); acc1<M>(acc, qq[1], v.y); acc1<M>(acc, qq[2], v.z); acc1<M>(acc, qq[3], v.w);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------- flat scan --------
+// grid = (workgroups, nq); each wave walks tiles gw, gw+tw, ... ; lane == row.
+// Output: partial[(q*gridDim.x + blockIdx.x)*k + i] = workgroup's i-th best key.
+constexpr int kScanBlock = 256;
+constexpr int kScanWaves = kScanBlock / 64;
+
+template <int M, int U>
+__global__ void __launch_bounds__(kScanBlock)
+k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t* __restrict__ partial) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);  // [kScanWaves][64]
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qi = blockIdx.y;
+    stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
+    __syncthreads();
+    const QConst qc = query_const<M>(q_lds, v.dim);
+
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const uint32_t kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+
+    for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
+        const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
+        typename MT<M>::A acc = row_accumulate<M, U>(p, 64, q_lds, v.dim4);
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        float dist = finalize<M>(acc, qc, rn);
+        uint64_t am = v.alive[t];                                     // wave-uniform
+        uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+        list_insert(list, thr, key, kth, lane);
+    }
+
+    // workgroup merge: waves 1.. hand their lists to wave 0 through LDS
+    wl[wave * 64 + lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        for (uint32_t w = 1; w < kScanWaves; w++) {
+            uint64_t key = lane < k ? wl[w * 64 + lane] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        if (lane < k) partial[((size_t)qi * gridDim.x + blockIdx.x) * k + lane] = list;
+    }
+}
+
+// one workgroup per query merges n_lists sorted lists of k keys into the final top-k
+constexpr int kMergeBlock = 1024;
+__global__ void __launch_bounds__(kMergeBlock)
+k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k,
+              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+    __shared__ uint64_t wl[kMergeBlock / 64][64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nw = blockDim.x >> 6;
+    const uint32_t qi = blockIdx.x;
+    const uint64_t* src = partial + (size_t)qi * n_lists * k;
+    const uint32_t total = n_lists * k;
+    const uint32_t kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    for (uint32_t base = wave * 64; base < total; base += nw * 64) {
+        uint32_t i = base + lane;
+        uint64_t key = i < total ? src[i] : kDeadKey;
+        list_insert(list, thr, key, kth, lane);
+    }
+    wl[wave][lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        for (uint32_t w = 1; w < nw; w++) {
+            uint64_t key = lane < k ? wl[w][lane] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        if (lane < k) {
+            bool dead = list == kDeadKey;
+            rows_out[(size_t)qi * k + lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
+            dist_out[(size_t)qi * k + lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+        }
+    }
+}
+
+// merge of (distance, row) pair lists, e.g. the all-gathered per-shard top-k of a sharded scan
+__global__ void __launch_bounds__(kMergeBlock)
+k_merge_pairs(const float* __restrict__ dist, const uint32_t* __restrict__ rows, uint32_t total, uint32_t k,
+              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+    __shared__ uint64_t wl[kMergeBlock / 64][64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nw = blockDim.x >> 6;
+    const uint32_t kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    for (uint32_t base = wave * 64; base < total; base += nw * 64) {
+        uint32_t i = base + lane;
+        uint64_t key = kDeadKey;
+        if (i < total && rows[i] != 0xFFFFFFFFu) key = make_key(dist[i], rows[i]);
+        list_insert(list, thr, key, kth, lane);
+    }
+    wl[wave][lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        for (uint32_t w = 1; w < nw; w++) {
+            uint64_t key = lane < k ? wl[w][lane] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        if (lane < k) {
+            bool dead = list == kDeadKey;
+            rows_out[lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
+            dist_out[lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+        }
+    }
+}
+
+// ---------------------------------------------------------------- full ranking -----
+// all keys: keys[row] = (ord(dist), row) or dead
+template <int M, int U>
+__global__ void __launch_bounds__(kScanBlock)
+k_flat_keys(IndexView v, const float* __restrict__ query, uint64_t* __restrict__ keys) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stage_query<M>(q_lds, query, v.dim, v.dim4);
+    __syncthreads();
+    const QConst qc = query_const<M>(q_lds, v.dim);
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
+        const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
+        typename MT<M>::A acc = row_accumulate<M, U>(p, 64, q_lds, v.dim4);
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        float dist = finalize<M>(acc, qc, rn);
+        uint64_t am = v.alive[t];
+        keys[row] = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+    }
+}
+
+// LSD radix sort of 64-bit keys, 8 bits per pass over the 32 distance bits only (the
+// row bits are already ascending in the input and every pass is stable, so equal
+// distances stay in row order).  Three kernels per pass: histogram, scan, scatter.
+constexpr int kRadixBlock = 256;
+constexpr int kRadixItems = 16;                       // keys per thread
+constexpr int kRadixTile = kRadixBlock * kRadixItems; // keys per workgroup
+
+__global__ void __launch_bounds__(kRadixBlock)
+k_radix_hist(const uint64_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t* __restrict__ hist /*[256][nblocks]*/) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRadixTile;
+    for (int i = 0; i < kRadixItems; i++) {
+        uint32_t idx = base + i * kRadixBlock + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan over hist laid out digit-major [256][nblocks] (single workgroup)
+__global__ void __launch_bounds__(1024)
+k_radix_scan(uint32_t* __restrict__ hist, uint32_t total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (total + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, total);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += hist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (uint32_t i = lo; i < hi; i++) { uint32_t c = hist[i]; hist[i] = run; run += c; }
+}
+
+// stable scatter: within a workgroup keys are ranked in index order
+__global__ void __launch_bounds__(kRadixBlock)
+k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n, uint32_t shift,
+                const uint32_t* __restrict__ hist) {
+    __shared__ uint32_t digit_base[256];                // global offset of this block's first key of each digit
+    __shared__ uint32_t wave_cnt[kRadixBlock / 64][256]; // per-wave digit counts within one round
+    __shared__ uint32_t running[256];                   // keys of each digit already placed by earlier rounds
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    digit_base[threadIdx.x] = hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+    running[threadIdx.x] = 0;
+    const uint32_t base = blockIdx.x * kRadixTile;
+    for (int i = 0; i < kRadixItems; i++) {             // rounds go in index order: round i covers base + i*256 ..
+        for (int w = 0; w < kRadixBlock / 64; w++) wave_cnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t idx = base + i * kRadixBlock + threadIdx.x;
+        bool valid = idx < n;
+        uint64_t key = valid ? in[idx] : 0;
+        uint32_t d = (uint32_t)(key >> shift) & 0xFF;
+        // rank among lanes of this wave with the same digit (match-any by 8 ballots)
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            uint64_t m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        uint32_t rank_in_wave = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1));
+        uint32_t wave_total = (uint32_t)__builtin_popcountll(peers);
+        if (valid && rank_in_wave == 0) wave_cnt[wave][d] = wave_total;
+        __syncthreads();
+        if (valid) {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; w++) before += wave_cnt[w][d];
+            out[digit_base[d] + running[d] + before + rank_in_wave] = key;
+        }
+        __syncthreads();
+        uint32_t tot = 0;
+        for (int w = 0; w < kRadixBlock / 64; w++) tot += wave_cnt[w][threadIdx.x];
+        running[threadIdx.x] += tot;
+        __syncthreads();
+    }
+}
+
+__global__ void k_emit_topk(const uint64_t* __restrict__ keys, uint32_t n, uint32_t k, uint32_t* rows_out, float* dist_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    uint64_t key = i < n ? keys[i] : kDeadKey;
+    bool dead = key == kDeadKey;
+    rows_out[i] = dead ? 0xFFFFFFFFu : (uint32_t)key;
+    dist_out[i] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(key >> 32));
+}
+
+// ---------------------------------------------------------------- gathers ----------
+// lane == listed row; one wave per 64 listed rows
+template <int M, int U>
+__global__ void __launch_bounds__(64)
+k_distance_rows(IndexView v, const float* __restrict__ query, const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    stage_query<M>(q_lds, query, v.dim, v.dim4);
+    __syncthreads();
+    const QConst qc = query_const<M>(q_lds, v.dim);
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = rows[i];
+    if (row >= v.n_rows) { out[i] = __uint_as_float(0x7FC00000u); return; }
+    const f4* p = reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63);
+    typename MT<M>::A acc = row_accumulate<M, U>(p, 64, q_lds, v.dim4);
+    double rn = 0.0;
+    if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+    out[i] = finalize<M>(acc, qc, rn);
+}
+
+// lane == pair; a, b row-major [n][dim]; plain scalar walk (dim need not be a multiple of 4)
+template <int M>
+__global__ void __launch_bounds__(64)
+k_distance_pairs(const float* __restrict__ a, const float* __restrict__ b, uint32_t n, uint32_t dim, float* __restrict__ out) {
+    using Q = typename MT<M>::Q;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float* pa = a + (size_t)i * dim;
+    const float* pb = b + (size_t)i * dim;
+    typename MT<M>::A acc = 0;
+    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+    double rn = 0.0;
+    if constexpr (M == QV_COSINE) {
+        double ma = 0.0, mb = 0.0;
+        for (uint32_t j = 0; j < dim; j++) {
+            double x = pa[j], y = pb[j];
+            acc = __builtin_fma(x, y, acc); ma = __builtin_fma(x, x, ma); mb = __builtin_fma(y, y, mb);
+        }
+        qc.qn = __builtin_sqrt(ma); rn = __builtin_sqrt(mb);
+    } else if constexpr (M == QV_COSINE_F32) {
+        float na = 0.0f, nb = 0.0f;
+        for (uint32_t j = 0; j < dim; j++) {
+            float x = pa[j], y = pb[j];
+            float p0 = x * y; acc = acc + p0; float p1 = x * x; na = na + p1; float p2 = y * y; nb = nb + p2;
+        }
+        qc.qn = (double)na; qc.qn32 = (float)__builtin_sqrt((double)na);
+        rn = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
+    } else {
+        for (uint32_t j = 0; j < dim; j++) acc1<M>(acc, (Q)pa[j], pb[j]);
+    }
+    out[i] = finalize<M>(acc, qc, rn);
+}
+
+// ---------------------------------------------------------------- ingest -----------
+// one wave per touched tile; lane == row within the tile
+__global__ void __launch_bounds__(64)
+k_ingest(IndexView v, const float* __restrict__ src, uint32_t row0, uint32_t n, uint32_t tile0) {
+    const uint32_t t = tile0 + blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t row = t * 64 + lane;
+    const bool mine = row >= row0 && row < row0 + n;
+    if (mine) {
+        const float* s = src + (size_t)(row - row0) * v.dim;
+        float4* dst = reinterpret_cast<float4*>(v.tiles) + (size_t)t * v.dim4 * 64 + lane;
+        double mb = 0.0; float nb = 0.0f;
+        const bool vec_ok = (v.dim & 3) == 0;
+        for (uint32_t c = 0; c < v.dim4; c++) {
+            float4 x;
+            if (vec_ok) x = *reinterpret_cast<const float4*>(s + 4 * c);
+            else {
+                uint32_t j = 4 * c;
+                x.x = j < v.dim ? s[j] : 0.f; x.y = j + 1 < v.dim ? s[j + 1] : 0.f;
+                x.z = j + 2 < v.dim ? s[j + 2] : 0.f; x.w = j + 3 < v.dim ? s[j + 3] : 0.f;
+            }
+            dst[(size_t)c * 64] = x;
+            if (v.metric == QV_COSINE) {                                  // distances.go:21 magnitudeB += b*b
+                mb = __builtin_fma((double)x.x, (double)x.x, mb); mb = __builtin_fma((double)x.y, (double)x.y, mb);
+                mb = __builtin_fma((double)x.z, (double)x.z, mb); mb = __builtin_fma((double)x.w, (double)x.w, mb);
+            } else if (v.metric == QV_COSINE_F32) {                       // adapter.go:119 normB += b*b (unfused)
+                float p; p = x.x * x.x; nb = nb + p; p = x.y * x.y; nb = nb + p; p = x.z * x.z; nb = nb + p; p = x.w * x.w; nb = nb + p;
+            }
+        }
+        if (v.metric == QV_COSINE) v.rnorm[row] = __builtin_sqrt(mb);
+        else if (v.metric == QV_COSINE_F32) v.rnorm[row] = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
+    }
+    uint64_t m = __ballot(mine);
+    if (lane == 0 && m) atomicOr(reinterpret_cast<unsigned long long*>(&v.alive[t]), (unsigned long long)m);
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ int32_t gen_int(uint64_t row_key, uint32_t col) {
+    uint64_t h = splitmix64(row_key + (uint64_t)col);
+    int32_t s = (int32_t)(h & 0xFFFF) + (int32_t)((h >> 16) & 0xFFFF) + (int32_t)((h >> 32) & 0xFFFF) + (int32_t)(h >> 48);
+    return s - 131070;
+}
+
+// the synthetic-corpus generator of DESIGN.md (SplitMix64 -> Irwin-Hall(4) integers -> unit L2),
+// written straight into the tile layout; integer arithmetic plus correctly rounded float64
+// sqrt/div only, so any IEEE host reproduces it bit for bit
+__global__ void __launch_bounds__(64)
+k_generate(IndexView v, uint64_t seed, uint64_t gen_row0, uint32_t row0, uint32_t n, uint32_t tile0) {
+    const uint32_t t = tile0 + blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t row = t * 64 + lane;
+    const bool mine = row >= row0 && row < row0 + n;
+    if (mine) {
+        const uint64_t g = gen_row0 + (row - row0);
+        const uint64_t row_key = splitmix64(seed ^ (g * 0xD1342543DE82EF95ull));
+        double sumsq = 0.0;
+        for (uint32_t c = 0; c < v.dim; c++) { double x = (double)gen_int(row_key, c); sumsq = __builtin_fma(x, x, sumsq); }
+        const double norm = sumsq > 0.0 ? __builtin_sqrt(sumsq) : 1.0;
+        float4* dst = reinterpret_cast<float4*>(v.tiles) + (size_t)t * v.dim4 * 64 + lane;
+        double mb = 0.0; float nb = 0.0f;
+        for (uint32_t c = 0; c < v.dim4; c++) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t col = 4 * c + j;
+                e[j] = col < v.dim ? (float)((double)gen_int(row_key, col) / norm) : 0.0f;
+                if (v.metric == QV_COSINE) mb = __builtin_fma((double)e[j], (double)e[j], mb);
+                else if (v.metric == QV_COSINE_F32) { float p = e[j] * e[j]; nb = nb + p; }
+            }
+            dst[(size_t)c * 64] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        if (v.metric == QV_COSINE) v.rnorm[row] = __builtin_sqrt(mb);
+        else if (v.metric == QV_COSINE_F32) v.rnorm[row] = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
+        if (v.rowmaj) {
+            float* rm = v.rowmaj + (size_t)row * v.dim;
+            for (uint32_t c = 0; c < v.dim; c++) rm[c] = (float)((double)gen_int(row_key, c) / norm);
+        }
+    }
+    uint64_t m = __ballot(mine);
+    if (lane == 0 && m) atomicOr(reinterpret_cast<unsigned long long*>(&v.alive[t]), (unsigned long long)m);
+}
+
+__global__ void k_set_alive(IndexView v, const uint32_t* __restrict__ rows, uint32_t n, int alive) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = rows[i];
+    if (r >= v.n_rows) return;
+    unsigned long long bit = 1ull << (r & 63);
+    if (alive) atomicOr(reinterpret_cast<unsigned long long*>(&v.alive[r >> 6]), bit);
+    else atomicAnd(reinterpret_cast<unsigned long long*>(&v.alive[r >> 6]), ~bit);
+}
+
+__global__ void k_fetch_row(IndexView v, uint32_t row, float* __restrict__ out) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.dim) return;
+    out[j] = v.tiles[((size_t)(row >> 6) * v.dim4 + (j >> 2)) * 256 + (row & 63) * 4 + (j & 3)];
+}
+
+// ---------------------------------------------------------------- launchers --------
+constexpr int kUnroll = 16;
+
+ScanPlan plan_scan(uint32_t n_tiles, int cus) {
+    ScanPlan p;
+    p.block = kScanBlock;
+    uint32_t want = (n_tiles + kScanWaves - 1) / kScanWaves;          // one tile per wave at most
+    uint32_t cap = (uint32_t)cus * 4;                                 // 4 workgroups (16 waves) per CU
+    p.grid = want < cap ? want : cap;
+    if (p.grid == 0) p.grid = 1;
+    p.n_lists = p.grid;
+    return p;
+}
+
+size_t scan_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k) { return (size_t)p.n_lists * nq * k * sizeof(uint64_t); }
+
+static size_t query_lds_bytes(int metric, uint32_t dim4) {
+    size_t q = (metric == QV_COSINE || metric == QV_DOT) ? sizeof(double) : sizeof(float);
+    return ((size_t)dim4 * 4 * q + 15) / 16 * 16;
+}
+
+template <typename F> static hipError_t set_lds(F f, size_t bytes) {
+    if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
+}
+
+#define QV_DISPATCH_METRIC(metric, CALL)                         \
+    switch (metric) {                                            \
+        case QV_COSINE:     { constexpr int MM = QV_COSINE;     CALL; } break; \
+        case QV_L2:         { constexpr int MM = QV_L2;         CALL; } break; \
+        case QV_L2SQ:       { constexpr int MM = QV_L2SQ;       CALL; } break; \
+        case QV_DOT:        { constexpr int MM = QV_DOT;        CALL; } break; \
+        case QV_L1:         { constexpr int MM = QV_L1;         CALL; } break; \
+        case QV_COSINE_F32: { constexpr int MM = QV_COSINE_F32; CALL; } break; \
+        case QV_L2_F32:     { constexpr int MM = QV_L2_F32;     CALL; } break; \
+        case QV_DOT_F32:    { constexpr int MM = QV_DOT_F32;    CALL; } break; \
+        default: return hipErrorInvalidValue;                    \
+    }
+
+hipError_t launch_merge_pairs(const float* d_dist, const uint32_t* d_rows, uint32_t n_lists, uint32_t k,
+                              uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    if (k == 0 || k > (uint32_t)kMaxFusedK || n_lists == 0) return hipErrorInvalidValue;
+    uint32_t total = n_lists * k;
+    uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
+    hipLaunchKernelGGL(k_merge_pairs, dim3(1), dim3(mblock), 0, s, d_dist, d_rows, total, k, d_rows_out, d_dist_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
+                            void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
+                            hipEvent_t ev0, hipEvent_t ev1) {
+    if (k == 0 || k > (uint32_t)kMaxFusedK || nq == 0) return hipErrorInvalidValue;
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
+    uint64_t* partial = static_cast<uint64_t*>(d_ws);
+    hipError_t e = hipSuccess;
+    QV_DISPATCH_METRIC(v.metric, {
+        e = set_lds(k_flat_scan<MM, kUnroll>, lds);
+        if (e != hipSuccess) return e;
+        if (ev0) (void)hipEventRecord(ev0, s);
+        hipLaunchKernelGGL((k_flat_scan<MM, kUnroll>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial);
+        if (ev1) (void)hipEventRecord(ev1, s);
+    });
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint32_t total = p.n_lists * k;
+    uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
+    hipLaunchKernelGGL(k_merge_lists, dim3(nq), dim3(mblock), 0, s, partial, p.n_lists, k, d_rows_out, d_dist_out);
+    return hipGetLastError();
+}
+
+size_t full_sort_workspace_bytes(uint32_t n_tiles) {
+    size_t n = (size_t)n_tiles * 64;
+    size_t nblocks = (n + kRadixTile - 1) / kRadixTile;
+    return 2 * n * sizeof(uint64_t) + 256 * nblocks * sizeof(uint32_t) + 256;
+}
+
+hipError_t launch_flat_fullsort(const IndexView& v, const ScanPlan& p, const float* d_query, uint32_t k,
+                                void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    const uint32_t n = v.n_tiles * 64;
+    uint64_t* ka = static_cast<uint64_t*>(d_ws);
+    uint64_t* kb = ka + n;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(kb + n);
+    const uint32_t nblocks = (n + kRadixTile - 1) / kRadixTile;
+    const size_t lds = query_lds_bytes(v.metric, v.dim4);
+    hipError_t e = hipSuccess;
+    QV_DISPATCH_METRIC(v.metric, {
+        e = set_lds(k_flat_keys<MM, kUnroll>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_flat_keys<MM, kUnroll>), dim3(p.grid), dim3(p.block), lds, s, v, d_query, ka);
+    });
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint64_t* in = ka; uint64_t* out = kb;
+    for (uint32_t shift = 32; shift < 64; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kRadixBlock), 0, s, in, n, shift, hist);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, hist, 256 * nblocks);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(kRadixBlock), 0, s, in, out, n, shift, hist);
+        uint64_t* t = in; in = out; out = t;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_emit_topk, dim3((k + 255) / 256), dim3(256), 0, s, in, n, k, d_rows_out, d_dist_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_distance_rows(const IndexView& v, const float* d_query, const uint32_t* d_rows, uint32_t n,
+                                float* d_dist_out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const size_t lds = query_lds_bytes(v.metric, v.dim4);
+    hipError_t e = hipSuccess;
+    QV_DISPATCH_METRIC(v.metric, {
+        e = set_lds(k_distance_rows<MM, kUnroll>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_distance_rows<MM, kUnroll>), dim3((n + 63) / 64), dim3(64), lds, s, v, d_query, d_rows, n, d_dist_out);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_distance_pairs(int metric, const float* d_a, const float* d_b, uint32_t n, uint32_t dim, float* d_out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    QV_DISPATCH_METRIC(metric, {
+        hipLaunchKernelGGL((k_distance_pairs<MM>), dim3((n + 63) / 64), dim3(64), 0, s, d_a, d_b, n, dim, d_out);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_ingest(const IndexView& v, const float* d_rows, uint32_t row0, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t t0 = row0 / 64, t1 = (row0 + n - 1) / 64;
+    hipLaunchKernelGGL(k_ingest, dim3(t1 - t0 + 1), dim3(64), 0, s, v, d_rows, row0, n, t0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (v.rowmaj) return hipMemcpyAsync(v.rowmaj + (size_t)row0 * v.dim, d_rows, (size_t)n * v.dim * sizeof(float), hipMemcpyDeviceToDevice, s);
+    return hipSuccess;
+}
+
+hipError_t launch_generate(const IndexView& v, uint64_t seed, uint64_t gen_row0, uint32_t row0, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t t0 = row0 / 64, t1 = (row0 + n - 1) / 64;
+    hipLaunchKernelGGL(k_generate, dim3(t1 - t0 + 1), dim3(64), 0, s, v, seed, gen_row0, row0, n, t0);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_alive(const IndexView& v, const uint32_t* d_rows, uint32_t n, int alive, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_set_alive, dim3((n + 255) / 256), dim3(256), 0, s, v, d_rows, n, alive);
+    return hipGetLastError();
+}
+
+hipError_t launch_fetch_row(const IndexView& v, uint32_t row, float* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_fetch_row, dim3((v.dim + 255) / 256), dim3(256), 0, s, v, row, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace qv

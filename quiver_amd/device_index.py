@@ -1,0 +1,152 @@
+"""DeviceIndex — a row-numbered, device-resident exact index: the Python face of one
+``qv_index`` (one GPU, one shard).  String ids live one layer up (quiver_amd.hybrid)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, metric_id
+
+
+def _f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class DeviceIndex:
+    def __init__(self, dim: int, metric="cosine", device: int = 0, rowmajor: bool = False):
+        self._h = C.c_void_p()
+        self.dim = int(dim)
+        self.metric = metric_id(metric)
+        self.device = device
+        check(lib().qv_index_create(C.byref(self._h), self.dim, self.metric, device, _lib.QV_FLAG_ROWMAJOR if rowmajor else 0))
+
+    # ---- lifecycle ----
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().qv_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def reserve(self, rows: int):
+        check(lib().qv_index_reserve(self._h, rows))
+
+    # ---- mutation ----
+    def add(self, rows) -> int:
+        rows = _f32c(rows)
+        if rows.ndim == 1:
+            rows = rows[None, :]
+        if rows.shape[1] != self.dim:
+            raise ValueError(f"vector dimension mismatch: expected {self.dim}, got {rows.shape[1]}")
+        first = C.c_uint32(0)
+        check(lib().qv_index_add(self._h, rows.ctypes.data, rows.shape[0], C.byref(first)))
+        return int(first.value)
+
+    def add_device(self, d_ptr: int, n: int, stream: int = 0) -> int:
+        first = C.c_uint32(0)
+        check(lib().qv_index_add_device(self._h, d_ptr, n, C.byref(first), stream))
+        return int(first.value)
+
+    def add_synthetic(self, seed: int, gen_row0: int, n: int) -> int:
+        first = C.c_uint32(0)
+        check(lib().qv_index_add_synthetic(self._h, seed, gen_row0, n, C.byref(first)))
+        return int(first.value)
+
+    def remove(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32).ravel()
+        check(lib().qv_index_remove(self._h, rows.ctypes.data, rows.size))
+
+    def update(self, row: int, vec):
+        vec = _f32c(vec)
+        if vec.size != self.dim:
+            raise ValueError(f"vector dimension mismatch: expected {self.dim}, got {vec.size}")
+        check(lib().qv_index_update(self._h, row, vec.ctypes.data))
+
+    # ---- queries ----
+    def rows(self) -> int:
+        return int(lib().qv_index_rows(self._h))
+
+    def size(self) -> int:
+        return int(lib().qv_index_size(self._h))
+
+    def __len__(self):
+        return self.size()
+
+    def get_row(self, row: int) -> np.ndarray:
+        out = np.empty(self.dim, dtype=np.float32)
+        check(lib().qv_index_get_row(self._h, row, out.ctypes.data))
+        return out
+
+    def search(self, queries, k: int, batched: bool = False):
+        """-> (rows [nq,k] uint32, dist [nq,k] float32, count [nq] uint32)"""
+        q = _f32c(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.dim:
+            raise ValueError(f"query dimension mismatch: expected {self.dim}, got {q.shape[1]}")
+        nq = q.shape[0]
+        kk = max(int(k), 0)
+        rows = np.full((nq, max(kk, 1)), 0xFFFFFFFF, dtype=np.uint32)
+        dist = np.full((nq, max(kk, 1)), np.inf, dtype=np.float32)
+        count = np.zeros(nq, dtype=np.uint32)
+        fn = lib().qv_index_search_batched if batched else lib().qv_index_search
+        check(fn(self._h, q.ctypes.data, nq, kk, rows.ctypes.data, dist.ctypes.data, count.ctypes.data))
+        return rows[:, :kk], dist[:, :kk], count
+
+    def search_device(self, d_queries: int, nq: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
+        check(lib().qv_index_search_device(self._h, d_queries, nq, k, d_rows_out, d_dist_out, stream))
+
+    def distance_rows(self, query, rows) -> np.ndarray:
+        q = _f32c(query)
+        if q.size != self.dim:
+            raise ValueError(f"query dimension mismatch: expected {self.dim}, got {q.size}")
+        r = np.ascontiguousarray(rows, dtype=np.uint32).ravel()
+        out = np.empty(r.size, dtype=np.float32)
+        check(lib().qv_distance_rows(self._h, q.ctypes.data, r.ctypes.data, r.size, out.ctypes.data))
+        return out
+
+    def distance_rows_device(self, d_query: int, d_rows: int, n: int, d_out: int, stream: int = 0):
+        check(lib().qv_distance_rows_device(self._h, d_query, d_rows, n, d_out, stream))
+
+
+    def profile(self, enable: bool):
+        check(lib().qv_index_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(lib().qv_index_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+
+def merge_topk_device(d_dist_lists: int, d_row_lists: int, n_lists: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
+    check(lib().qv_merge_topk_device(d_dist_lists, d_row_lists, n_lists, k, d_rows_out, d_dist_out, stream))
+
+
+def distance_pairs(metric, a, b, device: int = 0) -> np.ndarray:
+    a, b = _f32c(a), _f32c(b)
+    if a.ndim == 1:
+        a = a[None, :]
+    if b.ndim == 1:
+        b = b[None, :]
+    if a.shape != b.shape:
+        raise ValueError("vectors must have the same length")  # distances.go:13-15
+    out = np.empty(a.shape[0], dtype=np.float32)
+    check(lib().qv_distance_pairs(metric_id(metric), a.ctypes.data, b.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data, device))
+    return out
+
+
+def device_info(device: int = 0):
+    name = C.create_string_buffer(256)
+    cus, mem = C.c_int(0), C.c_uint64(0)
+    check(lib().qv_device_info(device, name, 256, C.byref(cus), C.byref(mem)))
+    return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}

@@ -1,0 +1,278 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (libqv.so), against
+the CPU oracle on the same seeded inputs.  Bar: identical top-k rows in identical
+order and BIT-IDENTICAL float32 distances (the kernels walk each row in the
+reference's element order and precision, so there is nothing to tolerate)."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KATS = json.load(open(os.path.join(O.ROOT, "tests", "golden", "ref_kats.json")))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _mk(dim, metric, rows=None, **kw):
+    import quiver_amd as q
+    idx = q.DeviceIndex(dim, metric, **kw)
+    if rows is not None and len(rows):
+        idx.add(rows)
+    return idx
+
+
+# ---------------------------------------------------------------- reference KATs ---
+
+@pytest.mark.parametrize("kat", KATS["distance"], ids=lambda k: k["src"])
+def test_distance_kats_through_abi(kat):
+    from quiver_amd.device_index import distance_pairs
+    got = distance_pairs(kat["metric"], kat["a"], kat["b"])[0]
+    assert abs(float(got) - kat["want"]) <= kat["tol"]
+    assert _bits(got) == _bits(O.distance(kat["metric"], kat["a"], kat["b"]))
+
+
+@pytest.mark.parametrize("kat", KATS["exact_search"], ids=lambda k: k["src"])
+def test_exact_search_kats_through_abi(kat):
+    rows = np.array(kat["rows"], dtype=np.float32)
+    idx = _mk(rows.shape[1], kat["metric"], rows)
+    r, d, c = idx.search(kat["query"], kat["k"])
+    n = int(c[0])
+    assert n == min(kat["k"], len(rows))
+    ids = [kat["ids"][i] for i in r[0, :n]]
+    if kat["exact_order"]:
+        assert ids[: len(kat["want_ids"])] == kat["want_ids"]
+    else:
+        assert set(kat["want_ids"]) <= set(ids)
+    assert all(d[0, i] <= d[0, i + 1] for i in range(n - 1))
+    er, ed = O.exact_search(kat["metric"], rows, kat["query"], kat["k"])
+    assert np.array_equal(r[0, :n], er) and np.array_equal(_bits(d[0, :n]), _bits(ed))
+    assert np.all(r[0, n:] == 0xFFFFFFFF) and np.all(np.isinf(d[0, n:]))
+
+
+def test_empty_index_and_k_errors():
+    import quiver_amd as q
+    idx = _mk(3, "cosine")
+    r, d, c = idx.search([1, 0, 0], 5)            # exact.go:96-98
+    assert c[0] == 0
+    r, d, c = idx.search([1, 0, 0], 0)            # empty wins over k<=0 (check order exact.go:96-106)
+    assert c[0] == 0
+    idx.add([[1, 0, 0]])
+    with pytest.raises(q.QvError) as e:
+        idx.search([1, 0, 0], 0)
+    assert str(e.value) == "k must be positive" and e.value.code == -3
+    with pytest.raises(ValueError) as e2:
+        idx.search([1, 0], 1)
+    assert str(e2.value) == "query dimension mismatch: expected 3, got 2"
+    with pytest.raises(ValueError) as e3:
+        idx.add([[1, 0]])
+    assert str(e3.value) == "vector dimension mismatch: expected 3, got 2"
+
+
+# ---------------------------------------------------------------- bit-exact parity ---
+
+@pytest.mark.parametrize("metric", range(8))
+@pytest.mark.parametrize("dim", [1, 3, 4, 7, 63, 64, 128, 200, 768])
+def test_topk_bitexact_vs_oracle(metric, dim):
+    rng = np.random.default_rng(100 * metric + dim)
+    n = 1500
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[5] = 0.0
+    rows[6] = rows[7]
+    qs = rng.standard_normal((4, dim)).astype(np.float32)
+    rows[8] = qs[0]
+    rows[9] = -qs[0]
+    idx = _mk(dim, metric, rows)
+    for k in (1, 10, 64):
+        r, d, c = idx.search(qs, k)
+        for qi in range(4):
+            er, ed = O.exact_search(metric, rows, qs[qi], k)
+            assert int(c[qi]) == len(er)
+            assert np.array_equal(r[qi], er), (metric, dim, k, qi)
+            assert np.array_equal(_bits(d[qi]), _bits(ed)), (metric, dim, k, qi)
+
+
+@pytest.mark.parametrize("metric", range(8))
+def test_all_distances_bitexact_via_distance_rows(metric):
+    rng = np.random.default_rng(metric)
+    rows = (rng.standard_normal((777, 96)) * rng.choice([1e-3, 1, 1e3], size=(777, 1))).astype(np.float32)
+    q = rng.standard_normal(96).astype(np.float32)
+    idx = _mk(96, metric, rows)
+    ids = rng.permutation(777).astype(np.uint32)
+    got = idx.distance_rows(q, ids)
+    want = O.all_distances(metric, rows, q)[ids]
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_ties_and_tombstones(metric):
+    rng = np.random.default_rng(7 + metric)
+    rows = rng.integers(-2, 3, size=(3000, 4)).astype(np.float32)      # few distinct distances: ties everywhere
+    q = np.array([1, 0, -1, 2], np.float32)
+    idx = _mk(4, metric, rows)
+    dead = np.nonzero(rng.random(3000) < 0.3)[0].astype(np.uint32)
+    idx.remove(dead)
+    idx.remove(dead[:10])                                              # removing twice is not an error (exact.go:61-70)
+    alive = np.ones(3000, bool)
+    alive[dead] = False
+    assert idx.size() == int(alive.sum()) and idx.rows() == 3000
+    for k in (1, 7, 64, 65, 500, 5000):
+        r, d, c = idx.search(q, k)
+        er, ed = O.exact_search(metric, rows, q, k, alive=alive)
+        assert int(c[0]) == len(er) == min(k, int(alive.sum()))
+        assert np.array_equal(r[0, : len(er)], er), (metric, k)       # ties resolved by row ascending
+        assert np.array_equal(_bits(d[0, : len(er)]), _bits(ed))
+
+
+def test_full_ranking_k_equals_n():                                    # collection.go:679-682: filters ask for k = Index.Size()
+    rows = O.gen_rows(5, 0, 20000, 32)
+    q = O.gen_rows(6, 0, 1, 32)[0]
+    idx = _mk(32, "cosine", rows)
+    r, d, c = idx.search(q, 20000)
+    er, ed = O.exact_search(0, rows, q, 20000)
+    assert int(c[0]) == 20000
+    assert np.array_equal(r[0], er) and np.array_equal(_bits(d[0]), _bits(ed))
+
+
+def test_update_and_revive():
+    rows = O.gen_rows(9, 0, 300, 16)
+    idx = _mk(16, "euclidean", rows)
+    new = O.gen_rows(10, 0, 1, 16)[0]
+    idx.remove([17])
+    idx.update(17, new)                                                # Update = delete + insert in place
+    idx.update(200, new * 2)
+    rows2 = rows.copy()
+    rows2[17] = new
+    rows2[200] = new * 2
+    assert idx.size() == 300
+    assert np.array_equal(idx.get_row(17), new)
+    r, d, c = idx.search(new, 5)
+    er, ed = O.exact_search(1, rows2, new, 5)
+    assert np.array_equal(r[0], er) and np.array_equal(_bits(d[0]), _bits(ed))
+    assert r[0, 0] == 17 and d[0, 0] == 0.0
+
+
+def test_copy_on_insert():                                             # exact_test.go:46-60
+    v = np.array([[1.0, 2.0, 3.0]], np.float32)
+    idx = _mk(3, "euclidean", v)
+    v[0, 0] = 99.0
+    assert np.array_equal(idx.get_row(0), np.array([1, 2, 3], np.float32))
+
+
+def test_incremental_adds_cross_tile_boundaries():
+    rows = O.gen_rows(13, 0, 1000, 24)
+    idx = _mk(24, "cosine")
+    pos = 0
+    for step in (1, 62, 1, 1, 63, 200, 5, 667):
+        first = idx.add(rows[pos: pos + step])
+        assert first == pos
+        pos += step
+    assert pos == 1000 and idx.size() == 1000
+    q = O.gen_rows(14, 0, 3, 24)
+    r, d, c = idx.search(q, 10)
+    for i in range(3):
+        er, ed = O.exact_search(0, rows, q[i], 10)
+        assert np.array_equal(r[i], er) and np.array_equal(_bits(d[i]), _bits(ed))
+
+
+def test_synthetic_generator_matches_oracle_bitwise():
+    idx = _mk(768, "cosine")
+    idx.add_synthetic(20260424, 1000, 200)
+    want = O.gen_rows(20260424, 1000, 200, 768)
+    for r in (0, 1, 63, 64, 65, 199):
+        assert np.array_equal(_bits(idx.get_row(r)), _bits(want[r])), r
+    idx2 = _mk(100, "hnsw_cosine")
+    idx2.add_synthetic(7, 0, 130)
+    want2 = O.gen_rows(7, 0, 130, 100)
+    for r in (0, 64, 129):
+        assert np.array_equal(_bits(idx2.get_row(r)), _bits(want2[r]))
+    q = O.gen_rows(8, 0, 1, 100)[0]
+    r, d, c = idx2.search(q, 10)
+    er, ed = O.exact_search(5, want2, q, 10)
+    assert np.array_equal(r[0], er) and np.array_equal(_bits(d[0]), _bits(ed))
+
+
+def test_config0_hybrid_exact_10kx128_cosine_k10_against_golden():
+    """BASELINE.json configs[0]; golden fixture = oracle output committed under tests/golden"""
+    g = np.load(os.path.join(O.ROOT, "tests", "golden", "flat_10kx128_cosine.npz"))
+    rows = O.gen_rows(int(g["corpus_seed"]), 0, 10000, 128)
+    qs = O.gen_rows(int(g["query_seed"]), 0, g["rows"].shape[0], 128)
+    idx = _mk(128, "cosine", rows)
+    r, d, c = idx.search(qs, 10)
+    assert np.array_equal(r, g["rows"])
+    assert np.array_equal(_bits(d), _bits(g["dist"]))
+
+
+def test_concurrent_searches_are_independent():                        # Collection.Search runs under RLock: many at once
+    rows = O.gen_rows(21, 0, 5000, 64)
+    idx = _mk(64, "cosine", rows)
+    qs = O.gen_rows(22, 0, 16, 64)
+    want = [O.exact_search(0, rows, q, 10) for q in qs]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                r, d, c = idx.search(qs[i], 10)
+                assert np.array_equal(r[0], want[i][0]) and np.array_equal(_bits(d[0]), _bits(want[i][1]))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(16)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[0]
+
+
+def test_device_pointer_entry_point_matches_host_entry_point():
+    import torch
+    rows = O.gen_rows(31, 0, 4000, 48)
+    idx = _mk(48, "dot_product", rows)
+    qs = O.gen_rows(32, 0, 5, 48)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((5, 10), dtype=torch.int32, device="cuda")
+    dd = torch.empty((5, 10), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    idx.search_device(dq.data_ptr(), 5, 10, dr.data_ptr(), dd.data_ptr(), s)
+    torch.cuda.synchronize()
+    r, d, c = idx.search(qs, 10)
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32), r)
+    assert np.array_equal(_bits(dd.cpu().numpy()), _bits(d))
+
+
+# ---------------------------------------------------------------- full-size checks ---
+
+def test_config1_flat_cosine_1Mx768_k10_full_oracle_and_properties():
+    """BASELINE.json configs[1] at full size.  Three queries against the complete CPU
+    oracle (bit-exact), plus size-independent properties: planted neighbours come back
+    first at distance ~0, results are sorted, and every returned distance equals the
+    oracle's distance for that row."""
+    n, dim, seed = 1_000_000, 768, 20260424
+    idx = _mk(dim, "cosine")
+    idx.reserve(n)
+    idx.add_synthetic(seed, 0, n)
+    assert idx.size() == n
+    qs = O.gen_rows(20260425, 0, 3, dim)
+    r, d, c = idx.search(qs, 10)
+    corpus = O.gen_rows(seed, 0, n, dim)          # ~3 GB host, a few seconds
+    for i in range(3):
+        er, ed = O.exact_search(0, corpus, qs[i], 10)
+        assert np.array_equal(r[i], er)
+        assert np.array_equal(_bits(d[i]), _bits(ed))
+    # planted neighbours: the query IS a corpus row
+    for row in (0, 63, 64, 123_457, 999_999):
+        rr, dd, _ = idx.search(corpus[row], 10)
+        assert rr[0, 0] == row and dd[0, 0] <= 1e-6
+        assert all(dd[0, j] <= dd[0, j + 1] for j in range(9))
+        for j in range(10):
+            assert _bits(dd[0, j]) == _bits(O.distance(0, corpus[row], corpus[rr[0, j]]))
+    # tombstone the best hit: it must disappear, everything else shifts up
+    idx.remove([int(r[0, 0])])
+    r2, d2, _ = idx.search(qs[0], 9)
+    assert np.array_equal(r2[0], r[0, 1:]) and np.array_equal(_bits(d2[0]), _bits(d[0, 1:]))
