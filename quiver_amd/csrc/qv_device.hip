@@ -24,6 +24,7 @@
 // float32-valued doubles are exact.
 #include "qv_device.h"
 #include "../../include/qv.h"
+#include <stdlib.h>
 
 namespace qv {
 
@@ -73,6 +74,22 @@ __device__ __forceinline__ void list_insert(uint64_t& list, uint64_t& thr, uint6
         list = lane > pos ? up : (lane == pos ? c : list);
         thr = readlane64(list, kth_lane);
     }
+}
+
+// ascending bitonic sort of one key per lane across the wave (21 compare-exchange steps)
+__device__ __forceinline__ uint64_t wave_sort64(uint64_t key, uint32_t lane) {
+#pragma unroll
+    for (uint32_t k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            uint32_t lo = __shfl_xor((uint32_t)key, (int)j), hi = __shfl_xor((uint32_t)(key >> 32), (int)j);
+            uint64_t other = ((uint64_t)hi << 32) | lo;
+            bool up = (lane & k2) == 0, lower = (lane & j) == 0;
+            uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
+            key = (lower == up) ? mn : mx;
+        }
+    }
+    return key;
 }
 
 // ---------------------------------------------------------------- metric traits ----
@@ -158,11 +175,21 @@ template <int M> __device__ __forceinline__ void stage_query(typename MT<M>::Q* 
 }
 
 // distance of the query (in LDS) to the row whose chunk c lives at p[c * stride4]
-template <int M, int U>
+// QN: also accumulate the query's own squared norm in the reference's element order
+// (distances.go:20 magnitudeA += a*a; adapter.go:118 normA += a*a).  It is an independent
+// dependency chain, so riding along with a row's dot product costs no time; a wave does it
+// on its first tile only.
+template <int M, int U, bool QN>
 __device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict__ p, uint32_t stride4,
-                                                            const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4) {
+                                                            const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4,
+                                                            typename MT<M>::A* qnorm2 = nullptr) {
     using Q = typename MT<M>::Q;
-    typename MT<M>::A acc = 0;
+    using A = typename MT<M>::A;
+    A acc = 0, qa = 0;
+    auto qn1 = [&](Q a) {
+        if constexpr (QN && M == QV_COSINE) qa = __builtin_fma(a, a, qa);
+        else if constexpr (QN && M == QV_COSINE_F32) { float pp = a * a; qa = qa + pp; }
+    };
     uint32_t c0 = 0;
     for (; c0 + U <= dim4; c0 += U) {
         f4 v[U];
@@ -171,16 +198,25 @@ __device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const Q* qq = q_lds + (size_t)(c0 + u) * 4;
-            acc1<M>(acc, qq[0], v[u].x); acc1<M>(acc, qq[1], v[u].y);
-            acc1<M>(acc, qq[2], v[u].z); acc1<M>(acc, qq[3], v[u].w);
+            acc1<M>(acc, qq[0], v[u].x); qn1(qq[0]); acc1<M>(acc, qq[1], v[u].y); qn1(qq[1]);
+            acc1<M>(acc, qq[2], v[u].z); qn1(qq[2]); acc1<M>(acc, qq[3], v[u].w); qn1(qq[3]);
         }
     }
     for (; c0 < dim4; c0++) {
         f4 v = __builtin_nontemporal_load(&p[(size_t)c0 * stride4]);
         const Q* qq = q_lds + (size_t)c0 * 4;
-        acc1<M>(acc, qq[0], v.x); acc1<M>(acc, qq[1], v.y); acc1<M>(acc, qq[2], v.z); acc1<M>(acc, qq[3], v.w);
+        acc1<M>(acc, qq[0], v.x); qn1(qq[0]); acc1<M>(acc, qq[1], v.y); qn1(qq[1]);
+        acc1<M>(acc, qq[2], v.z); qn1(qq[2]); acc1<M>(acc, qq[3], v.w); qn1(qq[3]);
     }
+    if constexpr (QN) *qnorm2 = qa;       // zero padding of the query adds +0 terms: exact
     return acc;
+}
+
+template <int M> __device__ __forceinline__ QConst qconst_from_norm2(typename MT<M>::A n2) {
+    QConst c; c.qn = 0.0; c.qn32 = 0.0f;
+    if constexpr (M == QV_COSINE) c.qn = __builtin_sqrt(n2);
+    else if constexpr (M == QV_COSINE_F32) { c.qn32 = (float)__builtin_sqrt((double)n2); c.qn = (double)n2; }
+    return c;
 }
 
 // ---------------------------------------------------------------- flat scan --------
@@ -202,23 +238,35 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
     const uint32_t qi = blockIdx.y;
     stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
     __syncthreads();
-    const QConst qc = query_const<M>(q_lds, v.dim);
 
     const uint32_t tw = gridDim.x * kScanWaves;
     const uint32_t kth = k - 1;
     uint64_t list = kDeadKey, thr = kDeadKey;
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
 
-    for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
-        const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
-        typename MT<M>::A acc = row_accumulate<M, U>(p, 64, q_lds, v.dim4);
+    auto finish_tile = [&](uint32_t t, typename MT<M>::A acc, bool first) {
         const uint32_t row = t * 64 + lane;
         double rn = 0.0;
         if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
         float dist = finalize<M>(acc, qc, rn);
         uint64_t am = v.alive[t];                                     // wave-uniform
         uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
-        list_insert(list, thr, key, kth, lane);
+        if (first) { list = wave_sort64(key, lane); thr = readlane64(list, kth); }   // empty list: sort the tile outright
+        else list_insert(list, thr, key, kth, lane);
+    };
+
+    uint32_t t = blockIdx.x * kScanWaves + wave;
+    if (t < v.n_tiles) {                                              // first tile: query norm rides along
+        typename MT<M>::A qn2 = 0;
+        typename MT<M>::A acc = row_accumulate<M, U, true>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4, &qn2);
+        qc = qconst_from_norm2<M>(qn2);
+        finish_tile(t, acc, true);
+        t += tw;
+    }
+    for (; t < v.n_tiles; t += tw) {
+        typename MT<M>::A acc = row_accumulate<M, U, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4);
+        finish_tile(t, acc, false);
     }
 
     // workgroup merge: waves 1.. hand their lists to wave 0 through LDS
@@ -233,12 +281,32 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
     }
 }
 
-// one workgroup per query merges n_lists sorted lists of k keys into the final top-k
+// One workgroup per query merges n_lists sorted lists of k keys into the final top-k.
+// Bound trick: the smallest k-th entry over all lists, B, is an upper bound of the final
+// k-th key (that list alone holds k keys <= B), so only keys <= B can be in the answer.
+// Typically a few dozen of the n_lists*k keys survive; one wave insertion-sorts them.
 constexpr int kMergeBlock = 1024;
+constexpr int kMergeCap = 2048;                       // survivors kept in LDS; more -> general path
+constexpr int kMergeHeads = 128;                      // sampled list heads ranked in LDS
+
+__device__ __forceinline__ uint64_t wave_min64(uint64_t x) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)x, off), hi = __shfl_xor((uint32_t)(x >> 32), off);
+        uint64_t y = ((uint64_t)hi << 32) | lo;
+        x = y < x ? y : x;
+    }
+    return x;
+}
+
 __global__ void __launch_bounds__(kMergeBlock)
 k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k,
               uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
     __shared__ uint64_t wl[kMergeBlock / 64][64];
+    __shared__ uint64_t surv[kMergeCap];
+    __shared__ uint32_t hd[kMergeHeads], hlt[kMergeHeads], hle[kMergeHeads];
+    __shared__ uint64_t s_bound, s_b1;
+    __shared__ uint32_t s_nsurv;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nw = blockDim.x >> 6;
@@ -246,24 +314,122 @@ k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k
     const uint64_t* src = partial + (size_t)qi * n_lists * k;
     const uint32_t total = n_lists * k;
     const uint32_t kth = k - 1;
-    uint64_t list = kDeadKey, thr = kDeadKey;
-    for (uint32_t base = wave * 64; base < total; base += nw * 64) {
-        uint32_t i = base + lane;
-        uint64_t key = i < total ? src[i] : kDeadKey;
-        list_insert(list, thr, key, kth, lane);
-    }
-    wl[wave][lane] = list;
+
+    // every global load of the common case is issued up front (one HBM/L2 latency, not three):
+    // this thread's <= 8 keys, one list's k-th key, one sampled list head
+    const bool small = total <= blockDim.x * 8;
+    uint64_t mine[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { uint32_t i = u * blockDim.x + threadIdx.x; mine[u] = (small && i < total) ? src[i] : kDeadKey; }
+    // sampled heads: m = min(n_lists, kMergeHeads) lists at a fixed stride.  Any k different
+    // lists each hold a key <= the k-th smallest of their heads, so a subset still gives a
+    // valid (slightly looser) bound, and the O(m^2) rank count stays ~0.5 us on one CU.
+    const uint32_t m = n_lists < (uint32_t)kMergeHeads ? n_lists : (uint32_t)kMergeHeads;
+    const uint32_t hstride = n_lists / m;
+    const bool use_heads = m >= k;
+    uint64_t b = kDeadKey;
+    for (uint32_t w = threadIdx.x; w < n_lists; w += blockDim.x) { uint64_t x = src[(size_t)w * k + kth]; b = x < b ? x : b; }
+    if (use_heads)
+        for (uint32_t w = threadIdx.x; w < m; w += blockDim.x) { hd[w] = (uint32_t)(src[(size_t)w * hstride * k] >> 32); hlt[w] = 0; hle[w] = 0; }
+
+    // phase A: two upper bounds of the final k-th key.
+    //   B0 = min over lists of their k-th key (that list alone has k keys <= B0);
+    //   B1 = from the k-th smallest sampled HEAD — the tight one when the winners are spread
+    //        over many lists, which is the common case.  Rank counting on the 32 distance bits:
+    //        head i qualifies when #{j: d_j < d_i} <= k-1 < #{j: d_j <= d_i}; then every key
+    //        with distance <= d_i is kept.
+    b = wave_min64(b);
+    if (lane == 0) wl[wave][0] = b;
+    if (threadIdx.x == 0) { s_nsurv = 0; s_b1 = kDeadKey; }
     __syncthreads();
+    if (use_heads) {
+        const uint32_t segs = blockDim.x >= m ? blockDim.x / m : 1;   // thread -> (head i, segment of j)
+        const uint32_t per = (m + segs - 1) / segs;
+        for (uint32_t i = threadIdx.x % m, sgm = blockDim.x >= m ? threadIdx.x / m : 0; sgm < segs && i < m; i += blockDim.x) {
+            const uint32_t h = hd[i];
+            uint32_t clt = 0, cle = 0;
+            const uint32_t j0 = sgm * per, j1 = min(j0 + per, m);
+            uint32_t j = j0;
+            for (; j + 16 <= j1; j += 16) {                           // batch the (broadcast) LDS reads
+                uint32_t x[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) x[u] = hd[j + u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { clt += x[u] < h ? 1u : 0u; cle += x[u] <= h ? 1u : 0u; }
+            }
+            for (; j < j1; j++) { uint32_t x = hd[j]; clt += x < h ? 1u : 0u; cle += x <= h ? 1u : 0u; }
+            if (clt) atomicAdd(&hlt[i], clt);
+            if (cle) atomicAdd(&hle[i], cle);
+            if (blockDim.x >= m) break;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
+            if (hlt[i] <= kth && kth < hle[i] && hd[i] != 0xFFFFFFFFu) s_b1 = ((uint64_t)hd[i] << 32) | 0xFFFFFFFFull;
+    }
     if (wave == 0) {
+        uint64_t x = lane < nw ? wl[lane][0] : kDeadKey;
+        x = wave_min64(x);
+        if (lane == 0) s_bound = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_b1 < s_bound) s_bound = s_b1;
+    __syncthreads();
+    const uint64_t bound = s_bound;
+    // phase B: keep keys <= bound
+    auto keep = [&](uint64_t key) {
+        if (key != kDeadKey && key <= bound) {
+            uint32_t pos = atomicAdd(&s_nsurv, 1u);
+            if (pos < (uint32_t)kMergeCap) surv[pos] = key;
+        }
+    };
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) keep(mine[u]);
+    } else {
+        for (uint32_t base = 0; base < total; base += blockDim.x * 8) {
+            uint64_t key[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { uint32_t i = base + u * blockDim.x + threadIdx.x; key[u] = i < total ? src[i] : kDeadKey; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) keep(key[u]);
+        }
+    }
+    __syncthreads();
+    const uint32_t ns = s_nsurv;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    if (ns <= 64) {
+        // phase C (common): one wave bitonic-sorts the survivors
+        if (wave != 0) return;
+        list = wave_sort64(lane < ns ? surv[lane] : kDeadKey, lane);
+    } else if (ns <= (uint32_t)kMergeCap) {
+        if (wave != 0) return;
+        list = wave_sort64(surv[lane], lane);
+        thr = readlane64(list, kth);
+        for (uint32_t base = 64; base < ns; base += 64) {
+            uint32_t i = base + lane;
+            uint64_t key = i < ns ? surv[i] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+    } else {
+        // general path (tiny indexes whose lists are mostly shorter than k): every wave
+        // reduces a slice, wave 0 merges the waves
+        for (uint32_t base = wave * 64; base < total; base += nw * 64) {
+            uint32_t i = base + lane;
+            uint64_t key = i < total ? src[i] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        wl[wave][lane] = list;
+        __syncthreads();
+        if (wave != 0) return;
         for (uint32_t w = 1; w < nw; w++) {
             uint64_t key = lane < k ? wl[w][lane] : kDeadKey;
             list_insert(list, thr, key, kth, lane);
         }
-        if (lane < k) {
-            bool dead = list == kDeadKey;
-            rows_out[(size_t)qi * k + lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
-            dist_out[(size_t)qi * k + lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
-        }
+    }
+    if (lane < k) {
+        bool dead = list == kDeadKey;
+        rows_out[(size_t)qi * k + lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
+        dist_out[(size_t)qi * k + lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
     }
 }
 
@@ -315,7 +481,7 @@ k_flat_keys(IndexView v, const float* __restrict__ query, uint64_t* __restrict__
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
         const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
-        typename MT<M>::A acc = row_accumulate<M, U>(p, 64, q_lds, v.dim4);
+        typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
         const uint32_t row = t * 64 + lane;
         double rn = 0.0;
         if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
@@ -434,7 +600,7 @@ k_distance_rows(IndexView v, const float* __restrict__ query, const uint32_t* __
     const uint32_t row = rows[i];
     if (row >= v.n_rows) { out[i] = __uint_as_float(0x7FC00000u); return; }
     const f4* p = reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63);
-    typename MT<M>::A acc = row_accumulate<M, U>(p, 64, q_lds, v.dim4);
+    typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
     double rn = 0.0;
     if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
     out[i] = finalize<M>(acc, qc, rn);
@@ -579,11 +745,19 @@ __global__ void k_fetch_row(IndexView v, uint32_t row, float* __restrict__ out) 
 // ---------------------------------------------------------------- launchers --------
 constexpr int kUnroll = 16;
 
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    int v = atoi(e);
+    return v > 0 ? v : dflt;
+}
+
 ScanPlan plan_scan(uint32_t n_tiles, int cus) {
     ScanPlan p;
     p.block = kScanBlock;
     uint32_t want = (n_tiles + kScanWaves - 1) / kScanWaves;          // one tile per wave at most
-    uint32_t cap = (uint32_t)cus * 4;                                 // 4 workgroups (16 waves) per CU
+    static const int wg_per_cu = env_int("QV_SCAN_WG_PER_CU", 2);     // 2 workgroups = 8 waves per CU: measured best (profiles/r01_sweep.txt)
+    uint32_t cap = (uint32_t)cus * (uint32_t)wg_per_cu;
     p.grid = want < cap ? want : cap;
     if (p.grid == 0) p.grid = 1;
     p.n_lists = p.grid;
@@ -631,6 +805,16 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
     uint64_t* partial = static_cast<uint64_t*>(d_ws);
     hipError_t e = hipSuccess;
+    static const int unroll = env_int("QV_SCAN_UNROLL", kUnroll);     // tuning knob (cosine only): loads in flight per wave
+    if (v.metric == QV_COSINE && unroll != kUnroll) {
+#define QV_SCAN_U(UU)                                                                                             \
+        case UU: e = set_lds(k_flat_scan<QV_COSINE, UU>, lds); if (e != hipSuccess) return e;                    \
+            if (ev0) (void)hipEventRecord(ev0, s);                                                                \
+            hipLaunchKernelGGL((k_flat_scan<QV_COSINE, UU>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial); \
+            if (ev1) (void)hipEventRecord(ev1, s); break;
+        switch (unroll) { QV_SCAN_U(4) QV_SCAN_U(8) QV_SCAN_U(12) QV_SCAN_U(24) QV_SCAN_U(32) default: return hipErrorInvalidValue; }
+#undef QV_SCAN_U
+    } else
     QV_DISPATCH_METRIC(v.metric, {
         e = set_lds(k_flat_scan<MM, kUnroll>, lds);
         if (e != hipSuccess) return e;
