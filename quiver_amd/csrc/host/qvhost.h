@@ -1,0 +1,167 @@
+// qvhost.h — host-side mirror (C++) of the reference's Go callers of the hot path,
+// written ABOVE the C ABI of include/qv.h.  The reference is Go and no Go toolchain
+// exists in this image, so the callers are restated in C++ with the same names,
+// argument meaning, check order and error wording as the Go packages they stand in for:
+//
+//   quiver::ExactIndex    pkg/hybrid/exact.go:14-160
+//   quiver::HNSW          pkg/hnsw/hnsw.go:58-842 (graph walk on the host; every distance
+//                         is a libqv call: one qv_distance_rows batch per searchLayer hop)
+//   quiver::HNSWAdapter   pkg/hnsw/adapter.go:15-95, 345-437 + pkg/hybrid/hnsw_adapter.go
+//   quiver::HybridIndex   pkg/hybrid/hybrid_index.go:15-811, adaptive.go:41-72, 226-231
+//
+// No arithmetic on vector data happens here: distances and selections are libqv's
+// (HIP) job; this layer owns string ids, check order, graph bookkeeping, re-rank order.
+// A flat extern "C" surface (qvh_*) at the bottom lets pytest drive it through ctypes.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/qv.h"
+
+namespace quiver {
+
+struct BasicSearchResult {   // pkg/types/search.go:9-14
+    std::string id;
+    float distance;
+};
+
+// error = empty string means nil
+using Error = std::string;
+
+class ExactIndex {
+public:
+    ExactIndex(qv_metric metric, int device);
+    ~ExactIndex();
+    Error Insert(const std::string& id, const float* v, uint32_t len);                 // exact.go:38-58
+    Error Delete(const std::string& id);                                               // exact.go:61-70
+    Error Search(const float* q, uint32_t len, int k, std::vector<BasicSearchResult>* out);   // exact.go:92-133
+    // nq searches in one device call (what BatchSearch's goroutine fan-out becomes)
+    Error SearchMany(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<BasicSearchResult>>* out);
+    int Size() const { return (int)row_of_.size(); }                                   // exact.go:136-141
+    // distance(vector of `id`, other) for the re-rank loop (hybrid_index.go:543)
+    Error DistancesTo(const float* other, uint32_t len, const std::vector<std::string>& ids, std::vector<float>* out);
+    bool Has(const std::string& id) const { return row_of_.count(id) != 0; }
+    int dim() const { return dim_; }
+
+private:
+    qv_metric metric_; int device_;
+    qv_index* h_ = nullptr;
+    int dim_ = 0;                                  // 0 until the first insert (exact.go:43-47)
+    std::unordered_map<std::string, uint32_t> row_of_;
+    std::vector<std::string> id_of_;               // row -> id ("" = tombstoned)
+};
+
+struct HNSWConfig {          // pkg/hnsw/hnsw.go:27-41; defaults hnsw.go:223-237
+    int M = 0, MaxM0 = 0, EfConstruction = 0, EfSearch = 0, MaxLevel = 0;
+    uint64_t seed = 1;       // the reference seeds from the wall clock (hnsw.go:248)
+};
+
+struct HNSWResult { std::string id; float distance; uint32_t index; };   // hnsw.go:87-95
+
+class HNSW {
+public:
+    HNSW(qv_metric metric, int device, const HNSWConfig& cfg);
+    ~HNSW();
+    Error Insert(const std::string& id, const float* v, uint32_t len);                 // hnsw.go:266-334
+    Error Delete(const std::string& id);                                               // hnsw.go:741-842
+    Error Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>* out);   // hnsw.go:602-713
+    uint32_t Size() const { return size_; }
+    // introspection for graph-equality tests
+    uint32_t Nodes() const { return (uint32_t)nodes_.size(); }
+    int NodeLevel(uint32_t n) const { return n < nodes_.size() && nodes_[n].alive ? nodes_[n].level : -1; }
+    const std::vector<uint32_t>* Links(uint32_t n, int level) const;
+    void EntryPoint(uint32_t* ep, int* lvl) const { *ep = entry_; *lvl = cur_level_; }
+    int RandomLevel();                                                                 // hnsw.go:716-738
+    uint64_t DistanceCalls() const { return n_calls_; }
+    uint64_t DistanceEvals() const { return n_evals_; }
+    void SetEfSearch(int ef) { if (ef > 0) efS_ = ef; }
+    bool IndexOf(const std::string& id, uint32_t* out) const;
+    const std::vector<float>& Vector(uint32_t n) const { return nodes_[n].vec; }
+    bool Alive(uint32_t n) const { return n < nodes_.size() && nodes_[n].alive; }
+    const std::string& IdOf(uint32_t n) const { return nodes_[n].id; }
+    // one device call: distance(query, node) for each listed node
+    Error Distances(const float* query, const std::vector<uint32_t>& nodes, std::vector<float>* out);
+
+private:
+    struct Node { std::string id; std::vector<float> vec; int level = 0; std::vector<std::vector<uint32_t>> conn; bool alive = false; };
+    struct Res { float dist; uint32_t idx; };
+    Error searchLayer(const float* q, uint32_t entry, int ef, int level, std::vector<Res>* out);   // hnsw.go:471-580
+    Error connectNode(uint32_t nodeIdx, const float* v, int level, int graphLevel);                // hnsw.go:337-468
+    static int selectNeighbors(std::vector<Res>& c, int k);                                        // hnsw.go:583-599
+    bool ok(uint32_t i) const { return i < nodes_.size() && nodes_[i].alive; }
+
+    qv_metric metric_; int device_;
+    qv_index* h_ = nullptr; int dim_ = 0;
+    int M_, maxM0_, efC_, efS_, maxLevel_;
+    std::vector<Node> nodes_;
+    std::unordered_map<std::string, uint32_t> by_id_;
+    uint32_t entry_ = 0; int cur_level_ = -1; uint32_t size_ = 0;
+    uint64_t rng_;
+    std::vector<uint32_t> visited_; uint32_t epoch_ = 0;
+    uint64_t n_calls_ = 0, n_evals_ = 0;
+};
+
+class HNSWAdapter {          // pkg/hnsw/adapter.go + pkg/hybrid/hnsw_adapter.go
+public:
+    HNSWAdapter(qv_metric metric, int device, const HNSWConfig& cfg) : hnsw_(metric, device, cfg) {}
+    Error Insert(const std::string& id, const float* v, uint32_t len);                 // hnsw_adapter.go:47-54
+    Error Delete(const std::string& id);                                               // hnsw_adapter.go:57-63
+    Error Search(const float* q, uint32_t len, int k, std::vector<BasicSearchResult>* out);        // hnsw_adapter.go:66-71 -> adapter.go:41-95
+    Error SearchWithNegative(const float* q, uint32_t len, const float* neg, uint32_t neg_len, float w, int k,
+                             std::vector<BasicSearchResult>* out);                     // hnsw_adapter.go:75-85 -> adapter.go:345-437
+    int Size() const { return (int)hnsw_.Size(); }
+    HNSW& graph() { return hnsw_; }
+
+private:
+    Error adapterSearch(const float* q, uint32_t len, int k, std::vector<BasicSearchResult>* out); // adapter.go:41-95
+    HNSW hnsw_;
+    int dim_ = 0;
+};
+
+struct HybridConfig {        // pkg/hybrid/types.go:27-45
+    qv_metric metric = QV_COSINE;
+    HNSWConfig hnsw;
+    int exact_threshold = 1000;
+    double exploration_factor = 0.1;   // adaptive.go:46; tests set 0 (adaptive_test.go:44-104)
+    uint64_t seed = 1;
+    int device = 0;
+};
+
+class HybridIndex {
+public:
+    explicit HybridIndex(const HybridConfig& cfg);
+    Error Insert(const std::string& id, const float* v, uint32_t len);                 // hybrid_index.go:86-129
+    Error InsertBatch(const std::vector<std::string>& ids, const std::vector<const float*>& vecs, const std::vector<uint32_t>& lens);  // :132-242
+    Error Delete(const std::string& id);                                               // :245-289
+    Error DeleteBatch(const std::vector<std::string>& ids);                            // :292-372
+    Error Search(const float* q, uint32_t len, int k, std::vector<BasicSearchResult>* out) { return searchWithStrategy(q, len, k, "", nullptr, 0, 0.5f, false, out, nullptr); }
+    // strategy: "", "exact", "hnsw".  neg may be null.  used_out receives the strategy taken.
+    Error searchWithStrategy(const float* q, uint32_t len, int k, const std::string& strategy, const float* neg, uint32_t neg_len,
+                             float neg_weight, bool has_weight, std::vector<BasicSearchResult>* out, std::string* used_out);   // :473-585
+    Error SearchWithRequest(const float* q, uint32_t len, int k, const std::string& force, const float* neg, uint32_t neg_len,
+                            float neg_weight, std::vector<BasicSearchResult>* out, std::string* used_out);                    // :383-470
+    Error BatchSearch(const float* qs, uint32_t len, uint32_t nq, int k, const std::string& force,
+                      std::vector<std::vector<BasicSearchResult>>* out, std::vector<std::string>* used_out);                  // :677-811
+    int Size() const { return (int)vectors_.size(); }
+    std::string SelectStrategy(int vectorCount, int dimension, int k);                 // adaptive.go:41-72
+    ExactIndex& exact() { return exact_; }
+    HNSWAdapter& hnsw() { return hnsw_; }
+
+private:
+    void updateThresholds() { exact_threshold_ = vector_count_; dim_threshold_ = avg_dim_; }      // adaptive.go:226-231 (the overwrite quirk)
+    HybridConfig cfg_;
+    ExactIndex exact_;
+    HNSWAdapter hnsw_;
+    std::map<std::string, std::vector<float>> vectors_;   // hybrid_index.go:33 (ordered: deterministic batch order)
+    int vector_dim_ = 0;
+    int vector_count_ = 0, avg_dim_ = 0;
+    std::vector<int> dimensions_;
+    int exact_threshold_, dim_threshold_ = 100;
+    uint64_t rng_;
+};
+
+}  // namespace quiver

@@ -1,0 +1,97 @@
+"""Mirror of pkg/hnsw/hnsw.go: the graph lives on the host (C++ quiver::HNSW), every
+distance is a libqv device call — one qv_distance_rows batch per searchLayer hop
+(hnsw.go:536-563)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._host import Results, check, f32, hlib
+from ._lib import metric_id
+
+DefaultM, DefaultEfConstruction, DefaultEfSearch, DefaultMaxLevel = 16, 200, 100, 16   # hnsw.go:16-25
+
+
+@dataclass
+class Config:                          # hnsw.go:27-41
+    M: int = 0
+    MaxM0: int = 0
+    EfConstruction: int = 0
+    EfSearch: int = 0
+    MaxLevel: int = 0
+    DistanceFunc: object = "hnsw_euclidean"
+    Seed: int = 1                      # the reference: time.Now().UnixNano() (hnsw.go:248)
+
+
+@dataclass
+class Result:                          # hnsw.go:87-95
+    VectorID: str
+    Distance: float
+    VectorIndex: int
+
+
+def _mid(df) -> int:
+    if isinstance(df, (int, str)):
+        return metric_id(df)
+    return getattr(df, "metric_id")
+
+
+class HNSW:
+    def __init__(self, config: Config = None, device: int = 0):
+        c = config or Config()
+        self._h = hlib().qvh_hnsw_new(_mid(c.DistanceFunc), device, c.M, c.MaxM0, c.EfConstruction, c.EfSearch, c.MaxLevel, c.Seed)
+
+    def __del__(self):
+        try:
+            hlib().qvh_hnsw_free(self._h)
+        except Exception:
+            pass
+
+    def Insert(self, id: str, vector) -> None:
+        v = f32(vector)
+        check(hlib().qvh_hnsw_insert(self._h, id.encode(), v.ctypes.data, v.size))
+
+    def Delete(self, id: str) -> None:
+        check(hlib().qvh_hnsw_delete(self._h, id.encode()))
+
+    def Search(self, query, k: int):
+        q = f32(query)
+        r = Results()
+        idx = np.zeros(max(k, 1) + 8, dtype=np.uint32)
+        check(hlib().qvh_hnsw_search(self._h, q.ctypes.data, q.size, k, r.h, idx.ctypes.data))
+        return [Result(i, d, int(idx[j])) for j, (i, d) in enumerate(r.list())]
+
+    def Size(self) -> int:
+        return hlib().qvh_hnsw_size(self._h)
+
+    # introspection (graph-equality tests against the oracle)
+    def nodes(self) -> int:
+        return hlib().qvh_hnsw_nodes(self._h)
+
+    def node_level(self, n: int) -> int:
+        return hlib().qvh_hnsw_node_level(self._h, n)
+
+    def links(self, n: int, level: int) -> np.ndarray:
+        out = np.empty(4096, dtype=np.uint32)
+        c = hlib().qvh_hnsw_links(self._h, n, level, out.ctypes.data, out.size)
+        return out[: max(c, 0)].copy()
+
+    def entry_point(self):
+        ep, lv = C.c_uint32(0), C.c_int(0)
+        hlib().qvh_hnsw_entry_point(self._h, C.byref(ep), C.byref(lv))
+        return int(ep.value), int(lv.value)
+
+    def set_ef_search(self, ef: int):
+        hlib().qvh_hnsw_set_ef_search(self._h, ef)
+
+    def distance_calls(self) -> int:
+        return int(hlib().qvh_hnsw_distance_calls(self._h))
+
+    def distance_evals(self) -> int:
+        return int(hlib().qvh_hnsw_distance_evals(self._h))
+
+
+def NewHNSW(config: Config) -> HNSW:   # hnsw.go:221-252
+    return HNSW(config)

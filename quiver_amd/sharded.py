@@ -1,0 +1,99 @@
+"""Sharded exact search: the multi-GPU form of the flat scan.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  Rank g owns the contiguous row shard [g*N/G, (g+1)*N/G); a
+query goes to every rank, each rank scans its shard for its local top-k, the k
+(distance, global row) pairs per rank are all-gathered (k*8 bytes per rank — a latency,
+not a bandwidth, collective) and merged on every rank under the same (distance, row)
+order the single-GPU scan uses, so the sharded result is identical to the unsharded one.
+
+The reference has no counterpart (single process); this is the one
+exchange step the path has.
+
+The shard backend and the merge are injected so the orchestration can be exercised on
+CPU with gloo: on the GPU they are `DeviceShard` (qv_index_search_device) and
+`qv_merge_topk_device`; the CPU tests plug in test-only stand-ins.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows: int, world: int, rank: int):
+    """contiguous row blocks; global row = base + local row"""
+    base = rank * n_rows // world
+    return base, (rank + 1) * n_rows // world - base
+
+
+class DeviceShard:
+    """a qv_index holding this rank's rows; search writes device tensors on the current stream"""
+
+    def __init__(self, index):
+        self.index = index
+
+    def search(self, d_query: torch.Tensor, k: int, rows_out: torch.Tensor, dist_out: torch.Tensor):
+        s = torch.cuda.current_stream().cuda_stream
+        self.index.search_device(d_query.data_ptr(), 1, k, rows_out.data_ptr(), dist_out.data_ptr(), s)
+
+
+def device_merge(g_dist: torch.Tensor, g_rows: torch.Tensor, k: int, rows_out: torch.Tensor, dist_out: torch.Tensor):
+    from .device_index import merge_topk_device
+    s = torch.cuda.current_stream().cuda_stream
+    merge_topk_device(g_dist.data_ptr(), g_rows.data_ptr(), g_dist.shape[0], k, rows_out.data_ptr(), dist_out.data_ptr(), s)
+
+
+class ShardedFlatSearch:
+    def __init__(self, shard, base_row: int, k: int, device, group=None,
+                 merge: Callable = device_merge, world: Optional[int] = None):
+        self.shard, self.base, self.k, self.device, self.group = shard, int(base_row), k, device, group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.merge = merge
+        self._pending = None
+
+    def _buffers(self):
+        k, G, dev = self.k, self.world, self.device
+        return dict(rows=torch.empty(k, dtype=torch.int32, device=dev), dist=torch.empty(k, dtype=torch.float32, device=dev),
+                    g_rows=torch.empty((G, k), dtype=torch.int32, device=dev), g_dist=torch.empty((G, k), dtype=torch.float32, device=dev),
+                    out_rows=torch.empty(k, dtype=torch.int32, device=dev), out_dist=torch.empty(k, dtype=torch.float32, device=dev))
+
+    def submit(self, d_query: torch.Tensor):
+        """local scan + start the exchange for this query; returns a ticket for finish().
+        Calling submit() for query i+1 before finish() of query i overlaps the exchange of i
+        with the scan of i+1 (the collectives run on the backend's own stream)."""
+        b = self._buffers()
+        self.shard.search(d_query, self.k, b["rows"], b["dist"])
+        if self.world == 1:
+            b["out_rows"], b["out_dist"] = b["rows"], b["dist"]
+            return b, None
+        # shard-local rows -> global rows; 0xFFFFFFFF (no result) stays put
+        valid = b["rows"] != -1
+        b["rows"] = torch.where(valid, b["rows"] + self.base, b["rows"])
+        w1 = dist.all_gather_into_tensor(b["g_dist"].view(-1), b["dist"], group=self.group, async_op=True)
+        w2 = dist.all_gather_into_tensor(b["g_rows"].view(-1), b["rows"], group=self.group, async_op=True)
+        return b, (w1, w2)
+
+    def finish(self, ticket):
+        b, works = ticket
+        if works is not None:
+            works[0].wait()
+            works[1].wait()
+            self.merge(b["g_dist"], b["g_rows"], self.k, b["out_rows"], b["out_dist"])
+        return b["out_rows"], b["out_dist"]
+
+    def search(self, d_query: torch.Tensor):
+        return self.finish(self.submit(d_query))
+
+    def search_stream(self, queries):
+        """pipelined: exchange of query i overlaps the scan of query i+1"""
+        out, pending = [], None
+        for q in queries:
+            t = self.submit(q)
+            if pending is not None:
+                out.append(self.finish(pending))
+            pending = t
+        if pending is not None:
+            out.append(self.finish(pending))
+        return out

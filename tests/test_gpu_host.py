@@ -1,0 +1,388 @@
+"""Host-side mirrors of the reference's Go callers (pkg/hybrid, pkg/hnsw, pkg/core,
+pkg/vectortypes) driving the HIP path; written to read like the reference's own tests
+(the cited *_test.go) and checked against the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KATS = json.load(open(os.path.join(O.ROOT, "tests", "golden", "ref_kats.json")))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ------------------------------------------------------------------ vectortypes ---
+
+def test_vectortypes_distance_funcs_kats():                     # distances_test.go:9-204
+    from quiver_amd import vectortypes as vt
+    fn = {0: vt.CosineDistance, 1: vt.EuclideanDistance, 2: vt.SquaredEuclideanDistance, 3: vt.DotProductDistance, 4: vt.ManhattanDistance}
+    for kat in KATS["distance"]:
+        if kat["metric"] in fn:
+            assert abs(float(fn[kat["metric"]](kat["a"], kat["b"])) - kat["want"]) <= kat["tol"], kat
+
+
+def test_vectortypes_panics_on_length_mismatch():               # distances_test.go:206-230
+    from quiver_amd import vectortypes as vt
+    for f in (vt.CosineDistance, vt.EuclideanDistance, vt.SquaredEuclideanDistance, vt.DotProductDistance, vt.ManhattanDistance):
+        with pytest.raises(ValueError, match="vectors must have the same length"):
+            f([1, 2, 3], [1, 2])
+
+
+def test_vectortypes_lookup_and_surfaces():                     # types_test.go:9-60; surface_test.go:7-208
+    from quiver_amd import vectortypes as vt
+    assert vt.GetDistanceFuncByType("invalid") is vt.CosineDistance          # types.go:46-47
+    assert vt.GetDistanceFuncByType(vt.Manhattan) is vt.ManhattanDistance
+    assert float(vt.ComputeDistance([1, 1, 0], [0, 0, 0], vt.Manhattan)) == 2.0   # types_test.go:44-49
+    with pytest.raises(ValueError):
+        vt.ComputeDistance([1, 2], [1], vt.Cosine)
+    assert float(vt.DotProductSurface.Distance([2, 0, 0], [2, 0, 0])) == -3.0     # surface_test.go:117-123
+    assert float(vt.GetSurfaceByType("nope").Distance([1, 0, 0], [0, 1, 0])) == 1.0
+    cm = vt.ContraMap(vt.CosineSurface, lambda s: [float(ord(c)) for c in s])     # surface_test.go:160-192
+    assert abs(float(cm.Distance("abc", "xyz")) - 0.0) < 0.1
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal((50, 33)).astype(np.float32), rng.standard_normal((50, 33)).astype(np.float32)
+    got = vt.batch_distances("euclidean", a, b)
+    want = np.array([O.distance(1, a[i], b[i]) for i in range(50)], np.float32)
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+# ------------------------------------------------------------------ hybrid.ExactIndex ---
+
+def test_exact_index_insert_delete_semantics():                 # exact_test.go:13-95
+    from quiver_amd import hybrid, vectortypes as vt
+    from quiver_amd._host import GoError
+    idx = hybrid.ExactIndex(vt.CosineDistance)
+    assert idx.Size() == 0
+    v = np.array([0.1, 0.2], np.float32)
+    idx.Insert("vec1", v)
+    v[0] = 99                                                    # copy-on-insert, exact_test.go:46-60
+    with pytest.raises(GoError) as e:
+        idx.Insert("vec1", [0.3, 0.4])
+    assert str(e.value) == "vector with ID vec1 already exists"
+    with pytest.raises(GoError) as e:
+        idx.Insert("vec2", [0.3])                                # exact_test.go:314-322
+    assert str(e.value) == "vector dimension mismatch: expected 2, got 1"
+    with pytest.raises(GoError) as e:
+        idx.Search([0.3], 1)                                     # exact_test.go:324-330
+    assert str(e.value) == "query dimension mismatch: expected 2, got 1"
+    with pytest.raises(GoError) as e:
+        idx.Search([0.1, 0.2], 0)
+    assert str(e.value) == "k must be positive"
+    r = idx.Search([0.1, 0.2], 5)
+    assert [x.ID for x in r] == ["vec1"] and r[0].Distance <= 1e-6
+    idx.Delete("nonexistent")                                    # exact_test.go:90-94: not an error
+    idx.Delete("vec1")
+    assert idx.Size() == 0
+    assert idx.Search([1, 2, 3], 3) == []                        # empty -> empty, nil (exact.go:96-98)
+    idx.Insert("a", [1, 2, 3])                                   # dimension resets when empty (exact.go:66-68)
+    assert idx.Size() == 1
+
+
+@pytest.mark.parametrize("kat", KATS["exact_search"], ids=lambda k: k["src"])
+def test_exact_index_search_kats(kat):                          # exact_test.go:97-205
+    from quiver_amd import hybrid
+    idx = hybrid.ExactIndex(kat["metric"])
+    for i, r in zip(kat["ids"], kat["rows"]):
+        idx.Insert(i, r)
+    res = idx.Search(kat["query"], kat["k"])
+    ids = [r.ID for r in res]
+    assert len(ids) == min(kat["k"], len(kat["ids"]))
+    if kat["exact_order"]:
+        assert ids[: len(kat["want_ids"])] == kat["want_ids"]
+    else:
+        assert set(kat["want_ids"]) <= set(ids)
+    assert all(res[i].Distance <= res[i + 1].Distance for i in range(len(res) - 1))
+
+
+# ------------------------------------------------------------------ hybrid.HybridIndex ---
+
+def _hybrid(metric="cosine", **kw):
+    from quiver_amd import hybrid
+    cfg = hybrid.IndexConfig(DistanceFunc=metric, ExplorationFactor=kw.pop("exploration", 0.0), Seed=kw.pop("seed", 3))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return hybrid.HybridIndex(cfg)
+
+
+def test_hybrid_forced_exact_and_batch_insert():                # hybrid_index_test.go:270-311
+    from quiver_amd import hybrid
+    idx = _hybrid()
+    idx.InsertBatch({"vec1": [1, 0, 0], "vec2": [0, 1, 0], "vec3": [0, 0, 1]})
+    assert idx.Size() == 3
+    resp = idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=[0.9, 0.1, 0.0], K=1, ForceStrategy=hybrid.ExactIndexType, IncludeStats=True))
+    assert resp.StrategyUsed == "exact" and len(resp.Results) == 1 and resp.Results[0].ID == "vec1"
+    resp = idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=[0.1, 0.9, 0.0], K=1, ForceStrategy=hybrid.ExactIndexType))
+    assert resp.Results[0].ID == "vec2"                          # hybrid_index_test.go:349-360
+
+
+def test_hybrid_errors_and_rollback():
+    from quiver_amd import hybrid
+    from quiver_amd._host import GoError
+    idx = _hybrid()
+    idx.Insert("a", [1, 0, 0])
+    with pytest.raises(GoError, match="vector with ID a already exists"):
+        idx.Insert("a", [0, 1, 0])
+    with pytest.raises(GoError, match="vector dimension mismatch: expected 3, got 2"):
+        idx.Insert("b", [0, 1])
+    with pytest.raises(GoError, match="vector dimension mismatch: expected 3, got 2"):
+        idx.InsertBatch({"c": [0, 1, 0], "d": [1, 1]})
+    assert idx.Size() == 1                                       # all-or-nothing
+    with pytest.raises(GoError, match="vector with ID a already exists"):
+        idx.InsertBatch({"e": [0, 1, 0], "a": [1, 1, 1]})
+    with pytest.raises(GoError, match="vector with ID zz not found"):
+        idx.Delete("zz")
+    with pytest.raises(GoError, match="some vectors not found"):
+        idx.DeleteBatch(["a", "zz"])
+    with pytest.raises(GoError, match="k must be positive"):
+        idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=[1, 0, 0], K=0))
+    with pytest.raises(GoError, match="query dimension mismatch: expected 3, got 2"):
+        idx.Search([1, 0], 1)
+    with pytest.raises(GoError, match="invalid search strategy: bogus"):
+        idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=[1, 0, 0], K=1, ForceStrategy="bogus"))
+    idx.DeleteBatch(["a"])
+    assert idx.Size() == 0
+    idx.Insert("n", [1, 2])                                      # dimension resets (hybrid_index.go:282-284)
+
+
+def test_hybrid_exact_distances_l2_unit_axes():                 # hybrid_property_test.go:443-461
+    idx = _hybrid("euclidean")
+    idx.Insert("a", [1, 0, 0]); idx.Insert("b", [0, 1, 0]); idx.Insert("c", [0, 0, 1])
+    from quiver_amd import hybrid
+    res = idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=[0, 0, 0], K=3, ForceStrategy="exact")).Results
+    assert len(res) == 3 and all(abs(r.Distance - 1.0) < 1e-3 for r in res)
+
+
+@pytest.mark.parametrize("kat", KATS["negative_rerank"], ids=lambda k: k["src"])
+def test_hybrid_negative_example_kats(kat):                     # hybrid_index_test.go:541-656; hybrid_index_rerank_test.go:9-47
+    from quiver_amd import hybrid
+    idx = _hybrid(kat["metric"])
+    for i, r in zip(kat["ids"], kat["rows"]):
+        idx.Insert(i, r)
+    req = hybrid.HybridSearchRequest(Query=kat["query"], K=kat["k"], NegativeExample=kat["negative"], NegativeWeight=kat["weight"],
+                                     ForceStrategy="exact")
+    res = idx.SearchWithRequest(req).Results
+    assert len(res) == kat["want_count"]
+    assert not any(np.isnan(r.Distance) for r in res)
+    if kat.get("want_all_equal"):
+        assert res[0].Distance == res[1].Distance == res[2].Distance
+    if "not_first" in kat:
+        assert res[0].ID != kat["not_first"]
+    # identical to the oracle's restatement of hybrid_index.go:517-570
+    rows = np.array(kat["rows"], np.float32)
+    order = sorted(range(len(kat["ids"])), key=lambda i: kat["ids"][i])
+    rank = np.empty(len(order), np.uint32); rank[order] = np.arange(len(order), dtype=np.uint32)
+    er, ed = O.exact_search_negative(kat["metric"], rows, kat["query"], kat["negative"], kat["weight"], kat["k"], id_rank=rank)
+    assert [r.ID for r in res] == [kat["ids"][i] for i in er]
+    assert np.array_equal(_bits([r.Distance for r in res]), _bits(ed))
+    # fluent form, hybrid_index_test.go:637-655
+    fres = idx.FluentSearch(kat["query"]).WithK(kat["k"]).WithNegativeExample(kat["negative"]).WithNegativeWeight(kat["weight"]).WithForceStrategy("exact").Execute()
+    assert [r.ID for r in fres.Results] == [r.ID for r in res]
+
+
+def test_hybrid_negative_rerank_random_vs_oracle():
+    from quiver_amd import hybrid
+    rows = O.gen_rows(61, 0, 500, 24)
+    ids = [f"v{i}" for i in range(500)]
+    idx = _hybrid("cosine")
+    idx.InsertBatch({i: r for i, r in zip(ids, rows)})
+    order = sorted(range(500), key=lambda i: ids[i])
+    rank = np.empty(500, np.uint32); rank[order] = np.arange(500, dtype=np.uint32)
+    qs, negs = O.gen_rows(62, 0, 5, 24), O.gen_rows(63, 0, 5, 24)
+    for q, n in zip(qs, negs):
+        for k, w in ((5, 0.5), (20, 0.9), (40, 0.1)):
+            res = idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=q, K=k, NegativeExample=n, NegativeWeight=w, ForceStrategy="exact")).Results
+            er, ed = O.exact_search_negative(0, rows, q, n, w, k, id_rank=rank)
+            assert [r.ID for r in res] == [ids[i] for i in er]
+            assert np.array_equal(_bits([r.Distance for r in res]), _bits(ed))
+
+
+def test_hybrid_batch_search_equals_single_searches():          # hybrid_index.go:677-811
+    from quiver_amd import hybrid
+    from quiver_amd._host import GoError
+    rows = O.gen_rows(71, 0, 3000, 32)
+    idx = _hybrid("cosine")
+    idx.InsertBatch({f"v{i}": r for i, r in enumerate(rows)})
+    qs = O.gen_rows(72, 0, 9, 32)
+    resp = idx.BatchSearch(hybrid.BatchSearchRequest(Queries=list(qs), K=7, ForceStrategy="exact"))
+    assert resp.StrategiesUsed == ["exact"] * 9
+    for i, q in enumerate(qs):
+        er, ed = O.exact_search(0, rows, q, 7)
+        assert [r.ID for r in resp.Results[i]] == [f"v{j}" for j in er]
+        assert np.array_equal(_bits([r.Distance for r in resp.Results[i]]), _bits(ed))
+    with pytest.raises(GoError, match="no queries provided"):
+        idx.BatchSearch(hybrid.BatchSearchRequest(Queries=[], K=3))
+    with pytest.raises(GoError, match="query 1 dimension mismatch"):
+        idx.BatchSearch(hybrid.BatchSearchRequest(Queries=[qs[0], qs[1][:5]], K=3))
+
+
+def test_selector_threshold_overwrite_quirk():                  # adaptive.go:226-231; adaptive_test.go:44-104
+    idx = _hybrid("cosine", exploration=0.0)
+    assert idx.SelectStrategy(10, 3, 5) == "exact"              # fresh: 10 < ExactThreshold=1000
+    assert idx.SelectStrategy(5000, 200, 10) == "hnsw"          # dim 200 > 100, k < 50
+    assert idx.SelectStrategy(5000, 200, 60) == "exact"
+    assert idx.SelectStrategy(5000, 50, 10) == "hnsw"
+    for i in range(5):
+        idx.Insert(f"v{i}", np.eye(4, dtype=np.float32)[i % 4] + i)
+    # Insert overwrote exactThreshold := VectorCount and dimThreshold := AvgDimension, so both
+    # comparisons are now always false for the index's own stats and un-forced searches go HNSW
+    assert idx.SelectStrategy(5, 4, 10) == "hnsw"
+
+
+# ------------------------------------------------------------------ hnsw.HNSW (host graph, GPU distances) ---
+
+def _build_both(metric, rows, seed, **cfg):
+    from quiver_amd import hnsw
+    h = hnsw.HNSW(hnsw.Config(DistanceFunc=metric, Seed=seed, **cfg))
+    o = O.HNSW(metric, rows.shape[1], seed=seed, M=cfg.get("M", 16), maxM0=cfg.get("MaxM0", 0),
+               efConstruction=cfg.get("EfConstruction", 200), efSearch=cfg.get("EfSearch", 100), maxLevel=cfg.get("MaxLevel", 16))
+    for i, r in enumerate(rows):
+        h.Insert(f"v{i}", r)
+        o.insert(r)
+    return h, o
+
+
+@pytest.mark.parametrize("metric", [6, 0, 5])
+def test_hnsw_graph_and_search_identical_to_oracle(metric):
+    """bit-identical distances => the host-driven graph (one device batch per hop) is the
+    SAME graph the CPU oracle builds from the same seed, and searches return the same
+    rows, distances and order"""
+    rows = O.gen_rows(81 + metric, 0, 400, 48)
+    h, o = _build_both(metric, rows, seed=11, EfConstruction=40, EfSearch=32)
+    assert h.nodes() == o.nodes() == 400 and h.entry_point() == o.entry_point()
+    for n in range(400):
+        assert h.node_level(n) == o.node_level(n)
+        for l in range(h.node_level(n) + 1):
+            assert np.array_equal(h.links(n, l), o.links(n, l)), (n, l)
+    for q in O.gen_rows(91, 0, 10, 48):
+        res = h.Search(q, 10)
+        er, ed = o.search(q, 10)
+        assert [r.VectorIndex for r in res] == er.tolist()
+        assert np.array_equal(_bits([r.Distance for r in res]), _bits(ed))
+        assert [r.VectorID for r in res] == [f"v{i}" for i in er]
+    assert h.distance_evals() > h.distance_calls() > 0            # batched: many evaluations per device call
+
+
+def test_hnsw_delete_topup_identical_to_oracle():
+    rows = O.gen_rows(95, 0, 150, 16)
+    h, o = _build_both(6, rows, seed=5, EfConstruction=30, EfSearch=20)
+    for n in range(0, 150, 3):
+        h.Delete(f"v{n}")
+        assert o.delete(n) == 0
+    assert h.Size() == o.size() == 100
+    from quiver_amd._host import GoError
+    with pytest.raises(GoError, match="vector with ID v0 not found"):
+        h.Delete("v0")
+    for q in O.gen_rows(96, 0, 5, 16):
+        res = h.Search(q, 100)                                    # under-filled -> exact top-up (hnsw.go:676-710)
+        er, ed = o.search(q, 100)
+        assert len(res) == 100
+        assert np.array_equal(_bits([r.Distance for r in res]), _bits(ed))
+        assert sorted(r.VectorIndex for r in res) == sorted(er.tolist())
+
+
+@pytest.mark.parametrize("kat", KATS["hnsw_properties"], ids=lambda k: k["src"])
+def test_hnsw_reference_tables(kat):                             # hnsw_test.go:154-256
+    from quiver_amd import hnsw
+    rows = np.array(kat["rows"], np.float32)
+    h = hnsw.HNSW(hnsw.Config(DistanceFunc=kat["metric"], Seed=1))
+    ids = kat.get("ids", [f"v{i}" for i in range(len(rows))])
+    for i, r in zip(ids, rows):
+        h.Insert(i, r)
+    res = h.Search(kat["query"], kat["k"])
+    assert 0 < len(res) <= kat["k"]
+    assert all(res[i].Distance <= res[i + 1].Distance for i in range(len(res) - 1))
+    if "must_contain_row" in kat:
+        assert ids[kat["must_contain_row"]] in [r.VectorID for r in res]
+
+
+def test_hnsw_adapter_fill_and_negative():                       # adapter.go:41-95, 345-437; adapter_test.go:136-248
+    from quiver_amd import hybrid
+    rows = O.gen_rows(101, 0, 60, 8)
+    a = hybrid.HNSWAdapter("euclidean", hybrid.HNSWConfig(EfConstruction=20, EfSearch=10), seed=2)
+    for i, r in enumerate(rows):
+        a.Insert(f"id{i}", r)
+    res = a.Search(rows[6], 5)
+    assert res[0].ID == "id6" and res[0].Distance == 0.0          # adapter_test.go: q == id6 -> first result id6
+    res = a.Search(rows[1], 60)                                   # k == size: the fill pass guarantees k results
+    assert len(res) == 60 and "id1" in [r.ID for r in res]
+    neg = a.SearchWithNegative(rows[3], rows[4], 0.5, 5)
+    assert len(neg) == 5 and all(neg[i].Distance <= neg[i + 1].Distance for i in range(4))
+    # weight 0 -> plain results truncated to k (adapter.go:366-372)
+    assert [r.ID for r in a.SearchWithNegative(rows[3], rows[4], 0.0, 5)] == [r.ID for r in a.Search(rows[3], 30)][:5]
+
+
+# ------------------------------------------------------------------ core.Collection surface ---
+
+def test_collection_add_search_fluent_filters():                # collection_test.go; collection.go:133-331, 637-807, 886-1108
+    from quiver_amd import core, hybrid
+    idx = _hybrid("cosine")
+    c = core.Collection("docs", 4, idx)
+    with pytest.raises(core.CoreError, match="vector ID cannot be empty"):
+        c.Add("", [1, 0, 0, 0])
+    with pytest.raises(core.ErrInvalidDimension, match="invalid vector dimension: expected 4, got 3"):
+        c.Add("x", [1, 0, 0])
+    with pytest.raises(core.ErrInvalidMetadata):
+        c.Add("x", [1, 0, 0, 0], "not json")
+    c.Add("x", [1, 0, 0, 0], json.dumps({"kind": "a", "n": 1}))
+    with pytest.raises(core.ErrVectorAlreadyExist, match="vector with the same ID already exists: x"):
+        c.Add("x", [0, 1, 0, 0])
+    with pytest.raises(core.CoreError, match="no vectors provided for batch insert"):
+        c.AddBatch([])
+    with pytest.raises(core.ErrInvalidDimension, match="for vector bad: expected 4, got 2"):
+        c.AddBatch([core.Vector("ok", [0, 1, 0, 0]), core.Vector("bad", [0, 1])])
+    assert c.Count() == 1
+    rows = O.gen_rows(111, 0, 200, 4)
+    c.AddBatch([core.Vector(f"v{i}", rows[i], json.dumps({"kind": "a" if i % 2 else "b", "n": i})) for i in range(200)])
+    assert c.Count() == 201
+    # un-filtered: TopK results, Score = 1 - Distance (collection.go:763)
+    q = rows[17]
+    resp = c.Search(core.SearchRequest(Vector=q, TopK=5, Options=core.SearchOptions(IncludeMetadata=True)))
+    assert len(resp.Results) <= 5 and resp.Metadata.IndexSize == 201
+    for it in resp.Results:
+        assert it.Score == float(np.float32(1.0) - np.float32(it.Distance))
+    with pytest.raises(core.CoreError, match="top_k must be greater than 0"):
+        c.Search(core.SearchRequest(Vector=q, TopK=0))
+    with pytest.raises(core.ErrInvalidDimension):
+        c.Search(core.SearchRequest(Vector=q[:3], TopK=1))
+
+
+def test_collection_filtered_search_is_a_full_ranking():        # collection.go:679-682: searchK = Index.Size()
+    from quiver_amd import core, hybrid
+    rows = O.gen_rows(121, 0, 300, 8)
+    ids = [f"v{i}" for i in range(300)]
+    ex = hybrid.ExactIndex("cosine")                              # a plain core.Index (no BatchIndex): AddBatch falls back to Insert
+    c = core.Collection("c", 8, ex)
+    c.AddBatch([core.Vector(ids[i], rows[i], json.dumps({"group": i % 7, "tag": "t%d" % (i % 3)})) for i in range(300)])
+    q = O.gen_rows(122, 0, 1, 8)[0]
+    resp = c.FluentSearch(q).WithK(10).Filter("group", 3).Execute()
+    er, ed = O.exact_search(0, rows, q, 300)                      # the full ranking the index is asked for
+    want = [(ids[r], d) for r, d in zip(er, ed) if r % 7 == 3][:10]
+    assert [it.ID for it in resp.Results] == [w[0] for w in want]
+    assert np.array_equal(_bits([it.Distance for it in resp.Results]), _bits([w[1] for w in want]))
+    assert all(json.loads(it.Metadata)["group"] == 3 for it in resp.Results)
+    resp2 = c.FluentSearch(q).WithK(4).FilterIn("tag", ["t0", "t2"]).FilterGreaterThan("group", 4).Execute()
+    want2 = [ids[r] for r in er if (r % 3) in (0, 2) and (r % 7) > 4][:4]
+    assert [it.ID for it in resp2.Results] == want2
+    # sticky builder errors (collection.go:932-1091)
+    with pytest.raises(core.CoreError, match="k must be greater than 0"):
+        c.FluentSearch(q).WithK(0).Filter("group", 1).Execute()
+    with pytest.raises(core.CoreError, match="filter field cannot be empty"):
+        c.FluentSearch(q).Filter("", 1).Execute()
+    with pytest.raises(core.ErrInvalidDimension):
+        c.FluentSearch(q[:2]).Execute()
+    assert len(c.FluentSearch(q).WithK(1000).Execute().Results) == 300   # k clamped to Count() (:924-926)
+    # update / delete keep the index and the maps in step (collection.go:356-465)
+    c.Update("v5", vector=q)
+    assert c.FluentSearch(q).WithK(1).Execute().Results[0].ID == "v5"
+    c.Delete("v5")
+    with pytest.raises(core.ErrVectorNotFound):
+        c.Get("v5")
+    c.DeleteBatch(["v6", "v7"])
+    assert c.Count() == 297
