@@ -54,7 +54,9 @@ typedef enum qv_metric {
     QV_COSINE_F32  = 5, /* hnsw.CosineDistanceFunc               adapter.go:105-136  */
     QV_L2_F32      = 6, /* hnsw.EuclideanDistanceFunc            adapter.go:139-151  */
     QV_DOT_F32     = 7, /* hnsw.DotProductDistanceFunc           adapter.go:154-165  */
-    QV_METRIC_COUNT = 8
+    QV_L2SQ_F64    = 8, /* ArrowHNSWIndex.Search re-score        index/arrow_hnsw.go:124-132
+                           (float64 difference, float64 unfused square-accumulate)   */
+    QV_METRIC_COUNT = 9
 } qv_metric;
 
 typedef enum qv_status {

@@ -13,10 +13,10 @@ from __future__ import annotations
 
 import numpy as np
 
-COSINE, L2, L2SQ, DOT, L1, COSINE_F32, L2_F32, DOT_F32 = range(8)
+COSINE, L2, L2SQ, DOT, L1, COSINE_F32, L2_F32, DOT_F32, L2SQ_F64 = range(9)
 METRIC_NAMES = {
     COSINE: "cosine", L2: "euclidean", L2SQ: "squared_euclidean", DOT: "dot_product", L1: "manhattan",
-    COSINE_F32: "hnsw_cosine", L2_F32: "hnsw_euclidean", DOT_F32: "hnsw_dot_product",
+    COSINE_F32: "hnsw_cosine", L2_F32: "hnsw_euclidean", DOT_F32: "hnsw_dot_product", L2SQ_F64: "arrow_squared_euclidean",
 }
 
 
@@ -69,6 +69,9 @@ def distances(metric: int, query: np.ndarray, rows: np.ndarray) -> np.ndarray:
         if metric == L2_F32:  # adapter.go:139-151
             diff = q32 - r32
             return np.sqrt(_seq_sum(diff * diff, np.float32).astype(np.float64)).astype(np.float32)
+        if metric == L2SQ_F64:  # index/arrow_hnsw.go:124-132
+            d = q64 - r64
+            return _seq_sum(d * d, np.float64).astype(np.float32)
         if metric == DOT_F32:  # adapter.go:154-165
             return (np.float32(1.0) - _seq_sum(q32 * r32, np.float32)).astype(np.float32)
     return distances(COSINE, query, rows)  # types.go:46-47 unknown -> cosine

@@ -115,6 +115,19 @@ static float dot_f32(const float* a, const float* b, uint32_t n) {
     return 1.0f - dot;
 }
 
+/* index/arrow_hnsw.go:124-132 — ArrowHNSWIndex.Search re-scores every hit itself: both
+ * vectors widened to float64 (arrow_hnsw.go:73-75, 109-112), d = q[j]-vec[j] in float64,
+ * dist += d*d sequentially (mul then add: unfused on amd64), float32(dist) */
+static float l2sq_f64(const float* a, const float* b, uint32_t n) {
+    double dist = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        double d = (double)a[i] - (double)b[i];
+        volatile double sq = d * d;
+        dist = dist + sq;
+    }
+    return (float)dist;
+}
+
 typedef float (*dist_fn)(const float*, const float*, uint32_t);
 static dist_fn metric_fn(int metric) {
     switch (metric) {
@@ -126,6 +139,7 @@ static dist_fn metric_fn(int metric) {
         case QVO_COSINE_F32: return cosine_f32;
         case QVO_L2_F32: return l2_f32;
         case QVO_DOT_F32: return dot_f32;
+        case QVO_L2SQ_F64: return l2sq_f64;
         default: return cosine_f64;                   /* types.go:46-47: unknown -> cosine */
     }
 }

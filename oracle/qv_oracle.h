@@ -20,9 +20,9 @@ extern "C" {
 
 /* same numbering as include/qv.h qv_metric (the oracle does not include qv.h on purpose) */
 enum { QVO_COSINE = 0, QVO_L2 = 1, QVO_L2SQ = 2, QVO_DOT = 3, QVO_L1 = 4,
-       QVO_COSINE_F32 = 5, QVO_L2_F32 = 6, QVO_DOT_F32 = 7, QVO_METRIC_COUNT = 8 };
+       QVO_COSINE_F32 = 5, QVO_L2_F32 = 6, QVO_DOT_F32 = 7, QVO_L2SQ_F64 = 8, QVO_METRIC_COUNT = 9 };
 
-/* pkg/vectortypes/distances.go:12-104 and pkg/hnsw/adapter.go:105-167 */
+/* pkg/vectortypes/distances.go:12-104, pkg/hnsw/adapter.go:105-167, index/arrow_hnsw.go:124-132 */
 float qvo_distance(int metric, const float* a, const float* b, uint32_t dim);
 
 /* counter-based synthetic unit vectors, integer arithmetic +

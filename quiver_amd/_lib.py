@@ -16,7 +16,7 @@ QV_FLAG_ROWMAJOR = 1
 # include/qv.h qv_metric
 METRICS = {
     "cosine": 0, "euclidean": 1, "squared_euclidean": 2, "dot_product": 3, "manhattan": 4,
-    "hnsw_cosine": 5, "hnsw_euclidean": 6, "hnsw_dot_product": 7,
+    "hnsw_cosine": 5, "hnsw_euclidean": 6, "hnsw_dot_product": 7, "arrow_squared_euclidean": 8,
 }
 
 

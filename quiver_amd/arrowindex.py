@@ -1,0 +1,123 @@
+"""Arrow columnar load -> device (north star: "pkg/arrowindex columnar load -> device").
+
+`index.ArrowHNSWIndex.Load` (index/arrow_hnsw.go:201-241) reads an Arrow IPC file with
+schema {id: utf8, vector: FixedSizeList<float32>[dim]}; per record batch the list's child
+array is ONE contiguous float32 buffer of rows*dim values (arrow_hnsw.go:222-225), which the
+reference then walks row by row, widening each to float64 and inserting into its graph.
+Here that child buffer is handed to libqv as it is — it already IS the row-major [rows][dim]
+matrix `qv_index_add` ingests (one H2D copy per <= 256 MiB, one ingest kernel), no per-row
+work on the host.  `Save` writes the same schema (arrow_hnsw.go:138-198).
+
+`ArrowFlatIndex` keeps ArrowHNSWIndex's Add / Search / Save / Load / Len surface and its
+distance definition: Search returns, for each hit, the squared L2 distance recomputed in
+float64 over float64-widened vectors and rounded to float32 (arrow_hnsw.go:124-132) —
+metric QV_L2SQ_F64.  The ranking is an exact scan (what the reference's graph search
+degenerates to when len(nodes) <= m, graph.go:482-484, and a recall-1.0 superset of it
+otherwise).  Arrow IPC reading/writing itself is pyarrow's job (storage only).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.ipc as ipc
+
+
+def schema_for(dim: int) -> pa.Schema:                        # arrow_hnsw.go:153-156
+    return pa.schema([pa.field("id", pa.string()), pa.field("vector", pa.list_(pa.float32(), dim))])
+
+
+def batch_values(batch: pa.RecordBatch, dim: int) -> np.ndarray:
+    """zero-copy view of a record batch's vectors as float32 [rows, dim] (arrow_hnsw.go:218-225)"""
+    col = batch.column(1)
+    if not pa.types.is_fixed_size_list(col.type) or col.type.list_size != dim or not pa.types.is_float32(col.type.value_type):
+        raise ValueError(f"vector column must be FixedSizeList<float32>[{dim}], got {col.type}")
+    if col.null_count:
+        raise ValueError("null vectors are not supported")
+    flat = col.flatten()                                       # accounts for the list array's offset
+    vals = flat.to_numpy(zero_copy_only=True)
+    return vals.reshape(len(col), dim)
+
+
+def save_ipc(path: str, ids: Sequence[str], vectors: np.ndarray) -> None:
+    vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+    n, dim = vectors.shape
+    if len(ids) != n:
+        raise ValueError("ids and vectors disagree")
+    arr = pa.FixedSizeListArray.from_arrays(pa.array(vectors.reshape(-1), type=pa.float32()), dim)
+    batch = pa.record_batch([pa.array(list(ids), type=pa.string()), arr], schema=schema_for(dim))
+    with ipc.new_file(path, schema_for(dim)) as w:
+        w.write_batch(batch)
+
+
+def load_ipc(path: str, dim: int, sink) -> List[str]:
+    """stream every record batch of an IPC file into `sink(values[rows, dim], ids)`; returns all ids"""
+    all_ids: List[str] = []
+    with pa.memory_map(path, "r") as src:
+        r = ipc.open_file(src)
+        for i in range(r.num_record_batches):                  # arrow_hnsw.go:215
+            b = r.get_batch(i)
+            ids = b.column(0).to_pylist()
+            sink(batch_values(b, dim), ids)
+            all_ids.extend(ids)
+    return all_ids
+
+
+class Result:                                                  # index/arrow_hnsw.go:19-23
+    __slots__ = ("ID", "Distance")
+
+    def __init__(self, id_: str, distance: float):
+        self.ID, self.Distance = id_, distance
+
+    def __repr__(self):
+        return f"Result(ID={self.ID!r}, Distance={self.Distance!r})"
+
+
+class ArrowFlatIndex:
+    def __init__(self, dim: int, device: int = 0):             # NewArrowHNSWIndex(dim), arrow_hnsw.go:39-55
+        from .device_index import DeviceIndex
+        self.dim = dim
+        self._idx = DeviceIndex(dim, "arrow_squared_euclidean", device=device)
+        self.idToIdx: dict = {}
+        self.idxToID: List[str] = []
+
+    def _add_block(self, values: np.ndarray, ids: Sequence[str]) -> None:
+        for id_ in ids:                                        # addRaw's duplicate check, arrow_hnsw.go:60-63
+            if id_ in self.idToIdx:
+                raise ValueError(f"vector with ID {id_} already exists")
+        if len(set(ids)) != len(ids):
+            raise ValueError("duplicate ids in one block")
+        first = self._idx.add(values)                          # the contiguous child buffer, as is
+        for j, id_ in enumerate(ids):
+            self.idToIdx[id_] = first + j
+            self.idxToID.append(id_)
+
+    def Add(self, vec, id: str) -> None:                       # arrow_hnsw.go:83-91
+        v = np.ascontiguousarray(vec.to_numpy(zero_copy_only=False) if isinstance(vec, pa.Array) else vec, dtype=np.float32)
+        if v.size != self.dim:
+            raise ValueError(f"dimension mismatch: got {v.size} want {self.dim}")
+        self._add_block(v.reshape(1, self.dim), [id])
+
+    def Search(self, query, k: int) -> List[Result]:           # arrow_hnsw.go:94-135
+        if k <= 0:
+            raise ValueError("k must be positive")
+        if query is None:
+            raise ValueError("invalid or nil query vector")
+        q = np.ascontiguousarray(query.to_numpy(zero_copy_only=False) if isinstance(query, pa.Array) else query, dtype=np.float32)
+        if q.size != self.dim:
+            raise ValueError(f"dimension mismatch: got {q.size} want {self.dim}")
+        rows, dist, count = self._idx.search(q, k)
+        n = int(count[0])
+        return [Result(self.idxToID[int(rows[0, i])], float(dist[0, i])) for i in range(n)]
+
+    def Len(self) -> int:
+        return self._idx.size()
+
+    def Save(self, path: str) -> None:                         # arrow_hnsw.go:138-198
+        n = self._idx.rows()
+        vecs = np.stack([self._idx.get_row(i) for i in range(n)]) if n else np.zeros((0, self.dim), np.float32)
+        save_ipc(path, self.idxToID, vecs)
+
+    def Load(self, path: str) -> None:                         # arrow_hnsw.go:201-241
+        load_ipc(path, self.dim, self._add_block)

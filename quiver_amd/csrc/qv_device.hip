@@ -103,6 +103,7 @@ template <> struct MT<QV_L1>         { using Q = float;  using A = double; stati
 template <> struct MT<QV_COSINE_F32> { using Q = float;  using A = float;  static constexpr bool needs_rnorm = true;  };
 template <> struct MT<QV_L2_F32>     { using Q = float;  using A = float;  static constexpr bool needs_rnorm = false; };
 template <> struct MT<QV_DOT_F32>    { using Q = float;  using A = float;  static constexpr bool needs_rnorm = false; };
+template <> struct MT<QV_L2SQ_F64>   { using Q = double; using A = double; static constexpr bool needs_rnorm = false; };
 
 // one element: a = query element (already in the metric's Q type), b = row element
 template <int M> __device__ __forceinline__ void acc1(typename MT<M>::A& acc, typename MT<M>::Q a, float b) {
@@ -111,6 +112,8 @@ template <int M> __device__ __forceinline__ void acc1(typename MT<M>::A& acc, ty
     } else if constexpr (M == QV_L2) {
         double d = (double)(a - b);                                   // float32 subtract, widen (distances.go:50)
         acc = __builtin_fma(d, d, acc);
+    } else if constexpr (M == QV_L2SQ_F64) {
+        double d = a - (double)b; double sq = d * d; acc = acc + sq;  // arrow_hnsw.go:128-129 (float64, unfused)
     } else if constexpr (M == QV_L1) {
         acc = acc + __builtin_fabs((double)(a - b));                  // distances.go:100
     } else if constexpr (M == QV_L2SQ || M == QV_L2_F32) {
@@ -152,8 +155,8 @@ template <int M> __device__ __forceinline__ float finalize(typename MT<M>::A acc
         return (float)__builtin_sqrt(acc);                            // :54
     } else if constexpr (M == QV_DOT) {
         return (float)(1.0 - acc);                                    // :89
-    } else if constexpr (M == QV_L1) {
-        return (float)acc;                                            // :103
+    } else if constexpr (M == QV_L1 || M == QV_L2SQ_F64) {
+        return (float)acc;                                            // :103 / arrow_hnsw.go:131
     } else if constexpr (M == QV_L2SQ) {
         return acc;                                                   // :71
     } else if constexpr (M == QV_COSINE_F32) {
@@ -767,7 +770,7 @@ ScanPlan plan_scan(uint32_t n_tiles, int cus) {
 size_t scan_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k) { return (size_t)p.n_lists * nq * k * sizeof(uint64_t); }
 
 static size_t query_lds_bytes(int metric, uint32_t dim4) {
-    size_t q = (metric == QV_COSINE || metric == QV_DOT) ? sizeof(double) : sizeof(float);
+    size_t q = (metric == QV_COSINE || metric == QV_DOT || metric == QV_L2SQ_F64) ? sizeof(double) : sizeof(float);
     return ((size_t)dim4 * 4 * q + 15) / 16 * 16;
 }
 
@@ -786,6 +789,7 @@ template <typename F> static hipError_t set_lds(F f, size_t bytes) {
         case QV_COSINE_F32: { constexpr int MM = QV_COSINE_F32; CALL; } break; \
         case QV_L2_F32:     { constexpr int MM = QV_L2_F32;     CALL; } break; \
         case QV_DOT_F32:    { constexpr int MM = QV_DOT_F32;    CALL; } break; \
+        case QV_L2SQ_F64:   { constexpr int MM = QV_L2SQ_F64;   CALL; } break; \
         default: return hipErrorInvalidValue;                    \
     }
 

@@ -77,7 +77,7 @@ def test_empty_index_and_k_errors():
 
 # ---------------------------------------------------------------- bit-exact parity ---
 
-@pytest.mark.parametrize("metric", range(8))
+@pytest.mark.parametrize("metric", range(9))
 @pytest.mark.parametrize("dim", [1, 3, 4, 7, 63, 64, 128, 200, 768])
 def test_topk_bitexact_vs_oracle(metric, dim):
     rng = np.random.default_rng(100 * metric + dim)
@@ -98,7 +98,7 @@ def test_topk_bitexact_vs_oracle(metric, dim):
             assert np.array_equal(_bits(d[qi]), _bits(ed)), (metric, dim, k, qi)
 
 
-@pytest.mark.parametrize("metric", range(8))
+@pytest.mark.parametrize("metric", range(9))
 def test_all_distances_bitexact_via_distance_rows(metric):
     rng = np.random.default_rng(metric)
     rows = (rng.standard_normal((777, 96)) * rng.choice([1e-3, 1, 1e3], size=(777, 1))).astype(np.float32)
@@ -110,7 +110,7 @@ def test_all_distances_bitexact_via_distance_rows(metric):
     assert np.array_equal(_bits(got), _bits(want))
 
 
-@pytest.mark.parametrize("metric", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("metric", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_ties_and_tombstones(metric):
     rng = np.random.default_rng(7 + metric)
     rows = rng.integers(-2, 3, size=(3000, 4)).astype(np.float32)      # few distinct distances: ties everywhere

@@ -386,3 +386,37 @@ def test_collection_filtered_search_is_a_full_ranking():        # collection.go:
         c.Get("v5")
     c.DeleteBatch(["v6", "v7"])
     assert c.Count() == 297
+
+
+# ------------------------------------------------------------------ Arrow columnar load -> device ---
+
+def test_arrow_ipc_load_to_device_and_search(tmp_path):          # index/arrow_hnsw_test.go:33-60; arrow_hnsw_property_test.go:142-171
+    import pyarrow as pa
+    from quiver_amd import arrowindex as ai
+    rows = O.gen_rows(131, 0, 700, 32)
+    ids = [f"id{i}" for i in range(700)]
+    p = str(tmp_path / "idx.arrow")
+    ai.save_ipc(p, ids, rows)
+    idx = ai.ArrowFlatIndex(32)
+    idx.Load(p)                                                   # FixedSizeList child buffer -> qv_index_add, no per-row work
+    assert idx.Len() == 700
+    q = O.gen_rows(132, 0, 1, 32)[0]
+    res = idx.Search(pa.array(q, type=pa.float32()), 10)
+    er, ed = O.exact_search(8, rows, q, 10)                       # metric 8 = arrow_hnsw.go:124-132 re-score
+    assert [r.ID for r in res] == [ids[i] for i in er]
+    assert np.array_equal(_bits([r.Distance for r in res]), _bits(ed))
+    p2 = str(tmp_path / "copy.arrow")
+    idx.Save(p2)                                                  # round trip (arrow_hnsw_test.go:33-60)
+    idx2 = ai.ArrowFlatIndex(32)
+    idx2.Load(p2)
+    assert [r.ID for r in idx2.Search(q, 10)] == [r.ID for r in res]
+    with pytest.raises(ValueError, match="already exists"):
+        idx2.Add(rows[0], "id0")
+    with pytest.raises(ValueError, match="dimension mismatch: got 3 want 32"):
+        idx2.Add(np.zeros(3, np.float32), "new")
+    with pytest.raises(ValueError, match="k must be positive"):
+        idx2.Search(q, 0)
+    axes = ai.ArrowFlatIndex(3)                                   # arrow_hnsw_property_test.go:142-171: unit axes -> 1.0
+    for i, name in enumerate("abc"):
+        axes.Add(np.eye(3, dtype=np.float32)[i], name)
+    assert all(abs(r.Distance - 1.0) < 1e-6 for r in axes.Search(np.zeros(3, np.float32), 3))

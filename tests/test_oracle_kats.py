@@ -92,7 +92,7 @@ def test_negative_rerank_kats(kat):
 
 # ---- C restatement == numpy restatement, bit for bit -------------------------------
 
-@pytest.mark.parametrize("metric", range(8))
+@pytest.mark.parametrize("metric", range(9))
 @pytest.mark.parametrize("dim", [1, 3, 7, 64, 128, 768])
 def test_c_equals_numpy_bitwise(metric, dim):
     rng = np.random.default_rng(1000 * metric + dim)
@@ -119,7 +119,7 @@ def test_exact_search_matches_numpy_with_ties_and_tombstones():
     rows = rng.integers(-2, 3, size=(500, 4)).astype(np.float32)  # many exact ties
     q = np.array([1, 0, -1, 2], np.float32)
     alive = rng.random(500) > 0.2
-    for metric in range(8):
+    for metric in range(9):
         for k in (1, 10, 64, 400, 1000):
             r1, d1 = O.exact_search(metric, rows, q, k, alive=alive)
             r2, d2 = ONP.exact_search(metric, rows, q, k, alive=alive)
