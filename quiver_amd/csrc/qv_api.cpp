@@ -420,7 +420,8 @@ static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, ui
 static size_t search_ws_bytes(const qv_index* idx, uint32_t nq, uint32_t kk, uint32_t k_stride) {
     const uint32_t n_tiles = (idx->n_rows + 63) / 64;
     const qv::ScanPlan plan = qv::plan_scan(n_tiles, idx->cus);
-    if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride) return qv::scan_workspace_bytes(plan, nq, kk);
+    if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride)   // partial lists + the multi-query kernels' query blocks
+        return qv::scan_workspace_bytes(plan, nq, kk) + (size_t)(nq + 16) * idx->dim4 * 4 * sizeof(double);
     return qv::full_sort_workspace_bytes(n_tiles);
 }
 

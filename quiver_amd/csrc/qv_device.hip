@@ -25,6 +25,7 @@
 #include "qv_device.h"
 #include "../../include/qv.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace qv {
 
@@ -281,6 +282,148 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
             list_insert(list, thr, key, kth, lane);
         }
         if (lane < k) partial[((size_t)qi * gridDim.x + blockIdx.x) * k + lane] = list;
+    }
+}
+
+// ---------------------------------------------------------------- multi-query scan --
+// QB queries share ONE pass over the corpus (HybridIndex.BatchSearch, hybrid_index.go:677-811,
+// is Q independent exact searches; here every 16-byte row chunk a lane loads is used for QB
+// dot products).  Same arithmetic contract: lane == row, each (row, query) distance is one
+// sequential chain over dims 0..D-1.  The query block sits in LDS interleaved by query
+// (q_lds[dim][QB]) so one ds_read_b128 feeds two (f64) or four (f32) queries of one dim.
+// grid = (workgroups, ceil(nq/QB)); partial layout identical to k_flat_scan.
+// one tile for QB queries: acc[j] = Σ_d f(q_j[d], row[d]); FIRST also accumulates the query norms
+template <int M, int U, int QB, bool FIRST>
+__device__ __forceinline__ void mq_tile(const f4* __restrict__ p, const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4,
+                                        typename MT<M>::A (&acc)[QB], typename MT<M>::A (&qa)[QB]) {
+    using Q = typename MT<M>::Q;
+    constexpr int VW = 16 / sizeof(Q);                          // queries per 16-byte LDS read (2 doubles or 4 floats)
+    typedef Q qvec __attribute__((ext_vector_type(VW)));
+    static_assert(QB % VW == 0, "QB must be a multiple of the LDS vector width");
+#pragma unroll
+    for (int j = 0; j < QB; j++) { acc[j] = 0; if constexpr (FIRST) qa[j] = 0; }
+    auto chunk = [&](uint32_t c, f4 x) {
+        const qvec* qq = reinterpret_cast<const qvec*>(q_lds + (size_t)c * 4 * QB);
+        const float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+#pragma unroll
+            for (int g = 0; g < QB / VW; g++) {
+                const qvec a = qq[d * (QB / VW) + g];             // one ds_read_b128, broadcast to the wave
+#pragma unroll
+                for (int t = 0; t < VW; t++) {
+                    const int j = g * VW + t;
+                    acc1<M>(acc[j], a[t], e[d]);
+                    if constexpr (FIRST && M == QV_COSINE) qa[j] = __builtin_fma(a[t], a[t], qa[j]);
+                    else if constexpr (FIRST && M == QV_COSINE_F32) { float pp = a[t] * a[t]; qa[j] = qa[j] + pp; }
+                }
+            }
+        }
+    };
+    uint32_t c0 = 0;
+    for (; c0 + U <= dim4; c0 += U) {
+        f4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * 64]);
+#pragma unroll
+        for (int u = 0; u < U; u++) chunk(c0 + u, x[u]);
+    }
+    for (; c0 < dim4; c0++) chunk(c0, __builtin_nontemporal_load(&p[(size_t)c0 * 64]));
+}
+
+// query blocks for the scalar-operand variant: qblk[group][dim4*4][QB] in the metric's Q type
+template <int M, int QB>
+__global__ void k_prep_qblk(const float* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t dim4, typename MT<M>::Q* __restrict__ qblk) {
+    using Q = typename MT<M>::Q;
+    const uint32_t per = dim4 * 4 * QB;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per) return;
+    const uint32_t d = i / QB, qq = i % QB, q0 = blockIdx.y * QB;
+    const uint32_t qi = q0 + qq < nq ? q0 + qq : nq - 1;
+    qblk[(size_t)blockIdx.y * per + i] = d < dim ? (Q)queries[(size_t)qi * dim + d] : (Q)0;
+}
+
+// SQ = true: the query block is read from GLOBAL memory at wave-uniform addresses, which the
+// compiler turns into scalar loads (s_load) and SGPR operands of v_fma_f64 — the LDS, which
+// bounds the LDS-staged form (one broadcast ds_read_b128 per 2 query values), is not touched.
+template <int M, int U, int QB, bool SQ>
+__global__ void __launch_bounds__(kScanBlock, 2)
+k_flat_scan_mq(IndexView v, const float* __restrict__ queries, const typename MT<M>::Q* __restrict__ qblk, uint32_t nq, uint32_t k,
+               uint64_t* __restrict__ partial) {
+    using Q = typename MT<M>::Q;
+    using A = typename MT<M>::A;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const size_t q_bytes = SQ ? 0 : (((size_t)v.dim4 * 4 * QB * sizeof(Q)) + 15) / 16 * 16;
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + q_bytes);                  // [waves][QB][64]
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t q0 = blockIdx.y * QB;
+    const Q* q_lds;
+    if constexpr (SQ) {
+        q_lds = qblk + (size_t)blockIdx.y * v.dim4 * 4 * QB;                     // global, uniform -> scalar loads
+    } else {
+        Q* ql = reinterpret_cast<Q*>(smem);                                      // [dim4*4][QB]
+        // stage QB queries, zero-padded in dim; query slots past nq replicate the last query (results dropped)
+        for (uint32_t i = threadIdx.x; i < v.dim4 * 4 * QB; i += blockDim.x) {
+            uint32_t d = i / QB, qq = i % QB;
+            uint32_t qi = q0 + qq < nq ? q0 + qq : nq - 1;
+            ql[i] = d < v.dim ? (Q)queries[(size_t)qi * v.dim + d] : (Q)0;
+        }
+        __syncthreads();
+        q_lds = ql;
+    }
+
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const uint32_t kth = k - 1;
+    uint64_t list[QB], thr[QB];
+    QConst qc[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) { list[j] = kDeadKey; thr[j] = kDeadKey; qc[j].qn = 0.0; qc[j].qn32 = 0.0f; }
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+
+    uint32_t t = blockIdx.x * kScanWaves + wave;
+    if (t < v.n_tiles) {                                                         // first tile: sort outright, query norms ride along
+        A acc[QB], qa[QB];
+        mq_tile<M, U, QB, true>(tiles + (size_t)t * v.dim4 * 64 + lane, q_lds, v.dim4, acc, qa);
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        const bool live = (v.alive[t] >> lane) & 1ull;
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            qc[j] = qconst_from_norm2<M>(qa[j]);
+            float dist = finalize<M>(acc[j], qc[j], rn);
+            list[j] = wave_sort64(live ? make_key(dist, row) : kDeadKey, lane);
+            thr[j] = readlane64(list[j], kth);
+        }
+        t += tw;
+    }
+    for (; t < v.n_tiles; t += tw) {
+        A acc[QB], qa[QB];
+        mq_tile<M, U, QB, false>(tiles + (size_t)t * v.dim4 * 64 + lane, q_lds, v.dim4, acc, qa);
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        const bool live = (v.alive[t] >> lane) & 1ull;
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            float dist = finalize<M>(acc[j], qc[j], rn);
+            list_insert(list[j], thr[j], live ? make_key(dist, row) : kDeadKey, kth, lane);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < QB; j++) wl[((size_t)wave * QB + j) * 64 + lane] = list[j];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            for (uint32_t w = 1; w < kScanWaves; w++) {
+                uint64_t key = lane < k ? wl[((size_t)w * QB + j) * 64 + lane] : kDeadKey;
+                list_insert(list[j], thr[j], key, kth, lane);
+            }
+            if (q0 + j < nq && lane < k) partial[((size_t)(q0 + j) * gridDim.x + blockIdx.x) * k + lane] = list[j];
+        }
     }
 }
 
@@ -767,7 +910,7 @@ ScanPlan plan_scan(uint32_t n_tiles, int cus) {
     return p;
 }
 
-size_t scan_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k) { return (size_t)p.n_lists * nq * k * sizeof(uint64_t); }
+size_t scan_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k) { return ((size_t)p.n_lists * 4 * nq * k * sizeof(uint64_t) + 255) / 256 * 256; }   // x4: the multi-query scan may use up to 8 WG/CU
 
 static size_t query_lds_bytes(int metric, uint32_t dim4) {
     size_t q = (metric == QV_COSINE || metric == QV_DOT || metric == QV_L2SQ_F64) ? sizeof(double) : sizeof(float);
@@ -809,6 +952,39 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
     uint64_t* partial = static_cast<uint64_t*>(d_ws);
     hipError_t e = hipSuccess;
+    static const int mq_min = env_int("QV_MQ_MIN", 2);                // nq >= this: queries share a corpus pass
+    if ((int)nq >= mq_min) {
+        // QB queries per corpus pass.  Measured on MI355X, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt):
+        // QB=8 is HBM-bound (0.454 ms/pass), QB=16 is f64-VALU-bound (0.75 ms/pass, 12.0 ms per 256 queries).
+        static const int mq_qb_env = env_int("QV_MQ_QB", 0), mq_wg = env_int("QV_MQ_WG_PER_CU", 2);
+        const int qb = mq_qb_env ? mq_qb_env : (nq >= 9 ? 16 : (nq >= 5 ? 8 : 4));
+        const uint32_t want = (v.n_tiles + kScanWaves - 1) / kScanWaves;
+        const uint32_t grid = std::max(1u, std::min(want, (uint32_t)mq_wg * (p.grid / 2 ? p.grid / 2 : 1)));   // p.grid = 2 WG/CU * CUs
+        void* qblk = static_cast<char*>(d_ws) + scan_workspace_bytes(p, nq, k);   // tail of the workspace
+#define QV_MQ_LAUNCH(MMM, QQ)                                                                                              \
+        {                                                                                                                     \
+            using QT = typename MT<MMM>::Q;                                                                                   \
+            const uint32_t groups = (nq + QQ - 1) / QQ;                                                                       \
+            const uint32_t per = v.dim4 * 4 * QQ;                                                                             \
+            hipLaunchKernelGGL((k_prep_qblk<MMM, QQ>), dim3((per + 255) / 256, groups), dim3(256), 0, s, d_queries, nq, v.dim, v.dim4, static_cast<QT*>(qblk)); \
+            const size_t lds_mq = (size_t)kScanWaves * QQ * 64 * sizeof(uint64_t);                                            \
+            if (ev0) (void)hipEventRecord(ev0, s);                                                                            \
+            hipLaunchKernelGGL((k_flat_scan_mq<MMM, 4, QQ, true>), dim3(grid, groups), dim3(p.block), lds_mq, s, v, d_queries, static_cast<const QT*>(qblk), nq, k, partial); \
+            if (ev1) (void)hipEventRecord(ev1, s);                                                                            \
+        }
+        if (qb == 16) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 16) }); }
+        else if (qb == 8) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 8) }); }
+        else if (qb == 4) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 4) }); }
+        else return hipErrorInvalidValue;
+#undef QV_MQ_LAUNCH
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        // partial lists are laid out with stride `grid` lists per query
+        uint32_t total = grid * k;
+        uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
+        hipLaunchKernelGGL(k_merge_lists, dim3(nq), dim3(mblock), 0, s, partial, grid, k, d_rows_out, d_dist_out);
+        return hipGetLastError();
+    }
     static const int unroll = env_int("QV_SCAN_UNROLL", kUnroll);     // tuning knob (cosine only): loads in flight per wave
     if (v.metric == QV_COSINE && unroll != kUnroll) {
 #define QV_SCAN_U(UU)                                                                                             \
