@@ -93,6 +93,7 @@ struct qv_index {
     std::mutex ctx_mu;
     std::vector<SearchCtx*> free_ctx;
     std::vector<SearchCtx*> all_ctx;
+    uint64_t batched_redo = 0;                 // queries the MFMA path handed back to the exact scan
     bool profiling = false;                    // qv_index_profile: event pairs around scan kernels
     std::mutex prof_mu;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -522,8 +523,69 @@ int qv_index_profile_read(qv_index* idx, double* scan_ms_sum_out, uint64_t* laun
 
 int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                             uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
-    // the MFMA pre-filter is not built yet; the exact scan gives the identical result
-    return qv_index_search(idx, queries, nq, k, rows_out, dist_out, count_out);
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (nq == 0) return QV_OK;
+    if (!queries || !count_out) return fail(QV_ERR_INVALID_ARG, "queries/count_out is null");
+    if (idx->n_live == 0) { for (uint32_t q = 0; q < nq; q++) count_out[q] = 0; return QV_OK; }
+    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");
+    if (!rows_out || !dist_out) return fail(QV_ERR_INVALID_ARG, "rows_out/dist_out is null");
+    const uint32_t kk = std::min(k, idx->n_live);
+    const qv::IndexView v = idx->view();
+    // the MFMA filter pays off for many queries over a large cosine/dot corpus; everything else
+    // (and any k > 64) takes the exact multi-query scan, which returns the same result
+    if (!qv::batched_supported(v, nq, kk) || kk != k || idx->n_live < 4 * kk)
+        return qv_index_search(idx, queries, nq, k, rows_out, dist_out, count_out);
+    HIPCHK(hipSetDevice(idx->device));
+    SearchCtx* c = nullptr;
+    int rc = acquire_ctx(idx, &c);
+    if (rc != QV_OK) return rc;
+    CtxGuard guard{idx, c};
+    const qv::ScanPlan plan = qv::plan_scan(v.n_tiles, idx->cus);
+    const size_t qbytes = (size_t)nq * idx->dim * sizeof(float);
+    const size_t obytes = (size_t)nq * kk * sizeof(uint32_t);
+    const size_t fbytes = (size_t)nq * sizeof(uint32_t);
+    if ((rc = c->d_q.ensure(qbytes)) || (rc = c->h_q.ensure(qbytes)) || (rc = c->d_rows.ensure(obytes)) || (rc = c->d_dist.ensure(obytes)) ||
+        (rc = c->h_rows.ensure(obytes)) || (rc = c->h_dist.ensure(obytes)) || (rc = c->h_ids.ensure(fbytes)) ||
+        (rc = c->ws.ensure(qv::batched_workspace_bytes(v, plan, nq, kk))))
+        return rc;
+    memcpy(c->h_q.p, queries, qbytes);
+    HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
+    uint32_t* d_ovf = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (idx->profiling && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {
+        std::lock_guard<std::mutex> g(idx->prof_mu);
+        idx->prof_events.emplace_back(ev0, ev1);
+    }
+    hipError_t e = qv::launch_batched(v, plan, static_cast<const float*>(c->d_q.p), nq, kk, c->ws.p, static_cast<uint32_t*>(c->d_rows.p),
+                                      static_cast<float*>(c->d_dist.p), &d_ovf, idx->cus, c->stream, ev0, ev1);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "batched launch failed: %s", hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(c->h_rows.p, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_ids.p, d_ovf, fbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(rows_out, c->h_rows.p, obytes);
+    memcpy(dist_out, c->h_dist.p, obytes);
+    for (uint32_t q = 0; q < nq; q++) count_out[q] = kk;
+    // queries whose candidate buffer overflowed (loose sample bound, e.g. a corpus sorted by cluster):
+    // redo them with the exact scan
+    const uint32_t* ovf = static_cast<const uint32_t*>(c->h_ids.p);
+    std::vector<uint32_t> redo;
+    for (uint32_t q = 0; q < nq; q++) if (ovf[q]) redo.push_back(q);
+    idx->batched_redo += redo.size();
+    guard.c = nullptr; release_ctx(idx, c);                          // qv_index_search takes its own context
+    if (!redo.empty()) {
+        std::vector<float> rq((size_t)redo.size() * idx->dim);
+        for (size_t i = 0; i < redo.size(); i++) memcpy(&rq[i * idx->dim], queries + (size_t)redo[i] * idx->dim, idx->dim * sizeof(float));
+        std::vector<uint32_t> rr((size_t)redo.size() * kk), rc2(redo.size());
+        std::vector<float> rd((size_t)redo.size() * kk);
+        rc = qv_index_search(idx, rq.data(), (uint32_t)redo.size(), kk, rr.data(), rd.data(), rc2.data());
+        if (rc != QV_OK) return rc;
+        for (size_t i = 0; i < redo.size(); i++) {
+            memcpy(rows_out + (size_t)redo[i] * kk, &rr[i * kk], kk * sizeof(uint32_t));
+            memcpy(dist_out + (size_t)redo[i] * kk, &rd[i * kk], kk * sizeof(float));
+        }
+    }
+    return QV_OK;
 }
 
 int qv_distance_rows_device(qv_index* idx, const float* d_query, const uint32_t* d_rows, uint32_t n,

@@ -70,6 +70,15 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
 hipError_t launch_merge_pairs(const float* d_dist, const uint32_t* d_rows, uint32_t n_lists, uint32_t k,
                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 
+// Batched path: fp32-MFMA filter + exact re-scoring (results identical to launch_flat_topk).
+// *d_overflow_out -> [nq] flags (device): 1 = candidate buffer overflowed, caller must redo that
+// query with launch_flat_topk.
+bool   batched_supported(const IndexView& v, uint32_t nq, uint32_t k);
+size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t nq, uint32_t k);
+hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k, void* d_ws,
+                          uint32_t* d_rows_out, float* d_dist_out, uint32_t** d_overflow_out, int cus, hipStream_t s,
+                          hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
 // Full ranking path (any k): all distances -> 64-bit keys -> stable radix sort -> first k.
 // d_keys_a/d_keys_b: two buffers of n_tiles*64 u64; d_hist: radix histogram workspace.
 size_t  full_sort_workspace_bytes(uint32_t n_tiles);

@@ -1,0 +1,96 @@
+"""Batched-query path (BASELINE configs[2]): fp32-MFMA filter + exact re-scoring must return
+exactly what the exact scan returns — same rows, same order, same float32 bits — including
+when the sample bound is loose (candidate overflow -> exact redo), with ties, tombstones and
+zero vectors; and the multi-query exact scan must equal per-query scans."""
+import numpy as np
+import pytest
+
+from tests import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _eq(a, b):
+    return np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1])) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot_product"])
+def test_mfma_batched_equals_exact_scan(metric):
+    import quiver_amd as q
+    n, dim, nq = 300_000, 768, 256
+    idx = q.DeviceIndex(dim, metric)
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    exact = idx.search(qs, 10)
+    batched = idx.search(qs, 10, batched=True)
+    assert _eq(exact, batched)
+    # and against the CPU oracle for a few queries (bit-exact)
+    corpus = O.gen_rows(20260424, 0, n, dim)
+    for i in (0, 17, 255):
+        er, ed = O.exact_search(q.metric_id(metric), corpus, qs[i], 10)
+        assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
+    # other k, fewer queries (not a multiple of 64)
+    for k, m in ((1, 100), (64, 40), (33, 64)):
+        assert _eq(idx.search(qs[:m], k), idx.search(qs[:m], k, batched=True))
+
+
+def test_mfma_batched_with_unrepresentative_sample_ties_and_tombstones():
+    """the first 32K rows (the sample) are all far from the queries, so the sample bound is
+    loose and candidate buffers overflow -> those queries are redone by the exact scan;
+    duplicated rows create exact ties that must come out in row order; dead rows never appear"""
+    import quiver_amd as q
+    dim, nq = 64, 64
+    rng = np.random.default_rng(5)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    far = -np.abs(rng.standard_normal((40_000, dim))).astype(np.float32) * np.sign(qs[0])      # anti-correlated with q0
+    near = (qs[rng.integers(0, nq, 230_000)] + 0.3 * rng.standard_normal((230_000, dim))).astype(np.float32)
+    rows = np.concatenate([far, near])
+    rows[100_000] = rows[100_001] = rows[150_000]          # exact ties
+    rows[200_000] = 0.0                                    # zero vector: cosine distance 1 by definition
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    dead = rng.choice(len(rows), 5000, replace=False).astype(np.uint32)
+    idx.remove(dead)
+    exact = idx.search(qs, 10)
+    batched = idx.search(qs, 10, batched=True)
+    assert _eq(exact, batched)
+    assert not np.isin(batched[0], dead).any()
+    alive = np.ones(len(rows), bool); alive[dead] = False
+    for i in (0, 1, 63):
+        er, ed = O.exact_search(0, rows, qs[i], 10, alive=alive)
+        assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
+
+
+def test_batched_falls_back_when_not_applicable():
+    import quiver_amd as q
+    rows = O.gen_rows(3, 0, 5000, 32)
+    qs = O.gen_rows(4, 0, 70, 32)
+    for metric in ("cosine", "euclidean", "manhattan"):
+        idx = q.DeviceIndex(32, metric)
+        idx.add(rows)
+        assert _eq(idx.search(qs, 5), idx.search(qs, 5, batched=True))          # small corpus / non-GEMM metric -> exact scan
+        assert _eq(idx.search(qs, 200), idx.search(qs, 200, batched=True))      # k > 64 -> full-ranking path
+
+
+@pytest.mark.parametrize("metric", range(9))
+def test_multi_query_scan_equals_single_query_scans(metric):
+    import quiver_amd as q
+    rng = np.random.default_rng(metric)
+    rows = rng.standard_normal((20_000, 100)).astype(np.float32)
+    rows[7] = rows[8]
+    idx = q.DeviceIndex(100, metric)
+    idx.add(rows)
+    idx.remove([3, 4, 5])
+    for nq in (2, 5, 9, 16, 37):
+        qs = rng.standard_normal((nq, 100)).astype(np.float32)
+        many = idx.search(qs, 10)
+        for i in range(nq):
+            one = idx.search(qs[i], 10)
+            assert np.array_equal(many[0][i], one[0][0]) and np.array_equal(_bits(many[1][i]), _bits(one[1][0]))
+    alive = np.ones(20_000, bool); alive[[3, 4, 5]] = False
+    er, ed = O.exact_search(metric, rows, qs[0], 10, alive=alive)
+    assert np.array_equal(many[0][0], er) and np.array_equal(_bits(many[1][0]), _bits(ed))
