@@ -72,7 +72,9 @@ Error ExactIndex::SearchMany(const float* qs, uint32_t len, uint32_t nq, int k, 
     uint32_t kk = (uint32_t)std::min<size_t>((size_t)k, row_of_.size());   // :109-111
     std::vector<uint32_t> rows((size_t)nq * kk), count(nq);
     std::vector<float> dist((size_t)nq * kk);
-    if (qv_index_search(h_, qs, nq, kk, rows.data(), dist.data(), count.data()) != QV_OK) return qv_err();
+    // nq > 1: the batched entry point (MFMA filter + exact re-score when it pays, exact multi-query scan otherwise)
+    if ((nq > 1 ? qv_index_search_batched(h_, qs, nq, kk, rows.data(), dist.data(), count.data())
+                : qv_index_search(h_, qs, nq, kk, rows.data(), dist.data(), count.data())) != QV_OK) return qv_err();
     for (uint32_t q = 0; q < nq; q++) {
         auto& o = (*out)[q];
         o.reserve(count[q]);

@@ -765,14 +765,15 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
                             float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq,
                             uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow) {
     const uint32_t q = blockIdx.x;                     // one block per (padded) query
-    for (uint32_t c = threadIdx.x; c < dim4; c += blockDim.x) {
+    const uint32_t dim4p = (dim4 + 1) & ~1u;           // chunk count padded to even: the MFMA step eats two chunks
+    for (uint32_t c = threadIdx.x; c < dim4p; c += blockDim.x) {
         f4 x = {0.f, 0.f, 0.f, 0.f};
-        if (q < nq) {
+        if (q < nq && c < dim4) {
             const float* src = queries + (size_t)q * dim;
             uint32_t j = 4 * c;
             x.x = j < dim ? src[j] : 0.f; x.y = j + 1 < dim ? src[j + 1] : 0.f; x.z = j + 2 < dim ? src[j + 2] : 0.f; x.w = j + 3 < dim ? src[j + 3] : 0.f;
         }
-        reinterpret_cast<f4*>(Qt)[((size_t)(q >> 5) * dim4 + c) * 32 + (q & 31)] = x;
+        reinterpret_cast<f4*>(Qt)[((size_t)(q >> 5) * dim4p + c) * 32 + (q & 31)] = x;
     }
     if (threadIdx.x == 0) {
         float c_ = __uint_as_float(0x7F800000u), m_ = 0.f;       // padded queries: +inf threshold, nothing passes
@@ -797,7 +798,7 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
 template <int METRIC>
 __global__ void __launch_bounds__(256, 1)
 k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
-              uint32_t* __restrict__ cand_rows, uint32_t* __restrict__ cand_cnt) {
+              uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
     __shared__ float s_c[4][64], s_m[4][64];                        // this wave's 64 queries' filter constants
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -817,8 +818,9 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     const f4* qt = reinterpret_cast<const f4*>(Qt);
     const uint32_t steps = (v.dim4 + 1) / 2;                       // 8 dims per step
-    const f4* a_base0 = qt + ((size_t)(2 * qb64) * v.dim4) * 32 + l31;
-    const f4* a_base1 = qt + ((size_t)(2 * qb64 + 1) * v.dim4) * 32 + l31;
+    const uint32_t dim4p = 2 * steps;                              // Qt is zero-padded to an even chunk count
+    const f4* a_base0 = qt + ((size_t)(2 * qb64) * dim4p) * 32 + l31;
+    const f4* a_base1 = qt + ((size_t)(2 * qb64 + 1) * dim4p) * 32 + l31;
 
     for (uint32_t g = gw / nqb64; g < n_groups; g += stride) {
         const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;     // odd tail: tile duplicated, masked below
@@ -832,17 +834,19 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+        // branch-free operand fetch: a step index past the end re-reads the last step (never used).
+        // For an odd dim4 the upper lane half of the last step reads Qt's zero padding on the A side
+        // and re-reads the last real chunk on the B side (0 * finite = 0).
         auto load = [&](uint32_t st, f4 (&A)[2], f4 (&B)[4]) {
-            uint32_t c = 2 * st + half;
-            const bool okc = c < v.dim4;                           // odd dim4: the upper half of the last step is zero
-            c = okc ? c : v.dim4 - 1;
-            const f4 z = {0.f, 0.f, 0.f, 0.f};
-            A[0] = okc ? a_base0[(size_t)c * 32] : z;
-            A[1] = okc ? a_base1[(size_t)c * 32] : z;
-            B[0] = okc ? __builtin_nontemporal_load(&b0[(size_t)c * 64]) : z;
-            B[1] = okc ? __builtin_nontemporal_load(&b0[(size_t)c * 64 + 32]) : z;
-            B[2] = okc ? __builtin_nontemporal_load(&b1[(size_t)c * 64]) : z;
-            B[3] = okc ? __builtin_nontemporal_load(&b1[(size_t)c * 64 + 32]) : z;
+            const uint32_t sc = st < steps ? st : steps - 1;
+            const uint32_t ca = 2 * sc + half;
+            const uint32_t cb = ca < v.dim4 ? ca : v.dim4 - 1;
+            A[0] = a_base0[(size_t)ca * 32];
+            A[1] = a_base1[(size_t)ca * 32];
+            B[0] = __builtin_nontemporal_load(&b0[(size_t)cb * 64]);
+            B[1] = __builtin_nontemporal_load(&b0[(size_t)cb * 64 + 32]);
+            B[2] = __builtin_nontemporal_load(&b1[(size_t)cb * 64]);
+            B[3] = __builtin_nontemporal_load(&b1[(size_t)cb * 64 + 32]);
         };
         auto mma = [&](const f4 (&A)[2], const f4 (&B)[4]) {
 #pragma unroll
@@ -856,15 +860,15 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         // 3-deep software pipeline over the K steps (operands for steps s+1, s+2 in flight while s computes)
         f4 A0[2], B0[4], A1[2], B1[4], A2[2], B2[4];
         load(0, A0, B0);
-        if (steps > 1) load(1, A1, B1);
+        load(1, A1, B1);
         uint32_t st = 0;
-        for (; st + 3 <= steps; st += 3) {
-            if (st + 2 < steps) load(st + 2, A2, B2);
-            mma(A0, B0);
-            if (st + 3 < steps) load(st + 3, A0, B0);
-            mma(A1, B1);
-            if (st + 4 < steps) load(st + 4, A1, B1);
-            mma(A2, B2);
+        for (; st + 3 <= steps; st += 3) {                          // sched_barrier: keep the issue order as written
+            load(st + 2, A2, B2); __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the loads next to their
+            mma(A0, B0);          __builtin_amdgcn_sched_barrier(0);   //  first use and waits vmcnt(0) mid-loop)
+            load(st + 3, A0, B0); __builtin_amdgcn_sched_barrier(0);
+            mma(A1, B1);          __builtin_amdgcn_sched_barrier(0);
+            load(st + 4, A1, B1); __builtin_amdgcn_sched_barrier(0);
+            mma(A2, B2);          __builtin_amdgcn_sched_barrier(0);
         }
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
@@ -894,7 +898,10 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
                         if (acc[i][j][r] >= thr) {
                             const uint32_t q = 64 * qb64 + ql;
                             uint32_t slot = atomicAdd(&cand_cnt[q], 1u);
-                            if (slot < (uint32_t)kMfmaCandCap) cand_rows[(size_t)q * kMfmaCandCap + slot] = row;
+                            if (slot < (uint32_t)kMfmaCandCap) {
+                                cand_rows[(size_t)q * kMfmaCandCap + slot] = row;
+                                cand_score[(size_t)q * kMfmaCandCap + slot] = acc[i][j][r];
+                            }
                         }
                     }
                 }
@@ -903,31 +910,85 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
     }
 }
 
-// exact re-scoring of one query's candidates + top-k; one workgroup per query
+// Exact re-scoring of one query's candidates + top-k; one workgroup per query.
+// Stage 1 narrows the candidates with their fp32 scores: with d~ the approximate distance and
+// e_r its error bound, d_r is in [d~ - e_r, d~ + e_r]; let H be the k-th smallest upper bound
+// over the candidates (which contain the true top-k).  Then the true k-th distance is <= H, so
+// only candidates with lower bound <= H can be in the answer — typically k..k+2 of hundreds.
+// Stage 2 re-scores those exactly (same arithmetic as k_flat_scan) and sorts them.
 template <int M, int U>
 __global__ void __launch_bounds__(256)
-k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ cand_rows, const uint32_t* __restrict__ cand_cnt,
-                 uint32_t k, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ overflow) {
+k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_score,
+                 const uint32_t* __restrict__ cand_cnt, uint32_t k, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out,
+                 uint32_t* __restrict__ overflow) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
-    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);   // [4][64]
+    uint32_t* surv = reinterpret_cast<uint32_t*>(wl + 4 * 64);                                               // [kMfmaCandCap]
+    __shared__ uint32_t s_ns;
+    __shared__ float s_H;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t qi = blockIdx.x;
     const uint32_t cnt = cand_cnt[qi];
     if (cnt > (uint32_t)kMfmaCandCap) { if (threadIdx.x == 0) overflow[qi] = 1; return; }
     stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
+    if (threadIdx.x == 0) s_ns = 0;
     __syncthreads();
-    const QConst qc = query_const<M>(q_lds, v.dim);
+    const QConst qc = query_const<M>(q_lds, v.dim);                 // exact |q| (every lane, same value)
     const uint32_t kth = k - 1;
-    uint64_t list = kDeadKey, thr = kDeadKey;
     const uint32_t* cr = cand_rows + (size_t)qi * kMfmaCandCap;
+    const float* cs = cand_score + (size_t)qi * kMfmaCandCap;
+    const double gamma = (double)(v.dim + 2) * 5.9604644775390625e-8 / (1.0 - (double)(v.dim + 2) * 5.9604644775390625e-8);
+
+    // ---- stage 1: H = k-th smallest upper bound
+    auto bounds = [&](uint32_t i, float& lo, float& hi) {
+        const uint32_t row = cr[i];
+        const double rn = v.rnorm[row], S = (double)cs[i];
+        double d, e;
+        if constexpr (M == QV_COSINE) {
+            if (qc.qn == 0.0 || rn == 0.0) { d = 1.0; e = 0.0; }
+            else { d = 1.0 - S / (qc.qn * rn); e = gamma + 2e-6; }  // |S~ - S| <= gamma |q||r|
+        } else {
+            d = 1.0 - S; e = gamma * qc.qn * rn + 2e-6 * (1.0 + __builtin_fabs(d));
+        }
+        lo = f32_down((float)(d - e)); hi = f32_up((float)(d + e));
+        if (!(d == d)) { lo = -__builtin_inff(); hi = __builtin_inff(); }   // NaN score: keep, the exact pass decides
+    };
+    uint64_t list = kDeadKey, thr = kDeadKey;
     for (uint32_t base = wave * 64; base < cnt; base += 4 * 64) {
         const uint32_t i = base + lane;
         uint64_t key = kDeadKey;
-        if (i < cnt) {
-            const uint32_t row = cr[i];
+        if (i < cnt) { float lo, hi; bounds(i, lo, hi); key = make_key(hi, i); }
+        list_insert(list, thr, key, kth, lane);
+    }
+    wl[wave * 64 + lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        for (uint32_t w = 1; w < 4; w++) {
+            uint64_t key = lane < k ? wl[w * 64 + lane] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        const uint64_t kk = readlane64(list, kth);
+        if (lane == 0) s_H = kk == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(kk >> 32));   // < k candidates: keep all
+    }
+    __syncthreads();
+    const float H = s_H;
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        float lo, hi; bounds(i, lo, hi);
+        if (lo <= H) surv[atomicAdd(&s_ns, 1u)] = cr[i];
+    }
+    __syncthreads();
+    const uint32_t ns = s_ns;
+
+    // ---- stage 2: exact distances of the survivors, top-k by (distance, row)
+    list = kDeadKey; thr = kDeadKey;
+    for (uint32_t base = wave * 64; base < ns; base += 4 * 64) {
+        const uint32_t i = base + lane;
+        uint64_t key = kDeadKey;
+        if (i < ns) {
+            const uint32_t row = surv[i];
             const f4* p = reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63);
             typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
             double rn = 0.0;
@@ -936,6 +997,7 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
         }
         list_insert(list, thr, key, kth, lane);
     }
+    __syncthreads();
     wl[wave * 64 + lane] = list;
     __syncthreads();
     if (wave == 0) {
@@ -1233,7 +1295,7 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
 
 // ---- MFMA batched path --------------------------------------------------------------
 uint32_t batched_sample_rows(uint32_t n_rows) {
-    static const int s = env_int("QV_MFMA_SAMPLE_ROWS", 32768);
+    static const int s = env_int("QV_MFMA_SAMPLE_ROWS", 8192);
     return std::min<uint32_t>(n_rows, (uint32_t)s);
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
@@ -1244,9 +1306,9 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     const uint32_t nq_pad = (nq + 63) / 64 * 64;
     size_t b = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);   // sample scan (partials + query blocks)
     b = (b + 255) / 256 * 256;
-    b += (size_t)nq_pad * v.dim4 * 16;                       // Qt
+    b += (size_t)nq_pad * (v.dim4 + 1) * 16;                 // Qt (chunk count padded to even)
     b += (size_t)nq_pad * 8;                                 // cq, mq
-    b += (size_t)nq * kMfmaCandCap * 4;                      // candidates
+    b += (size_t)nq * kMfmaCandCap * 8;                      // candidates: rows + fp32 scores
     b += (size_t)nq * 8;                                     // counters, overflow flags
     b += (size_t)nq * k * 8;                                 // sample rows/dist
     return b + 1024;
@@ -1259,10 +1321,11 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     char* w = static_cast<char*>(d_ws);
     size_t off = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);
     off = (off + 255) / 256 * 256;
-    float* Qt = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * v.dim4 * 16;
+    float* Qt = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * (v.dim4 + 1) * 16;
     float* cq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 4;
     float* mq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 4;
     uint32_t* cand = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * kMfmaCandCap * 4;
+    float* cscore = reinterpret_cast<float*>(w + off); off += (size_t)nq * kMfmaCandCap * 4;
     uint32_t* cnt = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
     uint32_t* ovf = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
     uint32_t* srows = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * k * 4;
@@ -1281,17 +1344,17 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     uint32_t grid = (uint32_t)cus;                                     // one 4-wave workgroup per CU (512-register waves)
     while ((grid * 4) % nqb64) grid++;                                 // every query block gets the same number of waves
     if (ev0) (void)hipEventRecord(ev0, s);
-    if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_mfma_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cnt);
-    else hipLaunchKernelGGL(k_mfma_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cnt);
+    if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_mfma_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+    else hipLaunchKernelGGL(k_mfma_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
     if (ev1) (void)hipEventRecord(ev1, s);
     // 4. exact re-scoring + selection
-    const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t);
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * sizeof(uint32_t);
     if (v.metric == QV_COSINE) {
         e = set_lds(k_rescore_select<QV_COSINE, 8>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_rescore_select<QV_COSINE, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cnt, k, d_rows_out, d_dist_out, ovf);
+        hipLaunchKernelGGL((k_rescore_select<QV_COSINE, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf);
     } else {
         e = set_lds(k_rescore_select<QV_DOT, 8>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_rescore_select<QV_DOT, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cnt, k, d_rows_out, d_dist_out, ovf);
+        hipLaunchKernelGGL((k_rescore_select<QV_DOT, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf);
     }
     *d_overflow_out = ovf;
     return hipGetLastError();
