@@ -174,6 +174,29 @@ int qv_merge_topk_device(const float* d_dist_lists, const uint32_t* d_row_lists,
 int qv_index_profile(qv_index* idx, int enable);
 int qv_index_profile_read(qv_index* idx, double* scan_ms_sum_out, uint64_t* launches_out);
 
+/* ---- device-resident HNSW traversal ------------------------------------------------
+ * Replaces hnsw.HNSW.Search (pkg/hnsw/hnsw.go:602-713) for a batch of queries: the graph a
+ * host-side HNSW built (levels + per-level adjacency, hnsw.go:44-56) is uploaded once, then
+ * whole queries are walked on the GPU, one wavefront per query, many in flight.  Node index
+ * == row of `idx` (the index must hold the nodes' vectors; QV_FLAG_ROWMAJOR makes the
+ * per-hop row gathers contiguous).  Results equal the reference's searchLayer semantics
+ * exactly (same heaps, same admission order, bit-identical distances).
+ *   levels     [n_nodes]            node level, -1 = tombstone (hnsw.go:829 Nodes[idx] = nil)
+ *   l0_deg     [n_nodes]            level-0 degree;  l0_links [n_nodes][max_m0]
+ *   up_off     [n_nodes]            first upper-level block of the node (level 1)
+ *   up_links   [n_up_blocks][1+max_m]  per (node, level>=1): degree, then links
+ * qv_graph_search: count_out[q] = results written (< k when the graph search under-filled:
+ * the caller tops up like hnsw.go:676-710) or 0xFFFFFFFF when the candidate heap overflowed
+ * (the caller must fall back to its host traversal).  evals_out (optional) = distance
+ * evaluations per query. */
+typedef struct qv_graph qv_graph;
+int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_t* levels, uint32_t max_m0, uint32_t max_m,
+                    const uint32_t* l0_deg, const uint32_t* l0_links, const uint32_t* up_off, const uint32_t* up_links,
+                    uint32_t n_up_blocks, uint32_t entry, int cur_level);
+int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+                    uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out);
+void qv_graph_destroy(qv_graph* g);
+
 /* Copy row `row` back to the host (ExactIndex keeps vectors readable,
  * hybrid_index.go:537 reads idx.vectors[id] for the re-rank). */
 int qv_index_get_row(qv_index* idx, uint32_t row, float* vec_out);

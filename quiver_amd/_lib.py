@@ -59,6 +59,10 @@ PROTOTYPES = {
     "qv_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_index_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "qv_index_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "qv_graph_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
+    "qv_graph_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qv_graph_destroy": (None, [C.c_void_p]),
     "qv_index_get_row": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "qv_last_error": (C.c_char_p, []),
     "qv_abi_version": (C.c_int, []),

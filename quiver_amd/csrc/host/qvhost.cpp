@@ -117,7 +117,7 @@ HNSW::HNSW(qv_metric metric, int device, const HNSWConfig& c) : metric_(metric),
     maxLevel_ = c.MaxLevel > 0 ? c.MaxLevel : 16;                      // :235-237
     rng_ = c.seed;
 }
-HNSW::~HNSW() { if (h_) qv_index_destroy(h_); }
+HNSW::~HNSW() { if (dg_) qv_graph_destroy(dg_); if (h_) qv_index_destroy(h_); }
 
 const std::vector<uint32_t>* HNSW::Links(uint32_t n, int level) const {
     if (!ok(n) || level < 0 || level > nodes_[n].level) return nullptr;
@@ -287,15 +287,16 @@ Error HNSW::Insert(const std::string& id, const float* v, uint32_t len) {   // h
     if (by_id_.count(id)) return fmt("vector with ID %s already exists", id.c_str());   // :269-272
     if (!h_) {
         if (len == 0) return "vector dimensions do not match";
-        if (qv_index_create(&h_, len, metric_, device_, 0) != QV_OK) return qv_err();
+        if (qv_index_create(&h_, len, metric_, device_, QV_FLAG_ROWMAJOR) != QV_OK) return qv_err();   // row gathers are this index's hot path
         dim_ = (int)len;
     } else if ((int)len != dim_) {
         if (size_ != 0) return "vector dimensions do not match";       // adapter.go:168 ErrDimensionMismatch from the distance func
         // every node is a tombstone: Go slices carry no dimension, so a new one is fine.
         // Rebuild the device index at the new dimension, keeping row == node index.
         if (len == 0) return "vector dimensions do not match";
+        if (dg_) { qv_graph_destroy(dg_); dg_ = nullptr; }
         qv_index_destroy(h_); h_ = nullptr;
-        if (qv_index_create(&h_, len, metric_, device_, 0) != QV_OK) return qv_err();
+        if (qv_index_create(&h_, len, metric_, device_, QV_FLAG_ROWMAJOR) != QV_OK) return qv_err();
         dim_ = (int)len;
         if (!nodes_.empty()) {
             std::vector<float> zeros((size_t)nodes_.size() * len, 0.f);
@@ -306,6 +307,7 @@ Error HNSW::Insert(const std::string& id, const float* v, uint32_t len) {   // h
             if (qv_index_remove(h_, dead.data(), (uint32_t)dead.size()) != QV_OK) return qv_err();
         }
     }
+    dg_dirty_ = true;
     int level = RandomLevel();                                         // :275
     int oldLevel = cur_level_;                                         // :276
     uint32_t row = 0;
@@ -333,6 +335,7 @@ Error HNSW::Delete(const std::string& id) {                            // hnsw.g
     if (it == by_id_.end()) return fmt("vector with ID %s not found", id.c_str());   // :745-749
     uint32_t idx = it->second;
     if (!ok(idx)) return fmt("vector index %u is invalid", idx);       // :752-755
+    dg_dirty_ = true;
     Node& nd = nodes_[idx];
     for (int level = 0; level <= nd.level; level++) {                  // :762
         if (level >= (int)nd.conn.size()) continue;
@@ -406,6 +409,106 @@ Error HNSW::Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>*
         if ((int)buf.size() > k) buf.resize(k);
     }
     for (auto& r : buf) out->push_back({nodes_[r.idx].id, r.dist, r.idx});
+    return "";
+}
+
+// flatten the host graph into the arrays qv_graph_create takes and upload it
+Error HNSW::syncDeviceGraph() {
+    if (dg_ && !dg_dirty_) return "";
+    if (dg_) { qv_graph_destroy(dg_); dg_ = nullptr; }
+    const uint32_t n = (uint32_t)nodes_.size();
+    uint32_t entry = entry_;
+    if (!ok(entry)) {                                                  // hnsw.go:621-629
+        uint32_t i; for (i = 0; i < n; i++) if (nodes_[i].alive) { entry = i; break; }
+        if (i == n) return "graph has no live node";
+    }
+    std::vector<int8_t> levels(n);
+    std::vector<uint32_t> l0deg(n), l0links((size_t)n * maxM0_, 0), upoff(n, 0), uplinks;
+    uint32_t blocks = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const Node& nd = nodes_[i];
+        levels[i] = nd.alive ? (int8_t)nd.level : (int8_t)-1;
+        if (!nd.alive) continue;
+        if ((int)nd.conn[0].size() > maxM0_) return "level-0 degree exceeds MaxM0";
+        l0deg[i] = (uint32_t)nd.conn[0].size();
+        std::copy(nd.conn[0].begin(), nd.conn[0].end(), l0links.begin() + (size_t)i * maxM0_);
+        if (nd.level >= 1) {
+            upoff[i] = blocks;
+            for (int l = 1; l <= nd.level; l++) {
+                if ((int)nd.conn[l].size() > M_) return "upper-level degree exceeds M";
+                uplinks.push_back((uint32_t)nd.conn[l].size());
+                for (int j = 0; j < M_; j++) uplinks.push_back(j < (int)nd.conn[l].size() ? nd.conn[l][j] : 0u);
+                blocks++;
+            }
+        }
+    }
+    if (uplinks.empty()) uplinks.assign((size_t)1 + M_, 0);
+    if (qv_graph_create(&dg_, h_, n, levels.data(), (uint32_t)maxM0_, (uint32_t)M_, l0deg.data(), l0links.data(), upoff.data(), uplinks.data(),
+                        std::max(blocks, 1u), entry, cur_level_) != QV_OK) return qv_err();
+    dg_dirty_ = false;
+    return "";
+}
+
+Error HNSW::SearchBatch(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<HNSWResult>>* out, std::vector<uint32_t>* evals_out) {
+    out->assign(nq, {});
+    if (evals_out) evals_out->assign(nq, 0);
+    if (nodes_.empty() || nq == 0) return "";                          // hnsw.go:606-608
+    if (k <= 0) return "k must be positive";                           // :610-612
+    if ((int)len != dim_) return "vector dimensions do not match";
+    if (k > (int)nodes_.size()) k = (int)nodes_.size();                // :615-617
+    if (size_ == 0) return "";                                         // :632-634
+    Error e = syncDeviceGraph();
+    if (!e.empty()) return e;
+    std::vector<uint32_t> rows((size_t)nq * k), cnt(nq), ev(nq);
+    std::vector<float> dist((size_t)nq * k);
+    if (k > 512 || efS_ > 512) { std::fill(cnt.begin(), cnt.end(), 0xFFFFFFFFu); }
+    else if (qv_graph_search(dg_, qs, nq, (uint32_t)k, (uint32_t)efS_, rows.data(), dist.data(), cnt.data(), ev.data()) != QV_OK) return qv_err();
+    std::vector<uint32_t> underfilled;
+    for (uint32_t q = 0; q < nq; q++) {
+        if (cnt[q] == (uint32_t)k) {
+            auto& o = (*out)[q];
+            for (int i = 0; i < k; i++) { uint32_t r = rows[(size_t)q * k + i]; o.push_back({nodes_[r].id, dist[(size_t)q * k + i], r}); }
+            if (evals_out) (*evals_out)[q] = ev[q];
+            n_evals_ += ev[q];
+        } else if (cnt[q] != 0xFFFFFFFFu) {
+            underfilled.push_back(q);                                  // graph search under-filled: exact top-up (hnsw.go:676-710)
+            if (evals_out) (*evals_out)[q] = ev[q];
+        } else {                                                       // device heap overflow: host traversal
+            device_fallbacks_++;
+            e = Search(qs + (size_t)q * len, len, k, &(*out)[q]);
+            if (!e.empty()) return e;
+        }
+    }
+    // Top-up = existing results + every other live node, sorted by (Distance, VectorID), first k
+    // (hnsw.go:676-710) — i.e. the exact top-k of all live nodes under that order.  One flat-scan
+    // call for all under-filled queries; ties at equal distance are re-ordered by id string, and
+    // the fetch is widened until the k-th distance's tie group is complete.
+    topups_ += (uint32_t)underfilled.size();
+    if (!underfilled.empty()) {
+        const uint32_t m = (uint32_t)underfilled.size();
+        std::vector<float> packed((size_t)m * len);
+        for (uint32_t j = 0; j < m; j++) memcpy(&packed[(size_t)j * len], qs + (size_t)underfilled[j] * len, len * sizeof(float));
+        uint32_t kk = std::min<uint32_t>(size_, (uint32_t)k + 8);
+        for (;;) {
+            std::vector<uint32_t> r2((size_t)m * kk), c2(m); std::vector<float> d2((size_t)m * kk);
+            if (qv_index_search_batched(h_, packed.data(), m, kk, r2.data(), d2.data(), c2.data()) != QV_OK) return qv_err();
+            bool widen = false;
+            for (uint32_t j = 0; j < m && !widen; j++)
+                if ((uint32_t)k < c2[j] && c2[j] == kk && kk < size_ && d2[(size_t)j * kk + k - 1] == d2[(size_t)j * kk + kk - 1]) widen = true;
+            if (widen) { kk = std::min<uint32_t>(size_, kk * 2); continue; }
+            for (uint32_t j = 0; j < m; j++) {
+                std::vector<HNSWResult> all;
+                for (uint32_t i = 0; i < c2[j]; i++) { uint32_t r = r2[(size_t)j * kk + i]; all.push_back({nodes_[r].id, d2[(size_t)j * kk + i], r}); }
+                std::stable_sort(all.begin(), all.end(), [](const HNSWResult& a, const HNSWResult& b) {          // :699-704
+                    if (a.distance == b.distance) return a.id < b.id;
+                    return a.distance < b.distance;
+                });
+                if ((int)all.size() > k) all.resize(k);
+                (*out)[underfilled[j]] = std::move(all);
+            }
+            break;
+        }
+    }
     return "";
 }
 
@@ -739,6 +842,21 @@ int qvh_hnsw_search(void* p, const float* q, uint32_t len, int k, void* res, uin
     for (size_t i = 0; i < hr.size(); i++) { r.push_back({hr[i].id, hr[i].distance}); if (idx_out) idx_out[i] = hr[i].index; }
     return ret(e);
 }
+int qvh_hnsw_search_batch(void* p, const float* qs, uint32_t len, uint32_t nq, int k, void* res, uint32_t* idx_out, uint32_t* evals_out) {
+    std::vector<std::vector<HNSWResult>> hr; std::vector<uint32_t> ev;
+    Error e = static_cast<HNSW*>(p)->SearchBatch(qs, len, nq, k, &hr, &ev);
+    auto& many = static_cast<Results*>(res)->many; many.assign(hr.size(), {});
+    auto& used = static_cast<Results*>(res)->used; used.assign(hr.size(), "hnsw");
+    for (size_t q = 0; q < hr.size(); q++)
+        for (size_t i = 0; i < hr[q].size(); i++) {
+            many[q].push_back({hr[q][i].id, hr[q][i].distance});
+            if (idx_out) idx_out[q * (size_t)k + i] = hr[q][i].index;
+        }
+    if (evals_out) for (size_t q = 0; q < ev.size(); q++) evals_out[q] = ev[q];
+    return ret(e);
+}
+uint32_t qvh_hnsw_device_fallbacks(void* p) { return static_cast<HNSW*>(p)->DeviceFallbacks(); }
+uint32_t qvh_hnsw_topups(void* p) { return static_cast<HNSW*>(p)->TopUps(); }
 uint32_t qvh_hnsw_size(void* p) { return static_cast<HNSW*>(p)->Size(); }
 uint32_t qvh_hnsw_nodes(void* p) { return static_cast<HNSW*>(p)->Nodes(); }
 int qvh_hnsw_node_level(void* p, uint32_t n) { return static_cast<HNSW*>(p)->NodeLevel(n); }

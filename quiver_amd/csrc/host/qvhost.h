@@ -69,6 +69,12 @@ public:
     Error Insert(const std::string& id, const float* v, uint32_t len);                 // hnsw.go:266-334
     Error Delete(const std::string& id);                                               // hnsw.go:741-842
     Error Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>* out);   // hnsw.go:602-713
+    // nq searches walked on the device, one wavefront per query (qv_graph_search); a query whose
+    // graph search under-fills (hnsw.go:676) or overflows the device heap is redone by Search()
+    Error SearchBatch(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<HNSWResult>>* out,
+                      std::vector<uint32_t>* evals_out = nullptr);
+    uint32_t DeviceFallbacks() const { return device_fallbacks_; }   // heap overflows redone on the host
+    uint32_t TopUps() const { return topups_; }                       // under-filled graph searches completed by an exact scan
     uint32_t Size() const { return size_; }
     // introspection for graph-equality tests
     uint32_t Nodes() const { return (uint32_t)nodes_.size(); }
@@ -103,6 +109,8 @@ private:
     uint64_t rng_;
     std::vector<uint32_t> visited_; uint32_t epoch_ = 0;
     uint64_t n_calls_ = 0, n_evals_ = 0;
+    qv_graph* dg_ = nullptr; bool dg_dirty_ = true; uint32_t device_fallbacks_ = 0, topups_ = 0;
+    Error syncDeviceGraph();
 };
 
 class HNSWAdapter {          // pkg/hnsw/adapter.go + pkg/hybrid/hnsw_adapter.go

@@ -109,6 +109,18 @@ struct qv_index {
     size_t tile_bytes() const { return (size_t)dim4 * 64 * 16; }
 };
 
+struct qv_graph {
+    qv_index* idx = nullptr;
+    qv::GraphView g{};
+    void *d_level = nullptr, *d_l0deg = nullptr, *d_l0links = nullptr, *d_upoff = nullptr, *d_uplinks = nullptr;
+    uint32_t* d_visited = nullptr;
+    uint32_t grid = 0;
+    uint32_t epoch = 0;
+    std::mutex mu;                              // one batch at a time (the visited stamps are per wave slot)
+    hipStream_t stream = nullptr;
+    Buf d_q, d_rows, d_dist, d_cnt, d_ev;
+};
+
 namespace {
 
 int acquire_ctx(qv_index* idx, SearchCtx** out) {
@@ -624,6 +636,90 @@ int qv_distance_rows(qv_index* idx, const float* query, const uint32_t* rows, ui
     HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(dist_out, c->h_dist.p, obytes);
+    return QV_OK;
+}
+
+int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_t* levels, uint32_t max_m0, uint32_t max_m,
+                    const uint32_t* l0_deg, const uint32_t* l0_links, const uint32_t* up_off, const uint32_t* up_links,
+                    uint32_t n_up_blocks, uint32_t entry, int cur_level) {
+    if (!out) return fail(QV_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!idx || !levels || !l0_deg || !l0_links || !up_off) return fail(QV_ERR_INVALID_ARG, "null argument");
+    if (n_nodes == 0 || n_nodes > idx->n_rows) return fail(QV_ERR_INVALID_ARG, "graph has %u nodes but the index holds %u rows", n_nodes, idx->n_rows);
+    if (max_m0 == 0 || max_m0 > 64 || max_m > 64) return fail(QV_ERR_UNSUPPORTED, "degree bounds above 64 are not supported (MaxM0=%u, M=%u)", max_m0, max_m);
+    if (entry >= n_nodes || levels[entry] < 0) return fail(QV_ERR_INVALID_ARG, "entry point %u is not a live node", entry);
+    HIPCHK(hipSetDevice(idx->device));
+    qv_graph* g = new (std::nothrow) qv_graph();
+    if (!g) return fail(QV_ERR_OOM, "out of host memory");
+    g->idx = idx;
+    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(&g->d_level, levels, (size_t)n_nodes);
+    if (e == hipSuccess) e = up(&g->d_l0deg, l0_deg, (size_t)n_nodes * 4);
+    if (e == hipSuccess) e = up(&g->d_l0links, l0_links, (size_t)n_nodes * max_m0 * 4);
+    if (e == hipSuccess) e = up(&g->d_upoff, up_off, (size_t)n_nodes * 4);
+    if (e == hipSuccess) e = up(&g->d_uplinks, up_links, (size_t)n_up_blocks * (1 + max_m) * 4);
+    // visited stamps: one uint32 per (wave slot, node) — sized for 288 GB HBM: 5 GB at 1M nodes x 1280 slots
+    g->grid = qv::hnsw_grid(idx->cus, idx->metric, idx->dim4, 0xFFFFFFFFu);
+    while (g->grid > 64 && (size_t)g->grid * n_nodes * 4 > ((size_t)16 << 30)) g->grid /= 2;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_visited), (size_t)g->grid * n_nodes * 4);
+    if (e == hipSuccess) e = hipMemset(g->d_visited, 0, (size_t)g->grid * n_nodes * 4);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { qv_graph_destroy(g); return fail(e == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "graph upload failed: %s", hipGetErrorString(e)); }
+    g->g.level = static_cast<const int8_t*>(g->d_level); g->g.l0_deg = static_cast<const uint32_t*>(g->d_l0deg);
+    g->g.l0_links = static_cast<const uint32_t*>(g->d_l0links); g->g.up_off = static_cast<const uint32_t*>(g->d_upoff);
+    g->g.up_links = static_cast<const uint32_t*>(g->d_uplinks);
+    g->g.n_nodes = n_nodes; g->g.max_m0 = max_m0; g->g.max_m = max_m ? max_m : 1; g->g.entry = entry; g->g.cur_level = cur_level;
+    *out = g;
+    return QV_OK;
+}
+
+void qv_graph_destroy(qv_graph* g) {
+    if (!g) return;
+    if (g->idx) (void)hipSetDevice(g->idx->device);
+    if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    (void)hipFree(g->d_level); (void)hipFree(g->d_l0deg); (void)hipFree(g->d_l0links); (void)hipFree(g->d_upoff); (void)hipFree(g->d_uplinks);
+    (void)hipFree(g->d_visited);
+    g->d_q.release(); g->d_rows.release(); g->d_dist.release(); g->d_cnt.release(); g->d_ev.release();
+    delete g;
+}
+
+int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+                    uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out) {
+    if (!g) return fail(QV_ERR_INVALID_ARG, "graph is null");
+    if (nq == 0) return QV_OK;
+    if (!queries || !rows_out || !dist_out || !count_out) return fail(QV_ERR_INVALID_ARG, "null argument");
+    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");                      // hnsw.go:610-612
+    if (k > 512 || ef_search > 512) return fail(QV_ERR_UNSUPPORTED, "k and efSearch above 512 are not supported on the device path");
+    qv_index* idx = g->idx;
+    HIPCHK(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> lock(g->mu);
+    const size_t qbytes = (size_t)nq * idx->dim * sizeof(float), obytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
+    int rc;
+    if ((rc = g->d_q.ensure(qbytes)) || (rc = g->d_rows.ensure(obytes)) || (rc = g->d_dist.ensure(obytes)) || (rc = g->d_cnt.ensure(cbytes)) ||
+        (rc = g->d_ev.ensure(cbytes)))
+        return rc;
+    const uint32_t grid = std::min(g->grid, nq);
+    const uint32_t per_wave = (nq + grid - 1) / grid;
+    const uint64_t need = (uint64_t)per_wave * 128 + 128;                 // stamps consumed by this batch per wave slot
+    if ((uint64_t)g->epoch + need >= 0xFFFFFF00ull) {                      // wrap: clear and restart
+        HIPCHK(hipMemsetAsync(g->d_visited, 0, (size_t)g->grid * g->g.n_nodes * 4, g->stream));
+        g->epoch = 0;
+    }
+    HIPCHK(hipMemcpyAsync(g->d_q.p, queries, qbytes, hipMemcpyHostToDevice, g->stream));
+    hipError_t e = qv::launch_hnsw_search(idx->view(), g->g, static_cast<const float*>(g->d_q.p), nq, k, ef_search, g->d_visited, grid, g->epoch,
+                                          static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
+                                          static_cast<uint32_t*>(g->d_ev.p), g->stream);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+    g->epoch += (uint32_t)need;
+    HIPCHK(hipMemcpyAsync(rows_out, g->d_rows.p, obytes, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipMemcpyAsync(dist_out, g->d_dist.p, obytes, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipMemcpyAsync(count_out, g->d_cnt.p, cbytes, hipMemcpyDeviceToHost, g->stream));
+    if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, g->d_ev.p, cbytes, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
     return QV_OK;
 }
 

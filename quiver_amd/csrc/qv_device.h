@@ -35,6 +35,16 @@ struct IndexView {
     int       metric;
 };
 
+struct GraphView {
+    const int8_t*   level;      // [n] node level, -1 = tombstone
+    const uint32_t* l0_deg;     // [n]
+    const uint32_t* l0_links;   // [n][max_m0]
+    const uint32_t* up_off;     // [n] first block of the node's upper levels (level 1 -> block up_off[n])
+    const uint32_t* up_links;   // blocks of (1 + max_m): degree, links
+    uint32_t n_nodes, max_m0, max_m;
+    uint32_t entry; int cur_level;
+};
+
 struct ScanPlan {
     uint32_t grid;        // workgroups
     uint32_t block;       // threads (multiple of 64)
@@ -78,6 +88,13 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
 hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k, void* d_ws,
                           uint32_t* d_rows_out, float* d_dist_out, uint32_t** d_overflow_out, int cus, hipStream_t s,
                           hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
+// Device-resident HNSW traversal (hnsw.go:471-713), one wave per query.
+size_t   hnsw_lds_bytes(int metric, uint32_t dim4);
+uint32_t hnsw_grid(int cus, int metric, uint32_t dim4, uint32_t nq);
+hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
+                              uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                              uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s);
 
 // Full ranking path (any k): all distances -> 64-bit keys -> stable radix sort -> first k.
 // d_keys_a/d_keys_b: two buffers of n_tiles*64 u64; d_hist: radix histogram workspace.

@@ -63,6 +63,26 @@ class HNSW:
         check(hlib().qvh_hnsw_search(self._h, q.ctypes.data, q.size, k, r.h, idx.ctypes.data))
         return [Result(i, d, int(idx[j])) for j, (i, d) in enumerate(r.list())]
 
+    def SearchBatch(self, queries, k: int, with_evals: bool = False):
+        """nq searches walked on the device (one wavefront per query); same results as Search()"""
+        qs = np.ascontiguousarray(queries, dtype=np.float32)
+        if qs.ndim == 1:
+            qs = qs[None, :]
+        nq, n = qs.shape
+        r = Results()
+        idx = np.zeros((nq, max(k, 1)), dtype=np.uint32)
+        ev = np.zeros(nq, dtype=np.uint32)
+        check(hlib().qvh_hnsw_search_batch(self._h, qs.ctypes.data, n, nq, k, r.h, idx.ctypes.data, ev.ctypes.data))
+        many, _ = r.many()
+        out = [[Result(i, d, int(idx[q, j])) for j, (i, d) in enumerate(many[q])] for q in range(nq)]
+        return (out, ev) if with_evals else out
+
+    def device_fallbacks(self) -> int:
+        return int(hlib().qvh_hnsw_device_fallbacks(self._h))
+
+    def topups(self) -> int:
+        return int(hlib().qvh_hnsw_topups(self._h))
+
     def Size(self) -> int:
         return hlib().qvh_hnsw_size(self._h)
 

@@ -420,3 +420,51 @@ def test_arrow_ipc_load_to_device_and_search(tmp_path):          # index/arrow_h
     for i, name in enumerate("abc"):
         axes.Add(np.eye(3, dtype=np.float32)[i], name)
     assert all(abs(r.Distance - 1.0) < 1e-6 for r in axes.Search(np.zeros(3, np.float32), 3))
+
+
+# ------------------------------------------------------------------ device-resident HNSW traversal ---
+
+@pytest.mark.parametrize("metric", [6, 0, 5, 3])
+@pytest.mark.parametrize("max_level", [16, 1])
+def test_hnsw_device_traversal_identical_to_oracle(metric, max_level):
+    """qv_graph_search: whole queries walked on the GPU, one wavefront each — same rows, order,
+    float32 bits and distance-evaluation counts as the CPU restatement of hnsw.go:602-713.
+    With the reference's default levels many level-0 searches under-fill (multi-level nodes keep
+    only self-links below their top level, hnsw.go:463-467) and are topped up by a brute-force pass
+    (hnsw.go:676-710): those queries come back through the host path.  MaxLevel=1 gives a
+    single-layer graph where that never happens, so every query stays on the device."""
+    rows = O.gen_rows(141 + metric, 0, 3000, 64)
+    h, o = _build_both(metric, rows, seed=21, EfConstruction=60, EfSearch=48, MaxLevel=max_level)
+    qs = O.gen_rows(151, 0, 100, 64)
+    res, ev = h.SearchBatch(qs, 10, with_evals=True)
+    full = 0
+    for i, q in enumerate(qs):
+        er, ed, ne = o.search(q, 10, with_evals=True)
+        assert [r.VectorIndex for r in res[i]] == er.tolist(), i
+        assert np.array_equal(_bits([r.Distance for r in res[i]]), _bits(ed))
+        if ne < 3000:                          # no brute-force top-up in the oracle: evaluation counts must agree
+            full += 1
+            assert int(ev[i]) == ne - 1        # the reference also evaluates the entry point once more up front (hnsw.go:637)
+    assert h.device_fallbacks() == 0 and full + h.topups() == 100 and full > 0
+    if max_level == 1:
+        assert h.topups() == 0
+    one = h.Search(qs[0], 10)                  # the host-driven traversal agrees too
+    assert [r.VectorIndex for r in one] == [r.VectorIndex for r in res[0]]
+
+
+def test_hnsw_device_traversal_after_deletes_falls_back_for_topup():
+    rows = O.gen_rows(161, 0, 400, 16)
+    h, o = _build_both(6, rows, seed=3, EfConstruction=30, EfSearch=20)
+    for n in range(0, 400, 2):
+        h.Delete(f"v{n}"); o.delete(n)
+    qs = O.gen_rows(162, 0, 20, 16)
+    res = h.SearchBatch(qs, 150)                                  # k > reachable: under-filled -> host top-up (hnsw.go:676-710)
+    for i, q in enumerate(qs):
+        er, ed = o.search(q, 150)
+        assert len(res[i]) == len(er) == 150
+        assert np.array_equal(_bits([r.Distance for r in res[i]]), _bits(ed))
+        assert sorted(r.VectorIndex for r in res[i]) == sorted(er.tolist())
+    res5 = h.SearchBatch(qs, 5)
+    for i, q in enumerate(qs):
+        er, ed = o.search(q, 5)
+        assert [r.VectorIndex for r in res5[i]] == er.tolist()
