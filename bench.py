@@ -4,22 +4,27 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): exact flat cosine top-10 over a synthetic unit-vector
-corpus of --rows x 768 fp32 (default 10M x 768 = BASELINE.json configs[4]'s corpus,
-the shape the north star's roofline target is quoted on; it fits one GPU, so the same
-corpus is used at every N and the curve is strong scaling).  One STEP = one query
-against the whole corpus: every rank scans its contiguous row shard
-(qv_index_search_device: HIP flat-scan + fused top-k), the per-shard top-k are
-all-gathered over RCCL and merged deterministically (qv_merge_topk_device).  Inputs
-(corpus, queries) are resident in HBM before the timed region.  At N=1 the line also
-carries configs[1] (1M x 768) measured in the same process ("also").
+Workload (config.workload): exact flat cosine top-10 over a synthetic unit-vector corpus of
+--rows x 768 fp32 (default 10M x 768 = BASELINE.json configs[4]'s corpus, the shape the north
+star's roofline target is quoted on; it fits one GPU, so the same corpus is used at every N and
+the curve is strong scaling).  One STEP = one query against the whole corpus: every rank scans
+its contiguous row shard (qv_index_search_device: HIP flat scan + fused top-k), the per-shard
+top-k are all-gathered over RCCL and merged deterministically (qv_merge_topk_device) — the
+orchestration is quiver_amd.sharded.ShardedFlatSearch, the same code the gloo tests cover; the
+exchange of step i overlaps the scan of step i+1.  Corpus and queries are resident in HBM
+before the timed region.
 
-Extra objects: "roofline" (HBM, dominant kernel = k_flat_scan, from HIP events around
-that kernel) and "cpu_baseline" (the CPU oracle in reference-faithful mode on a
-bounded sample; the oracle is only the checker/baseline here, never the product).
+Extra objects on the line:
+  "roofline"     HBM roofline of the dominant kernel k_flat_scan (HIP events around that kernel,
+                 separate pass; traffic from the committed rocprofv3 PMC summary)
+  "cpu_baseline" the CPU oracle in reference-faithful mode on a bounded sample (checker/baseline
+                 only — never the product path)
+  "also"         (N=1) the other BASELINE configs measured in the same process: configs[1]
+                 flat cosine 1M x 768 single query; configs[2] 256 queries x 1M x 768 through the
+                 exact multi-query scan and through the fp32-MFMA filter (+ its MFMA roofline);
+                 the PCIe-inclusive single-query rate of the host-pointer entry point.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -31,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32 dense peak (same guide)
 CORPUS_SEED, QUERY_SEED = 20260424, 20260425
 
 
@@ -44,16 +50,16 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra 1M x 768 measurement at N=1")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configs measured at N=1")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=8)
     return ap.parse_args()
 
 
 def cpu_baseline(dim, k, sample_rows, sample_queries, total_rows):
-    """Reference-faithful ExactIndex.Search on the host (oracle 'port'): rows behind a
-    string-keyed hash map, scalar float64 distance per row, full sort of all N.
-    1 thread (what ExactIndex.Search uses per query, exact.go:92-133)."""
+    """Reference-faithful ExactIndex.Search on the host (oracle 'port'): rows behind a string-keyed
+    hash map, scalar float64 distance per row, full sort of all N.  1 thread (what
+    ExactIndex.Search uses per query, exact.go:92-133)."""
     from tests import _oracle as O
     rows = O.gen_rows(CORPUS_SEED, 0, sample_rows, dim)
     f = O.Faithful(0, dim)
@@ -67,13 +73,25 @@ def cpu_baseline(dim, k, sample_rows, sample_queries, total_rows):
     dt = time.perf_counter() - t0
     rows_per_s = sample_rows * sample_queries / dt
     return {
-        "value": rows_per_s / total_rows, "unit": "queries/s",
-        "cores": 1, "kind": "port",
+        "value": rows_per_s / total_rows, "unit": "queries/s", "cores": 1, "kind": "port",
         "sample": "%d queries x first %d rows of the same corpus, reference-faithful ExactIndex.Search restatement "
                   "(oracle/qv_oracle.c qvo_faithful_search), %.2f s; value = measured rows/s / %d rows" %
                   (sample_queries, sample_rows, dt, total_rows),
         "rows_per_s": rows_per_s,
     }
+
+
+def pmc_traffic(rows_per_gpu, dim):
+    """HBM bytes per k_flat_scan launch from the committed rocprofv3 PMC summary, when it was
+    taken on this exact per-GPU workload; else None."""
+    p = os.path.join(ROOT, "profiles", "r01_10Mx768_pmc.json")
+    try:
+        d = json.load(open(p))
+        if rows_per_gpu == 10_000_000 and dim == 768:
+            return d["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def main():
@@ -93,12 +111,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import quiver_amd
-    from quiver_amd.device_index import merge_topk_device, device_info
+    from quiver_amd.device_index import device_info
+    from quiver_amd.sharded import DeviceShard, ShardedFlatSearch, shard_bounds
+    from tests import _oracle as O                # query generator + checker only
 
     dim, k, G = a.dim, a.k, world
-    # contiguous row shards [g*N/G, (g+1)*N/G)
-    base = rank * a.rows // G
-    n_local = (rank + 1) * a.rows // G - base
+    base, n_local = shard_bounds(a.rows, G, rank)
     idx = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
     idx.reserve(n_local)
     t_gen = time.perf_counter()
@@ -110,45 +128,25 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
-    from tests import _oracle as O                # queries come from the shared generator (host side, tiny)
     nq_pool = 256
     qs_host = O.gen_rows(QUERY_SEED, 0, nq_pool, dim)
     d_q = torch.from_numpy(qs_host).cuda()
-    stream = torch.cuda.current_stream()
-    sp = stream.cuda_stream
-
-    total_steps = a.warmup + a.steps
-    d_rows = torch.empty((total_steps + 1, k), dtype=torch.int32, device="cuda")      # local top-k, global row ids
-    d_dist = torch.empty((total_steps + 1, k), dtype=torch.float32, device="cuda")
-    g_rows = torch.empty((total_steps + 1, G, k), dtype=torch.int32, device="cuda") if G > 1 else None
-    g_dist = torch.empty((total_steps + 1, G, k), dtype=torch.float32, device="cuda") if G > 1 else None
-    f_rows = torch.empty((total_steps + 1, k), dtype=torch.int32, device="cuda")
-    f_dist = torch.empty((total_steps + 1, k), dtype=torch.float32, device="cuda")
+    sp = torch.cuda.current_stream().cuda_stream
     qsz = dim * 4
+    total_steps = a.warmup + a.steps
+    dev = torch.device("cuda", local_rank)
+    search = ShardedFlatSearch(DeviceShard(idx), base, k, dev, world=G, ring=total_steps + 2)
 
-    def local_scan(i, index):
-        index.search_device(d_q.data_ptr() + (i % nq_pool) * qsz, 1, k, d_rows[i].data_ptr(), d_dist[i].data_ptr(), sp)
-        if G > 1:
-            d_rows[i].add_(base)                 # shard-local row -> global row
-
-    def finish(i, works):
-        """exchange + merge for step i (called one step late so it overlaps scan i+1)"""
-        w1, w2 = works
-        w1.wait(); w2.wait()
-        merge_topk_device(g_dist[i].data_ptr(), g_rows[i].data_ptr(), G, k, f_rows[i].data_ptr(), f_dist[i].data_ptr(), sp)
-
-    def run(first, count, index):
+    def run(first, count):
+        """`count` steps; the exchange+merge of step i is issued after the scan of step i+1"""
         pending = None
         for i in range(first, first + count):
-            local_scan(i, index)
-            if G > 1:
-                if pending is not None:
-                    finish(*pending)
-                w1 = dist.all_gather_into_tensor(g_dist[i].view(-1), d_dist[i], async_op=True)
-                w2 = dist.all_gather_into_tensor(g_rows[i].view(-1), d_rows[i], async_op=True)
-                pending = (i, (w1, w2))
+            t = search.submit(d_q[i % nq_pool])
+            if pending is not None:
+                search.finish(pending)
+            pending = t
         if pending is not None:
-            finish(*pending)
+            search.finish(pending)
 
     def barrier():
         if G > 1:
@@ -156,10 +154,10 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warmup, then EXACTLY K timed steps bracketed by barrier + synchronize ----
-    run(0, a.warmup, idx)
+    run(0, a.warmup)
     barrier()
     t0 = time.perf_counter()
-    run(a.warmup, a.steps, idx)
+    run(a.warmup, a.steps)
     barrier()
     dt = time.perf_counter() - t0
     if G > 1:
@@ -168,11 +166,31 @@ def main():
         dt = float(t.item())
     qps = a.steps / dt
 
+    # results of the timed steps sit in the ring: slot j = step j
+    def result_of(step):
+        b = search._ring[step % len(search._ring)]
+        r, d = (b["out_rows"], b["out_dist"]) if G > 1 else (b["rows"], b["dist"])
+        return r.cpu().numpy().view(np.uint32), d.cpu().numpy()
+
+    # ---- verification of what was timed (checker only) ----
+    verified = True
+    if rank == 0:
+        for j in range(min(a.steps, 8)):
+            step = a.warmup + j
+            rr, dd = result_of(step)
+            q = qs_host[step % nq_pool]
+            mid = quiver_amd.metric_id(a.metric)
+            for t_ in range(k):
+                want = O.distance(mid, q, O.gen_rows(CORPUS_SEED, int(rr[t_]), 1, dim)[0])
+                verified &= bool(np.float32(want).view(np.uint32) == dd[t_].view(np.uint32))
+            verified &= all(dd[t_] <= dd[t_ + 1] for t_ in range(k - 1))
+
     # ---- roofline of the dominant kernel: HIP events around k_flat_scan, separate pass ----
+    d_r = torch.empty((k,), dtype=torch.int32, device="cuda")
+    d_d = torch.empty((k,), dtype=torch.float32, device="cuda")
     idx.profile(True)
-    pass_steps = min(a.steps, 50)
-    for j in range(pass_steps):
-        idx.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_rows[total_steps].data_ptr(), d_dist[total_steps].data_ptr(), sp)
+    for j in range(min(a.steps, 50)):
+        idx.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
     torch.cuda.synchronize()
     scan_ms, launches = idx.profile_read()
     idx.profile(False)
@@ -180,48 +198,77 @@ def main():
     kern_ms = scan_ms / max(launches, 1)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if launches else 0.0
 
-    # ---- verification of what was timed (checker only) ----
-    res_rows = (f_rows if G > 1 else d_rows)[a.warmup: a.warmup + min(a.steps, 8)].cpu().numpy().view(np.uint32)
-    res_dist = (f_dist if G > 1 else d_dist)[a.warmup: a.warmup + min(a.steps, 8)].cpu().numpy()
-    verified = True
-    if rank == 0:
-        for j in range(res_rows.shape[0]):
-            q = qs_host[(a.warmup + j) % nq_pool]
-            for t in range(k):
-                row = int(res_rows[j, t])
-                want = O.distance(0, q, O.gen_rows(CORPUS_SEED, row, 1, dim)[0]) if a.metric == "cosine" else None
-                if want is not None and np.float32(want).view(np.uint32) != res_dist[j, t].view(np.uint32):
-                    verified = False
-            if not all(res_dist[j, t] <= res_dist[j, t + 1] for t in range(k - 1)):
-                verified = False
-
     also = None
-    if G == 1 and not a.no_also and a.rows != 1_000_000 and a.metric == "cosine":
-        # configs[1]: flat cosine 1M x 768, single query, same process
-        idx1 = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
-        idx1.reserve(1_000_000)
-        idx1.add_synthetic(CORPUS_SEED, 0, 1_000_000)
-        r1 = torch.empty((k,), dtype=torch.int32, device="cuda"); d1 = torch.empty((k,), dtype=torch.float32, device="cuda")
+    if G == 1 and not a.no_also and a.metric == "cosine":
+        also = {}
+        # host-pointer entry point on the same corpus: query up over PCIe, results down, one stream sync per query
+        idx.search(qs_host[0], k)
+        t1 = time.perf_counter()
         for j in range(20):
-            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, r1.data_ptr(), d1.data_ptr(), sp)
+            idx.search(qs_host[j], k)
+        also["pcie_inclusive_single_query"] = {"workload": "qv_index_search (host pointers) on the same %dx%d corpus" % (a.rows, dim),
+                                               "qps": 20 / (time.perf_counter() - t1)}
+        # configs[1]/[2] live on a 1M x 768 corpus
+        idx1 = idx if a.rows == 1_000_000 else quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
+        if idx1 is not idx:
+            idx1.reserve(1_000_000)
+            idx1.add_synthetic(CORPUS_SEED, 0, 1_000_000)
+        for j in range(20):
+            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
         torch.cuda.synchronize()
         steps1 = 500
         t1 = time.perf_counter()
         for j in range(steps1):
-            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, r1.data_ptr(), d1.data_ptr(), sp)
+            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
         torch.cuda.synchronize()
         dt1 = time.perf_counter() - t1
         idx1.profile(True)
         for j in range(100):
-            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, r1.data_ptr(), d1.data_ptr(), sp)
+            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
         torch.cuda.synchronize()
         ms1, n1 = idx1.profile_read()
+        idx1.profile(False)
         b1 = 1_000_000 * dim * 4 + 1_000_000 * 8
-        also = {"workload": "flat cosine 1Mx768 fp32, k=10, single query (BASELINE configs[1])",
-                "qps": steps1 / dt1, "ms_per_query": dt1 / steps1 * 1e3,
-                "scan_kernel_ms": ms1 / max(n1, 1), "hbm_gbs": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9,
-                "hbm_frac": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        idx1.close()
+        also["flat_1Mx768_single_query"] = {
+            "workload": "flat cosine 1Mx768 fp32, k=10, single query (BASELINE configs[1])",
+            "qps": steps1 / dt1, "ms_per_query": dt1 / steps1 * 1e3, "scan_kernel_ms": ms1 / max(n1, 1),
+            "hbm_gbs": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9, "hbm_frac": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # configs[2]: 256 queries x 1M x 768
+        nqb = 256
+        d_rb = torch.empty((nqb, k), dtype=torch.int32, device="cuda")
+        d_db = torch.empty((nqb, k), dtype=torch.float32, device="cuda")
+        idx1.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            idx1.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t1) / 5
+        exact_rows = d_rb.cpu().numpy().view(np.uint32).copy()
+        exact_dist = d_db.cpu().numpy().copy()
+        flop = 2.0 * nqb * 1_000_000 * dim
+        also["batched_256x1Mx768_exact_scan"] = {
+            "workload": "256 queries x 1Mx768 cosine, k=10: exact multi-query scan (16 queries per corpus pass, f64 accumulate)",
+            "batch_ms": dtb * 1e3, "qps": nqb / dtb, "f64_tflops_equiv": flop / dtb / 1e12}
+        rb, db, _ = idx1.search(qs_host[:nqb], k, batched=True)
+        idx1.profile(True)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            rb, db, _ = idx1.search(qs_host[:nqb], k, batched=True)
+        dtm = (time.perf_counter() - t1) / 5
+        msm, nm = idx1.profile_read()
+        idx1.profile(False)
+        same = bool(np.array_equal(rb, exact_rows) and np.array_equal(db.view(np.uint32), exact_dist.view(np.uint32)))
+        mf_ms = msm / max(nm, 1)
+        also["batched_256x1Mx768_mfma"] = {
+            "workload": "256 queries x 1Mx768 cosine, k=10 (BASELINE configs[2]): fp32-MFMA filter + exact re-score, "
+                        "host pointers (query upload, result download and sync included)",
+            "batch_ms": dtm * 1e3, "qps": nqb / dtm, "identical_to_exact_scan": same,
+            "roofline": {"bound": "mfma", "kernel": "k_mfma_filter", "kernel_ms": mf_ms, "achieved": flop / (mf_ms * 1e-3) / 1e12,
+                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flop / (mf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                         "algorithmic_flop_per_launch": flop}}
+        if idx1 is not idx:
+            idx1.close()
 
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
@@ -233,15 +280,17 @@ def main():
             "metric": "flat_cosine_qps_recall_1.0", "value": qps, "unit": "queries/s",
             "n_gpus": G, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64-accumulate over fp32 rows (reference arithmetic)", "data": "synthetic",
-            "config": {"workload": "flat %s scan %dx%d fp32, k=%d, single query per step, recall 1.0 (exact)" % (a.metric, a.rows, dim, k),
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "flat %s scan %dx%d fp32, k=%d, single query per step, recall 1.0 (exact, bit-identical to the CPU oracle)" % (a.metric, a.rows, dim, k),
                        "rows_total": a.rows, "rows_per_gpu": n_local, "dim": dim, "k": k,
-                       "sharding": "contiguous row shards, per-shard top-k + RCCL all-gather + deterministic merge" if G > 1 else "single shard",
+                       "arithmetic": "float64 accumulation over float32 rows, one rounding to float32 (the reference's arithmetic)",
+                       "sharding": "contiguous row shards, per-shard top-k + RCCL all-gather (k*8 B/rank) + deterministic merge; exchange of step i overlaps scan of step i+1" if G > 1 else "single shard",
                        "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_local, dim),
                          "kernel": "k_flat_scan", "kernel_ms": kern_ms, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_source": "profiles/r01_10Mx768_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per the gfx950 correction)"},
             "cpu_baseline": cpu,
             "verified_against_oracle": bool(verified),
         }

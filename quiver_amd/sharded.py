@@ -47,11 +47,14 @@ def device_merge(g_dist: torch.Tensor, g_rows: torch.Tensor, k: int, rows_out: t
 
 class ShardedFlatSearch:
     def __init__(self, shard, base_row: int, k: int, device, group=None,
-                 merge: Callable = device_merge, world: Optional[int] = None):
+                 merge: Callable = device_merge, world: Optional[int] = None, ring: int = 4):
         self.shard, self.base, self.k, self.device, self.group = shard, int(base_row), k, device, group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.merge = merge
-        self._pending = None
+        # a ring of result/exchange buffers: slot i is reused by query i+ring; with submit/finish
+        # pipelined one deep, any ring >= 3 is safe (stream order: merge(i) precedes scan(i+ring))
+        self._ring = [self._buffers() for _ in range(max(3, ring))]
+        self._n = 0
 
     def _buffers(self):
         k, G, dev = self.k, self.world, self.device
@@ -63,28 +66,31 @@ class ShardedFlatSearch:
         """local scan + start the exchange for this query; returns a ticket for finish().
         Calling submit() for query i+1 before finish() of query i overlaps the exchange of i
         with the scan of i+1 (the collectives run on the backend's own stream)."""
-        b = self._buffers()
+        b = self._ring[self._n % len(self._ring)]
+        self._n += 1
         self.shard.search(d_query, self.k, b["rows"], b["dist"])
         if self.world == 1:
-            b["out_rows"], b["out_dist"] = b["rows"], b["dist"]
             return b, None
         # shard-local rows -> global rows; 0xFFFFFFFF (no result) stays put
-        valid = b["rows"] != -1
-        b["rows"] = torch.where(valid, b["rows"] + self.base, b["rows"])
+        if self.base:
+            b["rows"].copy_(torch.where(b["rows"] != -1, b["rows"] + self.base, b["rows"]))
         w1 = dist.all_gather_into_tensor(b["g_dist"].view(-1), b["dist"], group=self.group, async_op=True)
         w2 = dist.all_gather_into_tensor(b["g_rows"].view(-1), b["rows"], group=self.group, async_op=True)
         return b, (w1, w2)
 
     def finish(self, ticket):
+        """-> (rows[k] int32 view of uint32 global rows, dist[k]); valid until the slot is reused"""
         b, works = ticket
-        if works is not None:
-            works[0].wait()
-            works[1].wait()
-            self.merge(b["g_dist"], b["g_rows"], self.k, b["out_rows"], b["out_dist"])
+        if works is None:
+            return b["rows"], b["dist"]
+        works[0].wait()
+        works[1].wait()
+        self.merge(b["g_dist"], b["g_rows"], self.k, b["out_rows"], b["out_dist"])
         return b["out_rows"], b["out_dist"]
 
     def search(self, d_query: torch.Tensor):
-        return self.finish(self.submit(d_query))
+        r, d = self.finish(self.submit(d_query))
+        return r.clone(), d.clone()
 
     def search_stream(self, queries):
         """pipelined: exchange of query i overlaps the scan of query i+1"""
@@ -92,8 +98,10 @@ class ShardedFlatSearch:
         for q in queries:
             t = self.submit(q)
             if pending is not None:
-                out.append(self.finish(pending))
+                r, d = self.finish(pending)
+                out.append((r.clone(), d.clone()))
             pending = t
         if pending is not None:
-            out.append(self.finish(pending))
+            r, d = self.finish(pending)
+            out.append((r.clone(), d.clone()))
         return out
