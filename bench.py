@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs measured at N=1")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="with one rank, still run the RCCL all-gather + merge per step (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=8)
     return ap.parse_args()
@@ -106,14 +108,15 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_pg = world > 1 or a.force_exchange
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import quiver_amd
     from quiver_amd.device_index import device_info
     from quiver_amd.sharded import DeviceShard, ShardedFlatSearch, shard_bounds
-    from tests import _oracle as O                # query generator + checker only
 
     dim, k, G = a.dim, a.k, world
     base, n_local = shard_bounds(a.rows, G, rank)
@@ -128,14 +131,18 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
+    # queries: the product's own synthetic generator (seed QUERY_SEED), read back once
     nq_pool = 256
-    qs_host = O.gen_rows(QUERY_SEED, 0, nq_pool, dim)
+    qgen = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
+    qgen.add_synthetic(QUERY_SEED, 0, nq_pool)
+    qs_host = np.stack([qgen.get_row(i) for i in range(nq_pool)])
+    qgen.close()
     d_q = torch.from_numpy(qs_host).cuda()
     sp = torch.cuda.current_stream().cuda_stream
     qsz = dim * 4
     total_steps = a.warmup + a.steps
     dev = torch.device("cuda", local_rank)
-    search = ShardedFlatSearch(DeviceShard(idx), base, k, dev, world=G, ring=total_steps + 2)
+    search = ShardedFlatSearch(DeviceShard(idx), base, k, dev, world=G, ring=total_steps + 2, force_exchange=a.force_exchange)
 
     def run(first, count):
         """`count` steps; the exchange+merge of step i is issued after the scan of step i+1"""
@@ -149,7 +156,7 @@ def main():
             search.finish(pending)
 
     def barrier():
-        if G > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,7 +167,7 @@ def main():
     run(a.warmup, a.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if G > 1:
+    if use_pg:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -169,12 +176,14 @@ def main():
     # results of the timed steps sit in the ring: slot j = step j
     def result_of(step):
         b = search._ring[step % len(search._ring)]
-        r, d = (b["out_rows"], b["out_dist"]) if G > 1 else (b["rows"], b["dist"])
+        r, d = (b["out_rows"], b["out_dist"]) if (G > 1 or a.force_exchange) else (b["rows"], b["dist"])
         return r.cpu().numpy().view(np.uint32), d.cpu().numpy()
 
-    # ---- verification of what was timed (checker only) ----
+    # ---- verification of what was timed: the CPU oracle as the CHECKER (never on the timed path) ----
     verified = True
     if rank == 0:
+        from tests import _oracle as O
+        verified &= bool(np.array_equal(qs_host[:4].view(np.uint32), O.gen_rows(QUERY_SEED, 0, 4, dim).view(np.uint32)))
         for j in range(min(a.steps, 8)):
             step = a.warmup + j
             rr, dd = result_of(step)
@@ -297,7 +306,7 @@ def main():
         if also:
             out["also"] = also
         print(json.dumps(out), flush=True)
-    if G > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
     idx.close()

@@ -47,10 +47,12 @@ def device_merge(g_dist: torch.Tensor, g_rows: torch.Tensor, k: int, rows_out: t
 
 class ShardedFlatSearch:
     def __init__(self, shard, base_row: int, k: int, device, group=None,
-                 merge: Callable = device_merge, world: Optional[int] = None, ring: int = 4):
+                 merge: Callable = device_merge, world: Optional[int] = None, ring: int = 4,
+                 force_exchange: bool = False):
         self.shard, self.base, self.k, self.device, self.group = shard, int(base_row), k, device, group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.merge = merge
+        self.force_exchange = force_exchange          # run the all-gather + merge even with one rank (test hook)
         # a ring of result/exchange buffers: slot i is reused by query i+ring; with submit/finish
         # pipelined one deep, any ring >= 3 is safe (stream order: merge(i) precedes scan(i+ring))
         self._ring = [self._buffers() for _ in range(max(3, ring))]
@@ -69,7 +71,7 @@ class ShardedFlatSearch:
         b = self._ring[self._n % len(self._ring)]
         self._n += 1
         self.shard.search(d_query, self.k, b["rows"], b["dist"])
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return b, None
         # shard-local rows -> global rows; 0xFFFFFFFF (no result) stays put
         if self.base:
