@@ -317,3 +317,52 @@ def test_config4_flat_cosine_10Mx768_single_gpu_properties():
     merge_topk_device(gd.data_ptr(), gr.data_ptr(), 2, 10, orow.data_ptr(), odist.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(orow.cpu().numpy().view(np.uint32), r1[0]) and np.array_equal(_bits(odist.cpu().numpy()), _bits(d1[0]))
+
+
+@pytest.mark.parametrize("dim", [1536, 4096, 8192, 16384])
+def test_large_dimensions_use_more_lds(dim):
+    """the query is staged in LDS (float64 for cosine: 8*dim bytes, up to 128 KiB of the CU's 160 KiB)"""
+    rows = O.gen_rows(77, 0, 300, dim)
+    qs = O.gen_rows(78, 0, 3, dim)
+    for metric in (0, 1):
+        idx = _mk(dim, metric, rows)
+        r, d, c = idx.search(qs, 5)                       # multi-query path (scalar-operand query block)
+        r1, d1, c1 = idx.search(qs[0], 5)                 # single-query path (LDS-staged query)
+        er, ed = O.exact_search(metric, rows, qs[0], 5)
+        assert np.array_equal(r[0], er) and np.array_equal(_bits(d[0]), _bits(ed))
+        assert np.array_equal(r1[0], er) and np.array_equal(_bits(d1[0]), _bits(ed))
+        got = idx.distance_rows(qs[1], np.arange(300, dtype=np.uint32))
+        assert np.array_equal(_bits(got), _bits(O.all_distances(metric, rows, qs[1])))
+
+
+def test_dimension_above_the_supported_maximum_is_refused():
+    import quiver_amd as q
+    with pytest.raises(q.QvError) as e:
+        q.DeviceIndex(16385, "cosine")
+    assert e.value.code == -8
+
+
+@pytest.mark.parametrize("metric", [0, 1, 3, 4])
+def test_nan_and_inf_inputs_sort_last_like_the_oracle(metric):
+    """NaN/Inf are not pinned by the reference; declared behaviour: a NaN distance
+    sorts after every number (ties among NaNs by row), +Inf sorts after finite values"""
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((500, 16)).astype(np.float32)
+    rows[10, 3] = np.nan
+    rows[20, 0] = np.inf
+    rows[30, 5] = -np.inf
+    rows[40] = 0.0
+    q = rng.standard_normal(16).astype(np.float32)
+    idx = _mk(16, metric, rows)
+    for k in (5, 64, 500):
+        r, d, c = idx.search(q, k)
+        er, ed = O.exact_search(metric, rows, q, k)
+        assert np.array_equal(r[0], er), (metric, k)
+        assert np.array_equal(np.isnan(d[0]), np.isnan(ed))
+        fin = ~np.isnan(ed)
+        assert np.array_equal(_bits(d[0][fin]), _bits(ed[fin]))
+    rq = rows[10]                                           # a NaN query: every distance NaN -> row order
+    r, d, c = idx.search(rq, 7)
+    if metric in (0, 1, 3, 4):
+        er, ed = O.exact_search(metric, rows, rq, 7)
+        assert np.array_equal(r[0], er) and np.isnan(d[0]).all() == np.isnan(ed).all()
