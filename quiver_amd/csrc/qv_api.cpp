@@ -438,8 +438,9 @@ static size_t search_ws_bytes(const qv_index* idx, uint32_t nq, uint32_t kk, uin
     return qv::full_sort_workspace_bytes(n_tiles);
 }
 
-int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
-                    uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
+// the exact scans (single-query / multi-query / full ranking), host pointers
+static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                             uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
     if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
     if (nq == 0) return QV_OK;
     if (!queries || !count_out) return fail(QV_ERR_INVALID_ARG, "queries/count_out is null");
@@ -477,6 +478,14 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
         count_out[q] = kk;
     }
     return QV_OK;
+}
+
+int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                    uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
+    // many queries over a large cosine/dot corpus: the MFMA filter path returns the identical result faster
+    if (idx && nq >= 32 && k > 0 && idx->n_live >= 4 * (uint64_t)k && qv::batched_supported(idx->view(), nq, std::min(k, idx->n_live)))
+        return qv_index_search_batched(idx, queries, nq, k, rows_out, dist_out, count_out);
+    return exact_search_host(idx, queries, nq, k, rows_out, dist_out, count_out);
 }
 
 int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
@@ -546,7 +555,7 @@ int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, ui
     // the MFMA filter pays off for many queries over a large cosine/dot corpus; everything else
     // (and any k > 64) takes the exact multi-query scan, which returns the same result
     if (!qv::batched_supported(v, nq, kk) || kk != k || idx->n_live < 4 * kk)
-        return qv_index_search(idx, queries, nq, k, rows_out, dist_out, count_out);
+        return exact_search_host(idx, queries, nq, k, rows_out, dist_out, count_out);
     HIPCHK(hipSetDevice(idx->device));
     SearchCtx* c = nullptr;
     int rc = acquire_ctx(idx, &c);
@@ -584,13 +593,13 @@ int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, ui
     std::vector<uint32_t> redo;
     for (uint32_t q = 0; q < nq; q++) if (ovf[q]) redo.push_back(q);
     idx->batched_redo += redo.size();
-    guard.c = nullptr; release_ctx(idx, c);                          // qv_index_search takes its own context
+    guard.c = nullptr; release_ctx(idx, c);                          // the exact scan takes its own context
     if (!redo.empty()) {
         std::vector<float> rq((size_t)redo.size() * idx->dim);
         for (size_t i = 0; i < redo.size(); i++) memcpy(&rq[i * idx->dim], queries + (size_t)redo[i] * idx->dim, idx->dim * sizeof(float));
         std::vector<uint32_t> rr((size_t)redo.size() * kk), rc2(redo.size());
         std::vector<float> rd((size_t)redo.size() * kk);
-        rc = qv_index_search(idx, rq.data(), (uint32_t)redo.size(), kk, rr.data(), rd.data(), rc2.data());
+        rc = exact_search_host(idx, rq.data(), (uint32_t)redo.size(), kk, rr.data(), rd.data(), rc2.data());
         if (rc != QV_OK) return rc;
         for (size_t i = 0; i < redo.size(); i++) {
             memcpy(rows_out + (size_t)redo[i] * kk, &rr[i * kk], kk * sizeof(uint32_t));

@@ -14,6 +14,13 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+def _exact(idx, qs, k):
+    """the exact multi-query scan, forced: qv_index_search hands batches of >= 32 queries to the
+    MFMA path by itself, so the reference result is gathered 16 queries at a time"""
+    outs = [idx.search(qs[i: i + 16], k) for i in range(0, len(qs), 16)]
+    return tuple(np.concatenate([o[j] for o in outs]) for j in range(3))
+
+
 def _eq(a, b):
     return np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1])) and np.array_equal(a[2], b[2])
 
@@ -25,9 +32,10 @@ def test_mfma_batched_equals_exact_scan(metric):
     idx = q.DeviceIndex(dim, metric)
     idx.add_synthetic(20260424, 0, n)
     qs = O.gen_rows(20260425, 0, nq, dim)
-    exact = idx.search(qs, 10)
+    exact = _exact(idx, qs, 10)
     batched = idx.search(qs, 10, batched=True)
     assert _eq(exact, batched)
+    assert _eq(exact, idx.search(qs, 10))            # qv_index_search dispatches big batches to the same path
     # and against the CPU oracle for a few queries (bit-exact)
     corpus = O.gen_rows(20260424, 0, n, dim)
     for i in (0, 17, 255):
@@ -35,7 +43,7 @@ def test_mfma_batched_equals_exact_scan(metric):
         assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
     # other k, fewer queries (not a multiple of 64)
     for k, m in ((1, 100), (64, 40), (33, 64)):
-        assert _eq(idx.search(qs[:m], k), idx.search(qs[:m], k, batched=True))
+        assert _eq(_exact(idx, qs[:m], k), idx.search(qs[:m], k, batched=True))
 
 
 def test_mfma_batched_with_unrepresentative_sample_ties_and_tombstones():
@@ -55,7 +63,7 @@ def test_mfma_batched_with_unrepresentative_sample_ties_and_tombstones():
     idx.add(rows)
     dead = rng.choice(len(rows), 5000, replace=False).astype(np.uint32)
     idx.remove(dead)
-    exact = idx.search(qs, 10)
+    exact = _exact(idx, qs, 10)
     batched = idx.search(qs, 10, batched=True)
     assert _eq(exact, batched)
     assert not np.isin(batched[0], dead).any()

@@ -20,6 +20,7 @@ ap.add_argument("--m", type=int, default=16); ap.add_argument("--efc", type=int,
 ap.add_argument("--nq", type=int, default=1000); ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--max-level", type=int, default=16); ap.add_argument("--metric", default="cosine")
 ap.add_argument("--cpu-queries", type=int, default=100)
+ap.add_argument("--more-nq", type=int, nargs="*", default=[], help="extra batch sizes timed on the same graph")
 a = ap.parse_args()
 mid = quiver_amd.metric_id(a.metric)
 rows = O.gen_rows(20260424, 0, a.rows, a.dim)
@@ -37,6 +38,14 @@ t0 = time.perf_counter()
 res, ev = h.SearchBatch(qs, a.k, with_evals=True)
 t_gpu = time.perf_counter() - t0
 topups = h.topups()
+
+extra = {}
+for n2 in a.more_nq:
+    q2 = O.gen_rows(20260426, 0, n2, a.dim)
+    t0 = time.perf_counter()
+    r2, e2 = h.SearchBatch(q2, a.k, with_evals=True)
+    t2 = time.perf_counter() - t0
+    extra[str(n2)] = {"qps": n2 / t2, "batch_ms": t2 * 1e3, "evals_per_s": float(e2.sum()) / t2, "gather_GBps": float(e2.sum()) * a.dim * 4 / t2 / 1e9}
 
 # exact top-k for recall
 flat = quiver_amd.DeviceIndex(a.dim, mid); flat.add(rows)
@@ -65,4 +74,4 @@ print(json.dumps({
     "evals_per_s": float(ev.sum()) / t_gpu, "gather_GBps": float(ev.sum()) * a.dim * 4 / t_gpu / 1e9,
     "underfilled_queries_topped_up_by_exact_scan": topups - 0, "recall_at_10_vs_exact": hit / (a.nq * a.k),
     "cpu_oracle_qps_1core": a.cpu_queries / t_cpu, "cpu_build_s": t_cpu_build, "cpu_evals_per_query": cpu_evals / a.cpu_queries,
-    "graph_identical_to_cpu_graph": bool(same_graph), "results_identical_to_cpu_traversal": bool(identical)}))
+    "more_batches": extra, "graph_identical_to_cpu_graph": bool(same_graph), "results_identical_to_cpu_traversal": bool(identical)}))
