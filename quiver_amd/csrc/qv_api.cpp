@@ -114,8 +114,9 @@ struct qv_graph {
     qv::GraphView g{};
     void *d_level = nullptr, *d_l0deg = nullptr, *d_l0links = nullptr, *d_upoff = nullptr, *d_uplinks = nullptr;
     uint32_t* d_visited = nullptr;
-    uint32_t grid = 0;
+    uint32_t grid = 0, heap_grid = 0;           // wave slots: the wave-resident kernel / the exact-heap kernel
     uint32_t epoch = 0;
+    uint64_t tie_reruns = 0;
     std::mutex mu;                              // one batch at a time (the visited stamps are per wave slot)
     hipStream_t stream = nullptr;
     Buf d_q, d_rows, d_dist, d_cnt, d_ev;
@@ -672,7 +673,8 @@ int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_
     if (e == hipSuccess) e = up(&g->d_upoff, up_off, (size_t)n_nodes * 4);
     if (e == hipSuccess) e = up(&g->d_uplinks, up_links, (size_t)n_up_blocks * (1 + max_m) * 4);
     // visited stamps: one uint32 per (wave slot, node) — sized for 288 GB HBM: 5 GB at 1M nodes x 1280 slots
-    g->grid = qv::hnsw_grid(idx->cus, idx->metric, idx->dim4, 0xFFFFFFFFu);
+    g->heap_grid = qv::hnsw_grid(idx->cus, idx->metric, idx->dim4, 0xFFFFFFFFu);
+    g->grid = std::max(g->heap_grid, qv::hnsw_wave_grid(idx->cus, idx->metric, idx->dim4));
     while (g->grid > 64 && (size_t)g->grid * n_nodes * 4 > ((size_t)16 << 30)) g->grid /= 2;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_visited), (size_t)g->grid * n_nodes * 4);
     if (e == hipSuccess) e = hipMemset(g->d_visited, 0, (size_t)g->grid * n_nodes * 4);
@@ -712,23 +714,52 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
         (rc = g->d_ev.ensure(cbytes)))
         return rc;
     const uint32_t grid = std::min(g->grid, nq);
-    const uint32_t per_wave = (nq + grid - 1) / grid;
-    const uint64_t need = (uint64_t)per_wave * 128 + 128;                 // stamps consumed by this batch per wave slot
+    const uint32_t per_wave = (nq + std::min(grid, std::max(1u, g->heap_grid)) - 1) / std::min(grid, std::max(1u, g->heap_grid));
+    const uint64_t need = (uint64_t)per_wave * 256 + 256;                 // stamps consumed by this batch per wave slot (both passes)
     if ((uint64_t)g->epoch + need >= 0xFFFFFF00ull) {                      // wrap: clear and restart
         HIPCHK(hipMemsetAsync(g->d_visited, 0, (size_t)g->grid * g->g.n_nodes * 4, g->stream));
         g->epoch = 0;
     }
     HIPCHK(hipMemcpyAsync(g->d_q.p, queries, qbytes, hipMemcpyHostToDevice, g->stream));
-    hipError_t e = qv::launch_hnsw_search(idx->view(), g->g, static_cast<const float*>(g->d_q.p), nq, k, ef_search, g->d_visited, grid, g->epoch,
-                                          static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
-                                          static_cast<uint32_t*>(g->d_ev.p), g->stream);
+    // pass 1: wave-resident traversal (registers only); queries that meet equal distances / NaN report 0xFFFFFFFE
+    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, static_cast<const float*>(g->d_q.p), nq, k, ef_search, g->d_visited, grid, g->epoch,
+                                               static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
+                                               static_cast<uint32_t*>(g->d_ev.p), g->stream);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
-    g->epoch += (uint32_t)need;
+    g->epoch += (uint32_t)need / 2;
     HIPCHK(hipMemcpyAsync(rows_out, g->d_rows.p, obytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipMemcpyAsync(dist_out, g->d_dist.p, obytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipMemcpyAsync(count_out, g->d_cnt.p, cbytes, hipMemcpyDeviceToHost, g->stream));
     if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, g->d_ev.p, cbytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
+    // pass 2: the exact-heap kernel for the flagged queries (heap pop order under ties depends on the heap layout)
+    std::vector<uint32_t> redo;
+    for (uint32_t q = 0; q < nq; q++) if (count_out[q] == 0xFFFFFFFEu) redo.push_back(q);
+    if (!redo.empty()) {
+        g->tie_reruns += redo.size();
+        const uint32_t m = (uint32_t)redo.size();
+        std::vector<float> rq((size_t)m * idx->dim);
+        for (uint32_t i = 0; i < m; i++) memcpy(&rq[(size_t)i * idx->dim], queries + (size_t)redo[i] * idx->dim, idx->dim * sizeof(float));
+        std::vector<uint32_t> rr((size_t)m * k), rc(m), rev(m);
+        std::vector<float> rd((size_t)m * k);
+        HIPCHK(hipMemcpyAsync(g->d_q.p, rq.data(), rq.size() * sizeof(float), hipMemcpyHostToDevice, g->stream));
+        e = qv::launch_hnsw_search(idx->view(), g->g, static_cast<const float*>(g->d_q.p), m, k, ef_search, g->d_visited, std::min(g->heap_grid, m), g->epoch,
+                                   static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
+                                   static_cast<uint32_t*>(g->d_ev.p), g->stream);
+        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+        g->epoch += (uint32_t)need / 2;
+        HIPCHK(hipMemcpyAsync(rr.data(), g->d_rows.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipMemcpyAsync(rd.data(), g->d_dist.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipMemcpyAsync(rc.data(), g->d_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipMemcpyAsync(rev.data(), g->d_ev.p, (size_t)m * 4, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        for (uint32_t i = 0; i < m; i++) {
+            memcpy(rows_out + (size_t)redo[i] * k, &rr[(size_t)i * k], (size_t)k * 4);
+            memcpy(dist_out + (size_t)redo[i] * k, &rd[(size_t)i * k], (size_t)k * 4);
+            count_out[redo[i]] = rc[i];
+            if (evals_out) evals_out[redo[i]] = rev[i];
+        }
+    }
     return QV_OK;
 }
 

@@ -96,6 +96,12 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
                               uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
                               uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s);
 
+// wave-resident form (no LDS heaps); count_out = 0xFFFFFFFE for queries that met equal distances / NaN
+uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4);
+hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
+                                   uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                                   uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s);
+
 // Full ranking path (any k): all distances -> 64-bit keys -> stable radix sort -> first k.
 // d_keys_a/d_keys_b: two buffers of n_tiles*64 u64; d_hist: radix histogram workspace.
 size_t  full_sort_workspace_bytes(uint32_t n_tiles);

@@ -468,3 +468,20 @@ def test_hnsw_device_traversal_after_deletes_falls_back_for_topup():
     for i, q in enumerate(qs):
         er, ed = o.search(q, 5)
         assert [r.VectorIndex for r in res5[i]] == er.tolist()
+
+
+def test_hnsw_device_traversal_with_equal_distances_uses_the_exact_heap_kernel():
+    """duplicate vectors give exactly equal distances; with ties the reference's pop order depends
+    on its binary heaps' layout, so the wave-resident kernel flags those queries and the exact-heap
+    kernel re-runs them: still identical to the CPU restatement"""
+    rows = O.gen_rows(171, 0, 1500, 32)
+    rows[100:600] = rows[1000:1500]                 # 500 exact duplicates
+    h, o = _build_both(6, rows, seed=9, EfConstruction=40, EfSearch=64, MaxLevel=1)
+    qs = O.gen_rows(172, 0, 60, 32)
+    qs[:10] = rows[100:110]                         # queries equal to duplicated rows: distance-0 ties
+    res = h.SearchBatch(qs, 10)
+    for i, q in enumerate(qs):
+        er, ed = o.search(q, 10)
+        assert [r.VectorIndex for r in res[i]] == er.tolist(), i
+        assert np.array_equal(_bits([r.Distance for r in res[i]]), _bits(ed))
+    assert h.device_fallbacks() == 0
