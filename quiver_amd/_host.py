@@ -25,7 +25,8 @@ _SIGS = {
     "qvh_hnsw_new": (_vp, [_i, _i, _i, _i, _i, _i, _i, C.c_uint64]), "qvh_hnsw_free": (None, [_vp]),
     "qvh_hnsw_insert": (_i, [_vp, _cp, _vp, _u32]), "qvh_hnsw_delete": (_i, [_vp, _cp]),
     "qvh_hnsw_search": (_i, [_vp, _vp, _u32, _i, _vp, _vp]),
-    "qvh_hnsw_search_batch": (_i, [_vp, _vp, _u32, _u32, _i, _vp, _vp, _vp]), "qvh_hnsw_device_fallbacks": (_u32, [_vp]), "qvh_hnsw_topups": (_u32, [_vp]),
+    "qvh_hnsw_search_batch": (_i, [_vp, _vp, _u32, _u32, _i, _vp, _vp, _vp]), "qvh_hnsw_search_batch_raw": (_i, [_vp, _vp, _u32, _u32, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
+    "qvh_hnsw_device_fallbacks": (_u32, [_vp]), "qvh_hnsw_topups": (_u32, [_vp]),
     "qvh_hnsw_size": (_u32, [_vp]), "qvh_hnsw_nodes": (_u32, [_vp]), "qvh_hnsw_node_level": (_i, [_vp, _u32]),
     "qvh_hnsw_links": (_i, [_vp, _u32, _i, _vp, _u32]), "qvh_hnsw_entry_point": (None, [_vp, C.POINTER(_u32), C.POINTER(_i)]),
     "qvh_hnsw_set_ef_search": (None, [_vp, _i]),

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 
 namespace quiver {
 
@@ -449,6 +450,19 @@ Error HNSW::syncDeviceGraph() {
     return "";
 }
 
+Error HNSW::SearchBatchRaw(const float* qs, uint32_t len, uint32_t nq, int k, uint32_t* rows, float* dist, uint32_t* count, uint32_t* evals, double* seconds) {
+    if (seconds) *seconds = 0.0;
+    if (nodes_.empty() || nq == 0 || size_ == 0) return "graph is empty";
+    if (k <= 0) return "k must be positive";
+    if ((int)len != dim_) return "vector dimensions do not match";
+    Error e = syncDeviceGraph();
+    if (!e.empty()) return e;
+    auto t0 = std::chrono::steady_clock::now();
+    if (qv_graph_search(dg_, qs, nq, (uint32_t)k, (uint32_t)efS_, rows, dist, count, evals) != QV_OK) return qv_err();
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return "";
+}
+
 Error HNSW::SearchBatch(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<HNSWResult>>* out, std::vector<uint32_t>* evals_out) {
     out->assign(nq, {});
     if (evals_out) evals_out->assign(nq, 0);
@@ -854,6 +868,9 @@ int qvh_hnsw_search_batch(void* p, const float* qs, uint32_t len, uint32_t nq, i
         }
     if (evals_out) for (size_t q = 0; q < ev.size(); q++) evals_out[q] = ev[q];
     return ret(e);
+}
+int qvh_hnsw_search_batch_raw(void* p, const float* qs, uint32_t len, uint32_t nq, int k, uint32_t* rows, float* dist, uint32_t* count, uint32_t* evals, double* seconds) {
+    return ret(static_cast<HNSW*>(p)->SearchBatchRaw(qs, len, nq, k, rows, dist, count, evals, seconds));
 }
 uint32_t qvh_hnsw_device_fallbacks(void* p) { return static_cast<HNSW*>(p)->DeviceFallbacks(); }
 uint32_t qvh_hnsw_topups(void* p) { return static_cast<HNSW*>(p)->TopUps(); }

@@ -73,6 +73,8 @@ public:
     // graph search under-fills (hnsw.go:676) or overflows the device heap is redone by Search()
     Error SearchBatch(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<HNSWResult>>* out,
                       std::vector<uint32_t>* evals_out = nullptr);
+    // the device call alone (no id strings, no top-up): rows/dist [nq][k], count [nq]; seconds spent in qv_graph_search
+    Error SearchBatchRaw(const float* qs, uint32_t len, uint32_t nq, int k, uint32_t* rows, float* dist, uint32_t* count, uint32_t* evals, double* seconds);
     uint32_t DeviceFallbacks() const { return device_fallbacks_; }   // heap overflows redone on the host
     uint32_t TopUps() const { return topups_; }                       // under-filled graph searches completed by an exact scan
     uint32_t Size() const { return size_; }

@@ -1284,6 +1284,20 @@ k_hnsw_search(IndexView v, GraphView g, const float* __restrict__ queries, uint3
 // layout, so a query that ever sees two equal distances in the list (or a NaN) is flagged and
 // re-run by k_hnsw_search (the exact-heap form): results stay identical to the reference in all cases.
 constexpr uint32_t kHnswTieFlag = 0xFFFFFFFEu;
+constexpr int kHnswStageRows = 8;         // neighbour rows staged in LDS per round
+
+// a row staged in LDS (contiguous f4 chunks), same sequential-over-dims arithmetic as row_accumulate
+template <int M>
+__device__ __forceinline__ typename MT<M>::A row_accumulate_lds(const f4* p, const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4) {
+    typename MT<M>::A acc = 0;
+#pragma unroll 4
+    for (uint32_t c = 0; c < dim4; c++) {
+        const f4 x = p[c];
+        const typename MT<M>::Q* qq = q_lds + (size_t)c * 4;
+        acc1<M>(acc, qq[0], x.x); acc1<M>(acc, qq[1], x.y); acc1<M>(acc, qq[2], x.z); acc1<M>(acc, qq[3], x.w);
+    }
+    return acc;
+}
 
 template <int M, int U, int S>
 __global__ void __launch_bounds__(64)
@@ -1294,6 +1308,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const float* __restrict__ queries, 
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
     uint32_t* batch = reinterpret_cast<uint32_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);   // [64]
+    f4* stage = reinterpret_cast<f4*>(batch + 64);                    // [kHnswStageRows][dim4 + 1] (row-major index only)
     const uint32_t lane = threadIdx.x;
     uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
     uint32_t epoch = epoch0;
@@ -1306,14 +1321,37 @@ k_hnsw_search_wave(IndexView v, GraphView g, const float* __restrict__ queries, 
     uint32_t n_list = 0; bool tie = false;
     uint32_t n_eval = 0;
 
-    // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n)
+    // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n).
+    // With the row-major copy the neighbour rows are fetched COOPERATIVELY — all 64 lanes read one
+    // row's 16-byte chunks side by side (1 KiB per instruction, every load of a round in flight
+    // together) into LDS, padded by one chunk per row so the per-lane reads below spread over the
+    // banks — and then lane r walks ITS row sequentially from LDS.  (Each lane pulling its own row
+    // straight from memory meant 24 dependent latency rounds of 13-way scattered 16-byte loads per hop.)
     auto eval_keys = [&](uint32_t n) -> uint64_t {
         uint64_t kx = kDeadKey;
+        if (use_rm) {
+            const uint32_t pitch = v.dim4 + 1;
+            for (uint32_t base = 0; base < n; base += kHnswStageRows) {
+                const uint32_t cnt = n - base < (uint32_t)kHnswStageRows ? n - base : (uint32_t)kHnswStageRows;
+                __syncthreads();
+                for (uint32_t r = 0; r < cnt; r++) {
+                    const f4* src = reinterpret_cast<const f4*>(v.rowmaj + (size_t)batch[base + r] * v.dim);
+                    for (uint32_t c = lane; c < v.dim4; c += 64) stage[(size_t)r * pitch + c] = src[c];
+                }
+                __syncthreads();
+                if (lane >= base && lane < base + cnt) {
+                    const uint32_t row = batch[lane];
+                    typename MT<M>::A acc = row_accumulate_lds<M>(stage + (size_t)(lane - base) * pitch, q_lds, v.dim4);
+                    double rn = 0.0;
+                    if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+                    kx = make_key(finalize<M>(acc, qc, rn), row);
+                }
+            }
+            return kx;
+        }
         if (lane < n) {
             const uint32_t row = batch[lane];
-            typename MT<M>::A acc;
-            if (use_rm) acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
-            else acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
+            typename MT<M>::A acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
             double rn = 0.0;
             if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
             kx = make_key(finalize<M>(acc, qc, rn), row);
@@ -1756,7 +1794,7 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
 }
 
 // wave-resident form: registers only (plus the staged query); tie-flagged queries report kHnswTieFlag
-size_t hnsw_wave_lds_bytes(int metric, uint32_t dim4) { return query_lds_bytes(metric, dim4) + 64 * sizeof(uint32_t) + 64; }
+size_t hnsw_wave_lds_bytes(int metric, uint32_t dim4) { return query_lds_bytes(metric, dim4) + 64 * sizeof(uint32_t) + (size_t)kHnswStageRows * (dim4 + 1) * 16 + 64; }
 uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4) {
     const size_t lds = hnsw_wave_lds_bytes(metric, dim4);
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));

@@ -77,6 +77,16 @@ class HNSW:
         out = [[Result(i, d, int(idx[q, j])) for j, (i, d) in enumerate(many[q])] for q in range(nq)]
         return (out, ev) if with_evals else out
 
+    def search_batch_raw(self, queries, k: int):
+        """the device traversal alone: (rows [nq,k] uint32, dist [nq,k], count [nq], evals [nq], seconds in qv_graph_search)"""
+        qs = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, n = qs.shape
+        rows = np.empty((nq, k), np.uint32); dist = np.empty((nq, k), np.float32)
+        cnt = np.empty(nq, np.uint32); ev = np.empty(nq, np.uint32)
+        sec = C.c_double(0)
+        check(hlib().qvh_hnsw_search_batch_raw(self._h, qs.ctypes.data, n, nq, k, rows.ctypes.data, dist.ctypes.data, cnt.ctypes.data, ev.ctypes.data, C.byref(sec)))
+        return rows, dist, cnt, ev, float(sec.value)
+
     def device_fallbacks(self) -> int:
         return int(hlib().qvh_hnsw_device_fallbacks(self._h))
 
