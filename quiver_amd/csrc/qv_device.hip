@@ -807,9 +807,20 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
             const double qn = __builtin_sqrt(n2);
             const double U = (double)sample_dist[(size_t)q * k + (k - 1)];     // +inf if the sample held < k live rows
             const double gamma = (double)(dim + 2) * 5.9604644775390625e-8 / (1.0 - (double)(dim + 2) * 5.9604644775390625e-8);
-            double c = metric == QV_COSINE ? (1.0 - U - 4e-7) * qn : (1.0 - U - 4e-7 * (1.0 + __builtin_fabs(U)));
-            double m = (gamma + 1e-6) * qn;
-            if (!(U == U) || U > 3.0e38) { c = -3.0e38; m = 0.0; }            // no bound: everything is a candidate (overflow -> exact path)
+            double c, m;
+            if (metric == QV_L2 || metric == QV_L2SQ) {
+                // squared domain: real d^2 = |q|^2 + |r|^2 - 2S.  The reference value D relates to the real d by
+                // D = d(1+eta), |eta| <= 1.3e-7 (QV_L2: float32 differences, float64 sum, sqrt, one rounding) or
+                // D = d^2(1+eta), |eta| <= (K+2)u (QV_L2SQ: float32 accumulation), so D <= U implies d^2 <= T:
+                const double T = metric == QV_L2 ? U * U * (1.0 + 4e-7) : U * (1.0 + gamma + 2e-6);
+                c = n2 * (1.0 - 2e-6) - T;                           // A_q; test: 2S~ >= A_q + (1-2e-6)|r|^2 - B_q|r|
+                m = 2.0 * (gamma + 1e-6) * qn;                       // B_q
+                if (!(U == U) || U > 1.0e18) { c = -3.0e38; m = 0.0; }
+            } else {
+                c = metric == QV_COSINE ? (1.0 - U - 4e-7) * qn : (1.0 - U - 4e-7 * (1.0 + __builtin_fabs(U)));
+                m = (gamma + 1e-6) * qn;
+                if (!(U == U) || U > 3.0e38) { c = -3.0e38; m = 0.0; }            // no bound: everything is a candidate (overflow -> exact path)
+            }
             c_ = f32_down((float)c);                                         // round towards "keep more"
             m_ = f32_up((float)m);
         }
@@ -833,7 +844,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
     const uint32_t stride = tw / nqb64;
     {   // cosine: one constant t_q = c_q - m_q (test S~ >= t_q |r|); dot: c_q and m_q (test S~ >= c_q - m_q |r|)
         const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
-        s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
+        s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;     // L2 family: A_q (c) and B_q (m)
         s_m[wave][lane] = m;
     }
     __syncthreads();
@@ -905,20 +916,23 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
             const uint32_t row = t * 64 + 32 * (j & 1) + l31;
             const bool live = (v.alive[t] >> (32 * (j & 1) + l31)) & 1ull;
             const float rn = f32_up((float)v.rnorm[row]);
+            const float rlo = f32_down((float)v.rnorm[row]);
+            const float rn2c = f32_down(f32_down(rlo * rlo) * 0.999998f);   // (1-2e-6)|r|^2, rounded down (L2 family)
+            (void)rn2c;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 bool hit = false;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : s_c[wave][ql] - s_m[wave][ql] * rn;
+                    const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
                     hit |= acc[i][j][r] >= thr;
                 }
                 if (hit && live) {                                  // rare: a row that may be in some query's top-k
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : s_c[wave][ql] - s_m[wave][ql] * rn;
+                        const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
                         if (acc[i][j][r] >= thr) {
                             const uint32_t q = 64 * qb64 + ql;
                             uint32_t slot = atomicAdd(&cand_cnt[q], 1u);
@@ -960,7 +974,13 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
     stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
     if (threadIdx.x == 0) s_ns = 0;
     __syncthreads();
-    const QConst qc = query_const<M>(q_lds, v.dim);                 // exact |q| (every lane, same value)
+    const QConst qc = query_const<M>(q_lds, v.dim);                 // the metric's own query constant
+    double qn_l2 = qc.qn;                                           // |q| for the error bounds (every lane, same value)
+    if constexpr (M != QV_COSINE) {
+        double n2 = 0.0;
+        for (uint32_t i = 0; i < v.dim; i++) { double a = (double)q_lds[i]; n2 = __builtin_fma(a, a, n2); }
+        qn_l2 = __builtin_sqrt(n2);
+    }
     const uint32_t kth = k - 1;
     const uint32_t* cr = cand_rows + (size_t)qi * kMfmaCandCap;
     const float* cs = cand_score + (size_t)qi * kMfmaCandCap;
@@ -974,8 +994,17 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
         if constexpr (M == QV_COSINE) {
             if (qc.qn == 0.0 || rn == 0.0) { d = 1.0; e = 0.0; }
             else { d = 1.0 - S / (qc.qn * rn); e = gamma + 2e-6; }  // |S~ - S| <= gamma |q||r|
-        } else {
-            d = 1.0 - S; e = gamma * qc.qn * rn + 2e-6 * (1.0 + __builtin_fabs(d));
+        } else if constexpr (M == QV_DOT) {
+            d = 1.0 - S; e = gamma * qn_l2 * rn + 2e-6 * (1.0 + __builtin_fabs(d));
+        } else {                                                    // QV_L2 / QV_L2SQ: interval on d^2, then into the metric's units
+            const double q2 = qn_l2 * qn_l2, r2 = rn * rn;
+            const double d2 = q2 + r2 - 2.0 * S, e2 = 2.0 * gamma * qn_l2 * rn + 2e-6 * (q2 + r2);
+            double l2 = d2 - e2 > 0.0 ? d2 - e2 : 0.0, h2 = d2 + e2 > 0.0 ? d2 + e2 : 0.0;
+            if constexpr (M == QV_L2) { l2 = __builtin_sqrt(l2) * (1.0 - 4e-7); h2 = __builtin_sqrt(h2) * (1.0 + 4e-7); }
+            else { l2 = l2 * (1.0 - gamma - 2e-6); h2 = h2 * (1.0 + gamma + 2e-6); }
+            lo = f32_down((float)l2); hi = f32_up((float)h2);
+            if (!(d2 == d2)) { lo = -__builtin_inff(); hi = __builtin_inff(); }
+            return;
         }
         lo = f32_down((float)(d - e)); hi = f32_up((float)(d + e));
         if (!(d == d)) { lo = -__builtin_inff(); hi = __builtin_inff(); }   // NaN score: keep, the exact pass decides
@@ -1498,14 +1527,14 @@ k_ingest(IndexView v, const float* __restrict__ src, uint32_t row0, uint32_t n, 
                 x.z = j + 2 < v.dim ? s[j + 2] : 0.f; x.w = j + 3 < v.dim ? s[j + 3] : 0.f;
             }
             dst[(size_t)c * 64] = x;
-            if (v.metric == QV_COSINE || v.metric == QV_DOT) {            // distances.go:21 magnitudeB += b*b (DOT: |r| for the MFMA filter margin)
+            if (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) {   // distances.go:21 magnitudeB += b*b (non-cosine: |r| for the MFMA filter)
                 mb = __builtin_fma((double)x.x, (double)x.x, mb); mb = __builtin_fma((double)x.y, (double)x.y, mb);
                 mb = __builtin_fma((double)x.z, (double)x.z, mb); mb = __builtin_fma((double)x.w, (double)x.w, mb);
             } else if (v.metric == QV_COSINE_F32) {                       // adapter.go:119 normB += b*b (unfused)
                 float p; p = x.x * x.x; nb = nb + p; p = x.y * x.y; nb = nb + p; p = x.z * x.z; nb = nb + p; p = x.w * x.w; nb = nb + p;
             }
         }
-        if (v.metric == QV_COSINE || v.metric == QV_DOT) v.rnorm[row] = __builtin_sqrt(mb);
+        if (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) v.rnorm[row] = __builtin_sqrt(mb);
         else if (v.metric == QV_COSINE_F32) v.rnorm[row] = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
     }
     uint64_t m = __ballot(mine);
@@ -1547,12 +1576,12 @@ k_generate(IndexView v, uint64_t seed, uint64_t gen_row0, uint32_t row0, uint32_
             for (int j = 0; j < 4; j++) {
                 uint32_t col = 4 * c + j;
                 e[j] = col < v.dim ? (float)((double)gen_int(row_key, col) / norm) : 0.0f;
-                if (v.metric == QV_COSINE || v.metric == QV_DOT) mb = __builtin_fma((double)e[j], (double)e[j], mb);
+                if (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) mb = __builtin_fma((double)e[j], (double)e[j], mb);
                 else if (v.metric == QV_COSINE_F32) { float p = e[j] * e[j]; nb = nb + p; }
             }
             dst[(size_t)c * 64] = make_float4(e[0], e[1], e[2], e[3]);
         }
-        if (v.metric == QV_COSINE || v.metric == QV_DOT) v.rnorm[row] = __builtin_sqrt(mb);
+        if (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) v.rnorm[row] = __builtin_sqrt(mb);
         else if (v.metric == QV_COSINE_F32) v.rnorm[row] = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
         if (v.rowmaj) {
             float* rm = v.rowmaj + (size_t)row * v.dim;
@@ -1708,7 +1737,7 @@ uint32_t batched_sample_rows(uint32_t n_rows) {
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 262144), min_q = env_int("QV_MFMA_MIN_QUERIES", 32);
-    return (v.metric == QV_COSINE || v.metric == QV_DOT) && k <= (uint32_t)kMaxFusedK && nq >= (uint32_t)min_q && v.n_rows >= (uint32_t)min_rows;
+    return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxFusedK && nq >= (uint32_t)min_q && v.n_rows >= (uint32_t)min_rows;
 }
 size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t nq, uint32_t k) {
     const uint32_t nq_pad = (nq + 63) / 64 * 64;
@@ -1753,17 +1782,15 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     while ((grid * 4) % nqb64) grid++;                                 // every query block gets the same number of waves
     if (ev0) (void)hipEventRecord(ev0, s);
     if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_mfma_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
-    else hipLaunchKernelGGL(k_mfma_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+    else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_mfma_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+    else hipLaunchKernelGGL(k_mfma_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter
     if (ev1) (void)hipEventRecord(ev1, s);
     // 4. exact re-scoring + selection
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * sizeof(uint32_t);
-    if (v.metric == QV_COSINE) {
-        e = set_lds(k_rescore_select<QV_COSINE, 8>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_rescore_select<QV_COSINE, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf);
-    } else {
-        e = set_lds(k_rescore_select<QV_DOT, 8>, lds); if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_rescore_select<QV_DOT, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf);
-    }
+#define QV_RS(MMM) { e = set_lds(k_rescore_select<MMM, 8>, lds); if (e != hipSuccess) return e;                                   \
+        hipLaunchKernelGGL((k_rescore_select<MMM, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf); }
+    if (v.metric == QV_COSINE) QV_RS(QV_COSINE) else if (v.metric == QV_DOT) QV_RS(QV_DOT) else if (v.metric == QV_L2) QV_RS(QV_L2) else QV_RS(QV_L2SQ)
+#undef QV_RS
     *d_overflow_out = ovf;
     return hipGetLastError();
 }

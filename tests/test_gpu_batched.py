@@ -25,7 +25,7 @@ def _eq(a, b):
     return np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1])) and np.array_equal(a[2], b[2])
 
 
-@pytest.mark.parametrize("metric", ["cosine", "dot_product"])
+@pytest.mark.parametrize("metric", ["cosine", "dot_product", "euclidean", "squared_euclidean"])
 def test_mfma_batched_equals_exact_scan(metric):
     import quiver_amd as q
     n, dim, nq = 300_000, 768, 256
@@ -73,11 +73,30 @@ def test_mfma_batched_with_unrepresentative_sample_ties_and_tombstones():
         assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "squared_euclidean", "dot_product"])
+def test_mfma_batched_unnormalised_rows_and_queries(metric):
+    """rows and queries of very different lengths: the error margins scale with |q||r|"""
+    import quiver_amd as q
+    rng = np.random.default_rng(11)
+    n, dim, nq = 270_000, 96, 64
+    rows = (rng.standard_normal((n, dim)) * rng.choice([0.01, 1.0, 30.0], size=(n, 1))).astype(np.float32)
+    qs = (rng.standard_normal((nq, dim)) * rng.choice([0.1, 1.0, 10.0], size=(nq, 1))).astype(np.float32)
+    rows[123] = qs[0]                                       # an exact hit: distance 0 (or 1 - |q|^2 for dot)
+    idx = q.DeviceIndex(dim, metric)
+    idx.add(rows)
+    exact = _exact(idx, qs, 10)
+    batched = idx.search(qs, 10, batched=True)
+    assert _eq(exact, batched)
+    for i in (0, 5, 63):
+        er, ed = O.exact_search(q.metric_id(metric), rows, qs[i], 10)
+        assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
+
+
 def test_batched_falls_back_when_not_applicable():
     import quiver_amd as q
     rows = O.gen_rows(3, 0, 5000, 32)
     qs = O.gen_rows(4, 0, 70, 32)
-    for metric in ("cosine", "euclidean", "manhattan"):
+    for metric in ("cosine", "euclidean", "manhattan", "hnsw_cosine"):
         idx = q.DeviceIndex(32, metric)
         idx.add(rows)
         assert _eq(idx.search(qs, 5), idx.search(qs, 5, batched=True))          # small corpus / non-GEMM metric -> exact scan
