@@ -146,6 +146,13 @@ int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, u
 int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                             uint32_t* rows_out, float* dist_out, uint32_t* count_out);
 
+/* Device-pointer form of the batched path: enqueues on `stream`, no sync.  d_redo_flags_out[nq]
+ * (uint32) is set to 1 for queries whose candidate buffer overflowed: the caller must redo those
+ * with qv_index_search_device (their result rows are unspecified).  Returns QV_ERR_UNSUPPORTED when
+ * the MFMA path does not apply (metric, k > 64, small corpus, nq < 32): use qv_index_search_device. */
+int qv_index_search_batched_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
+                                   uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_redo_flags_out, void* stream);
+
 /* Replaces the neighbour loop of HNSW.searchLayer (hnsw.go:536-563) and the
  * re-rank loops (hybrid_index.go:536-546; adapter.go:387-415): distance of one
  * query to n listed rows.  dist_out[i] = distance(query, row rows[i]); dead rows

@@ -511,6 +511,33 @@ int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, u
     return enqueue_search(idx, d_queries, nq, kk, k, ws, 0, d_rows_out, d_dist_out, s);
 }
 
+int qv_index_search_batched_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
+                                   uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_redo_flags_out, void* stream) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (nq == 0) return QV_OK;
+    if (!d_queries || !d_rows_out || !d_dist_out || !d_redo_flags_out) return fail(QV_ERR_INVALID_ARG, "null device pointer");
+    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");
+    const qv::IndexView v = idx->view();
+    if (k > idx->n_live || idx->n_live < 4 * (uint64_t)k || !qv::batched_supported(v, nq, k))
+        return fail(QV_ERR_UNSUPPORTED, "the MFMA batched path does not apply to this index/query shape; use qv_index_search_device");
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const qv::ScanPlan plan = qv::plan_scan(v.n_tiles, idx->cus);
+    void* ws = nullptr;
+    int rc = stream_workspace(idx, s, qv::batched_workspace_bytes(v, plan, nq, k), &ws);
+    if (rc != QV_OK) return rc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (idx->profiling && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {
+        std::lock_guard<std::mutex> g(idx->prof_mu);
+        idx->prof_events.emplace_back(ev0, ev1);
+    }
+    uint32_t* d_ovf = nullptr;
+    hipError_t e = qv::launch_batched(v, plan, d_queries, nq, k, ws, d_rows_out, d_dist_out, &d_ovf, idx->cus, s, ev0, ev1);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "batched launch failed: %s", hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(d_redo_flags_out, d_ovf, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    return QV_OK;
+}
+
 int qv_merge_topk_device(const float* d_dist_lists, const uint32_t* d_row_lists, uint32_t n_lists, uint32_t k,
                          uint32_t* d_rows_out, float* d_dist_out, void* stream) {
     if (!d_dist_lists || !d_row_lists || !d_rows_out || !d_dist_out) return fail(QV_ERR_INVALID_ARG, "null device pointer");

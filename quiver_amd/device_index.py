@@ -106,6 +106,9 @@ class DeviceIndex:
     def search_device(self, d_queries: int, nq: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
         check(lib().qv_index_search_device(self._h, d_queries, nq, k, d_rows_out, d_dist_out, stream))
 
+    def search_batched_device(self, d_queries: int, nq: int, k: int, d_rows_out: int, d_dist_out: int, d_redo_flags: int, stream: int = 0):
+        check(lib().qv_index_search_batched_device(self._h, d_queries, nq, k, d_rows_out, d_dist_out, d_redo_flags, stream))
+
     def distance_rows(self, query, rows) -> np.ndarray:
         q = _f32c(query)
         if q.size != self.dim:

@@ -121,3 +121,25 @@ def test_multi_query_scan_equals_single_query_scans(metric):
     alive = np.ones(20_000, bool); alive[[3, 4, 5]] = False
     er, ed = O.exact_search(metric, rows, qs[0], 10, alive=alive)
     assert np.array_equal(many[0][0], er) and np.array_equal(_bits(many[1][0]), _bits(ed))
+
+
+def test_batched_device_pointer_entry_point():
+    import torch
+    import quiver_amd as q
+    idx = q.DeviceIndex(128, "cosine")
+    idx.add_synthetic(5, 0, 300_000)
+    qs = O.gen_rows(6, 0, 96, 128)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((96, 10), dtype=torch.int32, device="cuda")
+    dd = torch.empty((96, 10), dtype=torch.float32, device="cuda")
+    fl = torch.ones((96,), dtype=torch.int32, device="cuda")
+    idx.search_batched_device(dq.data_ptr(), 96, 10, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(fl.sum().item()) == 0
+    ex = _exact(idx, qs, 10)
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32), ex[0]) and np.array_equal(_bits(dd.cpu().numpy()), _bits(ex[1]))
+    small = q.DeviceIndex(128, "manhattan")
+    small.add_synthetic(5, 0, 1000)
+    with pytest.raises(q.QvError) as e:
+        small.search_batched_device(dq.data_ptr(), 96, 10, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), 0)
+    assert e.value.code == -8
