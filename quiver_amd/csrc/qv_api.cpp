@@ -1,4 +1,4 @@
-// qv_api.cpp — the C ABI of include/qv.h over the gfx950 kernels of qv_device.hip.
+// qv_api.cpp — the C ABI of include/qv.h over the gfx950 kernels (qv_*.hip).
 //
 // Host-side responsibilities only: argument checks in the reference's order and
 // wording, device-memory ownership (tile storage sized for 288 GB HBM3E: one

@@ -1,5 +1,5 @@
 // qv_device.h — internal interface between the C-ABI layer (qv_api.cpp) and the
-// gfx950 kernels (qv_device.hip).  Not installed; include/qv.h is the public ABI.
+// gfx950 kernels (qv_scan/qv_rank/qv_batched/qv_hnsw/qv_misc.hip; shared helpers in qv_kernels.h).  Not installed; include/qv.h is the public ABI.
 //
 // HBM layout of an index ("row tiles", the SoA layout of DESIGN.md §3):
 //   tiles   float  [n_tiles][dim4][64][4]   tile t holds rows 64t..64t+63; within a

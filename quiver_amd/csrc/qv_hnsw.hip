@@ -1,0 +1,445 @@
+// qv_hnsw.hip — device-resident HNSW traversal (exact-heap and wave-resident forms)
+// (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
+#include "qv_kernels.h"
+
+namespace qv {
+
+// ---------------------------------------------------------------- HNSW traversal ----
+// Device-resident restatement of hnsw.HNSW.Search (pkg/hnsw/hnsw.go:602-713) and searchLayer
+// (:471-580): one wavefront walks the graph for one query; many queries are in flight (the
+// path is latency-bound per query).  To return exactly what the reference
+// returns, the two heaps are the reference's binary heaps with its own sift loops
+// (hnsw.go:101-196), executed by lane 0 on LDS arrays, and a hop's neighbours are admitted
+// one by one in adjacency order (:536-563) after their distances have been computed together:
+// lane i scores the i-th unvisited neighbour with the same sequential-over-dims arithmetic
+// as every other kernel here, so distances — hence every heap decision — are bit-identical
+// to the CPU restatement.
+struct HRes { float dist; uint32_t idx; };
+constexpr int kHnswCandCap = 2048;     // candidate min-heap slots per query (overflow -> host path)
+constexpr int kHnswEfMax = 512;
+constexpr int kHnswMaxDeg = 64;
+
+__device__ __forceinline__ void h_min_up(HRes* rs, int j) {                      // hnsw.go:118-128
+    for (;;) { int i = (j - 1) / 2; if (i == j || rs[j].dist >= rs[i].dist) break; HRes t = rs[i]; rs[i] = rs[j]; rs[j] = t; j = i; }
+}
+__device__ __forceinline__ void h_min_down(HRes* rs, int i0, int n) {            // hnsw.go:130-148
+    int i = i0;
+    for (;;) {
+        int j1 = 2 * i + 1; if (j1 >= n || j1 < 0) break;
+        int j = j1, j2 = j1 + 1; if (j2 < n && rs[j2].dist < rs[j1].dist) j = j2;
+        if (rs[i].dist <= rs[j].dist) break;
+        HRes t = rs[i]; rs[i] = rs[j]; rs[j] = t; i = j;
+    }
+}
+__device__ __forceinline__ void h_max_up(HRes* rs, int j) {                      // hnsw.go:172-181
+    for (;;) { int i = (j - 1) / 2; if (i == j || rs[j].dist <= rs[i].dist) break; HRes t = rs[i]; rs[i] = rs[j]; rs[j] = t; j = i; }
+}
+__device__ __forceinline__ void h_max_down(HRes* rs, int i0, int n) {            // hnsw.go:183-200
+    int i = i0;
+    for (;;) {
+        int j1 = 2 * i + 1; if (j1 >= n || j1 < 0) break;
+        int j = j1, j2 = j1 + 1; if (j2 < n && rs[j2].dist > rs[j1].dist) j = j2;
+        if (rs[i].dist >= rs[j].dist) break;
+        HRes t = rs[i]; rs[i] = rs[j]; rs[j] = t; i = j;
+    }
+}
+
+// one wave (64-thread workgroup) per query stream
+template <int M, int U>
+__global__ void __launch_bounds__(64)
+k_hnsw_search(IndexView v, GraphView g, const float* __restrict__ queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+              uint32_t* __restrict__ visited /*[gridDim.x][n_nodes]*/, uint32_t epoch0,
+              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    unsigned char* base = smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16;
+    HRes* cand = reinterpret_cast<HRes*>(base);                       // [kHnswCandCap]
+    HRes* res = cand + kHnswCandCap;                                  // [kHnswEfMax + 1]
+    uint32_t* batch = reinterpret_cast<uint32_t*>(res + kHnswEfMax + 1);   // [kHnswMaxDeg]
+    float* bd = reinterpret_cast<float*>(batch + kHnswMaxDeg);        // [kHnswMaxDeg]
+    __shared__ int s_ncand, s_nres, s_state;                           // state: 0 run, 1 done, 2 overflow
+    __shared__ uint32_t s_cur;
+    const uint32_t lane = threadIdx.x;
+    uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
+    uint32_t epoch = epoch0;
+    const bool use_rm = v.rowmaj != nullptr && (v.dim & 3) == 0;
+
+    auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
+    // distances of batch[0..n) -> bd[0..n); lane i scores batch[i]
+    QConst qc;
+    auto eval = [&](uint32_t n) {
+        if (lane < n) {
+            const uint32_t row = batch[lane];
+            typename MT<M>::A acc;
+            if (use_rm) acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
+            else acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
+            double rn = 0.0;
+            if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+            bd[lane] = finalize<M>(acc, qc, rn);
+        }
+        __syncthreads();
+    };
+    // searchLayer (hnsw.go:471-580); result: res[0..s_nres) ascending; returns false on overflow
+    uint32_t n_eval = 0;
+    auto search_layer = [&](uint32_t entry, int ef, int level) -> bool {
+        epoch++;
+        if (lane == 0) { vis[entry] = epoch; batch[0] = entry; }
+        __syncthreads();
+        eval(1); n_eval += 1;                                          // :492
+        if (lane == 0) {
+            cand[0] = {bd[0], entry}; res[0] = {bd[0], entry};        // :498-506
+            s_ncand = 1; s_nres = 1; s_state = 0;
+        }
+        __syncthreads();
+        for (;;) {
+            if (lane == 0) {
+                int nc = s_ncand, nr = s_nres;
+                if (nc == 0) s_state = 1;                              // :509
+                else {
+                    nc--; HRes t = cand[0]; cand[0] = cand[nc]; cand[nc] = t; h_min_down(cand, 0, nc); HRes cur = cand[nc];   // :511 pop
+                    s_ncand = nc;
+                    if (nr >= ef && cur.dist > res[0].dist) s_state = 1;   // :514-516
+                    else s_cur = cur.idx;
+                }
+            }
+            __syncthreads();
+            if (s_state != 0) break;
+            const uint32_t cur = s_cur;
+            // neighbours of cur at `level` (:523-534)
+            uint32_t deg = 0; const uint32_t* links = nullptr;
+            if (alive(cur) && level <= (int)g.level[cur]) {
+                if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
+                else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
+            }
+            uint32_t c = 0xFFFFFFFFu; bool fresh = false;
+            if (lane < deg) {
+                c = links[lane];
+                fresh = alive(c) && vis[c] != epoch;                   // :539-543
+            }
+            // a list may hold the same node twice (the self-link quirk): only its first occurrence is new
+            for (uint32_t j = 0; j + 1 < deg; j++) {
+                uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                if (lane > j && c == cj) fresh = false;
+            }
+            const uint64_t fm = __ballot(fresh);
+            const uint32_t n = (uint32_t)__builtin_popcountll(fm);
+            if (fresh) { vis[c] = epoch; batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c; }   // :544, adjacency order kept
+            __syncthreads();
+            if (n == 0) continue;
+            eval(n); n_eval += n;                                      // :548 (batched)
+            if (lane == 0) {
+                int nc = s_ncand, nr = s_nres;
+                for (uint32_t i = 0; i < n; i++) {
+                    const float cd = bd[i];
+                    if (nr < ef || cd < res[0].dist) {                 // :553
+                        if (nc >= kHnswCandCap) { s_state = 2; break; }
+                        cand[nc] = {cd, batch[i]}; h_min_up(cand, nc); nc++;          // :554
+                        res[nr] = {cd, batch[i]}; h_max_up(res, nr); nr++;            // :555
+                        if (nr > ef) { nr--; HRes t = res[0]; res[0] = res[nr]; res[nr] = t; h_max_down(res, 0, nr); }   // :558-560
+                    }
+                }
+                s_ncand = nc; s_nres = nr;
+            }
+            __syncthreads();
+            if (s_state == 2) return false;
+        }
+        if (lane == 0) {                                               // :566-577 heap -> ascending slice, in place
+            int nr = s_nres;
+            for (int m = nr; m > 1; m--) { HRes t = res[0]; res[0] = res[m - 1]; res[m - 1] = t; h_max_down(res, 0, m - 1); }
+        }
+        __syncthreads();
+        return true;
+    };
+
+    for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
+        __syncthreads();
+        qc = query_const<M>(q_lds, v.dim);
+        n_eval = 0;
+        uint32_t entry = g.entry;
+        bool ok = true;
+        for (int level = g.cur_level; level > 0 && ok; level--) {       // :649-657
+            ok = search_layer(entry, 1, level);
+            if (ok && s_nres > 0) entry = res[0].idx;
+            __syncthreads();
+        }
+        const int ef = (int)ef_search > (int)k ? (int)ef_search : (int)k;   // :660-663
+        if (ok) ok = search_layer(entry, ef, 0);                        // :664
+        uint32_t cnt = 0xFFFFFFFFu;                                     // overflow marker
+        if (ok) {
+            cnt = (uint32_t)s_nres < k ? (uint32_t)s_nres : k;          // :670-672 (under-filled: the caller tops up, :676-710)
+            for (uint32_t i = lane; i < k; i += 64) {
+                rows_out[(size_t)qi * k + i] = i < cnt ? res[i].idx : 0xFFFFFFFFu;
+                dist_out[(size_t)qi * k + i] = i < cnt ? res[i].dist : __uint_as_float(0x7F800000u);
+            }
+        }
+        if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
+        __syncthreads();
+        epoch += 64;                                                    // distinct epochs for the next query of this wave
+    }
+}
+
+// ---------------------------------------------------------------- HNSW traversal, wave-resident form
+// Same traversal, without the serial LDS heaps.  Observation (no two entries of equal distance):
+//   * a node enters the candidate heap exactly when it enters the result heap (hnsw.go:553-555);
+//   * it leaves the result heap only by eviction, and an evicted node (distance > results.top from
+//     then on) is never expanded: when it is popped the loop stops (hnsw.go:514-516) and every
+//     other remaining candidate is no better;
+//   * sequential admission of a hop's neighbours (hnsw.go:553-560) leaves the ef smallest of
+//     (old results + neighbours), whatever the order.
+// So the whole searchLayer state is ONE ascending list of <= ef (distance, node) keys with an
+// "expanded" bit each: pop = first unexpanded entry; admit = sorted insert, drop the (ef+1)-th.
+// The list lives in registers, S keys per lane (ef <= 64*S), and is updated with ballots, popcounts,
+// readlanes and DPP wave shifts — no LDS, so ~4x more queries are resident and a hop's serial part
+// shrinks from ~40 us to ~1 us.  With equal distances the binary heaps' pop order depends on their
+// layout, so a query that ever sees two equal distances in the list (or a NaN) is flagged and
+// re-run by k_hnsw_search (the exact-heap form): results stay identical to the reference in all cases.
+constexpr uint32_t kHnswTieFlag = 0xFFFFFFFEu;
+constexpr int kHnswStageRows = 8;         // neighbour rows staged in LDS per round
+
+// a row staged in LDS (contiguous f4 chunks), same sequential-over-dims arithmetic as row_accumulate
+template <int M>
+__device__ __forceinline__ typename MT<M>::A row_accumulate_lds(const f4* p, const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4) {
+    typename MT<M>::A acc = 0;
+#pragma unroll 4
+    for (uint32_t c = 0; c < dim4; c++) {
+        const f4 x = p[c];
+        const typename MT<M>::Q* qq = q_lds + (size_t)c * 4;
+        acc1<M>(acc, qq[0], x.x); acc1<M>(acc, qq[1], x.y); acc1<M>(acc, qq[2], x.z); acc1<M>(acc, qq[3], x.w);
+    }
+    return acc;
+}
+
+template <int M, int U, int S>
+__global__ void __launch_bounds__(64)
+k_hnsw_search_wave(IndexView v, GraphView g, const float* __restrict__ queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+                   uint32_t* __restrict__ visited, uint32_t epoch0,
+                   uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    uint32_t* batch = reinterpret_cast<uint32_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);   // [64]
+    f4* stage = reinterpret_cast<f4*>(batch + 64);                    // [kHnswStageRows][dim4 + 1] (row-major index only)
+    const uint32_t lane = threadIdx.x;
+    uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
+    uint32_t epoch = epoch0;
+    const bool use_rm = v.rowmaj != nullptr && (v.dim & 3) == 0;
+    auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
+
+    QConst qc;
+    uint64_t key[S];          // ascending over index e = s*64 + lane; kDeadKey = empty
+    uint64_t expd[S];         // wave-uniform: bit l of expd[s] = entry (s,l) already expanded
+    uint32_t n_list = 0; bool tie = false;
+    uint32_t n_eval = 0;
+
+    // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n).
+    // With the row-major copy the neighbour rows are fetched COOPERATIVELY — all 64 lanes read one
+    // row's 16-byte chunks side by side (1 KiB per instruction, every load of a round in flight
+    // together) into LDS, padded by one chunk per row so the per-lane reads below spread over the
+    // banks — and then lane r walks ITS row sequentially from LDS.  (Each lane pulling its own row
+    // straight from memory meant 24 dependent latency rounds of 13-way scattered 16-byte loads per hop.)
+    auto eval_keys = [&](uint32_t n) -> uint64_t {
+        uint64_t kx = kDeadKey;
+        if (use_rm) {
+            const uint32_t pitch = v.dim4 + 1;
+            for (uint32_t base = 0; base < n; base += kHnswStageRows) {
+                const uint32_t cnt = n - base < (uint32_t)kHnswStageRows ? n - base : (uint32_t)kHnswStageRows;
+                __syncthreads();
+                for (uint32_t r = 0; r < cnt; r++) {
+                    const f4* src = reinterpret_cast<const f4*>(v.rowmaj + (size_t)batch[base + r] * v.dim);
+                    for (uint32_t c = lane; c < v.dim4; c += 64) stage[(size_t)r * pitch + c] = src[c];
+                }
+                __syncthreads();
+                if (lane >= base && lane < base + cnt) {
+                    const uint32_t row = batch[lane];
+                    typename MT<M>::A acc = row_accumulate_lds<M>(stage + (size_t)(lane - base) * pitch, q_lds, v.dim4);
+                    double rn = 0.0;
+                    if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+                    kx = make_key(finalize<M>(acc, qc, rn), row);
+                }
+            }
+            return kx;
+        }
+        if (lane < n) {
+            const uint32_t row = batch[lane];
+            typename MT<M>::A acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
+            double rn = 0.0;
+            if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+            kx = make_key(finalize<M>(acc, qc, rn), row);
+        }
+        return kx;
+    };
+    // sorted insert of x (distance part xd), list capacity ef
+    auto insert = [&](uint64_t x, uint32_t ef) {
+        const uint32_t xd = (uint32_t)(x >> 32);
+        if (xd == 0xFFFFFFFEu) tie = true;                              // NaN: heap order is not a function of distances
+        if (n_list >= ef) {
+            const uint32_t e = ef - 1;
+            uint64_t top = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) if ((int)(e >> 6) == s2) top = readlane64(key[s2], e & 63);
+            if (xd >= (uint32_t)(top >> 32)) { if (xd == (uint32_t)(top >> 32)) tie = true; return; }   // hnsw.go:553 strict <
+        }
+        uint32_t p = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) {
+            const uint32_t kd = (uint32_t)(key[s2] >> 32);
+            p += (uint32_t)__builtin_popcountll(__ballot(kd < xd));
+            if (__ballot(kd == xd && key[s2] != kDeadKey)) tie = true;
+        }
+        const uint32_t s0 = p >> 6, l0 = p & 63;
+        uint64_t carry = 0; uint64_t cbit = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) {
+            if ((uint32_t)s2 < s0) continue;
+            const uint64_t last = readlane64(key[s2], 63);
+            const uint64_t lastbit = (expd[s2] >> 63) & 1ull;
+            const uint64_t up = wave_shr1(key[s2]);
+            if ((uint32_t)s2 == s0) {
+                key[s2] = lane < l0 ? key[s2] : (lane == l0 ? x : up);
+                const uint64_t low = (1ull << l0) - 1;                   // bits below the insertion lane stay
+                expd[s2] = (expd[s2] & low) | ((expd[s2] & ~low) << 1);  // the rest move up; bit l0 = 0: new entry unexpanded
+            } else {
+                key[s2] = lane == 0 ? carry : up;
+                expd[s2] = (expd[s2] << 1) | cbit;
+            }
+            carry = last; cbit = lastbit;
+        }
+        if (n_list < ef) n_list++;
+        // drop whatever sits past the capacity
+        if (n_list == ef && ef < (uint32_t)(S * 64)) {
+            const uint32_t e = ef;
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) if ((int)(e >> 6) == s2) { if (lane == (e & 63)) key[s2] = kDeadKey; expd[s2] &= ~(1ull << (e & 63)); }
+        }
+    };
+
+    // searchLayer (hnsw.go:471-580)
+    auto search_layer = [&](uint32_t entry, uint32_t ef, int level) {
+        epoch++;
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) { key[s2] = kDeadKey; expd[s2] = 0; }
+        n_list = 0;
+        if (lane == 0) { vis[entry] = epoch; batch[0] = entry; }
+        __syncthreads();
+        uint64_t k0 = eval_keys(1); n_eval += 1;
+        insert(readlane64(k0, 0), ef);
+        for (;;) {
+            // pop: first unexpanded entry
+            uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) {
+                if (cur != 0xFFFFFFFFu) continue;
+                const uint64_t m = __ballot(key[s2] != kDeadKey) & ~expd[s2];
+                if (m) { const uint32_t l = (uint32_t)__builtin_ctzll(m); cur = (uint32_t)readlane64(key[s2], l); expd[s2] |= 1ull << l; }
+            }
+            if (cur == 0xFFFFFFFFu) break;
+            uint32_t deg = 0; const uint32_t* links = nullptr;
+            if (alive(cur) && level <= (int)g.level[cur]) {
+                if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
+                else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
+            }
+            uint32_t c = 0xFFFFFFFFu; bool fresh = false;
+            if (lane < deg) { c = links[lane]; fresh = alive(c) && vis[c] != epoch; }
+            for (uint32_t j = 0; j + 1 < deg; j++) {                     // repeated node in one list: first occurrence only
+                uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                if (lane > j && c == cj) fresh = false;
+            }
+            const uint64_t fm = __ballot(fresh);
+            const uint32_t nb = (uint32_t)__builtin_popcountll(fm);
+            __syncthreads();                                             // previous hop's batch[] reads are done
+            if (fresh) { vis[c] = epoch; batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c; }
+            __syncthreads();
+            if (nb == 0) continue;
+            const uint64_t kx = eval_keys(nb); n_eval += nb;
+            for (uint32_t i = 0; i < nb; i++) insert(readlane64(kx, i), ef);
+        }
+    };
+
+    for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        __syncthreads();
+        stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
+        __syncthreads();
+        qc = query_const<M>(q_lds, v.dim);
+        n_eval = 0; tie = false;
+        uint32_t entry = g.entry;
+        for (int level = g.cur_level; level > 0; level--) {             // hnsw.go:649-657
+            search_layer(entry, 1, level);
+            if (n_list > 0) entry = (uint32_t)readlane64(key[0], 0);
+        }
+        const uint32_t ef = ef_search > k ? ef_search : k;              // :660-663
+        search_layer(entry, ef, 0);                                     // :664
+        uint32_t cnt = n_list < k ? n_list : k;                         // :670-672
+        if (tie) cnt = kHnswTieFlag;
+        else {
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) {
+                const uint32_t e = (uint32_t)s2 * 64 + lane;
+                if (e < k) {
+                    const bool has = e < cnt;
+                    rows_out[(size_t)qi * k + e] = has ? (uint32_t)key[s2] : 0xFFFFFFFFu;
+                    dist_out[(size_t)qi * k + e] = has ? unord_f32((uint32_t)(key[s2] >> 32)) : __uint_as_float(0x7F800000u);
+                }
+            }
+        }
+        if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
+        epoch += 64;
+    }
+}
+
+// ---- HNSW traversal ------------------------------------------------------------------
+size_t hnsw_lds_bytes(int metric, uint32_t dim4) {
+    return query_lds_bytes(metric, dim4) + (size_t)(kHnswCandCap + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 8 + 64;
+}
+uint32_t hnsw_grid(int cus, int metric, uint32_t dim4, uint32_t nq) {
+    const size_t lds = hnsw_lds_bytes(metric, dim4);
+    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
+    return std::max(1u, std::min(nq, (uint32_t)cus * per_cu));
+}
+hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
+                              uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                              uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k == 0 || k > (uint32_t)kHnswEfMax || ef > (uint32_t)kHnswEfMax || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
+    const size_t lds = hnsw_lds_bytes(v.metric, v.dim4);
+    hipError_t e = hipSuccess;
+    QV_DISPATCH_METRIC(v.metric, {
+        e = set_lds(k_hnsw_search<MM, 16>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_hnsw_search<MM, 16>), dim3(grid), dim3(64), lds, s, v, g, d_queries, nq, k, ef, d_visited, epoch0,
+                           d_rows_out, d_dist_out, d_count_out, d_evals_out);
+    });
+    return hipGetLastError();
+}
+
+// wave-resident form: registers only (plus the staged query); tie-flagged queries report kHnswTieFlag
+size_t hnsw_wave_lds_bytes(int metric, uint32_t dim4) { return query_lds_bytes(metric, dim4) + 64 * sizeof(uint32_t) + (size_t)kHnswStageRows * (dim4 + 1) * 16 + 64; }
+uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4) {
+    const size_t lds = hnsw_wave_lds_bytes(metric, dim4);
+    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
+    static const int cap = env_int("QV_HNSW_WAVES_PER_CU", 16);
+    per_cu = std::min<uint32_t>(per_cu, (uint32_t)cap);
+    return (uint32_t)cus * per_cu;
+}
+hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
+                                   uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                                   uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    const uint32_t efx = ef > k ? ef : k;
+    if (k == 0 || efx > (uint32_t)kHnswEfMax || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
+    const size_t lds = hnsw_wave_lds_bytes(v.metric, v.dim4);
+    hipError_t e = hipSuccess;
+#define QV_HW(SS) QV_DISPATCH_METRIC(v.metric, {                                                                     \
+        e = set_lds(k_hnsw_search_wave<MM, 8, SS>, lds);                                                              \
+        if (e != hipSuccess) return e;                                                                                \
+        hipLaunchKernelGGL((k_hnsw_search_wave<MM, 8, SS>), dim3(grid), dim3(64), lds, s, v, g, d_queries, nq, k, ef, d_visited, epoch0, \
+                           d_rows_out, d_dist_out, d_count_out, d_evals_out);                                         \
+    })
+    if (efx <= 64) { QV_HW(1); } else if (efx <= 128) { QV_HW(2); } else if (efx <= 256) { QV_HW(4); } else { QV_HW(8); }
+#undef QV_HW
+    return hipGetLastError();
+}
+
+
+}  // namespace qv

@@ -1,0 +1,215 @@
+// qv_misc.hip — row gathers, pair distances, ingest, synthetic generator, tombstones
+// (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
+#include "qv_kernels.h"
+
+namespace qv {
+
+// ---------------------------------------------------------------- gathers ----------
+// lane == listed row; one wave per 64 listed rows
+template <int M, int U>
+__global__ void __launch_bounds__(64)
+k_distance_rows(IndexView v, const float* __restrict__ query, const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    stage_query<M>(q_lds, query, v.dim, v.dim4);
+    __syncthreads();
+    const QConst qc = query_const<M>(q_lds, v.dim);
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = rows[i];
+    if (row >= v.n_rows) { out[i] = __uint_as_float(0x7FC00000u); return; }
+    const f4* p = reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63);
+    typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
+    double rn = 0.0;
+    if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+    out[i] = finalize<M>(acc, qc, rn);
+}
+
+// lane == pair; a, b row-major [n][dim]; plain scalar walk (dim need not be a multiple of 4)
+template <int M>
+__global__ void __launch_bounds__(64)
+k_distance_pairs(const float* __restrict__ a, const float* __restrict__ b, uint32_t n, uint32_t dim, float* __restrict__ out) {
+    using Q = typename MT<M>::Q;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float* pa = a + (size_t)i * dim;
+    const float* pb = b + (size_t)i * dim;
+    typename MT<M>::A acc = 0;
+    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+    double rn = 0.0;
+    if constexpr (M == QV_COSINE) {
+        double ma = 0.0, mb = 0.0;
+        for (uint32_t j = 0; j < dim; j++) {
+            double x = pa[j], y = pb[j];
+            acc = __builtin_fma(x, y, acc); ma = __builtin_fma(x, x, ma); mb = __builtin_fma(y, y, mb);
+        }
+        qc.qn = __builtin_sqrt(ma); rn = __builtin_sqrt(mb);
+    } else if constexpr (M == QV_COSINE_F32) {
+        float na = 0.0f, nb = 0.0f;
+        for (uint32_t j = 0; j < dim; j++) {
+            float x = pa[j], y = pb[j];
+            float p0 = x * y; acc = acc + p0; float p1 = x * x; na = na + p1; float p2 = y * y; nb = nb + p2;
+        }
+        qc.qn = (double)na; qc.qn32 = (float)__builtin_sqrt((double)na);
+        rn = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
+    } else {
+        for (uint32_t j = 0; j < dim; j++) acc1<M>(acc, (Q)pa[j], pb[j]);
+    }
+    out[i] = finalize<M>(acc, qc, rn);
+}
+
+// ---------------------------------------------------------------- ingest -----------
+// one wave per touched tile; lane == row within the tile
+__global__ void __launch_bounds__(64)
+k_ingest(IndexView v, const float* __restrict__ src, uint32_t row0, uint32_t n, uint32_t tile0) {
+    const uint32_t t = tile0 + blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t row = t * 64 + lane;
+    const bool mine = row >= row0 && row < row0 + n;
+    if (mine) {
+        const float* s = src + (size_t)(row - row0) * v.dim;
+        float4* dst = reinterpret_cast<float4*>(v.tiles) + (size_t)t * v.dim4 * 64 + lane;
+        double mb = 0.0; float nb = 0.0f;
+        const bool vec_ok = (v.dim & 3) == 0;
+        for (uint32_t c = 0; c < v.dim4; c++) {
+            float4 x;
+            if (vec_ok) x = *reinterpret_cast<const float4*>(s + 4 * c);
+            else {
+                uint32_t j = 4 * c;
+                x.x = j < v.dim ? s[j] : 0.f; x.y = j + 1 < v.dim ? s[j + 1] : 0.f;
+                x.z = j + 2 < v.dim ? s[j + 2] : 0.f; x.w = j + 3 < v.dim ? s[j + 3] : 0.f;
+            }
+            dst[(size_t)c * 64] = x;
+            if (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) {   // distances.go:21 magnitudeB += b*b (non-cosine: |r| for the MFMA filter)
+                mb = __builtin_fma((double)x.x, (double)x.x, mb); mb = __builtin_fma((double)x.y, (double)x.y, mb);
+                mb = __builtin_fma((double)x.z, (double)x.z, mb); mb = __builtin_fma((double)x.w, (double)x.w, mb);
+            } else if (v.metric == QV_COSINE_F32) {                       // adapter.go:119 normB += b*b (unfused)
+                float p; p = x.x * x.x; nb = nb + p; p = x.y * x.y; nb = nb + p; p = x.z * x.z; nb = nb + p; p = x.w * x.w; nb = nb + p;
+            }
+        }
+        if (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) v.rnorm[row] = __builtin_sqrt(mb);
+        else if (v.metric == QV_COSINE_F32) v.rnorm[row] = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
+    }
+    uint64_t m = __ballot(mine);
+    if (lane == 0 && m) atomicOr(reinterpret_cast<unsigned long long*>(&v.alive[t]), (unsigned long long)m);
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ int32_t gen_int(uint64_t row_key, uint32_t col) {
+    uint64_t h = splitmix64(row_key + (uint64_t)col);
+    int32_t s = (int32_t)(h & 0xFFFF) + (int32_t)((h >> 16) & 0xFFFF) + (int32_t)((h >> 32) & 0xFFFF) + (int32_t)(h >> 48);
+    return s - 131070;
+}
+
+// the synthetic-corpus generator of DESIGN.md (SplitMix64 -> Irwin-Hall(4) integers -> unit L2),
+// written straight into the tile layout; integer arithmetic plus correctly rounded float64
+// sqrt/div only, so any IEEE host reproduces it bit for bit
+__global__ void __launch_bounds__(64)
+k_generate(IndexView v, uint64_t seed, uint64_t gen_row0, uint32_t row0, uint32_t n, uint32_t tile0) {
+    const uint32_t t = tile0 + blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t row = t * 64 + lane;
+    const bool mine = row >= row0 && row < row0 + n;
+    if (mine) {
+        const uint64_t g = gen_row0 + (row - row0);
+        const uint64_t row_key = splitmix64(seed ^ (g * 0xD1342543DE82EF95ull));
+        double sumsq = 0.0;
+        for (uint32_t c = 0; c < v.dim; c++) { double x = (double)gen_int(row_key, c); sumsq = __builtin_fma(x, x, sumsq); }
+        const double norm = sumsq > 0.0 ? __builtin_sqrt(sumsq) : 1.0;
+        float4* dst = reinterpret_cast<float4*>(v.tiles) + (size_t)t * v.dim4 * 64 + lane;
+        double mb = 0.0; float nb = 0.0f;
+        for (uint32_t c = 0; c < v.dim4; c++) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t col = 4 * c + j;
+                e[j] = col < v.dim ? (float)((double)gen_int(row_key, col) / norm) : 0.0f;
+                if (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) mb = __builtin_fma((double)e[j], (double)e[j], mb);
+                else if (v.metric == QV_COSINE_F32) { float p = e[j] * e[j]; nb = nb + p; }
+            }
+            dst[(size_t)c * 64] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        if (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) v.rnorm[row] = __builtin_sqrt(mb);
+        else if (v.metric == QV_COSINE_F32) v.rnorm[row] = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
+        if (v.rowmaj) {
+            float* rm = v.rowmaj + (size_t)row * v.dim;
+            for (uint32_t c = 0; c < v.dim; c++) rm[c] = (float)((double)gen_int(row_key, c) / norm);
+        }
+    }
+    uint64_t m = __ballot(mine);
+    if (lane == 0 && m) atomicOr(reinterpret_cast<unsigned long long*>(&v.alive[t]), (unsigned long long)m);
+}
+
+__global__ void k_set_alive(IndexView v, const uint32_t* __restrict__ rows, uint32_t n, int alive) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = rows[i];
+    if (r >= v.n_rows) return;
+    unsigned long long bit = 1ull << (r & 63);
+    if (alive) atomicOr(reinterpret_cast<unsigned long long*>(&v.alive[r >> 6]), bit);
+    else atomicAnd(reinterpret_cast<unsigned long long*>(&v.alive[r >> 6]), ~bit);
+}
+
+__global__ void k_fetch_row(IndexView v, uint32_t row, float* __restrict__ out) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.dim) return;
+    out[j] = v.tiles[((size_t)(row >> 6) * v.dim4 + (j >> 2)) * 256 + (row & 63) * 4 + (j & 3)];
+}
+
+hipError_t launch_distance_rows(const IndexView& v, const float* d_query, const uint32_t* d_rows, uint32_t n,
+                                float* d_dist_out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const size_t lds = query_lds_bytes(v.metric, v.dim4);
+    hipError_t e = hipSuccess;
+    QV_DISPATCH_METRIC(v.metric, {
+        e = set_lds(k_distance_rows<MM, kUnroll>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_distance_rows<MM, kUnroll>), dim3((n + 63) / 64), dim3(64), lds, s, v, d_query, d_rows, n, d_dist_out);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_distance_pairs(int metric, const float* d_a, const float* d_b, uint32_t n, uint32_t dim, float* d_out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    QV_DISPATCH_METRIC(metric, {
+        hipLaunchKernelGGL((k_distance_pairs<MM>), dim3((n + 63) / 64), dim3(64), 0, s, d_a, d_b, n, dim, d_out);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_ingest(const IndexView& v, const float* d_rows, uint32_t row0, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t t0 = row0 / 64, t1 = (row0 + n - 1) / 64;
+    hipLaunchKernelGGL(k_ingest, dim3(t1 - t0 + 1), dim3(64), 0, s, v, d_rows, row0, n, t0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (v.rowmaj) return hipMemcpyAsync(v.rowmaj + (size_t)row0 * v.dim, d_rows, (size_t)n * v.dim * sizeof(float), hipMemcpyDeviceToDevice, s);
+    return hipSuccess;
+}
+
+hipError_t launch_generate(const IndexView& v, uint64_t seed, uint64_t gen_row0, uint32_t row0, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint32_t t0 = row0 / 64, t1 = (row0 + n - 1) / 64;
+    hipLaunchKernelGGL(k_generate, dim3(t1 - t0 + 1), dim3(64), 0, s, v, seed, gen_row0, row0, n, t0);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_alive(const IndexView& v, const uint32_t* d_rows, uint32_t n, int alive, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_set_alive, dim3((n + 255) / 256), dim3(256), 0, s, v, d_rows, n, alive);
+    return hipGetLastError();
+}
+
+hipError_t launch_fetch_row(const IndexView& v, uint32_t row, float* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_fetch_row, dim3((v.dim + 255) / 256), dim3(256), 0, s, v, row, d_out);
+    return hipGetLastError();
+}
+
+
+}  // namespace qv

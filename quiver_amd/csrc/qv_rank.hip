@@ -1,0 +1,190 @@
+// qv_rank.hip — full ranking: all keys + stable LSD radix sort
+// (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
+#include "qv_kernels.h"
+
+namespace qv {
+
+// ---------------------------------------------------------------- full ranking -----
+// all keys: keys[row] = (ord(dist), row) or dead
+template <int M, int U>
+__global__ void __launch_bounds__(kScanBlock)
+k_flat_keys(IndexView v, const float* __restrict__ query, uint64_t* __restrict__ keys) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stage_query<M>(q_lds, query, v.dim, v.dim4);
+    __syncthreads();
+    const QConst qc = query_const<M>(q_lds, v.dim);
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
+        const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
+        typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        float dist = finalize<M>(acc, qc, rn);
+        uint64_t am = v.alive[t];
+        keys[row] = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+    }
+}
+
+// LSD radix sort of 64-bit keys, 8 bits per pass over the 32 distance bits only (the
+// row bits are already ascending in the input and every pass is stable, so equal
+// distances stay in row order).  Three kernels per pass: histogram, scan, scatter.
+constexpr int kRadixBlock = 256;
+constexpr int kRadixItems = 16;                       // keys per thread
+constexpr int kRadixTile = kRadixBlock * kRadixItems; // keys per workgroup
+
+__global__ void __launch_bounds__(kRadixBlock)
+k_radix_hist(const uint64_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t* __restrict__ hist /*[256][nblocks]*/) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRadixTile;
+    for (int i = 0; i < kRadixItems; i++) {
+        uint32_t idx = base + i * kRadixBlock + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of the digit-major histogram [256][nblocks], two small kernels:
+// (1) one workgroup per digit turns its row into within-digit exclusive prefixes and a digit total,
+// (2) one workgroup scans the 256 totals.  (A single-workgroup scan of the whole table was 92 us
+// per pass at 1M keys — most of the sort.)
+__global__ void __launch_bounds__(256)
+k_radix_scan_digits(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t* __restrict__ dtot) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t s_run;
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t x = i < nblocks ? row[i] : 0;
+        uint32_t inc = x;                                              // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(inc, off); if ((int)lane >= off) inc += y; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = s_run;
+        for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+        if (i < nblocks) row[i] = before + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dtot[blockIdx.x] = s_run;
+}
+__global__ void __launch_bounds__(256)
+k_radix_scan_totals(const uint32_t* __restrict__ dtot, uint32_t* __restrict__ dbase) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t x = dtot[threadIdx.x];
+    uint32_t inc = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(inc, off); if ((int)lane >= off) inc += y; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+    dbase[threadIdx.x] = before + inc - x;
+}
+
+// stable scatter: within a workgroup keys are ranked in index order
+__global__ void __launch_bounds__(kRadixBlock)
+k_radix_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n, uint32_t shift,
+                const uint32_t* __restrict__ hist, const uint32_t* __restrict__ dbase) {
+    __shared__ uint32_t digit_base[256];                // global offset of this block's first key of each digit
+    __shared__ uint32_t wave_cnt[kRadixBlock / 64][256]; // per-wave digit counts within one round
+    __shared__ uint32_t running[256];                   // keys of each digit already placed by earlier rounds
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    digit_base[threadIdx.x] = dbase[threadIdx.x] + hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+    running[threadIdx.x] = 0;
+    const uint32_t base = blockIdx.x * kRadixTile;
+    for (int i = 0; i < kRadixItems; i++) {             // rounds go in index order: round i covers base + i*256 ..
+        for (int w = 0; w < kRadixBlock / 64; w++) wave_cnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t idx = base + i * kRadixBlock + threadIdx.x;
+        bool valid = idx < n;
+        uint64_t key = valid ? in[idx] : 0;
+        uint32_t d = (uint32_t)(key >> shift) & 0xFF;
+        // rank among lanes of this wave with the same digit (match-any by 8 ballots)
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            uint64_t m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        uint32_t rank_in_wave = (uint32_t)__builtin_popcountll(peers & ((1ull << lane) - 1));
+        uint32_t wave_total = (uint32_t)__builtin_popcountll(peers);
+        if (valid && rank_in_wave == 0) wave_cnt[wave][d] = wave_total;
+        __syncthreads();
+        if (valid) {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; w++) before += wave_cnt[w][d];
+            out[digit_base[d] + running[d] + before + rank_in_wave] = key;
+        }
+        __syncthreads();
+        uint32_t tot = 0;
+        for (int w = 0; w < kRadixBlock / 64; w++) tot += wave_cnt[w][threadIdx.x];
+        running[threadIdx.x] += tot;
+        __syncthreads();
+    }
+}
+
+__global__ void k_emit_topk(const uint64_t* __restrict__ keys, uint32_t n, uint32_t k, uint32_t* rows_out, float* dist_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    uint64_t key = i < n ? keys[i] : kDeadKey;
+    bool dead = key == kDeadKey;
+    rows_out[i] = dead ? 0xFFFFFFFFu : (uint32_t)key;
+    dist_out[i] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(key >> 32));
+}
+
+size_t full_sort_workspace_bytes(uint32_t n_tiles) {
+    size_t n = (size_t)n_tiles * 64;
+    size_t nblocks = (n + kRadixTile - 1) / kRadixTile;
+    return 2 * n * sizeof(uint64_t) + (256 * nblocks + 512) * sizeof(uint32_t) + 256;
+}
+
+hipError_t launch_flat_fullsort(const IndexView& v, const ScanPlan& p, const float* d_query, uint32_t k,
+                                void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    const uint32_t n = v.n_tiles * 64;
+    uint64_t* ka = static_cast<uint64_t*>(d_ws);
+    uint64_t* kb = ka + n;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(kb + n);
+    const uint32_t nblocks = (n + kRadixTile - 1) / kRadixTile;
+    uint32_t* dtot = hist + (size_t)256 * nblocks;
+    uint32_t* dbase = dtot + 256;
+    const size_t lds = query_lds_bytes(v.metric, v.dim4);
+    hipError_t e = hipSuccess;
+    QV_DISPATCH_METRIC(v.metric, {
+        e = set_lds(k_flat_keys<MM, kUnroll>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_flat_keys<MM, kUnroll>), dim3(p.grid), dim3(p.block), lds, s, v, d_query, ka);
+    });
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint64_t* in = ka; uint64_t* out = kb;
+    for (uint32_t shift = 32; shift < 64; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kRadixBlock), 0, s, in, n, shift, hist);
+        hipLaunchKernelGGL(k_radix_scan_digits, dim3(256), dim3(256), 0, s, hist, nblocks, dtot);
+        hipLaunchKernelGGL(k_radix_scan_totals, dim3(1), dim3(256), 0, s, dtot, dbase);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(kRadixBlock), 0, s, in, out, n, shift, hist, dbase);
+        uint64_t* t = in; in = out; out = t;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_emit_topk, dim3((k + 255) / 256), dim3(256), 0, s, in, n, k, d_rows_out, d_dist_out);
+    return hipGetLastError();
+}
+
+
+}  // namespace qv

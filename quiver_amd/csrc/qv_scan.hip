@@ -1,0 +1,481 @@
+// qv_scan.hip — flat scan + fused top-k (single- and multi-query), list merges
+// (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
+#include "qv_kernels.h"
+
+namespace qv {
+
+// ---------------------------------------------------------------- flat scan --------
+// grid = (workgroups, nq); each wave walks tiles gw, gw+tw, ... ; lane == row.
+// Output: partial[(q*gridDim.x + blockIdx.x)*k + i] = workgroup's i-th best key.
+
+template <int M, int U>
+__global__ void __launch_bounds__(kScanBlock)
+k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t* __restrict__ partial) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);  // [kScanWaves][64]
+
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qi = blockIdx.y;
+    stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
+    __syncthreads();
+
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const uint32_t kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+
+    auto finish_tile = [&](uint32_t t, typename MT<M>::A acc, bool first) {
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        float dist = finalize<M>(acc, qc, rn);
+        uint64_t am = v.alive[t];                                     // wave-uniform
+        uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+        if (first) { list = wave_sort64(key, lane); thr = readlane64(list, kth); }   // empty list: sort the tile outright
+        else list_insert(list, thr, key, kth, lane);
+    };
+
+    uint32_t t = blockIdx.x * kScanWaves + wave;
+    if (t < v.n_tiles) {                                              // first tile: query norm rides along
+        typename MT<M>::A qn2 = 0;
+        typename MT<M>::A acc = row_accumulate<M, U, true>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4, &qn2);
+        qc = qconst_from_norm2<M>(qn2);
+        finish_tile(t, acc, true);
+        t += tw;
+    }
+    for (; t < v.n_tiles; t += tw) {
+        typename MT<M>::A acc = row_accumulate<M, U, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4);
+        finish_tile(t, acc, false);
+    }
+
+    // workgroup merge: waves 1.. hand their lists to wave 0 through LDS
+    wl[wave * 64 + lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        for (uint32_t w = 1; w < kScanWaves; w++) {
+            uint64_t key = lane < k ? wl[w * 64 + lane] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        if (lane < k) partial[((size_t)qi * gridDim.x + blockIdx.x) * k + lane] = list;
+    }
+}
+
+// ---------------------------------------------------------------- multi-query scan --
+// QB queries share ONE pass over the corpus (HybridIndex.BatchSearch, hybrid_index.go:677-811,
+// is Q independent exact searches; here every 16-byte row chunk a lane loads is used for QB
+// dot products).  Same arithmetic contract: lane == row, each (row, query) distance is one
+// sequential chain over dims 0..D-1.  The query block sits in LDS interleaved by query
+// (q_lds[dim][QB]) so one ds_read_b128 feeds two (f64) or four (f32) queries of one dim.
+// grid = (workgroups, ceil(nq/QB)); partial layout identical to k_flat_scan.
+// one tile for QB queries: acc[j] = Σ_d f(q_j[d], row[d]); FIRST also accumulates the query norms
+template <int M, int U, int QB, bool FIRST>
+__device__ __forceinline__ void mq_tile(const f4* __restrict__ p, const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4,
+                                        typename MT<M>::A (&acc)[QB], typename MT<M>::A (&qa)[QB]) {
+    using Q = typename MT<M>::Q;
+    constexpr int VW = 16 / sizeof(Q);                          // queries per 16-byte LDS read (2 doubles or 4 floats)
+    typedef Q qvec __attribute__((ext_vector_type(VW)));
+    static_assert(QB % VW == 0, "QB must be a multiple of the LDS vector width");
+#pragma unroll
+    for (int j = 0; j < QB; j++) { acc[j] = 0; if constexpr (FIRST) qa[j] = 0; }
+    auto chunk = [&](uint32_t c, f4 x) {
+        const qvec* qq = reinterpret_cast<const qvec*>(q_lds + (size_t)c * 4 * QB);
+        const float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+#pragma unroll
+            for (int g = 0; g < QB / VW; g++) {
+                const qvec a = qq[d * (QB / VW) + g];             // one ds_read_b128, broadcast to the wave
+#pragma unroll
+                for (int t = 0; t < VW; t++) {
+                    const int j = g * VW + t;
+                    acc1<M>(acc[j], a[t], e[d]);
+                    if constexpr (FIRST && M == QV_COSINE) qa[j] = __builtin_fma(a[t], a[t], qa[j]);
+                    else if constexpr (FIRST && M == QV_COSINE_F32) { float pp = a[t] * a[t]; qa[j] = qa[j] + pp; }
+                }
+            }
+        }
+    };
+    uint32_t c0 = 0;
+    for (; c0 + U <= dim4; c0 += U) {
+        f4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) x[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * 64]);
+#pragma unroll
+        for (int u = 0; u < U; u++) chunk(c0 + u, x[u]);
+    }
+    for (; c0 < dim4; c0++) chunk(c0, __builtin_nontemporal_load(&p[(size_t)c0 * 64]));
+}
+
+// query blocks for the scalar-operand variant: qblk[group][dim4*4][QB] in the metric's Q type
+template <int M, int QB>
+__global__ void k_prep_qblk(const float* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t dim4, typename MT<M>::Q* __restrict__ qblk) {
+    using Q = typename MT<M>::Q;
+    const uint32_t per = dim4 * 4 * QB;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per) return;
+    const uint32_t d = i / QB, qq = i % QB, q0 = blockIdx.y * QB;
+    const uint32_t qi = q0 + qq < nq ? q0 + qq : nq - 1;
+    qblk[(size_t)blockIdx.y * per + i] = d < dim ? (Q)queries[(size_t)qi * dim + d] : (Q)0;
+}
+
+// SQ = true: the query block is read from GLOBAL memory at wave-uniform addresses, which the
+// compiler turns into scalar loads (s_load) and SGPR operands of v_fma_f64 — the LDS, which
+// bounds the LDS-staged form (one broadcast ds_read_b128 per 2 query values), is not touched.
+template <int M, int U, int QB, bool SQ>
+__global__ void __launch_bounds__(kScanBlock, 2)
+k_flat_scan_mq(IndexView v, const float* __restrict__ queries, const typename MT<M>::Q* __restrict__ qblk, uint32_t nq, uint32_t k,
+               uint64_t* __restrict__ partial) {
+    using Q = typename MT<M>::Q;
+    using A = typename MT<M>::A;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const size_t q_bytes = SQ ? 0 : (((size_t)v.dim4 * 4 * QB * sizeof(Q)) + 15) / 16 * 16;
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + q_bytes);                  // [waves][QB][64]
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t q0 = blockIdx.y * QB;
+    const Q* q_lds;
+    if constexpr (SQ) {
+        q_lds = qblk + (size_t)blockIdx.y * v.dim4 * 4 * QB;                     // global, uniform -> scalar loads
+    } else {
+        Q* ql = reinterpret_cast<Q*>(smem);                                      // [dim4*4][QB]
+        // stage QB queries, zero-padded in dim; query slots past nq replicate the last query (results dropped)
+        for (uint32_t i = threadIdx.x; i < v.dim4 * 4 * QB; i += blockDim.x) {
+            uint32_t d = i / QB, qq = i % QB;
+            uint32_t qi = q0 + qq < nq ? q0 + qq : nq - 1;
+            ql[i] = d < v.dim ? (Q)queries[(size_t)qi * v.dim + d] : (Q)0;
+        }
+        __syncthreads();
+        q_lds = ql;
+    }
+
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const uint32_t kth = k - 1;
+    uint64_t list[QB], thr[QB];
+    QConst qc[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) { list[j] = kDeadKey; thr[j] = kDeadKey; qc[j].qn = 0.0; qc[j].qn32 = 0.0f; }
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+
+    uint32_t t = blockIdx.x * kScanWaves + wave;
+    if (t < v.n_tiles) {                                                         // first tile: sort outright, query norms ride along
+        A acc[QB], qa[QB];
+        mq_tile<M, U, QB, true>(tiles + (size_t)t * v.dim4 * 64 + lane, q_lds, v.dim4, acc, qa);
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        const bool live = (v.alive[t] >> lane) & 1ull;
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            qc[j] = qconst_from_norm2<M>(qa[j]);
+            float dist = finalize<M>(acc[j], qc[j], rn);
+            list[j] = wave_sort64(live ? make_key(dist, row) : kDeadKey, lane);
+            thr[j] = readlane64(list[j], kth);
+        }
+        t += tw;
+    }
+    for (; t < v.n_tiles; t += tw) {
+        A acc[QB], qa[QB];
+        mq_tile<M, U, QB, false>(tiles + (size_t)t * v.dim4 * 64 + lane, q_lds, v.dim4, acc, qa);
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        const bool live = (v.alive[t] >> lane) & 1ull;
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            float dist = finalize<M>(acc[j], qc[j], rn);
+            list_insert(list[j], thr[j], live ? make_key(dist, row) : kDeadKey, kth, lane);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < QB; j++) wl[((size_t)wave * QB + j) * 64 + lane] = list[j];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            for (uint32_t w = 1; w < kScanWaves; w++) {
+                uint64_t key = lane < k ? wl[((size_t)w * QB + j) * 64 + lane] : kDeadKey;
+                list_insert(list[j], thr[j], key, kth, lane);
+            }
+            if (q0 + j < nq && lane < k) partial[((size_t)(q0 + j) * gridDim.x + blockIdx.x) * k + lane] = list[j];
+        }
+    }
+}
+
+// One workgroup per query merges n_lists sorted lists of k keys into the final top-k.
+// Bound trick: the smallest k-th entry over all lists, B, is an upper bound of the final
+// k-th key (that list alone holds k keys <= B), so only keys <= B can be in the answer.
+// Typically a few dozen of the n_lists*k keys survive; one wave insertion-sorts them.
+constexpr int kMergeBlock = 1024;
+constexpr int kMergeCap = 2048;                       // survivors kept in LDS; more -> general path
+constexpr int kMergeHeads = 128;                      // sampled list heads ranked in LDS
+
+__device__ __forceinline__ uint64_t wave_min64(uint64_t x) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)x, off), hi = __shfl_xor((uint32_t)(x >> 32), off);
+        uint64_t y = ((uint64_t)hi << 32) | lo;
+        x = y < x ? y : x;
+    }
+    return x;
+}
+
+__global__ void __launch_bounds__(kMergeBlock)
+k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k,
+              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+    __shared__ uint64_t wl[kMergeBlock / 64][64];
+    __shared__ uint64_t surv[kMergeCap];
+    __shared__ uint32_t hd[kMergeHeads], hlt[kMergeHeads], hle[kMergeHeads];
+    __shared__ uint64_t s_bound, s_b1;
+    __shared__ uint32_t s_nsurv;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nw = blockDim.x >> 6;
+    const uint32_t qi = blockIdx.x;
+    const uint64_t* src = partial + (size_t)qi * n_lists * k;
+    const uint32_t total = n_lists * k;
+    const uint32_t kth = k - 1;
+
+    // every global load of the common case is issued up front (one HBM/L2 latency, not three):
+    // this thread's <= 8 keys, one list's k-th key, one sampled list head
+    const bool small = total <= blockDim.x * 8;
+    uint64_t mine[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { uint32_t i = u * blockDim.x + threadIdx.x; mine[u] = (small && i < total) ? src[i] : kDeadKey; }
+    // sampled heads: m = min(n_lists, kMergeHeads) lists at a fixed stride.  Any k different
+    // lists each hold a key <= the k-th smallest of their heads, so a subset still gives a
+    // valid (slightly looser) bound, and the O(m^2) rank count stays ~0.5 us on one CU.
+    const uint32_t m = n_lists < (uint32_t)kMergeHeads ? n_lists : (uint32_t)kMergeHeads;
+    const uint32_t hstride = n_lists / m;
+    const bool use_heads = m >= k;
+    uint64_t b = kDeadKey;
+    for (uint32_t w = threadIdx.x; w < n_lists; w += blockDim.x) { uint64_t x = src[(size_t)w * k + kth]; b = x < b ? x : b; }
+    if (use_heads)
+        for (uint32_t w = threadIdx.x; w < m; w += blockDim.x) { hd[w] = (uint32_t)(src[(size_t)w * hstride * k] >> 32); hlt[w] = 0; hle[w] = 0; }
+
+    // phase A: two upper bounds of the final k-th key.
+    //   B0 = min over lists of their k-th key (that list alone has k keys <= B0);
+    //   B1 = from the k-th smallest sampled HEAD — the tight one when the winners are spread
+    //        over many lists, which is the common case.  Rank counting on the 32 distance bits:
+    //        head i qualifies when #{j: d_j < d_i} <= k-1 < #{j: d_j <= d_i}; then every key
+    //        with distance <= d_i is kept.
+    b = wave_min64(b);
+    if (lane == 0) wl[wave][0] = b;
+    if (threadIdx.x == 0) { s_nsurv = 0; s_b1 = kDeadKey; }
+    __syncthreads();
+    if (use_heads) {
+        const uint32_t segs = blockDim.x >= m ? blockDim.x / m : 1;   // thread -> (head i, segment of j)
+        const uint32_t per = (m + segs - 1) / segs;
+        for (uint32_t i = threadIdx.x % m, sgm = blockDim.x >= m ? threadIdx.x / m : 0; sgm < segs && i < m; i += blockDim.x) {
+            const uint32_t h = hd[i];
+            uint32_t clt = 0, cle = 0;
+            const uint32_t j0 = sgm * per, j1 = min(j0 + per, m);
+            uint32_t j = j0;
+            for (; j + 16 <= j1; j += 16) {                           // batch the (broadcast) LDS reads
+                uint32_t x[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) x[u] = hd[j + u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { clt += x[u] < h ? 1u : 0u; cle += x[u] <= h ? 1u : 0u; }
+            }
+            for (; j < j1; j++) { uint32_t x = hd[j]; clt += x < h ? 1u : 0u; cle += x <= h ? 1u : 0u; }
+            if (clt) atomicAdd(&hlt[i], clt);
+            if (cle) atomicAdd(&hle[i], cle);
+            if (blockDim.x >= m) break;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x)
+            if (hlt[i] <= kth && kth < hle[i] && hd[i] != 0xFFFFFFFFu) s_b1 = ((uint64_t)hd[i] << 32) | 0xFFFFFFFFull;
+    }
+    if (wave == 0) {
+        uint64_t x = lane < nw ? wl[lane][0] : kDeadKey;
+        x = wave_min64(x);
+        if (lane == 0) s_bound = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_b1 < s_bound) s_bound = s_b1;
+    __syncthreads();
+    const uint64_t bound = s_bound;
+    // phase B: keep keys <= bound
+    auto keep = [&](uint64_t key) {
+        if (key != kDeadKey && key <= bound) {
+            uint32_t pos = atomicAdd(&s_nsurv, 1u);
+            if (pos < (uint32_t)kMergeCap) surv[pos] = key;
+        }
+    };
+    if (small) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) keep(mine[u]);
+    } else {
+        for (uint32_t base = 0; base < total; base += blockDim.x * 8) {
+            uint64_t key[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { uint32_t i = base + u * blockDim.x + threadIdx.x; key[u] = i < total ? src[i] : kDeadKey; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) keep(key[u]);
+        }
+    }
+    __syncthreads();
+    const uint32_t ns = s_nsurv;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    if (ns <= 64) {
+        // phase C (common): one wave bitonic-sorts the survivors
+        if (wave != 0) return;
+        list = wave_sort64(lane < ns ? surv[lane] : kDeadKey, lane);
+    } else if (ns <= (uint32_t)kMergeCap) {
+        if (wave != 0) return;
+        list = wave_sort64(surv[lane], lane);
+        thr = readlane64(list, kth);
+        for (uint32_t base = 64; base < ns; base += 64) {
+            uint32_t i = base + lane;
+            uint64_t key = i < ns ? surv[i] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+    } else {
+        // general path (tiny indexes whose lists are mostly shorter than k): every wave
+        // reduces a slice, wave 0 merges the waves
+        for (uint32_t base = wave * 64; base < total; base += nw * 64) {
+            uint32_t i = base + lane;
+            uint64_t key = i < total ? src[i] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        wl[wave][lane] = list;
+        __syncthreads();
+        if (wave != 0) return;
+        for (uint32_t w = 1; w < nw; w++) {
+            uint64_t key = lane < k ? wl[w][lane] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+    }
+    if (lane < k) {
+        bool dead = list == kDeadKey;
+        rows_out[(size_t)qi * k + lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
+        dist_out[(size_t)qi * k + lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+    }
+}
+
+// merge of (distance, row) pair lists, e.g. the all-gathered per-shard top-k of a sharded scan
+__global__ void __launch_bounds__(kMergeBlock)
+k_merge_pairs(const float* __restrict__ dist, const uint32_t* __restrict__ rows, uint32_t total, uint32_t k,
+              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+    __shared__ uint64_t wl[kMergeBlock / 64][64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nw = blockDim.x >> 6;
+    const uint32_t kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    for (uint32_t base = wave * 64; base < total; base += nw * 64) {
+        uint32_t i = base + lane;
+        uint64_t key = kDeadKey;
+        if (i < total && rows[i] != 0xFFFFFFFFu) key = make_key(dist[i], rows[i]);
+        list_insert(list, thr, key, kth, lane);
+    }
+    wl[wave][lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        for (uint32_t w = 1; w < nw; w++) {
+            uint64_t key = lane < k ? wl[w][lane] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        if (lane < k) {
+            bool dead = list == kDeadKey;
+            rows_out[lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
+            dist_out[lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+        }
+    }
+}
+
+ScanPlan plan_scan(uint32_t n_tiles, int cus) {
+    ScanPlan p;
+    p.block = kScanBlock;
+    uint32_t want = (n_tiles + kScanWaves - 1) / kScanWaves;          // one tile per wave at most
+    static const int wg_per_cu = env_int("QV_SCAN_WG_PER_CU", 2);     // 2 workgroups = 8 waves per CU: measured best (profiles/r01_sweep.txt)
+    uint32_t cap = (uint32_t)cus * (uint32_t)wg_per_cu;
+    p.grid = want < cap ? want : cap;
+    if (p.grid == 0) p.grid = 1;
+    p.n_lists = p.grid;
+    return p;
+}
+
+size_t scan_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k) { return ((size_t)p.n_lists * 4 * nq * k * sizeof(uint64_t) + 255) / 256 * 256; }   // x4: the multi-query scan may use up to 8 WG/CU
+
+hipError_t launch_merge_pairs(const float* d_dist, const uint32_t* d_rows, uint32_t n_lists, uint32_t k,
+                              uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    if (k == 0 || k > (uint32_t)kMaxFusedK || n_lists == 0) return hipErrorInvalidValue;
+    uint32_t total = n_lists * k;
+    uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
+    hipLaunchKernelGGL(k_merge_pairs, dim3(1), dim3(mblock), 0, s, d_dist, d_rows, total, k, d_rows_out, d_dist_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
+                            void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
+                            hipEvent_t ev0, hipEvent_t ev1) {
+    if (k == 0 || k > (uint32_t)kMaxFusedK || nq == 0) return hipErrorInvalidValue;
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
+    uint64_t* partial = static_cast<uint64_t*>(d_ws);
+    hipError_t e = hipSuccess;
+    static const int mq_min = env_int("QV_MQ_MIN", 2);                // nq >= this: queries share a corpus pass
+    if ((int)nq >= mq_min) {
+        // QB queries per corpus pass.  Measured on MI355X, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt):
+        // QB=8 is HBM-bound (0.454 ms/pass), QB=16 is f64-VALU-bound (0.75 ms/pass, 12.0 ms per 256 queries).
+        static const int mq_qb_env = env_int("QV_MQ_QB", 0), mq_wg = env_int("QV_MQ_WG_PER_CU", 2);
+        const int qb = mq_qb_env ? mq_qb_env : (nq >= 9 ? 16 : (nq >= 5 ? 8 : 4));
+        const uint32_t want = (v.n_tiles + kScanWaves - 1) / kScanWaves;
+        const uint32_t grid = std::max(1u, std::min(want, (uint32_t)mq_wg * (p.grid / 2 ? p.grid / 2 : 1)));   // p.grid = 2 WG/CU * CUs
+        void* qblk = static_cast<char*>(d_ws) + scan_workspace_bytes(p, nq, k);   // tail of the workspace
+#define QV_MQ_LAUNCH(MMM, QQ)                                                                                              \
+        {                                                                                                                     \
+            using QT = typename MT<MMM>::Q;                                                                                   \
+            const uint32_t groups = (nq + QQ - 1) / QQ;                                                                       \
+            const uint32_t per = v.dim4 * 4 * QQ;                                                                             \
+            hipLaunchKernelGGL((k_prep_qblk<MMM, QQ>), dim3((per + 255) / 256, groups), dim3(256), 0, s, d_queries, nq, v.dim, v.dim4, static_cast<QT*>(qblk)); \
+            const size_t lds_mq = (size_t)kScanWaves * QQ * 64 * sizeof(uint64_t);                                            \
+            if (ev0) (void)hipEventRecord(ev0, s);                                                                            \
+            hipLaunchKernelGGL((k_flat_scan_mq<MMM, 4, QQ, true>), dim3(grid, groups), dim3(p.block), lds_mq, s, v, d_queries, static_cast<const QT*>(qblk), nq, k, partial); \
+            if (ev1) (void)hipEventRecord(ev1, s);                                                                            \
+        }
+        if (qb == 16) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 16) }); }
+        else if (qb == 8) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 8) }); }
+        else if (qb == 4) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 4) }); }
+        else return hipErrorInvalidValue;
+#undef QV_MQ_LAUNCH
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        // partial lists are laid out with stride `grid` lists per query
+        uint32_t total = grid * k;
+        uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
+        hipLaunchKernelGGL(k_merge_lists, dim3(nq), dim3(mblock), 0, s, partial, grid, k, d_rows_out, d_dist_out);
+        return hipGetLastError();
+    }
+    static const int unroll = env_int("QV_SCAN_UNROLL", kUnroll);     // tuning knob (cosine only): loads in flight per wave
+    if (v.metric == QV_COSINE && unroll != kUnroll) {
+#define QV_SCAN_U(UU)                                                                                             \
+        case UU: e = set_lds(k_flat_scan<QV_COSINE, UU>, lds); if (e != hipSuccess) return e;                    \
+            if (ev0) (void)hipEventRecord(ev0, s);                                                                \
+            hipLaunchKernelGGL((k_flat_scan<QV_COSINE, UU>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial); \
+            if (ev1) (void)hipEventRecord(ev1, s); break;
+        switch (unroll) { QV_SCAN_U(4) QV_SCAN_U(8) QV_SCAN_U(12) QV_SCAN_U(24) QV_SCAN_U(32) default: return hipErrorInvalidValue; }
+#undef QV_SCAN_U
+    } else
+    QV_DISPATCH_METRIC(v.metric, {
+        e = set_lds(k_flat_scan<MM, kUnroll>, lds);
+        if (e != hipSuccess) return e;
+        if (ev0) (void)hipEventRecord(ev0, s);
+        hipLaunchKernelGGL((k_flat_scan<MM, kUnroll>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial);
+        if (ev1) (void)hipEventRecord(ev1, s);
+    });
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint32_t total = p.n_lists * k;
+    uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
+    hipLaunchKernelGGL(k_merge_lists, dim3(nq), dim3(mblock), 0, s, partial, p.n_lists, k, d_rows_out, d_dist_out);
+    return hipGetLastError();
+}
+
+
+}  // namespace qv
