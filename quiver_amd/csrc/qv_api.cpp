@@ -119,7 +119,7 @@ struct qv_graph {
     uint64_t tie_reruns = 0;
     std::mutex mu;                              // one batch at a time (the visited stamps are per wave slot)
     hipStream_t stream = nullptr;
-    Buf d_q, d_rows, d_dist, d_cnt, d_ev;
+    Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev;
 };
 
 namespace {
@@ -721,7 +721,7 @@ void qv_graph_destroy(qv_graph* g) {
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
     (void)hipFree(g->d_level); (void)hipFree(g->d_l0deg); (void)hipFree(g->d_l0links); (void)hipFree(g->d_upoff); (void)hipFree(g->d_uplinks);
     (void)hipFree(g->d_visited);
-    g->d_q.release(); g->d_rows.release(); g->d_dist.release(); g->d_cnt.release(); g->d_ev.release();
+    g->d_q.release(); g->d_qblk.release(); g->d_rows.release(); g->d_dist.release(); g->d_cnt.release(); g->d_ev.release();
     delete g;
 }
 
@@ -738,7 +738,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     const size_t qbytes = (size_t)nq * idx->dim * sizeof(float), obytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
     int rc;
     if ((rc = g->d_q.ensure(qbytes)) || (rc = g->d_rows.ensure(obytes)) || (rc = g->d_dist.ensure(obytes)) || (rc = g->d_cnt.ensure(cbytes)) ||
-        (rc = g->d_ev.ensure(cbytes)))
+        (rc = g->d_ev.ensure(cbytes)) || (rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4))))
         return rc;
     const uint32_t grid = std::min(g->grid, nq);
     const uint32_t per_wave = (nq + std::min(grid, std::max(1u, g->heap_grid)) - 1) / std::min(grid, std::max(1u, g->heap_grid));
@@ -749,7 +749,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     }
     HIPCHK(hipMemcpyAsync(g->d_q.p, queries, qbytes, hipMemcpyHostToDevice, g->stream));
     // pass 1: wave-resident traversal (registers only); queries that meet equal distances / NaN report 0xFFFFFFFE
-    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, static_cast<const float*>(g->d_q.p), nq, k, ef_search, g->d_visited, grid, g->epoch,
+    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, static_cast<const float*>(g->d_q.p), g->d_qblk.p, nq, k, ef_search, g->d_visited, grid, g->epoch,
                                                static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
                                                static_cast<uint32_t*>(g->d_ev.p), g->stream);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));

@@ -98,7 +98,8 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
 
 // wave-resident form (no LDS heaps); count_out = 0xFFFFFFFE for queries that met equal distances / NaN
 uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4);
-hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
+size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4);   // workspace for the converted queries + per-query constants
+hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
                                    uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
                                    uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s);
 

@@ -191,41 +191,135 @@ k_hnsw_search(IndexView v, GraphView g, const float* __restrict__ queries, uint3
 // So the whole searchLayer state is ONE ascending list of <= ef (distance, node) keys with an
 // "expanded" bit each: pop = first unexpanded entry; admit = sorted insert, drop the (ef+1)-th.
 // The list lives in registers, S keys per lane (ef <= 64*S), and is updated with ballots, popcounts,
-// readlanes and DPP wave shifts — no LDS, so ~4x more queries are resident and a hop's serial part
-// shrinks from ~40 us to ~1 us.  With equal distances the binary heaps' pop order depends on their
+// readlanes and DPP wave shifts — no LDS heaps, so a hop's serial part shrinks from ~40 us to a few us
+// and the LDS is left to the row stream below.  With equal distances the binary heaps' pop order depends on their
 // layout, so a query that ever sees two equal distances in the list (or a NaN) is flagged and
 // re-run by k_hnsw_search (the exact-heap form): results stay identical to the reference in all cases.
 constexpr uint32_t kHnswTieFlag = 0xFFFFFFFEu;
-constexpr int kHnswStageRows = 8;         // neighbour rows staged in LDS per round
+// Neighbour rows of one hop are streamed through LDS in column slabs by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR destination, every piece of a slab in flight at once):
+//   slab   = kHnswSlab consecutive 16-byte chunks of up to kHnswRound rows, two slab buffers;
+//   piece  = one DMA instruction = 8 rows x 128 contiguous bytes (lane L: row L/8, 16-byte slot L%8),
+//            the shape the memory system serves at full rate for gathered rows;
+//   image  = [group of 8 rows][piece of 8 chunks][row][slot]; slot j of row r holds chunk j ^ sw(r),
+//            sw = (r%8) ^ ((r/8)&1) — applied on the SOURCE address, the LDS destination of a DMA is
+//            lane-linear — so that the per-lane reads "chunk c of MY row" of 16 rows cover all 64 banks.
+// While lane r walks slab s of its row sequentially (same arithmetic order as everywhere else), slab
+// s+1 is landing in the other buffer.  The query is NOT in LDS: it is pre-converted to the metric's
+// Q type in global memory (k_hnsw_prep_queries) and read at wave-uniform addresses, i.e. by scalar
+// loads straight into SGPR operands of v_fma_f64.
+// What bounds it (tools/ubench/f64chain.hip, MI355X): a dependent v_fma_f64 chain runs at 10.6 cycles per
+// element, v_cvt_f64_f32 issues in ~12.6 and v_fma_f64 in ~8.6, so one wave-hop costs 768 x 21 cycles of
+// VALU issue whatever the lane count: with 4 waves per SIMD the kernel is VALU-issue-bound on the
+// convert + fma pair, which is why occupancy (small slabs, no query in LDS) is what pays.
+#ifndef QV_HNSW_SLAB
+#define QV_HNSW_SLAB 8
+#endif
+constexpr int kHnswSlab = QV_HNSW_SLAB;   // chunks per slab (128 B of each row): 2 x 4 KiB of slab buffers per wave -> 16 waves per CU
+                                          // (measured 5k x 768, efSearch 128: slab 8 -> 554k QPS, 16 -> 430k, 32 -> 209k: occupancy wins)
+constexpr int kHnswRound = 32;            // rows per round (MaxM0 = 32 by default: one round per hop)
+constexpr int kHnswSlabBytes = kHnswRound * kHnswSlab * 16;
 
-// a row staged in LDS (contiguous f4 chunks), same sequential-over-dims arithmetic as row_accumulate
-template <int M>
-__device__ __forceinline__ typename MT<M>::A row_accumulate_lds(const f4* p, const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4) {
-    typename MT<M>::A acc = 0;
-#pragma unroll 4
-    for (uint32_t c = 0; c < dim4; c++) {
-        const f4 x = p[c];
-        const typename MT<M>::Q* qq = q_lds + (size_t)c * 4;
-        acc1<M>(acc, qq[0], x.x); acc1<M>(acc, qq[1], x.y); acc1<M>(acc, qq[2], x.z); acc1<M>(acc, qq[3], x.w);
-    }
-    return acc;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+__device__ __forceinline__ void glds16(const float* g, lds_u8* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
+
+// what this lane fetches in the DMA pieces of a round: for each group of 8 rows, row (group*8 + lane/8), slot lane%8.
+// src* already include the swizzled slot offset; lanes of rows beyond the round's count point at the round's first
+// row (valid memory) and fill LDS slots nobody reads, so a full piece needs no exec masking.
+struct DmaRole {
+    const float* src0; const float* src1; const float* src2; const float* src3;
+    uint32_t sw0, sw1;      // slot -> chunk swizzle for even / odd groups (tail pieces only)
+    uint32_t ng;
+};
+__device__ __forceinline__ void dma_role(DmaRole& r, const float* rowmaj, uint32_t dim, const lds_u32* batch, uint32_t cnt, uint32_t lane) {
+    const uint32_t drow = lane >> 3, dslot = lane & 7;
+    r.ng = (cnt + 7) >> 3;
+    r.sw0 = dslot ^ drow; r.sw1 = dslot ^ drow ^ 1u;
+    r.src0 = rowmaj + (size_t)batch[drow < cnt ? drow : 0u] * dim + r.sw0 * 4;
+    r.src1 = rowmaj + (size_t)batch[8 + drow < cnt ? 8 + drow : 0u] * dim + r.sw1 * 4;
+    r.src2 = rowmaj + (size_t)batch[16 + drow < cnt ? 16 + drow : 0u] * dim + r.sw0 * 4;
+    r.src3 = rowmaj + (size_t)batch[24 + drow < cnt ? 24 + drow : 0u] * dim + r.sw1 * 4;
+}
+template <bool FULL>
+__device__ __forceinline__ void dma_issue_group(const float* src, uint32_t sw, uint32_t chunk0, uint32_t dim4, lds_u8* dst) {
+#pragma unroll
+    for (int p = 0; p < kHnswSlab / 8; p++) {
+        const uint32_t cbase = chunk0 + (uint32_t)p * 8;
+        if (FULL) glds16(src + (size_t)cbase * 4, dst + p * 1024);
+        else if (cbase + sw < dim4) glds16(src + (size_t)cbase * 4, dst + p * 1024);
+    }
+}
+__device__ __forceinline__ void dma_issue_slab(const DmaRole& r, uint32_t sl, uint32_t dim4, lds_u8* buf) {
+    const uint32_t chunk0 = sl * kHnswSlab;
+    constexpr int G = kHnswSlab / 8 * 1024;
+    if (chunk0 + kHnswSlab <= dim4) {
+        dma_issue_group<true>(r.src0, r.sw0, chunk0, dim4, buf);
+        if (r.ng > 1) dma_issue_group<true>(r.src1, r.sw1, chunk0, dim4, buf + G);
+        if (r.ng > 2) dma_issue_group<true>(r.src2, r.sw0, chunk0, dim4, buf + 2 * G);
+        if (r.ng > 3) dma_issue_group<true>(r.src3, r.sw1, chunk0, dim4, buf + 3 * G);
+    } else {
+        dma_issue_group<false>(r.src0, r.sw0, chunk0, dim4, buf);
+        if (r.ng > 1) dma_issue_group<false>(r.src1, r.sw1, chunk0, dim4, buf + G);
+        if (r.ng > 2) dma_issue_group<false>(r.src2, r.sw0, chunk0, dim4, buf + 2 * G);
+        if (r.ng > 3) dma_issue_group<false>(r.src3, r.sw1, chunk0, dim4, buf + 3 * G);
+    }
+}
+// lane walks slab `sl` of row r (0..31) of the round, sequentially over the dims
+template <int M>
+__device__ __forceinline__ void slab_accumulate(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, const typename MT<M>::Q* __restrict__ q,
+                                                uint32_t sl, uint32_t dim4) {
+    typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    const uint32_t mg = r >> 3, mr = r & 7, msw = mr ^ (mg & 1);
+    const lds_u8* mine = buf + mg * (kHnswSlab / 8 * 1024) + mr * 128;
+    const uint32_t c0 = sl * kHnswSlab, c1 = c0 + kHnswSlab < dim4 ? c0 + kHnswSlab : dim4;
+    uint32_t c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        const lds_u8* pc = mine + ((c - c0) >> 3) * 1024;
+        f4 x0 = *(lds_f4p)(pc + ((0u ^ msw) << 4)), x1 = *(lds_f4p)(pc + ((1u ^ msw) << 4)), x2 = *(lds_f4p)(pc + ((2u ^ msw) << 4)), x3 = *(lds_f4p)(pc + ((3u ^ msw) << 4));
+        f4 x4 = *(lds_f4p)(pc + ((4u ^ msw) << 4)), x5 = *(lds_f4p)(pc + ((5u ^ msw) << 4)), x6 = *(lds_f4p)(pc + ((6u ^ msw) << 4)), x7 = *(lds_f4p)(pc + ((7u ^ msw) << 4));
+        const typename MT<M>::Q* qq = q + (size_t)c * 4;          // wave-uniform global address: scalar loads, SGPR operands
+#define QV_ACC4(X, O) acc1<M>(acc, qq[O], X.x); acc1<M>(acc, qq[O + 1], X.y); acc1<M>(acc, qq[O + 2], X.z); acc1<M>(acc, qq[O + 3], X.w);
+        QV_ACC4(x0, 0) QV_ACC4(x1, 4) QV_ACC4(x2, 8) QV_ACC4(x3, 12) QV_ACC4(x4, 16) QV_ACC4(x5, 20) QV_ACC4(x6, 24) QV_ACC4(x7, 28)
+    }
+    for (; c < c1; c++) {
+        const f4 x = *(lds_f4p)(mine + ((c - c0) >> 3) * 1024 + ((((c - c0) & 7) ^ msw) << 4));
+        const typename MT<M>::Q* qq = q + (size_t)c * 4;
+        QV_ACC4(x, 0)
+    }
+#undef QV_ACC4
+}
+
+#ifdef QV_HNSW_PROF
+#define HTICK(ph) tick(ph)
+#else
+#define HTICK(ph)
+#endif
 
 template <int M, int U, int S>
 __global__ void __launch_bounds__(64)
-k_hnsw_search_wave(IndexView v, GraphView g, const float* __restrict__ queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t nq, uint32_t k, uint32_t ef_search,
                    uint32_t* __restrict__ visited, uint32_t epoch0,
                    uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
-    Q* q_lds = reinterpret_cast<Q*>(smem);
-    uint32_t* batch = reinterpret_cast<uint32_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);   // [64]
-    f4* stage = reinterpret_cast<f4*>(batch + 64);                    // [kHnswStageRows][dim4 + 1] (row-major index only)
+    uint32_t* batch = reinterpret_cast<uint32_t*>(smem);                   // [64]
+    // the same regions as LDS-address-space pointers (ds_read / LDS-DMA destinations)
+    lds_u32* batch_l = (lds_u32*)smem;
+    lds_u8* slabs_l = (lds_u8*)(batch_l + 64);                             // 2 x kHnswSlabBytes (row-major index only)
+    const Q* q_g = qblk;                                                   // this wave's query, zero-padded to dim4*4, in the metric's Q type
     const uint32_t lane = threadIdx.x;
     uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
     uint32_t epoch = epoch0;
     const bool use_rm = v.rowmaj != nullptr && (v.dim & 3) == 0;
     auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
+#ifdef QV_HNSW_PROF
+    uint64_t T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_last = __builtin_readcyclecounter(); const uint64_t wc0 = wall_clock64(); uint64_t hops = 0;
+    auto tick = [&](int ph) { uint64_t t = __builtin_readcyclecounter(); T[ph] += t - t_last; t_last = t; };
+#endif
 
     QConst qc;
     uint64_t key[S];          // ascending over index e = s*64 + lane; kDeadKey = empty
@@ -233,37 +327,41 @@ k_hnsw_search_wave(IndexView v, GraphView g, const float* __restrict__ queries, 
     uint32_t n_list = 0; bool tie = false;
     uint32_t n_eval = 0;
 
-    // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n).
-    // With the row-major copy the neighbour rows are fetched COOPERATIVELY — all 64 lanes read one
-    // row's 16-byte chunks side by side (1 KiB per instruction, every load of a round in flight
-    // together) into LDS, padded by one chunk per row so the per-lane reads below spread over the
-    // banks — and then lane r walks ITS row sequentially from LDS.  (Each lane pulling its own row
-    // straight from memory meant 24 dependent latency rounds of 13-way scattered 16-byte loads per hop.)
+    // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n)
     auto eval_keys = [&](uint32_t n) -> uint64_t {
         uint64_t kx = kDeadKey;
         if (use_rm) {
-            const uint32_t pitch = v.dim4 + 1;
-            for (uint32_t base = 0; base < n; base += kHnswStageRows) {
-                const uint32_t cnt = n - base < (uint32_t)kHnswStageRows ? n - base : (uint32_t)kHnswStageRows;
-                __syncthreads();
-                for (uint32_t r = 0; r < cnt; r++) {
-                    const f4* src = reinterpret_cast<const f4*>(v.rowmaj + (size_t)batch[base + r] * v.dim);
-                    for (uint32_t c = lane; c < v.dim4; c += 64) stage[(size_t)r * pitch + c] = src[c];
+            const uint32_t nslab = (v.dim4 + kHnswSlab - 1) / kHnswSlab;
+            for (uint32_t base = 0; base < n; base += kHnswRound) {
+                const uint32_t cnt = n - base < (uint32_t)kHnswRound ? n - base : (uint32_t)kHnswRound;
+                const bool me = lane >= base && lane < base + cnt;       // row r of this round sits on lane base + r of kx
+                const uint32_t myrow = me ? batch_l[lane] : 0u;
+                double rn = 0.0;
+                if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[myrow]; }
+                DmaRole role;
+                dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
+                typename MT<M>::A acc = 0;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                dma_issue_slab(role, 0, v.dim4, slabs_l);
+                for (uint32_t sl = 0; sl < nslab; sl++) {
+                    HTICK(5);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl has landed
+                    HTICK(2);
+                    if (sl + 1 < nslab) dma_issue_slab(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);   // lands while slab sl is consumed
+                    __builtin_amdgcn_sched_barrier(0);
+                    HTICK(6);
+                    if (me) slab_accumulate<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, (lane - base) & 31u, q_g, sl, v.dim4);
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this buffer's reads are done before it is refilled
+                    HTICK(3);
                 }
-                __syncthreads();
-                if (lane >= base && lane < base + cnt) {
-                    const uint32_t row = batch[lane];
-                    typename MT<M>::A acc = row_accumulate_lds<M>(stage + (size_t)(lane - base) * pitch, q_lds, v.dim4);
-                    double rn = 0.0;
-                    if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
-                    kx = make_key(finalize<M>(acc, qc, rn), row);
-                }
+                if (me) kx = make_key(finalize<M>(acc, qc, rn), myrow);
             }
             return kx;
         }
         if (lane < n) {
             const uint32_t row = batch[lane];
-            typename MT<M>::A acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
+            typename MT<M>::A acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_g, v.dim4);
             double rn = 0.0;
             if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
             kx = make_key(finalize<M>(acc, qc, rn), row);
@@ -315,61 +413,70 @@ k_hnsw_search_wave(IndexView v, GraphView g, const float* __restrict__ queries, 
         }
     };
 
-    // searchLayer (hnsw.go:471-580)
-    auto search_layer = [&](uint32_t entry, uint32_t ef, int level) {
-        epoch++;
-#pragma unroll
-        for (int s2 = 0; s2 < S; s2++) { key[s2] = kDeadKey; expd[s2] = 0; }
-        n_list = 0;
-        if (lane == 0) { vis[entry] = epoch; batch[0] = entry; }
-        __syncthreads();
-        uint64_t k0 = eval_keys(1); n_eval += 1;
-        insert(readlane64(k0, 0), ef);
-        for (;;) {
-            // pop: first unexpanded entry
-            uint32_t cur = 0xFFFFFFFFu;
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) {
-                if (cur != 0xFFFFFFFFu) continue;
-                const uint64_t m = __ballot(key[s2] != kDeadKey) & ~expd[s2];
-                if (m) { const uint32_t l = (uint32_t)__builtin_ctzll(m); cur = (uint32_t)readlane64(key[s2], l); expd[s2] |= 1ull << l; }
-            }
-            if (cur == 0xFFFFFFFFu) break;
-            uint32_t deg = 0; const uint32_t* links = nullptr;
-            if (alive(cur) && level <= (int)g.level[cur]) {
-                if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
-                else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
-            }
-            uint32_t c = 0xFFFFFFFFu; bool fresh = false;
-            if (lane < deg) { c = links[lane]; fresh = alive(c) && vis[c] != epoch; }
-            for (uint32_t j = 0; j + 1 < deg; j++) {                     // repeated node in one list: first occurrence only
-                uint32_t cj = __builtin_amdgcn_readlane(c, j);
-                if (lane > j && c == cj) fresh = false;
-            }
-            const uint64_t fm = __ballot(fresh);
-            const uint32_t nb = (uint32_t)__builtin_popcountll(fm);
-            __syncthreads();                                             // previous hop's batch[] reads are done
-            if (fresh) { vis[c] = epoch; batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c; }
-            __syncthreads();
-            if (nb == 0) continue;
-            const uint64_t kx = eval_keys(nb); n_eval += nb;
-            for (uint32_t i = 0; i < nb; i++) insert(readlane64(kx, i), ef);
-        }
-    };
-
     for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
-        __syncthreads();
-        stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
-        __syncthreads();
-        qc = query_const<M>(q_lds, v.dim);
+        q_g = qblk + (size_t)qi * v.dim4 * 4;
+        qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
         n_eval = 0; tie = false;
         uint32_t entry = g.entry;
-        for (int level = g.cur_level; level > 0; level--) {             // hnsw.go:649-657
-            search_layer(entry, 1, level);
-            if (n_list > 0) entry = (uint32_t)readlane64(key[0], 0);
+        // Search (hnsw.go:649-664): ef = 1 on the upper levels, max(efSearch, k) on level 0.  One loop body serves every
+        // level and the entry-point evaluation (a "hop" whose only neighbour is the entry), so each piece of the
+        // traversal is instantiated once.
+        for (int level = g.cur_level; level >= 0; level--) {
+            const uint32_t ef = level > 0 ? 1u : (ef_search > k ? ef_search : k);
+            // searchLayer (hnsw.go:471-580)
+            epoch++;
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) { key[s2] = kDeadKey; expd[s2] = 0; }
+            n_list = 0;
+            bool first = true;
+            for (;;) {
+                uint32_t nb;
+                if (first) {                                                 // :492-506: the entry point itself
+                    first = false;
+                    __syncthreads();
+                    if (lane == 0) { vis[entry] = epoch; batch[0] = entry; }
+                    __syncthreads();
+                    nb = 1;
+                } else {
+                    // pop: first unexpanded entry
+                    uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int s2 = 0; s2 < S; s2++) {
+                        if (cur != 0xFFFFFFFFu) continue;
+                        const uint64_t m = __ballot(key[s2] != kDeadKey) & ~expd[s2];
+                        if (m) { const uint32_t l = (uint32_t)__builtin_ctzll(m); cur = (uint32_t)readlane64(key[s2], l); expd[s2] |= 1ull << l; }
+                    }
+                    if (cur == 0xFFFFFFFFu) break;
+                    HTICK(0);
+                    uint32_t deg = 0; const uint32_t* links = nullptr;
+                    if (alive(cur) && level <= (int)g.level[cur]) {
+                        if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
+                        else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
+                    }
+                    uint32_t c = 0xFFFFFFFFu; bool fresh = false;
+                    if (lane < deg) { c = links[lane]; fresh = alive(c) && vis[c] != epoch; }
+                    for (uint32_t j = 0; j + 1 < deg; j++) {                 // repeated node in one list: first occurrence only
+                        uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                        if (lane > j && c == cj) fresh = false;
+                    }
+                    const uint64_t fm = __ballot(fresh);
+                    nb = (uint32_t)__builtin_popcountll(fm);
+                    __syncthreads();                                         // previous hop's batch[] reads are done
+                    if (fresh) { vis[c] = epoch; batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c; }
+                    __syncthreads();
+                    HTICK(1);
+                    if (nb == 0) continue;
+                }
+                const uint64_t kx = eval_keys(nb); n_eval += nb;
+                HTICK(7);
+                for (uint32_t i = 0; i < nb; i++) insert(readlane64(kx, i), ef);
+                HTICK(4);
+#ifdef QV_HNSW_PROF
+                hops++;
+#endif
+            }
+            if (level > 0 && n_list > 0) entry = (uint32_t)readlane64(key[0], 0);   // :649-657
         }
-        const uint32_t ef = ef_search > k ? ef_search : k;              // :660-663
-        search_layer(entry, ef, 0);                                     // :664
         uint32_t cnt = n_list < k ? n_list : k;                         // :670-672
         if (tie) cnt = kHnswTieFlag;
         else {
@@ -384,6 +491,11 @@ k_hnsw_search_wave(IndexView v, GraphView g, const float* __restrict__ queries, 
             }
         }
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
+#ifdef QV_HNSW_PROF
+        if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 777) && qi >= nq - gridDim.x)
+            printf("blk %u: pop %llu links+vis %llu dma-wait %llu issue %llu compute %llu insert %llu other %llu/%llu hops %llu evals(last q) %u wall(10ns) %llu cyc %llu\n", blockIdx.x, T[0], T[1], T[2], T[6], T[3], T[4], T[5], T[7], hops, n_eval,
+                   (unsigned long long)(wall_clock64() - wc0), (unsigned long long)(T[0]+T[1]+T[2]+T[3]+T[4]+T[5]+T[6]+T[7]));
+#endif
         epoch += 64;
     }
 }
@@ -414,7 +526,21 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
 }
 
 // wave-resident form: registers only (plus the staged query); tie-flagged queries report kHnswTieFlag
-size_t hnsw_wave_lds_bytes(int metric, uint32_t dim4) { return query_lds_bytes(metric, dim4) + 64 * sizeof(uint32_t) + (size_t)kHnswStageRows * (dim4 + 1) * 16 + 64; }
+// the wave kernel keeps no query in LDS: queries are pre-converted to the metric's Q type (zero-padded to dim4*4)
+// in global memory and read at wave-uniform addresses, i.e. by scalar loads into SGPR operands of v_fma_f64
+template <int M>
+__global__ void k_hnsw_prep_queries(const float* __restrict__ queries, uint32_t dim, uint32_t dim4, typename MT<M>::Q* __restrict__ qblk, double* __restrict__ qconst) {
+    using Q = typename MT<M>::Q;
+    const float* q = queries + (size_t)blockIdx.x * dim;
+    Q* out = qblk + (size_t)blockIdx.x * dim4 * 4;
+    for (uint32_t i = threadIdx.x; i < dim4 * 4; i += blockDim.x) out[i] = i < dim ? (Q)q[i] : (Q)0;
+    if (threadIdx.x == 0) {
+        const QConst c = query_const<M>(q, dim);          // same element order as everywhere else (distances.go:20)
+        qconst[(size_t)blockIdx.x * 2] = c.qn; qconst[(size_t)blockIdx.x * 2 + 1] = (double)c.qn32;
+    }
+}
+size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4) { return (size_t)nq * dim4 * 4 * sizeof(double) + (size_t)nq * 2 * sizeof(double); }
+size_t hnsw_wave_lds_bytes(int /*metric*/, uint32_t /*dim4*/) { return 64 * sizeof(uint32_t) + 2 * (size_t)kHnswSlabBytes + 64; }
 uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4) {
     const size_t lds = hnsw_wave_lds_bytes(metric, dim4);
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
@@ -422,7 +548,7 @@ uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4) {
     per_cu = std::min<uint32_t>(per_cu, (uint32_t)cap);
     return (uint32_t)cus * per_cu;
 }
-hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
+hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
                                    uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
                                    uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s) {
     if (nq == 0) return hipSuccess;
@@ -430,10 +556,15 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     if (k == 0 || efx > (uint32_t)kHnswEfMax || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
     const size_t lds = hnsw_wave_lds_bytes(v.metric, v.dim4);
     hipError_t e = hipSuccess;
+    double* d_qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qblk) + (size_t)nq * v.dim4 * 4 * sizeof(double));
+    QV_DISPATCH_METRIC(v.metric, {
+        hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
+    });
 #define QV_HW(SS) QV_DISPATCH_METRIC(v.metric, {                                                                     \
         e = set_lds(k_hnsw_search_wave<MM, 8, SS>, lds);                                                              \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL((k_hnsw_search_wave<MM, 8, SS>), dim3(grid), dim3(64), lds, s, v, g, d_queries, nq, k, ef, d_visited, epoch0, \
+        hipLaunchKernelGGL((k_hnsw_search_wave<MM, 8, SS>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
+                           static_cast<const double*>(d_qconst), nq, k, ef, d_visited, epoch0,                       \
                            d_rows_out, d_dist_out, d_count_out, d_evals_out);                                         \
     })
     if (efx <= 64) { QV_HW(1); } else if (efx <= 128) { QV_HW(2); } else if (efx <= 256) { QV_HW(4); } else { QV_HW(8); }

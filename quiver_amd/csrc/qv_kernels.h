@@ -129,15 +129,16 @@ template <int M> __device__ __forceinline__ void acc1(typename MT<M>::A& acc, ty
 // wave in the reference's element order (distances.go:20: magnitudeA += a*a)
 struct QConst { double qn; float qn32; };
 
-template <int M> __device__ __forceinline__ QConst query_const(const typename MT<M>::Q* q, uint32_t dim) {
+template <int M, typename T> __device__ __forceinline__ QConst query_const(const T* q, uint32_t dim) {
+    using Q = typename MT<M>::Q;
     QConst c; c.qn = 0.0; c.qn32 = 0.0f;
     if constexpr (M == QV_COSINE) {
         double ma = 0.0;
-        for (uint32_t i = 0; i < dim; i++) ma = __builtin_fma(q[i], q[i], ma);
+        for (uint32_t i = 0; i < dim; i++) { const Q a = (Q)q[i]; ma = __builtin_fma(a, a, ma); }
         c.qn = __builtin_sqrt(ma);                                    // sqrt(ma) == 0  <=>  ma == 0
     } else if constexpr (M == QV_COSINE_F32) {
         float na = 0.0f;
-        for (uint32_t i = 0; i < dim; i++) { float p = q[i] * q[i]; na = na + p; }
+        for (uint32_t i = 0; i < dim; i++) { const Q a = (Q)q[i]; float p = a * a; na = na + p; }
         c.qn32 = (float)__builtin_sqrt((double)na);                   // adapter.go:128
         c.qn = (double)na;                                            // zero test is on na itself (adapter.go:122)
     }

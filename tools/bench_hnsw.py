@@ -20,6 +20,7 @@ ap.add_argument("--m", type=int, default=16); ap.add_argument("--efc", type=int,
 ap.add_argument("--nq", type=int, default=1000); ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--max-level", type=int, default=16); ap.add_argument("--metric", default="cosine")
 ap.add_argument("--cpu-queries", type=int, default=100)
+ap.add_argument("--skip-cpu", action="store_true")
 ap.add_argument("--more-nq", type=int, nargs="*", default=[], help="extra batch sizes timed on the same graph")
 a = ap.parse_args()
 mid = quiver_amd.metric_id(a.metric)
@@ -53,6 +54,10 @@ flat = quiver_amd.DeviceIndex(a.dim, mid); flat.add(rows)
 er, ed, _ = flat.search(qs, a.k, batched=True)
 hit = sum(len(set(r.VectorIndex for r in res[i]) & set(er[i].tolist())) for i in range(a.nq))
 
+if a.skip_cpu:
+    print(json.dumps({"workload": "HNSW %dx%d efS=%d MaxLevel=%d" % (a.rows, a.dim, a.efs, a.max_level), "device_call_only": extra,
+                      "recall_at_10_vs_exact": hit / (a.nq * a.k)}))
+    sys.exit(0)
 # CPU oracle on the identical graph
 t0 = time.perf_counter()
 o = O.HNSW(mid, a.dim, M=a.m, efConstruction=a.efc, efSearch=a.efs, maxLevel=a.max_level, seed=7)
