@@ -81,6 +81,9 @@ int       qvo_hnsw_entry_point(const qvo_hnsw*, uint32_t* ep_out, int* cur_level
 int       qvo_hnsw_node_level(const qvo_hnsw*, uint32_t node); /* -1 if deleted */
 /* copy out node's links at `level`; returns count (<= cap) or -1 */
 int       qvo_hnsw_links(const qvo_hnsw*, uint32_t node, int level, uint32_t* out, uint32_t cap);
+/* test scaffolding (not a reference function): install a ready-made single-layer graph; rows are borrowed */
+int       qvo_hnsw_load_flat(qvo_hnsw*, uint32_t n, const float* rows, const uint32_t* deg, const uint32_t* links,
+                             uint32_t stride, uint32_t entry);
 /* the level law alone, for property tests: p(level>=l+1 | level>=l) = 0.25, <= min(MaxLevel,10) draws */
 int       qvo_hnsw_random_level(qvo_hnsw*);
 

@@ -31,6 +31,7 @@ typedef struct {
     uint32_t* conn_len;
     uint32_t* conn_cap;
     int alive;
+    int borrowed;      /* vec points into the caller's array (qvo_hnsw_load_flat) */
 } node_t;
 
 struct qvo_hnsw {
@@ -109,7 +110,7 @@ void qvo_hnsw_destroy(qvo_hnsw* h) {
     for (uint32_t i = 0; i < h->n_nodes; i++) {
         node_t* nd = &h->nodes[i];
         for (int l = 0; l <= nd->level; l++) free(nd->conn[l]);
-        free(nd->conn); free(nd->conn_len); free(nd->conn_cap); free(nd->vec);
+        free(nd->conn); free(nd->conn_len); free(nd->conn_cap); if (!nd->borrowed) free(nd->vec);
     }
     free(h->nodes); free(h->visited); free(h);
 }
@@ -263,6 +264,26 @@ int64_t qvo_hnsw_insert(qvo_hnsw* h, const float* vec) {
         if (level > h->cur_level) { h->entry = idx; h->cur_level = level; }
     }
     return idx;
+}
+
+/* Test scaffolding, not a reference function: install a ready-made single-layer graph (every node at
+ * level 0, links as given) so that Search (hnsw.go:602-713) can be run on graphs that were not built by
+ * Insert — e.g. an exact k-NN graph at a size where the sequential reference build is impractical.
+ * `rows` is BORROWED (must outlive the index).  The index must be empty. */
+int qvo_hnsw_load_flat(qvo_hnsw* h, uint32_t n, const float* rows, const uint32_t* deg, const uint32_t* links, uint32_t stride, uint32_t entry) {
+    if (!h || h->n_nodes != 0 || n == 0 || entry >= n) return -1;
+    h->nodes = (node_t*)calloc(n, sizeof(node_t)); h->cap_nodes = n;
+    for (uint32_t i = 0; i < n; i++) {
+        node_t* nd = &h->nodes[i];
+        nd->vec = (float*)(rows + (size_t)i * h->dim); nd->borrowed = 1; nd->level = 0; nd->alive = 1;
+        nd->conn = (uint32_t**)calloc(1, sizeof(uint32_t*)); nd->conn_len = (uint32_t*)calloc(1, sizeof(uint32_t)); nd->conn_cap = (uint32_t*)calloc(1, sizeof(uint32_t));
+        uint32_t d = deg[i] < stride ? deg[i] : stride;
+        nd->conn[0] = (uint32_t*)malloc((d ? d : 1) * sizeof(uint32_t));
+        memcpy(nd->conn[0], links + (size_t)i * stride, d * sizeof(uint32_t));
+        nd->conn_len[0] = d; nd->conn_cap[0] = d ? d : 1;
+    }
+    h->n_nodes = n; h->size = n; h->entry = entry; h->cur_level = 0;
+    return 0;
 }
 
 /* Delete, hnsw.go:741-842 */

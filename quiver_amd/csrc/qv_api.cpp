@@ -699,10 +699,14 @@ int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_
     if (e == hipSuccess) e = up(&g->d_l0links, l0_links, (size_t)n_nodes * max_m0 * 4);
     if (e == hipSuccess) e = up(&g->d_upoff, up_off, (size_t)n_nodes * 4);
     if (e == hipSuccess) e = up(&g->d_uplinks, up_links, (size_t)n_up_blocks * (1 + max_m) * 4);
-    // visited stamps: one uint32 per (wave slot, node) — sized for 288 GB HBM: 5 GB at 1M nodes x 1280 slots
+    // visited stamps: one uint32 per (wave slot, node) — sized for 288 GB HBM: 16 GB at 1M nodes x 4096 slots;
+    // never more than half of what is free (fewer resident queries instead)
     g->heap_grid = qv::hnsw_grid(idx->cus, idx->metric, idx->dim4, 0xFFFFFFFFu);
     g->grid = std::max(g->heap_grid, qv::hnsw_wave_grid(idx->cus, idx->metric, idx->dim4));
-    while (g->grid > 64 && (size_t)g->grid * n_nodes * 4 > ((size_t)16 << 30)) g->grid /= 2;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)32 << 30;
+    while (g->grid > 64 && (size_t)g->grid * n_nodes * 4 > free_b / 2) g->grid /= 2;
+    g->heap_grid = std::min(g->heap_grid, g->grid);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_visited), (size_t)g->grid * n_nodes * 4);
     if (e == hipSuccess) e = hipMemset(g->d_visited, 0, (size_t)g->grid * n_nodes * 4);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);

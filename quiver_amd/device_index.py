@@ -131,6 +131,56 @@ class DeviceIndex:
         return float(ms.value), int(n.value)
 
 
+class DeviceGraph:
+    """An HNSW graph resident on the device over the rows of a DeviceIndex (qv_graph_* of include/qv.h):
+    the whole of HNSW.Search (pkg/hnsw/hnsw.go:602-672) runs on the GPU, one wavefront per query.
+
+    levels [n] int8 (-1 = tombstone), l0_deg [n], l0_links [n, max_m0]; upper levels as up_off [n] and
+    up_links [n_blocks, 1 + max_m] (degree, links) — pass None for a single-layer graph."""
+
+    def __init__(self, index: DeviceIndex, levels, l0_deg, l0_links, entry: int, cur_level: int = 0, up_off=None, up_links=None, max_m: int = 0):
+        self.index = index
+        levels = np.ascontiguousarray(levels, dtype=np.int8)
+        l0_deg = np.ascontiguousarray(l0_deg, dtype=np.uint32)
+        l0_links = np.ascontiguousarray(l0_links, dtype=np.uint32)
+        n = levels.size
+        if l0_deg.size != n or l0_links.ndim != 2 or l0_links.shape[0] != n:
+            raise ValueError("levels, l0_deg and l0_links must describe the same nodes")
+        if up_off is None:
+            up_off = np.zeros(n, dtype=np.uint32); up_links = np.zeros((1, 1 + max(max_m, 1)), dtype=np.uint32); n_blocks = 0
+        else:
+            up_off = np.ascontiguousarray(up_off, dtype=np.uint32); up_links = np.ascontiguousarray(up_links, dtype=np.uint32); n_blocks = up_links.shape[0]
+            max_m = up_links.shape[1] - 1
+        self._g = C.c_void_p()
+        check(lib().qv_graph_create(C.byref(self._g), index.handle, n, levels.ctypes.data, l0_links.shape[1], max(max_m, 1), l0_deg.ctypes.data,
+                                    l0_links.ctypes.data, up_off.ctypes.data, up_links.ctypes.data, n_blocks, int(entry), int(cur_level)))
+
+    def search(self, queries, k: int, ef_search: int, with_evals: bool = False):
+        """rows [nq, k] uint32 (0xFFFFFFFF = unfilled), dist [nq, k] float32, count [nq] (< k: the graph search
+        under-filled and the caller tops up like hnsw.go:676-710)"""
+        q = _f32c(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.index.dim:
+            raise ValueError("query dimension %d does not match index dimension %d" % (q.shape[1], self.index.dim))
+        nq = q.shape[0]
+        rows = np.empty((nq, max(k, 1)), dtype=np.uint32); dist = np.empty((nq, max(k, 1)), dtype=np.float32)
+        count = np.empty(nq, dtype=np.uint32); evals = np.empty(nq, dtype=np.uint32)
+        check(lib().qv_graph_search(self._g, q.ctypes.data, nq, k, ef_search, rows.ctypes.data, dist.ctypes.data, count.ctypes.data, evals.ctypes.data))
+        return (rows, dist, count, evals) if with_evals else (rows, dist, count)
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g.value:
+            lib().qv_graph_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def merge_topk_device(d_dist_lists: int, d_row_lists: int, n_lists: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
     check(lib().qv_merge_topk_device(d_dist_lists, d_row_lists, n_lists, k, d_rows_out, d_dist_out, stream))
 

@@ -62,6 +62,8 @@ def _load():
     lib.qvo_hnsw_node_level.argtypes = [C.c_void_p, C.c_uint32]
     lib.qvo_hnsw_links.argtypes = [C.c_void_p, C.c_uint32, C.c_int, _u32p, C.c_uint32]
     lib.qvo_hnsw_random_level.argtypes = [C.c_void_p]
+    lib.qvo_hnsw_load_flat.argtypes = [C.c_void_p, C.c_uint32, _f32p, _u32p, _u32p, C.c_uint32, C.c_uint32]
+    lib.qvo_hnsw_load_flat.restype = C.c_int
     return lib
 
 
@@ -219,6 +221,14 @@ class HNSW:
 
     def random_level(self) -> int:
         return lib().qvo_hnsw_random_level(self._h)
+
+    def load_flat(self, rows, deg, links, entry: int):
+        """test scaffolding: install a ready-made single-layer graph (rows are borrowed, kept alive here)"""
+        self._rows = np.ascontiguousarray(rows, dtype=np.float32)
+        deg = np.ascontiguousarray(deg, dtype=np.uint32); links = np.ascontiguousarray(links, dtype=np.uint32)
+        assert self._rows.shape == (deg.size, self.dim) and links.shape[0] == deg.size
+        if lib().qvo_hnsw_load_flat(self._h, deg.size, self._rows, deg, links, links.shape[1], entry) != 0:
+            raise RuntimeError("load_flat failed (index not empty / bad entry)")
 
     def __del__(self):
         try:

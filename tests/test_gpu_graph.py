@@ -1,0 +1,66 @@
+"""Device graph traversal (qv_graph_*) on graphs that were NOT built by Insert: an exact k-NN graph made
+with the product's own flat scan.  The oracle runs HNSW.Search (pkg/hnsw/hnsw.go:602-713) on the
+identical graph (qvo_hnsw_load_flat); rows, distance bits, counts and evaluation counts must agree."""
+import numpy as np
+import pytest
+
+import quiver_amd
+from tests import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _knn_graph(rows, metric, m):
+    """exact m-NN lists (self excluded) through the product's flat scan"""
+    n = rows.shape[0]
+    idx = quiver_amd.DeviceIndex(rows.shape[1], metric, rowmajor=True)
+    idx.add(rows)
+    nbr, _, _ = idx.search(rows, m + 1)
+    links = np.zeros((n, m), np.uint32); deg = np.zeros(n, np.uint32)
+    for i in range(n):
+        l = [int(x) for x in nbr[i] if int(x) != i][:m]
+        deg[i] = len(l); links[i, :len(l)] = l
+    return idx, deg, links
+
+
+@pytest.mark.parametrize("metric,dim,n,m,ef,k", [
+    ("cosine", 768, 3000, 32, 128, 10),
+    ("cosine", 100, 2500, 16, 64, 10),       # dim4 = 25: partial DMA pieces
+    ("l2", 64, 2000, 32, 200, 50),           # ef > 128: 4 list registers per lane
+    ("dot", 36, 1500, 24, 40, 40),           # dim4 = 9: one full piece + a tail
+    ("cosine_f32", 128, 2000, 32, 128, 10),
+    ("l2sq", 20, 1000, 8, 16, 5),
+])
+def test_knn_graph_traversal_identical_to_oracle(metric, dim, n, m, ef, k):
+    mid = quiver_amd.metric_id(metric)
+    rows = O.gen_rows(4242, 0, n, dim)
+    idx, deg, links = _knn_graph(rows, metric, m)
+    g = quiver_amd.DeviceGraph(idx, np.zeros(n, np.int8), deg, links, entry=7)
+    o = O.HNSW(mid, dim, M=max(m // 2, 1), maxM0=m, efSearch=ef, maxLevel=1, seed=1)
+    o.load_flat(rows, deg, links, 7)
+    qs = O.gen_rows(4243, 0, 96, dim)
+    r, d, c, ev = g.search(qs, k, ef, with_evals=True)
+    for i in range(qs.shape[0]):
+        ro, do, eo = o.search(qs[i], k, with_evals=True)
+        if c[i] == k:                                     # filled by the graph search alone
+            assert r[i].tolist() == ro.tolist(), i
+            assert d[i].tobytes() == do.tobytes(), i
+            assert int(ev[i]) == eo - 1, i               # the reference also evaluates the entry point once more up front (hnsw.go:637)
+        else:                                             # under-filled: the caller tops up (hnsw.go:676-710); the prefix must agree
+            assert c[i] < k
+            assert r[i, :c[i]].tolist() == ro[:c[i]].tolist(), i
+
+
+def test_knn_graph_with_duplicate_rows_goes_through_the_exact_heap_kernel():
+    rows = O.gen_rows(5150, 0, 1200, 48)
+    rows[600:] = rows[:600]                                # every vector twice: equal distances everywhere
+    idx, deg, links = _knn_graph(rows, "cosine", 16)
+    g = quiver_amd.DeviceGraph(idx, np.zeros(1200, np.int8), deg, links, entry=0)
+    o = O.HNSW(0, 48, M=8, maxM0=16, efSearch=64, maxLevel=1, seed=1)
+    o.load_flat(rows, deg, links, 0)
+    qs = O.gen_rows(5151, 0, 32, 48)
+    r, d, c, ev = g.search(qs, 10, 64, with_evals=True)
+    for i in range(32):
+        ro, do, eo = o.search(qs[i], 10, with_evals=True)
+        n = min(int(c[i]), 10)
+        assert r[i, :n].tolist() == ro[:n].tolist() and d[i, :n].tobytes() == do[:n].tobytes()

@@ -160,3 +160,25 @@ def test_same_seed_same_graph_different_seed_may_differ():
         for l in range(h1.node_level(n) + 1):
             assert np.array_equal(h1.links(n, l), h2.links(n, l))
     assert h1.entry_point() == h2.entry_point()
+
+
+def test_load_flat_reproduces_a_built_single_layer_graph():
+    """qvo_hnsw_load_flat (test scaffolding) + Search == Search on the graph Insert built"""
+    rows = O.gen_rows(77, 0, 600, 32)
+    a = O.HNSW(0, 32, M=8, efConstruction=40, efSearch=48, maxLevel=1, seed=3)
+    for r in rows:
+        a.insert(r)
+    ep, lvl = a.entry_point()
+    assert lvl == 0
+    deg = np.zeros(600, np.uint32); links = np.zeros((600, 16), np.uint32)
+    for n in range(600):
+        l = a.links(n, 0); deg[n] = l.size; links[n, :l.size] = l
+    b = O.HNSW(0, 32, M=8, efConstruction=40, efSearch=48, maxLevel=1, seed=99)
+    b.load_flat(rows, deg, links, ep)
+    assert b.size() == 600 and b.entry_point() == (ep, 0)
+    for q in O.gen_rows(78, 0, 40, 32):
+        ra, da, ea = a.search(q, 10, with_evals=True)
+        rb, db, eb = b.search(q, 10, with_evals=True)
+        assert ra.tolist() == rb.tolist() and da.tobytes() == db.tobytes() and ea == eb
+    with pytest.raises(RuntimeError):
+        b.load_flat(rows, deg, links, ep)          # not empty any more
