@@ -53,8 +53,8 @@ def parse():
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs measured at N=1")
     ap.add_argument("--force-exchange", action="store_true",
                     help="with one rank, still run the RCCL all-gather + merge per step (exercises the N>1 code path on a 1-GPU box)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
-    ap.add_argument("--cpu-sample-queries", type=int, default=8)
+    ap.add_argument("--cpu-sample-rows", type=int, default=500_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=30)
     return ap.parse_args()
 
 
@@ -284,6 +284,41 @@ def main():
                          "pmc": "profiles/r01_sweep_mq.txt: SQ_VALU_MFMA_BUSY_CYCLES = 81.8 % of kernel cycles at an effective 1.99 GHz"}}
         if idx1 is not idx:
             idx1.close()
+        # configs[3] shape at reduced N: HNSW traversal (efSearch=128, MaxM0=32) on an exact 32-NN graph over 100k rows,
+        # built here by the product's own scan (the reference's sequential Insert build is not a data-parallel path)
+        try:
+            hn, hm, hef, hq = 100_000, 32, 128, 8192
+            hidx = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank, rowmajor=True)
+            hidx.add_synthetic(CORPUS_SEED, 0, hn)
+            hrows = np.stack([hidx.get_row(i) for i in range(hn)])
+            t1 = time.perf_counter()
+            links = np.empty((hn, hm), np.uint32); cols = np.arange(hm)[None, :]
+            for s0 in range(0, hn, 8192):
+                e0 = min(hn, s0 + 8192)
+                nbr, _, _ = hidx.search(hrows[s0:e0], hm + 1, batched=True)
+                me = np.arange(s0, e0, dtype=np.uint32)[:, None]
+                hit = nbr == me
+                pos = np.where(hit.any(axis=1), hit.argmax(axis=1), hm)[:, None]
+                links[s0:e0] = np.where(cols < pos, nbr[:, :hm], nbr[:, 1:hm + 1])
+            t_knn = time.perf_counter() - t1
+            graph = quiver_amd.DeviceGraph(hidx, np.zeros(hn, np.int8), np.full(hn, hm, np.uint32), links, entry=0)
+            qg2 = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
+            qg2.add_synthetic(QUERY_SEED, 0, hq)
+            hqs = np.stack([qg2.get_row(i) for i in range(hq)]); qg2.close()
+            graph.search(hqs[:512], k, hef)
+            t1 = time.perf_counter()
+            _, _, hcnt, hev = graph.search(hqs, k, hef, with_evals=True)
+            dth = time.perf_counter() - t1
+            also["hnsw_traversal_100kx768"] = {
+                "workload": "HNSW.Search on the device (BASELINE configs[3] shape, reduced N): efSearch=%d, MaxM0=%d, k=%d, %d queries on an exact "
+                            "%d-NN graph over %dx%d rows; qv_graph_search incl. query upload and result download" % (hef, hm, k, hq, hm, hn, dim),
+                "qps": hq / dth, "batch_ms": dth * 1e3, "distance_evals_per_query": float(hev.mean()), "distance_evals_per_s": float(hev.sum()) / dth,
+                "gathered_GBps": float(hev.sum()) * dim * 4 / dth / 1e9, "underfilled_queries": int((hcnt < k).sum()), "knn_graph_build_s": t_knn,
+                "parity": "tests/test_gpu_graph.py, tests/test_gpu_host.py: rows, float32 bits and evaluation counts equal the CPU traversal of the same graph",
+                "larger": "profiles/r01_hnsw_knn_1Mx768.json (1Mx768: 223k QPS), profiles/r01_hnsw_20kx768.jsonl (reference-built graph: 378k QPS)"}
+            graph.close(); hidx.close()
+        except Exception as ex:                                   # a measurement beside the headline; never fail the bench line over it
+            also["hnsw_traversal_100kx768"] = {"error": str(ex)}
 
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:

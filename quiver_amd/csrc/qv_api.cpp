@@ -435,7 +435,7 @@ static size_t search_ws_bytes(const qv_index* idx, uint32_t nq, uint32_t kk, uin
     const uint32_t n_tiles = (idx->n_rows + 63) / 64;
     const qv::ScanPlan plan = qv::plan_scan(n_tiles, idx->cus);
     if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride)   // partial lists + the multi-query kernels' query blocks
-        return qv::scan_workspace_bytes(plan, nq, kk) + (size_t)(nq + 16) * idx->dim4 * 4 * sizeof(double);
+        return qv::scan_workspace_bytes(plan, nq, kk) + std::max((size_t)(nq + 16) * idx->dim4 * 4 * sizeof(double), qv::mq64_workspace_bytes(nq, idx->dim4));
     return qv::full_sort_workspace_bytes(n_tiles);
 }
 

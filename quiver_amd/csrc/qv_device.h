@@ -54,6 +54,12 @@ struct ScanPlan {
 // how many workgroups a scan over n_tiles uses on a device with `cus` CUs
 ScanPlan plan_scan(uint32_t n_tiles, int cus);
 
+// exact multi-query scan on the f64 matrix cores (qv_mq64.hip): 0 = not applicable, else 16-query blocks per pass
+int mq64_blocks(int metric, uint32_t dim4, uint32_t nq);
+size_t mq64_workspace_bytes(uint32_t nq, uint32_t dim4);
+hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_queries, uint32_t nq, uint32_t k, void* d_qws, uint64_t* partial,
+                                 uint32_t* grid_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+
 // bytes of workspace for nq queries at list length k (partial lists)
 size_t scan_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k);
 

@@ -1,0 +1,307 @@
+// qv_mq64.hip — exact multi-query flat scan on the float64 matrix cores (cosine / dot).
+//
+// What it replaces: HybridIndex.BatchSearch's per-query ExactIndex.Search calls
+// (pkg/hybrid/hybrid_index.go:677-811 -> exact.go:92-133), 16 or 32 queries per corpus pass, with the
+// reference's arithmetic: float64 accumulation of exact float32 products over dims 0..D-1 IN ORDER
+// (pkg/vectortypes/distances.go:17-22, :82-86).
+//
+// Why a matrix instruction can be bit-exact here: v_mfma_f64_16x16x4_f64 computes, for every output,
+//     d = fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, c))))
+// — a sequential chain of individually rounded IEEE FMAs over k = 0..3 (tools/ubench/mfma_f64_order.hip:
+// 51,200 of 51,200 outputs equal to that chain on MI355X; the reverse order or a singly rounded sum would
+// not match).  Chaining one MFMA per 16-byte chunk with C = the previous D therefore reproduces the scalar
+// loop's rounding sequence exactly, at 77.5 TFLOP/s measured (tools/ubench/mfma_f64_rate.hip) against
+// ~37 TFLOP/s for the same chain written with v_fma_f64 (k_flat_scan_mq, f64-VALU-issue-bound).
+//
+// Operand mapping (lane l of the wave):
+//   A[i][k] = query (16*nb + i), dim 4c+k      lane l supplies i = l%16, k = l/16   (from LDS, f32 -> f64)
+//   B[k][j] = row (64t + 16g + j), dim 4c+k    lane l supplies k = l/16, j = l%16
+//   D: lane l, register r  <->  query 16*nb + 4r + l/16,  row 64t + 16g + l%16
+// The corpus stays in its tile layout ([dim4][64 rows][4 dims], lane == row, one f4 per lane and chunk):
+// the 4 components of the 4 lane blocks are transposed in registers with two v_permlane32_swap and two
+// v_permlane16_swap (gfx950), which turns "lane 16g+j holds dims 4c..4c+3 of row 16g+j" into "register g,
+// lane 16k+j holds dim 4c+k of row 16g+j" — exactly the four B operands of the chunk.
+#include "qv_kernels.h"
+
+namespace qv {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMq64Waves = 4;                    // waves that share out the tiles; H such sets per workgroup (one per 16-query block)
+constexpr int kMq64U = 8;                        // chunks per register block (double-buffered)
+
+// query fragments for one group of 16*NB queries: qfrag[nb][c][lane] = q_{16nb + lane%16}[4c + lane/16] (float32,
+// zero beyond dim; query slots past nq replicate the last query, their results are dropped), and per-query constants
+template <int M, int NB>
+__global__ void k_mq64_prep(const float* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t dim4,
+                            float* __restrict__ qfrag, double* __restrict__ qconst) {
+    const uint32_t grp = blockIdx.y;
+    const uint32_t per = (uint32_t)NB * dim4 * 64;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < per; i += gridDim.x * blockDim.x) {
+        const uint32_t lane = i & 63, c = (i >> 6) % dim4, nb = (i >> 6) / dim4;
+        uint32_t qi = grp * 16 * NB + nb * 16 + (lane & 15); if (qi >= nq) qi = nq - 1;
+        const uint32_t d = c * 4 + (lane >> 4);
+        qfrag[(size_t)grp * per + i] = d < dim ? queries[(size_t)qi * dim + d] : 0.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16 * NB) {
+        uint32_t qi = grp * 16 * NB + threadIdx.x; if (qi >= nq) qi = nq - 1;
+        const QConst c = query_const<M>(queries + (size_t)qi * dim, dim);     // the query's own norm, element order of distances.go:20
+        qconst[(size_t)grp * 16 * NB + threadIdx.x] = c.qn;
+    }
+}
+
+// 4x4 transpose between "component of the f4" and "16-lane block" (see the header comment)
+__device__ __forceinline__ void transpose_blocks(const f4 x, float& y0, float& y1, float& y2, float& y3) {
+    const auto u02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.x), __float_as_uint(x.z), false, false);
+    const auto u13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.y), __float_as_uint(x.w), false, false);
+    const auto a = __builtin_amdgcn_permlane16_swap(u02[0], u13[0], false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(u02[1], u13[1], false, false);
+    y0 = __uint_as_float(a[0]); y1 = __uint_as_float(a[1]); y2 = __uint_as_float(b[0]); y3 = __uint_as_float(b[1]);
+}
+
+// list maintenance happens once per query on the first tile and rarely afterwards; kept out of line so that the
+// 16*NB lists (distinct registers) do not each inline a bitonic network and an insertion loop
+__attribute__((noinline)) __device__ uint64_t sort_out_of_line(uint64_t key, uint32_t lane) { return wave_sort64(key, lane); }
+__attribute__((noinline)) __device__ uint64_t insert_out_of_line(uint64_t list, uint64_t cand, uint32_t kth, uint32_t lane) {
+    uint64_t thr = readlane64(list, kth);
+    list_insert(list, thr, cand, kth, lane);
+    return list;
+}
+
+// H = 16-query blocks per pass.  A single wave per SIMD issues f64 MFMAs at half the pipe's rate (mfma_f64_rate.hip:
+// 38.9 vs 77.5 TFLOP/s), so the workgroup is H sets of 4 waves — two waves per SIMD for H = 2 — and set h computes
+// query block h for the SAME tiles as the other set: the second read of a tile is an L2 hit, HBM sees it once.
+// Each wave carries 16 accumulator chains x 4 row groups (64 VGPRs) and 16 lists, which fits 256 registers.
+template <int M, int H>
+__global__ void __launch_bounds__(256 * H, 2 / H)
+k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* __restrict__ qconst_g, uint32_t nq, uint32_t k,
+                 uint64_t* __restrict__ partial) {
+    static_assert(M == QV_COSINE || M == QV_DOT, "the f64 matrix path covers the fma(q, x, acc) metrics");
+    constexpr int NB = 1;            // 16-query blocks per WAVE
+    constexpr int Q = 16;            // queries per wave
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) uint64_t lds_u64;
+    float* qf = reinterpret_cast<float*>(smem);                                   // [NB][dim4][64]
+    const lds_f32* qf3 = (const lds_f32*)smem;                                    // same, as an LDS-address-space pointer (ds_read)
+    const size_t qf_bytes = (size_t)H * v.dim4 * 64 * sizeof(float);
+    lds_u64* scratch = (lds_u64*)((__attribute__((address_space(3))) unsigned char*)smem + qf_bytes);   // [waves][4][64] first-tile transpose
+    const uint32_t lane = lane_id();
+    const uint32_t wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t half = wave_all / kMq64Waves, wave = wave_all % kMq64Waves;      // query block of this wave, tile slot of this wave
+    const uint32_t grp = blockIdx.y, q0 = (grp * H + half) * 16;
+    const uint32_t blk = lane >> 4, j16 = lane & 15;
+
+    {   // stage this group's query fragments (all H blocks)
+        const f4* src = reinterpret_cast<const f4*>(qfrag_g + (size_t)grp * H * v.dim4 * 64);
+        f4* dst = reinterpret_cast<f4*>(qf);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)H * v.dim4 * 16; i += blockDim.x) dst[i] = src[i];
+    }
+    qf3 += half * v.dim4 * 64;                                                      // this wave's query block
+    // per-lane query constants: register (nb, r) belongs to query 16nb + 4r + blk
+    double qn[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) qn[nb][r] = qconst_g[q0 + nb * 16 + r * 4 + blk];   // qconst is laid out by query index
+    __syncthreads();
+
+    const uint32_t kth = k - 1;
+    uint64_t list[Q];                      // wave-resident ascending top-k list per query (one key per lane)
+    uint64_t thrv[NB][4];                  // per lane: current k-th key of "its" query for register (nb, r)
+#pragma unroll
+    for (int i = 0; i < Q; i++) list[i] = kDeadKey;
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) thrv[nb][r] = kDeadKey;
+
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t tw = gridDim.x * kMq64Waves;
+    bool first = true;
+    lds_u64* my_scratch = scratch + wave_all * 4 * 64;
+
+    for (uint32_t t = blockIdx.x * kMq64Waves + wave; t < v.n_tiles; t += tw) {
+        const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
+        d4 acc[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc[nb][g] = (d4){0.0, 0.0, 0.0, 0.0};
+        // per-row constants of this tile, in the output mapping (row 16g + j16)
+        double rn[4];
+        const uint64_t alive_word = v.alive[t];
+#pragma unroll
+        for (int g = 0; g < 4; g++) { rn[g] = 0.0; if constexpr (MT<M>::needs_rnorm) rn[g] = v.rnorm[(size_t)t * 64 + g * 16 + j16]; }
+
+        // one chunk: B operands from the row chunk (transpose + widen), A operands = the queries' values for this chunk
+        auto step = [&](const f4 x, const float (&qa)[NB]) {
+            float y0, y1, y2, y3;
+            transpose_blocks(x, y0, y1, y2, y3);
+            const double b0 = (double)y0, b1 = (double)y1, b2 = (double)y2, b3 = (double)y3;
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                const double a = (double)qa[nb];
+                acc[nb][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[nb][0], 0, 0, 0);
+                acc[nb][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[nb][1], 0, 0, 0);
+                acc[nb][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[nb][2], 0, 0, 0);
+                acc[nb][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[nb][3], 0, 0, 0);
+            }
+        };
+        auto load_q = [&](float (&qa)[kMq64U][NB], uint32_t c0) {
+#pragma unroll
+            for (int u = 0; u < kMq64U; u++)
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) qa[u][nb] = qf3[((uint32_t)nb * v.dim4 + c0 + u) * 64 + lane];
+        };
+        // chunks in order, kMq64U at a time; the next block's row chunks (HBM) and query values (LDS) are requested
+        // before the current block is consumed, so the matrix pipe never waits on a load it has just issued
+        f4 xa[kMq64U], xb[kMq64U];
+        float qa[kMq64U][NB], qb2[kMq64U][NB];
+        const uint32_t nblk = v.dim4 / kMq64U;
+        if (nblk) {
+#pragma unroll
+            for (int u = 0; u < kMq64U; u++) xa[u] = p[(size_t)u * 64];
+            load_q(qa, 0);
+        }
+        for (uint32_t bi = 0; bi < nblk; bi++) {
+            const uint32_t c0 = bi * kMq64U;
+            if (bi + 1 < nblk) {
+#pragma unroll
+                for (int u = 0; u < kMq64U; u++) xb[u] = p[(size_t)(c0 + kMq64U + u) * 64];
+                load_q(qb2, c0 + kMq64U);
+            }
+#pragma unroll
+            for (int u = 0; u < kMq64U; u++) step(xa[u], qa[u]);
+#pragma unroll
+            for (int u = 0; u < kMq64U; u++) {
+                xa[u] = xb[u];
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) qa[u][nb] = qb2[u][nb];
+            }
+            // keep the accumulators in the accumulation registers across the back-edge
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) asm volatile("" : "+v"(acc[nb][g]));
+        }
+        for (uint32_t c = nblk * kMq64U; c < v.dim4; c++) {
+            float q1[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) q1[nb] = qf3[((uint32_t)nb * v.dim4 + c) * 64 + lane];
+            step(p[(size_t)c * 64], q1);
+        }
+
+        // epilogue: distances -> keys; lane (blk, j16), register (nb, g, r) = (query 16nb+4r+blk, row 64t+16g+j16)
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                QConst qc; qc.qn = qn[nb][r]; qc.qn32 = 0.0f;
+                uint64_t key[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t row = t * 64 + g * 16 + j16;
+                    const bool live = (alive_word >> (g * 16 + j16)) & 1ull;
+                    key[g] = live ? make_key(finalize<M>(acc[nb][g][r], qc, rn[g]), row) : kDeadKey;
+                }
+                // Common case (after the first tile): no candidate beats its query's current k-th key — one ballot.
+                // Otherwise regroup the 4 x 64 candidates of these four queries through LDS to one per lane and
+                // hand each query's 64 to its list: sorted outright on the first tile, inserted afterwards.
+                bool slow = first;
+                uint64_t hits = ~0ull;
+                if (!first) {
+                    hits = __ballot(key[0] < thrv[nb][r] || key[1] < thrv[nb][r] || key[2] < thrv[nb][r] || key[3] < thrv[nb][r]);
+                    slow = hits != 0;
+                }
+                if (slow) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) my_scratch[blk * 64 + g * 16 + j16] = key[g];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int qb = 0; qb < 4; qb++) {
+                        if (((hits >> (16 * qb)) & 0xFFFFull) == 0) continue;
+                        const uint64_t cand = my_scratch[qb * 64 + lane];
+                        uint64_t& l = list[nb * 16 + r * 4 + qb];
+                        l = first ? sort_out_of_line(cand, lane) : insert_out_of_line(l, cand, kth, lane);
+                        const uint64_t thr = readlane64(l, kth);
+                        if (blk == (uint32_t)qb) thrv[nb][r] = thr;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        first = false;
+    }
+
+    // merge each set's 4 per-wave lists per query (the query fragments are dead: reuse their LDS)
+    __syncthreads();
+    lds_u64* wl = (lds_u64*)smem + (size_t)half * (kMq64Waves - 1) * Q * 64;      // [waves-1][Q][64] per set
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < Q; i++) wl[((wave - 1) * Q + i) * 64 + lane] = list[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+            for (uint32_t w = 0; w + 1 < (uint32_t)kMq64Waves; w++) {
+                const uint64_t key = lane < k ? wl[(w * Q + i) * 64 + lane] : kDeadKey;
+                list[i] = insert_out_of_line(list[i], key, kth, lane);
+            }
+            if (q0 + i < nq && lane < k) partial[((size_t)(q0 + i) * gridDim.x + blockIdx.x) * k + lane] = list[i];
+        }
+    }
+}
+
+size_t mq64_lds_bytes(uint32_t dim4, int nb) {
+    const size_t qf = (size_t)nb * dim4 * 64 * sizeof(float);
+    const size_t merge = (size_t)nb * (kMq64Waves - 1) * 16 * 64 * sizeof(uint64_t);
+    return std::max(qf + (size_t)nb * kMq64Waves * 4 * 64 * sizeof(uint64_t), merge);
+}
+// 0 = not applicable (metric / dimension); else the number of 16-query blocks per pass
+int mq64_blocks(int metric, uint32_t dim4, uint32_t nq) {
+    static const int enabled = env_int("QV_MQ64", 1);
+    if (enabled != 1 || (metric != QV_COSINE && metric != QV_DOT)) return 0;
+    // Measured (256 x 1M x 768): H = 1 with two workgroups per CU on distinct tiles is HBM-bound at 16 queries per pass
+    // (0.47 ms) = 7.5 ms; H = 2 (32 queries per pass, two wave sets sharing tiles) is bound by the DP pipe that
+    // f64 MFMA and v_cvt_f64_f32 share (tools/ubench/mfma_f64_mix.hip: strictly additive) = 9.7 ms.  H = 2 stays selectable.
+    static const int h = env_int("QV_MQ64_H", 1);
+    const int nb = (h == 2 && nq > 16) ? 2 : 1;
+    if (mq64_lds_bytes(dim4, nb) * (nb == 1 ? 2 : 1) <= 156 * 1024) return nb;
+    if (nb == 2 && mq64_lds_bytes(dim4, 1) * 2 <= 156 * 1024) return 1;
+    if (mq64_lds_bytes(dim4, 1) <= 156 * 1024) return 1;
+    return 0;
+}
+size_t mq64_workspace_bytes(uint32_t nq, uint32_t dim4) { return (size_t)(nq + 32) * dim4 * 4 * sizeof(float) + (size_t)(nq + 32) * sizeof(double) + 256; }
+
+// partial[(q * grid + wg) * k + i]; returns the grid used through *grid_out
+hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_queries, uint32_t nq, uint32_t k, void* d_qws, uint64_t* partial,
+                                 uint32_t* grid_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    const int nb = mq64_blocks(v.metric, v.dim4, nq);
+    if (nb == 0) return hipErrorInvalidValue;
+    const uint32_t Q = 16u * (uint32_t)nb, groups = (nq + Q - 1) / Q;
+    float* qfrag = static_cast<float*>(d_qws);
+    double* qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qws) + (((size_t)groups * Q * v.dim4 * 4 * sizeof(float)) + 255) / 256 * 256);
+    const uint32_t want = (v.n_tiles + kMq64Waves - 1) / kMq64Waves;
+    const uint32_t grid = std::max(1u, std::min(want, (uint32_t)cus * (nb == 1 ? 2u : 1u)));   // H = 1: two workgroups (8 waves) per CU
+    const size_t lds = mq64_lds_bytes(v.dim4, nb);
+    hipError_t e = hipSuccess;
+#define QV_MQ64(MMM, NBB)                                                                                                         \
+    {                                                                                                                             \
+        const uint32_t per = (uint32_t)NBB * v.dim4 * 64;                                                                          \
+        hipLaunchKernelGGL((k_mq64_prep<MMM, NBB>), dim3(std::min<uint32_t>((per + 255) / 256, 64), groups), dim3(256), 0, s, d_queries, nq, v.dim, v.dim4, qfrag, qconst); \
+        e = set_lds(k_flat_scan_mq64<MMM, NBB>, lds);                                                                             \
+        if (e != hipSuccess) return e;                                                                                            \
+        if (ev0) (void)hipEventRecord(ev0, s);                                                                                    \
+        hipLaunchKernelGGL((k_flat_scan_mq64<MMM, NBB>), dim3(grid, groups), dim3(256 * NBB), lds, s, v, qfrag, qconst, nq, k, partial); \
+        if (ev1) (void)hipEventRecord(ev1, s);                                                                                    \
+    }
+    if (v.metric == QV_COSINE) { if (nb == 2) QV_MQ64(QV_COSINE, 2) else QV_MQ64(QV_COSINE, 1) }
+    else { if (nb == 2) QV_MQ64(QV_DOT, 2) else QV_MQ64(QV_DOT, 1) }
+#undef QV_MQ64
+    *grid_out = grid;
+    return hipGetLastError();
+}
+
+}  // namespace qv

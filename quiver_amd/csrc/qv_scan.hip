@@ -428,6 +428,21 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
         const uint32_t want = (v.n_tiles + kScanWaves - 1) / kScanWaves;
         const uint32_t grid = std::max(1u, std::min(want, (uint32_t)mq_wg * (p.grid / 2 ? p.grid / 2 : 1)));   // p.grid = 2 WG/CU * CUs
         void* qblk = static_cast<char*>(d_ws) + scan_workspace_bytes(p, nq, k);   // tail of the workspace
+        // >= 9 cosine/dot queries: the same exact arithmetic on the f64 matrix cores (qv_mq64.hip), 16 or 32 queries per pass
+        static const int mq64_min = env_int("QV_MQ64_MIN", 9);
+        static const int trace = env_int("QV_TRACE", 0);                  // QV_TRACE=1: name the scan kernel chosen, on stderr
+        // (not for short scans: its first tile per wave pays 16 out-of-line sorts; measured slower below ~4 tiles per wave)
+        if ((int)nq >= mq64_min && mq_qb_env == 0 && v.n_tiles >= 16u * p.grid && mq64_blocks(v.metric, v.dim4, nq) != 0) {
+            uint32_t g64 = 0;
+            if (trace) fprintf(stderr, "qv: scan kernel = k_flat_scan_mq64 (nq=%u, tiles=%u)\n", nq, v.n_tiles);
+            e = launch_flat_scan_mq64(v, (int)(p.grid / 2 ? p.grid / 2 : 1), d_queries, nq, k, qblk, partial, &g64, s, ev0, ev1);
+            if (e != hipSuccess) return e;
+            const uint32_t total64 = g64 * k;
+            const uint32_t mb64 = total64 >= 16 * 64 * 4 ? kMergeBlock : (total64 >= 4 * 64 ? 256 : 64);
+            hipLaunchKernelGGL(k_merge_lists, dim3(nq), dim3(mb64), 0, s, partial, g64, k, d_rows_out, d_dist_out);
+            return hipGetLastError();
+        }
+        if (trace) fprintf(stderr, "qv: scan kernel = k_flat_scan_mq QB=%d (nq=%u, tiles=%u)\n", qb, nq, v.n_tiles);
 #define QV_MQ_LAUNCH(MMM, QQ)                                                                                              \
         {                                                                                                                     \
             using QT = typename MT<MMM>::Q;                                                                                   \
