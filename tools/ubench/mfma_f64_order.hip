@@ -1,6 +1,6 @@
 // Probe: does v_mfma_f64_16x16x4_f64 accumulate its 4 k-steps as a sequential chain of IEEE FMAs
 // (k = 0,1,2,3, each rounded), i.e. is D bit-identical to fma(a3,b3,fma(a2,b2,fma(a1,b1,fma(a0,b0,c))))?
-// hipcc --offload-arch=gfx950 -O2 mfma_f64_order.hip -o mfma_f64_order
+// make -C tools/ubench && tools/ubench/bin/mfma_f64_order
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
