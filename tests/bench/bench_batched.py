@@ -1,7 +1,7 @@
 """Batched-query measurement (BASELINE configs[2] shape: 256 queries x 1M x 768).
-python tools/bench_batched.py [--rows 1000000] [--nq 256] [--metric cosine] [--reps 5]"""
+python tests/bench/bench_batched.py [--rows 1000000] [--nq 256] [--metric cosine] [--reps 5]"""
 import argparse, json, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import quiver_amd
 from tests import _oracle as O

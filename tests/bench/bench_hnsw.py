@@ -1,14 +1,14 @@
 """HNSW measurement (BASELINE configs[3] shape, reduced N: the reference's sequential graph
 build — efConstruction searches per insert — is not a data-parallel path).
 
-  python tools/bench_hnsw.py [--rows 20000] [--dim 768] [--efc 100] [--efs 128] [--nq 1000] [--max-level 16]
+  python tests/bench/bench_hnsw.py [--rows 20000] [--dim 768] [--efc 100] [--efs 128] [--nq 1000] [--max-level 16]
 
 Builds the graph with the product host HNSW (every distance a libqv call), walks --nq queries on
 the device (qv_graph_search, one wavefront per query), and reports QPS, distance evaluations/s,
 gathered GB/s, recall@10 against the exact scan, and — beside it — the CPU oracle traversing the
 IDENTICAL graph (same seed -> same graph, asserted) on one core."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quiver_amd
 from quiver_amd import hnsw

@@ -7,10 +7,10 @@ re-score), i.e. a graph of the same shape and degree over the same kind of vecto
 HNSW.Search on the IDENTICAL graph (qvo_hnsw_load_flat) for a sample of the queries: results must be
 bit-identical.  Recall is reported against the exact scan.
 
-  python tools/bench_hnsw_knn.py [--rows 1000000] [--dim 768] [--m 32] [--efs 128] [--nq 16384] [--cpu-queries 50]
+  python tests/bench/bench_hnsw_knn.py [--rows 1000000] [--dim 768] [--m 32] [--efs 128] [--nq 16384] [--cpu-queries 50]
 """
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import quiver_amd
 from tests import _oracle as O
