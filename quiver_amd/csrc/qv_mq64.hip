@@ -27,8 +27,18 @@ namespace qv {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMq64Waves = 4;                    // waves that share out the tiles; H such sets per workgroup (one per 16-query block)
-constexpr int kMq64U = 8;                        // chunks per register block (double-buffered)
+// Shapes of the workgroup (template parameters of the kernel):
+//   W  waves that share out the tiles;  H  such wave sets per workgroup, set h computing query blocks h*NB.. for the SAME tiles;
+//   NB 16-query blocks per wave;  U chunks per register block (double-buffered);  WGS workgroups per CU
+struct Mq64Shape { int h, nb, u, w, wgs; };
+static Mq64Shape mq64_shape() {
+    // Measured, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt).  0: 16 queries/pass, 2 x 4 waves per CU on distinct tiles;
+    // 1: 32 queries/pass as two 4-wave sets sharing tiles; 2: 32 queries/pass, 8 waves per CU with two blocks per wave
+    static const int mode = env_int("QV_MQ64_MODE", 3) - 1;          // env value 1..3 -> mode 0..2 (0 = unset)
+    if (mode == 0) return {1, 1, 8, 4, 2};
+    if (mode == 1) return {2, 1, 8, 4, 1};
+    return {1, 2, 4, 8, 1};
+}
 
 // query fragments for one group of 16*NB queries: qfrag[nb][c][lane] = q_{16nb + lane%16}[4c + lane/16] (float32,
 // zero beyond dim; query slots past nq replicate the last query, their results are dropped), and per-query constants
@@ -68,36 +78,35 @@ __attribute__((noinline)) __device__ uint64_t insert_out_of_line(uint64_t list, 
     return list;
 }
 
-// H = 16-query blocks per pass.  A single wave per SIMD issues f64 MFMAs at half the pipe's rate (mfma_f64_rate.hip:
-// 38.9 vs 77.5 TFLOP/s), so the workgroup is H sets of 4 waves — two waves per SIMD for H = 2 — and set h computes
-// query block h for the SAME tiles as the other set: the second read of a tile is an L2 hit, HBM sees it once.
-// Each wave carries 16 accumulator chains x 4 row groups (64 VGPRs) and 16 lists, which fits 256 registers.
-template <int M, int H>
-__global__ void __launch_bounds__(256 * H, 2 / H)
+// A single wave per SIMD issues f64 MFMAs at half the pipe's rate (mfma_f64_rate.hip: 38.9 vs 77.5 TFLOP/s), and
+// v_cvt_f64_f32 shares the DP pipe with them (mfma_f64_mix.hip), so the shapes trade registers for waves per SIMD and
+// MFMAs per row convert: see Mq64Shape above.  With H > 1, set h computes its query blocks for the SAME tiles as the
+// other sets (the second read of a tile is an L2 hit, HBM sees it once).
+template <int M, int H, int NB, int U, int W, int WGS>
+__global__ void __launch_bounds__(64 * W * H, WGS)
 k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* __restrict__ qconst_g, uint32_t nq, uint32_t k,
                  uint64_t* __restrict__ partial) {
     static_assert(M == QV_COSINE || M == QV_DOT, "the f64 matrix path covers the fma(q, x, acc) metrics");
-    constexpr int NB = 1;            // 16-query blocks per WAVE
-    constexpr int Q = 16;            // queries per wave
+    constexpr int Q = 16 * NB;       // queries per wave (NB 16-query blocks)
     extern __shared__ __align__(16) unsigned char smem[];
     typedef __attribute__((address_space(3))) float lds_f32;
     typedef __attribute__((address_space(3))) uint64_t lds_u64;
     float* qf = reinterpret_cast<float*>(smem);                                   // [NB][dim4][64]
     const lds_f32* qf3 = (const lds_f32*)smem;                                    // same, as an LDS-address-space pointer (ds_read)
-    const size_t qf_bytes = (size_t)H * v.dim4 * 64 * sizeof(float);
+    const size_t qf_bytes = (size_t)H * NB * v.dim4 * 64 * sizeof(float);
     lds_u64* scratch = (lds_u64*)((__attribute__((address_space(3))) unsigned char*)smem + qf_bytes);   // [waves][4][64] first-tile transpose
     const uint32_t lane = lane_id();
     const uint32_t wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t half = wave_all / kMq64Waves, wave = wave_all % kMq64Waves;      // query block of this wave, tile slot of this wave
-    const uint32_t grp = blockIdx.y, q0 = (grp * H + half) * 16;
+    const uint32_t half = wave_all / W, wave = wave_all % W;      // query block of this wave, tile slot of this wave
+    const uint32_t grp = blockIdx.y, q0 = (grp * H + half) * Q;
     const uint32_t blk = lane >> 4, j16 = lane & 15;
 
     {   // stage this group's query fragments (all H blocks)
-        const f4* src = reinterpret_cast<const f4*>(qfrag_g + (size_t)grp * H * v.dim4 * 64);
+        const f4* src = reinterpret_cast<const f4*>(qfrag_g + (size_t)grp * H * NB * v.dim4 * 64);
         f4* dst = reinterpret_cast<f4*>(qf);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)H * v.dim4 * 16; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (uint32_t)H * NB * v.dim4 * 16; i += blockDim.x) dst[i] = src[i];
     }
-    qf3 += half * v.dim4 * 64;                                                      // this wave's query block
+    qf3 += half * NB * v.dim4 * 64;                                                      // this wave's query block
     // per-lane query constants: register (nb, r) belongs to query 16nb + 4r + blk
     double qn[NB][4];
 #pragma unroll
@@ -117,11 +126,11 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
         for (int r = 0; r < 4; r++) thrv[nb][r] = kDeadKey;
 
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
-    const uint32_t tw = gridDim.x * kMq64Waves;
+    const uint32_t tw = gridDim.x * W;
     bool first = true;
     lds_u64* my_scratch = scratch + wave_all * 4 * 64;
 
-    for (uint32_t t = blockIdx.x * kMq64Waves + wave; t < v.n_tiles; t += tw) {
+    for (uint32_t t = blockIdx.x * W + wave; t < v.n_tiles; t += tw) {
         const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
         d4 acc[NB][4];
 #pragma unroll
@@ -148,33 +157,33 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
                 acc[nb][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[nb][3], 0, 0, 0);
             }
         };
-        auto load_q = [&](float (&qa)[kMq64U][NB], uint32_t c0) {
+        auto load_q = [&](float (&qa)[U][NB], uint32_t c0) {
 #pragma unroll
-            for (int u = 0; u < kMq64U; u++)
+            for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) qa[u][nb] = qf3[((uint32_t)nb * v.dim4 + c0 + u) * 64 + lane];
         };
-        // chunks in order, kMq64U at a time; the next block's row chunks (HBM) and query values (LDS) are requested
+        // chunks in order, U at a time; the next block's row chunks (HBM) and query values (LDS) are requested
         // before the current block is consumed, so the matrix pipe never waits on a load it has just issued
-        f4 xa[kMq64U], xb[kMq64U];
-        float qa[kMq64U][NB], qb2[kMq64U][NB];
-        const uint32_t nblk = v.dim4 / kMq64U;
+        f4 xa[U], xb[U];
+        float qa[U][NB], qb2[U][NB];
+        const uint32_t nblk = v.dim4 / U;
         if (nblk) {
 #pragma unroll
-            for (int u = 0; u < kMq64U; u++) xa[u] = p[(size_t)u * 64];
+            for (int u = 0; u < U; u++) xa[u] = p[(size_t)u * 64];
             load_q(qa, 0);
         }
         for (uint32_t bi = 0; bi < nblk; bi++) {
-            const uint32_t c0 = bi * kMq64U;
+            const uint32_t c0 = bi * U;
             if (bi + 1 < nblk) {
 #pragma unroll
-                for (int u = 0; u < kMq64U; u++) xb[u] = p[(size_t)(c0 + kMq64U + u) * 64];
-                load_q(qb2, c0 + kMq64U);
+                for (int u = 0; u < U; u++) xb[u] = p[(size_t)(c0 + U + u) * 64];
+                load_q(qb2, c0 + U);
             }
 #pragma unroll
-            for (int u = 0; u < kMq64U; u++) step(xa[u], qa[u]);
+            for (int u = 0; u < U; u++) step(xa[u], qa[u]);
 #pragma unroll
-            for (int u = 0; u < kMq64U; u++) {
+            for (int u = 0; u < U; u++) {
                 xa[u] = xb[u];
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) qa[u][nb] = qb2[u][nb];
@@ -185,7 +194,7 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
 #pragma unroll
                 for (int g = 0; g < 4; g++) asm volatile("" : "+v"(acc[nb][g]));
         }
-        for (uint32_t c = nblk * kMq64U; c < v.dim4; c++) {
+        for (uint32_t c = nblk * U; c < v.dim4; c++) {
             float q1[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) q1[nb] = qf3[((uint32_t)nb * v.dim4 + c) * 64 + lane];
@@ -236,7 +245,7 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
 
     // merge each set's 4 per-wave lists per query (the query fragments are dead: reuse their LDS)
     __syncthreads();
-    lds_u64* wl = (lds_u64*)smem + (size_t)half * (kMq64Waves - 1) * Q * 64;      // [waves-1][Q][64] per set
+    lds_u64* wl = (lds_u64*)smem + (size_t)half * (W - 1) * Q * 64;      // [waves-1][Q][64] per set
     if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < Q; i++) wl[((wave - 1) * Q + i) * 64 + lane] = list[i];
@@ -245,7 +254,7 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
     if (wave == 0) {
 #pragma unroll
         for (int i = 0; i < Q; i++) {
-            for (uint32_t w = 0; w + 1 < (uint32_t)kMq64Waves; w++) {
+            for (uint32_t w = 0; w + 1 < (uint32_t)W; w++) {
                 const uint64_t key = lane < k ? wl[(w * Q + i) * 64 + lane] : kDeadKey;
                 list[i] = insert_out_of_line(list[i], key, kth, lane);
             }
@@ -254,51 +263,49 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
     }
 }
 
-size_t mq64_lds_bytes(uint32_t dim4, int nb) {
-    const size_t qf = (size_t)nb * dim4 * 64 * sizeof(float);
-    const size_t merge = (size_t)nb * (kMq64Waves - 1) * 16 * 64 * sizeof(uint64_t);
-    return std::max(qf + (size_t)nb * kMq64Waves * 4 * 64 * sizeof(uint64_t), merge);
+static size_t mq64_lds_bytes(uint32_t dim4, const Mq64Shape& sh) {
+    const size_t qf = (size_t)sh.h * sh.nb * dim4 * 64 * sizeof(float);
+    const size_t merge = (size_t)sh.h * (sh.w - 1) * 16 * sh.nb * 64 * sizeof(uint64_t);
+    return std::max(qf + (size_t)sh.h * sh.w * 4 * 64 * sizeof(uint64_t), merge);
 }
-// 0 = not applicable (metric / dimension); else the number of 16-query blocks per pass
+// 0 = not applicable (metric / dimension); else queries per pass
 int mq64_blocks(int metric, uint32_t dim4, uint32_t nq) {
     static const int enabled = env_int("QV_MQ64", 1);
     if (enabled != 1 || (metric != QV_COSINE && metric != QV_DOT)) return 0;
-    // Measured (256 x 1M x 768): H = 1 with two workgroups per CU on distinct tiles is HBM-bound at 16 queries per pass
-    // (0.47 ms) = 7.5 ms; H = 2 (32 queries per pass, two wave sets sharing tiles) is bound by the DP pipe that
-    // f64 MFMA and v_cvt_f64_f32 share (tools/ubench/mfma_f64_mix.hip: strictly additive) = 9.7 ms.  H = 2 stays selectable.
-    static const int h = env_int("QV_MQ64_H", 1);
-    const int nb = (h == 2 && nq > 16) ? 2 : 1;
-    if (mq64_lds_bytes(dim4, nb) * (nb == 1 ? 2 : 1) <= 156 * 1024) return nb;
-    if (nb == 2 && mq64_lds_bytes(dim4, 1) * 2 <= 156 * 1024) return 1;
-    if (mq64_lds_bytes(dim4, 1) <= 156 * 1024) return 1;
-    return 0;
+    const Mq64Shape sh = mq64_shape();
+    if (mq64_lds_bytes(dim4, sh) * sh.wgs > 158 * 1024) return 0;
+    return 16 * sh.h * sh.nb;
 }
-size_t mq64_workspace_bytes(uint32_t nq, uint32_t dim4) { return (size_t)(nq + 32) * dim4 * 4 * sizeof(float) + (size_t)(nq + 32) * sizeof(double) + 256; }
+size_t mq64_workspace_bytes(uint32_t nq, uint32_t dim4) { return (size_t)(nq + 32) * dim4 * 4 * sizeof(float) + (size_t)(nq + 32) * sizeof(double) + 512; }
 
 // partial[(q * grid + wg) * k + i]; returns the grid used through *grid_out
 hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_queries, uint32_t nq, uint32_t k, void* d_qws, uint64_t* partial,
                                  uint32_t* grid_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    const int nb = mq64_blocks(v.metric, v.dim4, nq);
-    if (nb == 0) return hipErrorInvalidValue;
-    const uint32_t Q = 16u * (uint32_t)nb, groups = (nq + Q - 1) / Q;
+    if (mq64_blocks(v.metric, v.dim4, nq) == 0) return hipErrorInvalidValue;
+    const Mq64Shape sh = mq64_shape();
+    const uint32_t B = (uint32_t)(sh.h * sh.nb), Q = 16u * B, groups = (nq + Q - 1) / Q;
     float* qfrag = static_cast<float*>(d_qws);
     double* qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qws) + (((size_t)groups * Q * v.dim4 * 4 * sizeof(float)) + 255) / 256 * 256);
-    const uint32_t want = (v.n_tiles + kMq64Waves - 1) / kMq64Waves;
-    const uint32_t grid = std::max(1u, std::min(want, (uint32_t)cus * (nb == 1 ? 2u : 1u)));   // H = 1: two workgroups (8 waves) per CU
-    const size_t lds = mq64_lds_bytes(v.dim4, nb);
+    const uint32_t want = (v.n_tiles + (uint32_t)sh.w - 1) / (uint32_t)sh.w;
+    const uint32_t grid = std::max(1u, std::min(want, (uint32_t)cus * (uint32_t)sh.wgs));
+    const size_t lds = mq64_lds_bytes(v.dim4, sh);
     hipError_t e = hipSuccess;
-#define QV_MQ64(MMM, NBB)                                                                                                         \
+#define QV_MQ64(MMM, HH, NBB, UU, WW, GG)                                                                                         \
     {                                                                                                                             \
-        const uint32_t per = (uint32_t)NBB * v.dim4 * 64;                                                                          \
-        hipLaunchKernelGGL((k_mq64_prep<MMM, NBB>), dim3(std::min<uint32_t>((per + 255) / 256, 64), groups), dim3(256), 0, s, d_queries, nq, v.dim, v.dim4, qfrag, qconst); \
-        e = set_lds(k_flat_scan_mq64<MMM, NBB>, lds);                                                                             \
+        const uint32_t per = (uint32_t)(HH * NBB) * v.dim4 * 64;                                                                   \
+        hipLaunchKernelGGL((k_mq64_prep<MMM, HH * NBB>), dim3(std::min<uint32_t>((per + 255) / 256, 64), groups), dim3(256), 0, s, d_queries, nq, v.dim, v.dim4, qfrag, qconst); \
+        e = set_lds(k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>, lds);                                                             \
         if (e != hipSuccess) return e;                                                                                            \
         if (ev0) (void)hipEventRecord(ev0, s);                                                                                    \
-        hipLaunchKernelGGL((k_flat_scan_mq64<MMM, NBB>), dim3(grid, groups), dim3(256 * NBB), lds, s, v, qfrag, qconst, nq, k, partial); \
+        hipLaunchKernelGGL((k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>), dim3(grid, groups), dim3(64 * WW * HH), lds, s, v, qfrag, qconst, nq, k, partial); \
         if (ev1) (void)hipEventRecord(ev1, s);                                                                                    \
     }
-    if (v.metric == QV_COSINE) { if (nb == 2) QV_MQ64(QV_COSINE, 2) else QV_MQ64(QV_COSINE, 1) }
-    else { if (nb == 2) QV_MQ64(QV_DOT, 2) else QV_MQ64(QV_DOT, 1) }
+#define QV_MQ64_SHAPES(MMM)                                                                  \
+    if (sh.h == 1 && sh.nb == 1) QV_MQ64(MMM, 1, 1, 8, 4, 2)                                  \
+    else if (sh.h == 2) QV_MQ64(MMM, 2, 1, 8, 4, 1)                                           \
+    else QV_MQ64(MMM, 1, 2, 4, 8, 1)
+    if (v.metric == QV_COSINE) { QV_MQ64_SHAPES(QV_COSINE) } else { QV_MQ64_SHAPES(QV_DOT) }
+#undef QV_MQ64_SHAPES
 #undef QV_MQ64
     *grid_out = grid;
     return hipGetLastError();
