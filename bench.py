@@ -309,10 +309,23 @@ def main():
             t1 = time.perf_counter()
             _, _, hcnt, hev = graph.search(hqs, k, hef, with_evals=True)
             dth = time.perf_counter() - t1
+            # the same batch with queries and results resident on the device (qv_graph_search_device)
+            dq = torch.from_numpy(hqs).cuda()
+            dr = torch.empty((hq, k), dtype=torch.int32, device="cuda"); dd2 = torch.empty((hq, k), dtype=torch.float32, device="cuda")
+            dc = torch.empty(hq, dtype=torch.int32, device="cuda")
+            graph.search_device(dq.data_ptr(), hq, k, hef, dr.data_ptr(), dd2.data_ptr(), dc.data_ptr(), 0, sp)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                graph.search_device(dq.data_ptr(), hq, k, hef, dr.data_ptr(), dd2.data_ptr(), dc.data_ptr(), 0, sp)
+            torch.cuda.synchronize()
+            dthd = (time.perf_counter() - t1) / 3
             also["hnsw_traversal_100kx768"] = {
                 "workload": "HNSW.Search on the device (BASELINE configs[3] shape, reduced N): efSearch=%d, MaxM0=%d, k=%d, %d queries on an exact "
                             "%d-NN graph over %dx%d rows; qv_graph_search incl. query upload and result download" % (hef, hm, k, hq, hm, hn, dim),
                 "qps": hq / dth, "batch_ms": dth * 1e3, "distance_evals_per_query": float(hev.mean()), "distance_evals_per_s": float(hev.sum()) / dth,
+                "device_resident": {"qps": hq / dthd, "batch_ms": dthd * 1e3, "distance_evals_per_s": float(hev.sum()) / dthd,
+                                    "gathered_GBps": float(hev.sum()) * dim * 4 / dthd / 1e9},
                 "gathered_GBps": float(hev.sum()) * dim * 4 / dth / 1e9, "underfilled_queries": int((hcnt < k).sum()), "knn_graph_build_s": t_knn,
                 "parity": "tests/test_gpu_graph.py, tests/test_gpu_host.py: rows, float32 bits and evaluation counts equal the CPU traversal of the same graph",
                 "larger": "profiles/r01_hnsw_knn_1Mx768.json (1Mx768: 223k QPS), profiles/r01_hnsw_20kx768.jsonl (reference-built graph: 378k QPS)"}

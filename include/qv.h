@@ -202,6 +202,12 @@ int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_
                     uint32_t n_up_blocks, uint32_t entry, int cur_level);
 int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out);
+/* Device-pointer form: queries, results, counts (and optional evals) live on the device; the traversal is
+ * enqueued on `stream` (0 = the graph's own stream) with no synchronisation.  One pass only: a query that
+ * met two equal distances or a NaN on its way reports count 0xFFFFFFFE and must be redone through
+ * qv_graph_search (which runs the exact-heap kernel for those); everything else is final. */
+int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+                           uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_count_out, uint32_t* d_evals_out, void* stream);
 void qv_graph_destroy(qv_graph* g);
 
 /* Copy row `row` back to the host (ExactIndex keeps vectors readable,

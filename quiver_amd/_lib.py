@@ -63,6 +63,7 @@ PROTOTYPES = {
     "qv_graph_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]),
     "qv_graph_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qv_graph_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_graph_destroy": (None, [C.c_void_p]),
     "qv_index_get_row": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "qv_last_error": (C.c_char_p, []),

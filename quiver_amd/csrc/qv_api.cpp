@@ -794,6 +794,33 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     return QV_OK;
 }
 
+int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+                           uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_count_out, uint32_t* d_evals_out, void* stream) {
+    if (!g) return fail(QV_ERR_INVALID_ARG, "graph is null");
+    if (nq == 0) return QV_OK;
+    if (!d_queries || !d_rows_out || !d_dist_out || !d_count_out) return fail(QV_ERR_INVALID_ARG, "null device pointer");
+    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");                      // hnsw.go:610-612
+    if (k > 512 || ef_search > 512) return fail(QV_ERR_UNSUPPORTED, "k and efSearch above 512 are not supported on the device path");
+    qv_index* idx = g->idx;
+    HIPCHK(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> lock(g->mu);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g->stream;
+    int rc;
+    if ((rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4)))) return rc;
+    const uint32_t grid = std::min(g->grid, nq);
+    const uint32_t per_wave = (nq + grid - 1) / grid;
+    const uint64_t need = (uint64_t)per_wave * 128 + 128;                  // stamps consumed by this batch per wave slot
+    if ((uint64_t)g->epoch + need >= 0xFFFFFF00ull) {
+        HIPCHK(hipMemsetAsync(g->d_visited, 0, (size_t)g->grid * g->g.n_nodes * 4, s));
+        g->epoch = 0;
+    }
+    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, d_queries, g->d_qblk.p, nq, k, ef_search, g->d_visited, grid, g->epoch,
+                                               d_rows_out, d_dist_out, d_count_out, d_evals_out, s);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+    g->epoch += (uint32_t)need;
+    return QV_OK;
+}
+
 int qv_distance_pairs(qv_metric metric, const float* a, const float* b, uint32_t n, uint32_t dim, float* dist_out, int device) {
     if ((int)metric < 0 || (int)metric >= QV_METRIC_COUNT) return fail(QV_ERR_INVALID_ARG, "unknown metric %d", (int)metric);
     if (n == 0) return QV_OK;

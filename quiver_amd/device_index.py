@@ -169,6 +169,11 @@ class DeviceGraph:
         check(lib().qv_graph_search(self._g, q.ctypes.data, nq, k, ef_search, rows.ctypes.data, dist.ctypes.data, count.ctypes.data, evals.ctypes.data))
         return (rows, dist, count, evals) if with_evals else (rows, dist, count)
 
+    def search_device(self, d_queries: int, nq: int, k: int, ef_search: int, d_rows_out: int, d_dist_out: int, d_count_out: int,
+                      d_evals_out: int = 0, stream: int = 0):
+        """device pointers in and out, enqueued on `stream`, no sync; count 0xFFFFFFFE = redo that query through search()"""
+        check(lib().qv_graph_search_device(self._g, d_queries, nq, k, ef_search, d_rows_out, d_dist_out, d_count_out, d_evals_out or None, stream or None))
+
     def close(self):
         if getattr(self, "_g", None) is not None and self._g.value:
             lib().qv_graph_destroy(self._g)

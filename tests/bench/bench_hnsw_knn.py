@@ -12,6 +12,7 @@ bit-identical.  Recall is reported against the exact scan.
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
+import torch                      # before libqv: both must share one HIP runtime (torch bundles its own)
 import quiver_amd
 from tests import _oracle as O
 
@@ -60,6 +61,24 @@ for n2 in sorted({min(a.nq, 4096), a.nq}):
     runs[str(n2)] = {"qps": n2 / t, "batch_ms": t * 1e3, "evals_per_query": float(ev.mean()), "evals_per_s": float(ev.sum()) / t,
                      "gather_GBps": float(ev.sum()) * D * 4 / t / 1e9, "underfilled": int((c < a.k).sum())}
 
+# the same batches with queries and results resident on the device (qv_graph_search_device): no PCIe in the timed region
+dq = torch.from_numpy(qs).cuda()
+dr = torch.empty((a.nq, a.k), dtype=torch.int32, device="cuda"); dd = torch.empty((a.nq, a.k), dtype=torch.float32, device="cuda")
+dc = torch.empty(a.nq, dtype=torch.int32, device="cuda"); de = torch.empty(a.nq, dtype=torch.int32, device="cuda")
+sp = torch.cuda.current_stream().cuda_stream
+runs_dev = {}
+for n2 in sorted({min(a.nq, 4096), a.nq}):
+    g.search_device(dq.data_ptr(), n2, a.k, a.efs, dr.data_ptr(), dd.data_ptr(), dc.data_ptr(), de.data_ptr(), sp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        g.search_device(dq.data_ptr(), n2, a.k, a.efs, dr.data_ptr(), dd.data_ptr(), dc.data_ptr(), de.data_ptr(), sp)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 3
+    evs = float(de[:n2].sum().item())
+    runs_dev[str(n2)] = {"qps": n2 / t, "batch_ms": t * 1e3, "evals_per_s": evs / t, "gather_GBps": evs * D * 4 / t / 1e9,
+                         "tie_flagged": int((dc[:n2].cpu().numpy().view(np.uint32) == 0xFFFFFFFE).sum())}
+
 er, ed, _ = idx.search(qs, a.k, batched=True)
 hit = sum(len(set(r[i, :min(int(c[i]), a.k)].tolist()) & set(er[i].tolist())) for i in range(a.nq))
 
@@ -77,6 +96,6 @@ print(json.dumps({
     "workload": "HNSW traversal on an exact %d-NN graph, %dx%d %s, efSearch=%d, k=%d" % (M, N, D, a.metric, a.efs, a.k),
     "graph": "exact k-NN graph built by the product's batched flat scan (single layer, entry = node 0); not the reference's insertion-built graph",
     "gen_rows_s_cpu": t_gen, "knn_graph_build_s_gpu": t_knn, "knn_queries_per_s": N / t_knn,
-    "device_call_only": runs, "recall_at_%d_vs_exact" % a.k: hit / (a.nq * a.k),
+    "device_call_only": runs, "device_resident": runs_dev, "recall_at_%d_vs_exact" % a.k: hit / (a.nq * a.k),
     "cpu_oracle_qps_1core": a.cpu_queries / t_cpu if a.cpu_queries else None, "cpu_evals_per_query": cpu_evals / max(a.cpu_queries, 1),
     "results_identical_to_cpu_traversal": bool(identical), "cpu_queries_checked": a.cpu_queries}))

@@ -64,3 +64,27 @@ def test_knn_graph_with_duplicate_rows_goes_through_the_exact_heap_kernel():
         ro, do, eo = o.search(qs[i], 10, with_evals=True)
         n = min(int(c[i]), 10)
         assert r[i, :n].tolist() == ro[:n].tolist() and d[i, :n].tobytes() == do[:n].tobytes()
+
+
+def test_device_pointer_form_equals_host_pointer_form():
+    import torch
+    n, dim, m, ef, k = 4000, 96, 24, 100, 10
+    rows = O.gen_rows(777, 0, n, dim)
+    idx, deg, links = _knn_graph(rows, "cosine", m)
+    g = quiver_amd.DeviceGraph(idx, np.zeros(n, np.int8), deg, links, entry=11)
+    qs = O.gen_rows(778, 0, 300, dim)
+    r, d, c, ev = g.search(qs, k, ef, with_evals=True)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((300, k), dtype=torch.int32, device="cuda"); dd = torch.empty((300, k), dtype=torch.float32, device="cuda")
+    dc = torch.empty(300, dtype=torch.int32, device="cuda"); de = torch.empty(300, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):                                      # repeated calls: fresh visited epochs each time
+        g.search_device(dq.data_ptr(), 300, k, ef, dr.data_ptr(), dd.data_ptr(), dc.data_ptr(), de.data_ptr(), s)
+    torch.cuda.synchronize()
+    c2 = dc.cpu().numpy().view(np.uint32)
+    ok = c2 != 0xFFFFFFFE                                   # tie-flagged queries are redone by the host-pointer form only
+    assert ok.sum() >= 290
+    assert np.array_equal(c2[ok], c[ok])
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32)[ok], r[ok])
+    assert np.array_equal(dd.cpu().numpy().view(np.uint32)[ok], d.view(np.uint32)[ok])
+    assert np.array_equal(de.cpu().numpy().view(np.uint32)[ok], ev[ok])
