@@ -377,7 +377,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             uint64_t top = 0;
 #pragma unroll
             for (int s2 = 0; s2 < S; s2++) if ((int)(e >> 6) == s2) top = readlane64(key[s2], e & 63);
-            if (xd >= (uint32_t)(top >> 32)) { if (xd == (uint32_t)(top >> 32)) tie = true; return; }   // hnsw.go:553 strict <
+            if (xd >= (uint32_t)(top >> 32)) return;    // hnsw.go:553 strict <: a key equal to the current worst is rejected whatever the heap layout
         }
         uint32_t p = 0;
 #pragma unroll
