@@ -752,7 +752,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
         g->epoch = 0;
     }
     HIPCHK(hipMemcpyAsync(g->d_q.p, queries, qbytes, hipMemcpyHostToDevice, g->stream));
-    // pass 1: wave-resident traversal (registers only); queries that meet equal distances / NaN report 0xFFFFFFFE
+    // pass 1: wave-resident traversal (list in registers, rows streamed through LDS); queries that meet equal distances / NaN report 0xFFFFFFFE
     hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, static_cast<const float*>(g->d_q.p), g->d_qblk.p, nq, k, ef_search, g->d_visited, grid, g->epoch,
                                                static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
                                                static_cast<uint32_t*>(g->d_ev.p), g->stream);

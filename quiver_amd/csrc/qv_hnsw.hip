@@ -525,7 +525,7 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
     return hipGetLastError();
 }
 
-// wave-resident form: registers only (plus the staged query); tie-flagged queries report kHnswTieFlag
+// wave-resident form: the list in registers, the LDS for the row slabs; tie-flagged queries report kHnswTieFlag
 // the wave kernel keeps no query in LDS: queries are pre-converted to the metric's Q type (zero-padded to dim4*4)
 // in global memory and read at wave-uniform addresses, i.e. by scalar loads into SGPR operands of v_fma_f64
 template <int M>
