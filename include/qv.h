@@ -205,7 +205,8 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
 /* Device-pointer form: queries, results, counts (and optional evals) live on the device; the traversal is
  * enqueued on `stream` (0 = the graph's own stream) with no synchronisation.  One pass only: a query that
  * met two equal distances or a NaN on its way reports count 0xFFFFFFFE and must be redone through
- * qv_graph_search (which runs the exact-heap kernel for those); everything else is final. */
+ * qv_graph_search (which runs the exact-heap kernel for those); everything else is final.  Traversals on one
+ * graph are ordered one after another whatever their streams (they share the visited stamps). */
 int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef_search,
                            uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_count_out, uint32_t* d_evals_out, void* stream);
 void qv_graph_destroy(qv_graph* g);

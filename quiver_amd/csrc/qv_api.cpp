@@ -119,6 +119,7 @@ struct qv_graph {
     uint64_t tie_reruns = 0;
     std::mutex mu;                              // one batch at a time (the visited stamps are per wave slot)
     hipStream_t stream = nullptr;
+    hipEvent_t ev_last = nullptr;               // end of the most recent traversal: the next one (on any stream) waits for it
     Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev;
 };
 
@@ -439,6 +440,8 @@ static size_t search_ws_bytes(const qv_index* idx, uint32_t nq, uint32_t kk, uin
     return qv::full_sort_workspace_bytes(n_tiles);
 }
 
+constexpr uint32_t kHostBatch = 8192;   // queries per device pass of the host-pointer entry points
+
 // the exact scans (single-query / multi-query / full ranking), host pointers
 static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                              uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
@@ -451,6 +454,14 @@ static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, u
     }
     if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");        // exact.go:104-106
     if (!rows_out || !dist_out) return fail(QV_ERR_INVALID_ARG, "rows_out/dist_out is null");
+    if (nq > kHostBatch) {                                                        // bound the workspace: very large batches go in slices
+        for (uint32_t q0 = 0; q0 < nq; q0 += kHostBatch) {
+            const int rc0 = exact_search_host(idx, queries + (size_t)q0 * idx->dim, std::min(kHostBatch, nq - q0), k,
+                                              rows_out + (size_t)q0 * k, dist_out + (size_t)q0 * k, count_out + q0);
+            if (rc0 != QV_OK) return rc0;
+        }
+        return QV_OK;
+    }
     const uint32_t kk = std::min(k, idx->n_live);                                // exact.go:109-111
     HIPCHK(hipSetDevice(idx->device));
     SearchCtx* c = nullptr;
@@ -584,6 +595,14 @@ int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, ui
     // (and any k > 64) takes the exact multi-query scan, which returns the same result
     if (!qv::batched_supported(v, nq, kk) || kk != k || idx->n_live < 4 * kk)
         return exact_search_host(idx, queries, nq, k, rows_out, dist_out, count_out);
+    if (nq > kHostBatch) {
+        for (uint32_t q0 = 0; q0 < nq; q0 += kHostBatch) {
+            const int rc0 = qv_index_search_batched(idx, queries + (size_t)q0 * idx->dim, std::min(kHostBatch, nq - q0), k,
+                                                    rows_out + (size_t)q0 * k, dist_out + (size_t)q0 * k, count_out + q0);
+            if (rc0 != QV_OK) return rc0;
+        }
+        return QV_OK;
+    }
     HIPCHK(hipSetDevice(idx->device));
     SearchCtx* c = nullptr;
     int rc = acquire_ctx(idx, &c);
@@ -710,6 +729,7 @@ int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_visited), (size_t)g->grid * n_nodes * 4);
     if (e == hipSuccess) e = hipMemset(g->d_visited, 0, (size_t)g->grid * n_nodes * 4);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_last, hipEventDisableTiming);
     if (e != hipSuccess) { qv_graph_destroy(g); return fail(e == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "graph upload failed: %s", hipGetErrorString(e)); }
     g->g.level = static_cast<const int8_t*>(g->d_level); g->g.l0_deg = static_cast<const uint32_t*>(g->d_l0deg);
     g->g.l0_links = static_cast<const uint32_t*>(g->d_l0links); g->g.up_off = static_cast<const uint32_t*>(g->d_upoff);
@@ -722,6 +742,7 @@ int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_
 void qv_graph_destroy(qv_graph* g) {
     if (!g) return;
     if (g->idx) (void)hipSetDevice(g->idx->device);
+    if (g->ev_last) { (void)hipEventSynchronize(g->ev_last); (void)hipEventDestroy(g->ev_last); }
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
     (void)hipFree(g->d_level); (void)hipFree(g->d_l0deg); (void)hipFree(g->d_l0links); (void)hipFree(g->d_upoff); (void)hipFree(g->d_uplinks);
     (void)hipFree(g->d_visited);
@@ -751,6 +772,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
         HIPCHK(hipMemsetAsync(g->d_visited, 0, (size_t)g->grid * g->g.n_nodes * 4, g->stream));
         g->epoch = 0;
     }
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_last, 0));               // after any device-form traversal still running on another stream
     HIPCHK(hipMemcpyAsync(g->d_q.p, queries, qbytes, hipMemcpyHostToDevice, g->stream));
     // pass 1: wave-resident traversal (list in registers, rows streamed through LDS); queries that meet equal distances / NaN report 0xFFFFFFFE
     hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, static_cast<const float*>(g->d_q.p), g->d_qblk.p, nq, k, ef_search, g->d_visited, grid, g->epoch,
@@ -805,6 +827,8 @@ int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uin
     HIPCHK(hipSetDevice(idx->device));
     std::lock_guard<std::mutex> lock(g->mu);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g->stream;
+    // the visited stamps and the converted-query workspace belong to one traversal at a time: order this one after the last
+    HIPCHK(hipStreamWaitEvent(s, g->ev_last, 0));
     int rc;
     if ((rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4)))) return rc;
     const uint32_t grid = std::min(g->grid, nq);
@@ -818,6 +842,7 @@ int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uin
                                                d_rows_out, d_dist_out, d_count_out, d_evals_out, s);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
     g->epoch += (uint32_t)need;
+    HIPCHK(hipEventRecord(g->ev_last, s));
     return QV_OK;
 }
 

@@ -366,3 +366,20 @@ def test_nan_and_inf_inputs_sort_last_like_the_oracle(metric):
     if metric in (0, 1, 3, 4):
         er, ed = O.exact_search(metric, rows, rq, 7)
         assert np.array_equal(r[0], er) and np.isnan(d[0]).all() == np.isnan(ed).all()
+
+
+def test_very_large_host_batch_is_sliced_without_changing_results():
+    """host-pointer entry points bound their workspace by slicing batches of more than 8192 queries"""
+    n, dim, k, nq = 3000, 16, 5, 8192 + 37
+    rows = O.gen_rows(31337, 0, n, dim)
+    qs = O.gen_rows(31338, 0, nq, dim)
+    import quiver_amd
+    idx = quiver_amd.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    r, d, c = idx.search(qs, k)
+    assert (c == k).all()
+    for i in list(range(0, 40)) + [8191, 8192, 8193, nq - 1]:
+        ro, do = O.exact_search(0, rows, qs[i], k)
+        assert r[i].tolist() == ro.tolist() and d[i].tobytes() == do.tobytes()
+    r2, d2, _ = idx.search(qs, k, batched=True)
+    assert np.array_equal(r, r2) and np.array_equal(d.view(np.uint32), d2.view(np.uint32))
