@@ -139,6 +139,15 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
 int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
                            uint32_t* d_rows_out, float* d_dist_out, void* stream);
 
+/* Filtered exact search: only rows whose bit is set in `mask` (bit r%64 of word r/64; host memory,
+ * ceil(qv_index_rows/64) words) are candidates.  This is the row-bitmap form of a filtered
+ * Collection.Search (collection.go:679-759 ranks ALL rows — searchK = Index.Size() — and keeps the first k
+ * whose metadata matches; when the match set is known up front the same k results come from a top-k over
+ * the matching rows, without producing or downloading the full ranking).  count_out[q] =
+ * min(k, live rows selected by mask); other arguments and ordering as qv_index_search. */
+int qv_index_search_masked(qv_index* idx, const float* queries, uint32_t nq, uint32_t k, const uint64_t* mask,
+                           uint32_t* rows_out, float* dist_out, uint32_t* count_out);
+
 /* Batched-query path: approximate scores by fp32 MFMA GEMM with fused per-tile
  * candidate selection, then exact re-scoring of the candidates with the same
  * arithmetic as qv_index_search, so results are identical to it.  Same

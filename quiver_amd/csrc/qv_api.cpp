@@ -64,11 +64,11 @@ struct Workspace { Buf ws; };
 
 struct SearchCtx {
     hipStream_t stream = nullptr;
-    Buf d_q, d_rows, d_dist, d_ids, ws;
-    PinBuf h_q, h_rows, h_dist, h_ids;
+    Buf d_q, d_rows, d_dist, d_ids, d_mask, ws;
+    PinBuf h_q, h_rows, h_dist, h_ids, h_mask;
     void release() {
-        d_q.release(); d_rows.release(); d_dist.release(); d_ids.release(); ws.release();
-        h_q.release(); h_rows.release(); h_dist.release(); h_ids.release();
+        d_q.release(); d_rows.release(); d_dist.release(); d_ids.release(); d_mask.release(); ws.release();
+        h_q.release(); h_rows.release(); h_dist.release(); h_ids.release(); h_mask.release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -406,8 +406,10 @@ int qv_index_get_row(qv_index* idx, uint32_t row, float* vec_out) {
 // shared by the host and device entry points: enqueue nq searches of list length kk
 // (kk = min(k, live)), results written with row stride k_stride
 static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
-                          void* ws, size_t ws_bytes, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
-    const qv::IndexView v = idx->view();
+                          void* ws, size_t ws_bytes, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
+                          const uint64_t* d_candidates = nullptr /* row bitmap replacing the tombstone bitmap (filtered search) */) {
+    qv::IndexView v = idx->view();
+    if (d_candidates) v.alive = const_cast<uint64_t*>(d_candidates);   // read-only in every scan kernel
     const qv::ScanPlan plan = qv::plan_scan(v.n_tiles, idx->cus);
     (void)ws_bytes;
     if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride) {
@@ -498,6 +500,64 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
     if (idx && nq >= 32 && k > 0 && idx->n_live >= 4 * (uint64_t)k && qv::batched_supported(idx->view(), nq, std::min(k, idx->n_live)))
         return qv_index_search_batched(idx, queries, nq, k, rows_out, dist_out, count_out);
     return exact_search_host(idx, queries, nq, k, rows_out, dist_out, count_out);
+}
+
+int qv_index_search_masked(qv_index* idx, const float* queries, uint32_t nq, uint32_t k, const uint64_t* mask,
+                           uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (nq == 0) return QV_OK;
+    if (!queries || !count_out || !mask) return fail(QV_ERR_INVALID_ARG, "queries/mask/count_out is null");
+    if (idx->n_live == 0) { for (uint32_t q = 0; q < nq; q++) count_out[q] = 0; return QV_OK; }      // exact.go:96-98
+    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");                             // exact.go:104-106
+    if (!rows_out || !dist_out) return fail(QV_ERR_INVALID_ARG, "rows_out/dist_out is null");
+    if (nq > kHostBatch) {
+        for (uint32_t q0 = 0; q0 < nq; q0 += kHostBatch) {
+            const int rc0 = qv_index_search_masked(idx, queries + (size_t)q0 * idx->dim, std::min(kHostBatch, nq - q0), k, mask,
+                                                   rows_out + (size_t)q0 * k, dist_out + (size_t)q0 * k, count_out + q0);
+            if (rc0 != QV_OK) return rc0;
+        }
+        return QV_OK;
+    }
+    HIPCHK(hipSetDevice(idx->device));
+    SearchCtx* c = nullptr;
+    int rc = acquire_ctx(idx, &c);
+    if (rc != QV_OK) return rc;
+    CtxGuard guard{idx, c};
+    // candidates = live AND selected; the tile loop reads whole 64-row words, so the bitmap covers every tile
+    const size_t words = ((size_t)idx->n_rows + 63) / 64;
+    if ((rc = c->h_mask.ensure(words * 8)) || (rc = c->d_mask.ensure(words * 8))) return rc;
+    uint64_t* hm = static_cast<uint64_t*>(c->h_mask.p);
+    uint64_t matching = 0;
+    for (size_t w = 0; w < words; w++) {
+        const uint64_t a = w < idx->alive_host.size() ? idx->alive_host[w] : 0;
+        hm[w] = a & mask[w];
+        matching += (uint64_t)__builtin_popcountll(hm[w]);
+    }
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, matching);                // the first k matches of the full ranking
+    for (uint32_t q = 0; q < nq; q++) count_out[q] = kk;
+    if (kk == 0) return QV_OK;
+    const size_t qbytes = (size_t)nq * idx->dim * sizeof(float);
+    const size_t obytes = (size_t)nq * kk * sizeof(uint32_t);
+    if ((rc = c->d_q.ensure(qbytes)) || (rc = c->h_q.ensure(qbytes)) || (rc = c->d_rows.ensure(obytes)) || (rc = c->d_dist.ensure(obytes)) ||
+        (rc = c->h_rows.ensure(obytes)) || (rc = c->h_dist.ensure(obytes)) || (rc = c->ws.ensure(search_ws_bytes(idx, nq, kk, kk))))
+        return rc;
+    memcpy(c->h_q.p, queries, qbytes);
+    HIPCHK(hipMemcpyAsync(c->d_mask.p, c->h_mask.p, words * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_search(idx, static_cast<const float*>(c->d_q.p), nq, kk, kk, c->ws.p, c->ws.cap,
+                        static_cast<uint32_t*>(c->d_rows.p), static_cast<float*>(c->d_dist.p), c->stream, static_cast<const uint64_t*>(c->d_mask.p));
+    if (rc != QV_OK) return rc;
+    HIPCHK(hipMemcpyAsync(c->h_rows.p, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t* hr = static_cast<const uint32_t*>(c->h_rows.p);
+    const float* hd = static_cast<const float*>(c->h_dist.p);
+    for (uint32_t q = 0; q < nq; q++) {
+        memcpy(rows_out + (size_t)q * k, hr + (size_t)q * kk, (size_t)kk * sizeof(uint32_t));
+        memcpy(dist_out + (size_t)q * k, hd + (size_t)q * kk, (size_t)kk * sizeof(float));
+        for (uint32_t i = kk; i < k; i++) { rows_out[(size_t)q * k + i] = 0xFFFFFFFFu; dist_out[(size_t)q * k + i] = __builtin_inff(); }
+    }
+    return QV_OK;
 }
 
 int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,

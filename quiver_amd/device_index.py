@@ -106,6 +106,28 @@ class DeviceIndex:
     def search_device(self, d_queries: int, nq: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
         check(lib().qv_index_search_device(self._h, d_queries, nq, k, d_rows_out, d_dist_out, stream))
 
+    def search_masked(self, queries, k: int, mask):
+        """exact top-k among the rows selected by `mask` (bool [rows] or packed uint64 words): filtered search without a full ranking"""
+        q = _f32c(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.dim:
+            raise ValueError("query dimension %d does not match index dimension %d" % (q.shape[1], self.dim))
+        m = np.asarray(mask)
+        words = (self.rows() + 63) // 64
+        if m.dtype == np.bool_:
+            if m.size != self.rows():
+                raise ValueError("mask must have one entry per row")
+            pad = np.zeros(words * 64, dtype=np.uint8); pad[:m.size] = m
+            m = np.packbits(pad, bitorder="little").view(np.uint64)
+        m = np.ascontiguousarray(m, dtype=np.uint64)
+        if m.size != words:
+            raise ValueError("mask must have ceil(rows/64) words")
+        nq = q.shape[0]
+        rows = np.empty((nq, max(k, 1)), dtype=np.uint32); dist = np.empty((nq, max(k, 1)), dtype=np.float32); cnt = np.empty(nq, dtype=np.uint32)
+        check(lib().qv_index_search_masked(self._h, q.ctypes.data, nq, k, m.ctypes.data, rows.ctypes.data, dist.ctypes.data, cnt.ctypes.data))
+        return rows, dist, cnt
+
     def search_batched_device(self, d_queries: int, nq: int, k: int, d_rows_out: int, d_dist_out: int, d_redo_flags: int, stream: int = 0):
         check(lib().qv_index_search_batched_device(self._h, d_queries, nq, k, d_rows_out, d_dist_out, d_redo_flags, stream))
 

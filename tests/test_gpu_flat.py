@@ -383,3 +383,44 @@ def test_very_large_host_batch_is_sliced_without_changing_results():
         assert r[i].tolist() == ro.tolist() and d[i].tobytes() == do.tobytes()
     r2, d2, _ = idx.search(qs, k, batched=True)
     assert np.array_equal(r, r2) and np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric,n,dim,nq,k,frac", [
+    ("cosine", 5000, 48, 1, 10, 0.3),        # single-query scan
+    ("l2", 5000, 20, 6, 64, 0.5),            # multi-query scan, full-width lists
+    ("cosine", 3000, 16, 3, 500, 0.4),       # k > 64: full ranking of the selected rows
+    ("dot", 2000, 33, 2, 50, 0.01),          # fewer matches than k
+    ("cosine", 530_000, 16, 12, 10, 0.2),    # long scan, >= 9 queries: the f64-matrix kernel with a row bitmap
+])
+def test_masked_search_equals_oracle_over_selected_rows(metric, n, dim, nq, k, frac):
+    """qv_index_search_masked = the first k of the full ranking that pass the filter (collection.go:679-759)"""
+    import quiver_amd
+    mid = quiver_amd.metric_id(metric)
+    rows = O.gen_rows(4711, 0, n, dim)
+    idx = quiver_amd.DeviceIndex(dim, metric)
+    idx.add(rows)
+    dead = np.arange(5, n, 97, dtype=np.uint32)
+    idx.remove(dead)
+    alive = np.ones(n, np.uint8); alive[dead] = 0
+    rng = np.random.default_rng(12)
+    mask = rng.random(n) < frac
+    mask[dead[:10]] = True                                     # selecting a tombstoned row selects nothing
+    qs = O.gen_rows(4712, 0, nq, dim)
+    r, d, c = idx.search_masked(qs, k, mask)
+    sel = (alive.astype(bool) & mask).astype(np.uint8)
+    want = min(k, int(sel.sum()))
+    assert (c == want).all()
+    for i in range(nq):
+        ro, do = O.exact_search(mid, rows, qs[i], k, alive=sel)
+        assert ro.size == want
+        assert r[i, :want].tolist() == ro.tolist(), (metric, i)
+        assert d[i, :want].tobytes() == do.tobytes(), (metric, i)
+        assert (r[i, want:] == 0xFFFFFFFF).all()
+    # an empty selection is an empty result, not an error
+    r0, d0, c0 = idx.search_masked(qs, k, np.zeros(n, bool))
+    assert (c0 == 0).all()
+    # and the filtered first-k of the FULL ranking (what Collection.Search does above the seam) is the same list
+    if n <= 5000:
+        fr, fd, _ = idx.search(qs[:1], idx.size())
+        first = [int(x) for x in fr[0] if mask[int(x)]][:want]
+        assert first == r[0, :want].tolist()
