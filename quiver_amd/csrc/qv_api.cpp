@@ -856,7 +856,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
         std::vector<uint32_t> rr((size_t)m * k), rc(m), rev(m);
         std::vector<float> rd((size_t)m * k);
         HIPCHK(hipMemcpyAsync(g->d_q.p, rq.data(), rq.size() * sizeof(float), hipMemcpyHostToDevice, g->stream));
-        e = qv::launch_hnsw_search(idx->view(), g->g, static_cast<const float*>(g->d_q.p), m, k, ef_search, g->d_visited, std::min(g->heap_grid, m), g->epoch,
+        e = qv::launch_hnsw_search(idx->view(), g->g, static_cast<const float*>(g->d_q.p), g->d_qblk.p, m, k, ef_search, g->d_visited, std::min(g->heap_grid, m), g->epoch,
                                    static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
                                    static_cast<uint32_t*>(g->d_ev.p), g->stream);
         if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));

@@ -98,7 +98,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
 // Device-resident HNSW traversal (hnsw.go:471-713), one wave per query.
 size_t   hnsw_lds_bytes(int metric, uint32_t dim4);
 uint32_t hnsw_grid(int cus, int metric, uint32_t dim4, uint32_t nq);
-hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
+hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
                               uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
                               uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s);
 

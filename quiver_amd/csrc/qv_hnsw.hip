@@ -44,142 +44,6 @@ __device__ __forceinline__ void h_max_down(HRes* rs, int i0, int n) {           
     }
 }
 
-// one wave (64-thread workgroup) per query stream
-template <int M, int U>
-__global__ void __launch_bounds__(64)
-k_hnsw_search(IndexView v, GraphView g, const float* __restrict__ queries, uint32_t nq, uint32_t k, uint32_t ef_search,
-              uint32_t* __restrict__ visited /*[gridDim.x][n_nodes]*/, uint32_t epoch0,
-              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
-    using Q = typename MT<M>::Q;
-    extern __shared__ __align__(16) unsigned char smem[];
-    Q* q_lds = reinterpret_cast<Q*>(smem);
-    unsigned char* base = smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16;
-    HRes* cand = reinterpret_cast<HRes*>(base);                       // [kHnswCandCap]
-    HRes* res = cand + kHnswCandCap;                                  // [kHnswEfMax + 1]
-    uint32_t* batch = reinterpret_cast<uint32_t*>(res + kHnswEfMax + 1);   // [kHnswMaxDeg]
-    float* bd = reinterpret_cast<float*>(batch + kHnswMaxDeg);        // [kHnswMaxDeg]
-    __shared__ int s_ncand, s_nres, s_state;                           // state: 0 run, 1 done, 2 overflow
-    __shared__ uint32_t s_cur;
-    const uint32_t lane = threadIdx.x;
-    uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
-    uint32_t epoch = epoch0;
-    const bool use_rm = v.rowmaj != nullptr && (v.dim & 3) == 0;
-
-    auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
-    // distances of batch[0..n) -> bd[0..n); lane i scores batch[i]
-    QConst qc;
-    auto eval = [&](uint32_t n) {
-        if (lane < n) {
-            const uint32_t row = batch[lane];
-            typename MT<M>::A acc;
-            if (use_rm) acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
-            else acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
-            double rn = 0.0;
-            if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
-            bd[lane] = finalize<M>(acc, qc, rn);
-        }
-        __syncthreads();
-    };
-    // searchLayer (hnsw.go:471-580); result: res[0..s_nres) ascending; returns false on overflow
-    uint32_t n_eval = 0;
-    auto search_layer = [&](uint32_t entry, int ef, int level) -> bool {
-        epoch++;
-        if (lane == 0) { vis[entry] = epoch; batch[0] = entry; }
-        __syncthreads();
-        eval(1); n_eval += 1;                                          // :492
-        if (lane == 0) {
-            cand[0] = {bd[0], entry}; res[0] = {bd[0], entry};        // :498-506
-            s_ncand = 1; s_nres = 1; s_state = 0;
-        }
-        __syncthreads();
-        for (;;) {
-            if (lane == 0) {
-                int nc = s_ncand, nr = s_nres;
-                if (nc == 0) s_state = 1;                              // :509
-                else {
-                    nc--; HRes t = cand[0]; cand[0] = cand[nc]; cand[nc] = t; h_min_down(cand, 0, nc); HRes cur = cand[nc];   // :511 pop
-                    s_ncand = nc;
-                    if (nr >= ef && cur.dist > res[0].dist) s_state = 1;   // :514-516
-                    else s_cur = cur.idx;
-                }
-            }
-            __syncthreads();
-            if (s_state != 0) break;
-            const uint32_t cur = s_cur;
-            // neighbours of cur at `level` (:523-534)
-            uint32_t deg = 0; const uint32_t* links = nullptr;
-            if (alive(cur) && level <= (int)g.level[cur]) {
-                if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
-                else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
-            }
-            uint32_t c = 0xFFFFFFFFu; bool fresh = false;
-            if (lane < deg) {
-                c = links[lane];
-                fresh = alive(c) && vis[c] != epoch;                   // :539-543
-            }
-            // a list may hold the same node twice (the self-link quirk): only its first occurrence is new
-            for (uint32_t j = 0; j + 1 < deg; j++) {
-                uint32_t cj = __builtin_amdgcn_readlane(c, j);
-                if (lane > j && c == cj) fresh = false;
-            }
-            const uint64_t fm = __ballot(fresh);
-            const uint32_t n = (uint32_t)__builtin_popcountll(fm);
-            if (fresh) { vis[c] = epoch; batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c; }   // :544, adjacency order kept
-            __syncthreads();
-            if (n == 0) continue;
-            eval(n); n_eval += n;                                      // :548 (batched)
-            if (lane == 0) {
-                int nc = s_ncand, nr = s_nres;
-                for (uint32_t i = 0; i < n; i++) {
-                    const float cd = bd[i];
-                    if (nr < ef || cd < res[0].dist) {                 // :553
-                        if (nc >= kHnswCandCap) { s_state = 2; break; }
-                        cand[nc] = {cd, batch[i]}; h_min_up(cand, nc); nc++;          // :554
-                        res[nr] = {cd, batch[i]}; h_max_up(res, nr); nr++;            // :555
-                        if (nr > ef) { nr--; HRes t = res[0]; res[0] = res[nr]; res[nr] = t; h_max_down(res, 0, nr); }   // :558-560
-                    }
-                }
-                s_ncand = nc; s_nres = nr;
-            }
-            __syncthreads();
-            if (s_state == 2) return false;
-        }
-        if (lane == 0) {                                               // :566-577 heap -> ascending slice, in place
-            int nr = s_nres;
-            for (int m = nr; m > 1; m--) { HRes t = res[0]; res[0] = res[m - 1]; res[m - 1] = t; h_max_down(res, 0, m - 1); }
-        }
-        __syncthreads();
-        return true;
-    };
-
-    for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
-        stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
-        __syncthreads();
-        qc = query_const<M>(q_lds, v.dim);
-        n_eval = 0;
-        uint32_t entry = g.entry;
-        bool ok = true;
-        for (int level = g.cur_level; level > 0 && ok; level--) {       // :649-657
-            ok = search_layer(entry, 1, level);
-            if (ok && s_nres > 0) entry = res[0].idx;
-            __syncthreads();
-        }
-        const int ef = (int)ef_search > (int)k ? (int)ef_search : (int)k;   // :660-663
-        if (ok) ok = search_layer(entry, ef, 0);                        // :664
-        uint32_t cnt = 0xFFFFFFFFu;                                     // overflow marker
-        if (ok) {
-            cnt = (uint32_t)s_nres < k ? (uint32_t)s_nres : k;          // :670-672 (under-filled: the caller tops up, :676-710)
-            for (uint32_t i = lane; i < k; i += 64) {
-                rows_out[(size_t)qi * k + i] = i < cnt ? res[i].idx : 0xFFFFFFFFu;
-                dist_out[(size_t)qi * k + i] = i < cnt ? res[i].dist : __uint_as_float(0x7F800000u);
-            }
-        }
-        if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
-        __syncthreads();
-        epoch += 64;                                                    // distinct epochs for the next query of this wave
-    }
-}
-
 // ---------------------------------------------------------------- HNSW traversal, wave-resident form
 // Same traversal, without the serial LDS heaps.  Observation (no two entries of equal distance):
 //   * a node enters the candidate heap exactly when it enters the result heap (hnsw.go:553-555);
@@ -293,11 +157,184 @@ __device__ __forceinline__ void slab_accumulate(typename MT<M>::A& acc, const ld
 #undef QV_ACC4
 }
 
+// distance of the wave's query to the rows batch[0..n) (n <= 64): lane i returns distance(query, batch[i]).
+// Row-major copy present: LDS-DMA slabs as described above; otherwise each lane pulls its row from the tile layout.
+template <int M, int U>
+__device__ __forceinline__ float hnsw_eval_rows(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l,
+                                                const typename MT<M>::Q* __restrict__ q_g, const QConst& qc, uint32_t n, uint32_t lane) {
+    float out = 0.0f;
+    const bool use_rm = v.rowmaj != nullptr && (v.dim & 3) == 0;
+    if (use_rm) {
+        const uint32_t nslab = (v.dim4 + kHnswSlab - 1) / kHnswSlab;
+        for (uint32_t base = 0; base < n; base += kHnswRound) {
+            const uint32_t cnt = n - base < (uint32_t)kHnswRound ? n - base : (uint32_t)kHnswRound;
+            const bool me = lane >= base && lane < base + cnt;       // row r of this round sits on lane base + r
+            const uint32_t myrow = me ? batch_l[lane] : 0u;
+            double rn = 0.0;
+            if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[myrow]; }
+            DmaRole role;
+            dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
+            typename MT<M>::A acc = 0;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            dma_issue_slab(role, 0, v.dim4, slabs_l);
+            for (uint32_t sl = 0; sl < nslab; sl++) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl has landed
+                if (sl + 1 < nslab) dma_issue_slab(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);   // lands while slab sl is consumed
+                __builtin_amdgcn_sched_barrier(0);
+                if (me) slab_accumulate<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, (lane - base) & 31u, q_g, sl, v.dim4);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this buffer's reads are done before it is refilled
+            }
+            if (me) out = finalize<M>(acc, qc, rn);
+        }
+        return out;
+    }
+    if (lane < n) {
+        const uint32_t row = batch_l[lane];
+        typename MT<M>::A acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_g, v.dim4);
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        out = finalize<M>(acc, qc, rn);
+    }
+    return out;
+}
+
 #ifdef QV_HNSW_PROF
 #define HTICK(ph) tick(ph)
 #else
 #define HTICK(ph)
 #endif
+
+// one wave (64-thread workgroup) per query stream
+template <int M, int U>
+__global__ void __launch_bounds__(64)
+k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t nq, uint32_t k, uint32_t ef_search,
+              uint32_t* __restrict__ visited /*[gridDim.x][n_nodes]*/, uint32_t epoch0,
+              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // LDS: two row slabs (hnsw_eval_rows) | candidate heap | result heap | the hop's batch | its distances
+    lds_u8* slabs_l = (lds_u8*)smem;
+    unsigned char* base = smem + 2 * kHnswSlabBytes;
+    HRes* cand = reinterpret_cast<HRes*>(base);                       // [kHnswCandCap]
+    HRes* res = cand + kHnswCandCap;                                  // [kHnswEfMax + 1]
+    uint32_t* batch = reinterpret_cast<uint32_t*>(res + kHnswEfMax + 1);   // [kHnswMaxDeg]
+    float* bd = reinterpret_cast<float*>(batch + kHnswMaxDeg);        // [kHnswMaxDeg]
+    const lds_u32* batch_l = (const lds_u32*)((lds_u8*)smem + 2 * kHnswSlabBytes + (size_t)(kHnswCandCap + kHnswEfMax + 1) * sizeof(HRes));
+    const Q* q_g = qblk;
+    __shared__ int s_ncand, s_nres, s_state;                           // state: 0 run, 1 done, 2 overflow
+    __shared__ uint32_t s_cur;
+    const uint32_t lane = threadIdx.x;
+    uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
+    uint32_t epoch = epoch0;
+
+    auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
+    // distances of batch[0..n) -> bd[0..n); lane i scores batch[i]
+    QConst qc;
+    auto eval = [&](uint32_t n) {
+        const float dd = hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
+        if (lane < n) bd[lane] = dd;
+        __syncthreads();
+    };
+    // searchLayer (hnsw.go:471-580); result: res[0..s_nres) ascending; returns false on overflow
+    uint32_t n_eval = 0;
+    auto search_layer = [&](uint32_t entry, int ef, int level) -> bool {
+        epoch++;
+        if (lane == 0) { vis[entry] = epoch; batch[0] = entry; }
+        __syncthreads();
+        eval(1); n_eval += 1;                                          // :492
+        if (lane == 0) {
+            cand[0] = {bd[0], entry}; res[0] = {bd[0], entry};        // :498-506
+            s_ncand = 1; s_nres = 1; s_state = 0;
+        }
+        __syncthreads();
+        for (;;) {
+            if (lane == 0) {
+                int nc = s_ncand, nr = s_nres;
+                if (nc == 0) s_state = 1;                              // :509
+                else {
+                    nc--; HRes t = cand[0]; cand[0] = cand[nc]; cand[nc] = t; h_min_down(cand, 0, nc); HRes cur = cand[nc];   // :511 pop
+                    s_ncand = nc;
+                    if (nr >= ef && cur.dist > res[0].dist) s_state = 1;   // :514-516
+                    else s_cur = cur.idx;
+                }
+            }
+            __syncthreads();
+            if (s_state != 0) break;
+            const uint32_t cur = s_cur;
+            // neighbours of cur at `level` (:523-534)
+            uint32_t deg = 0; const uint32_t* links = nullptr;
+            if (alive(cur) && level <= (int)g.level[cur]) {
+                if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
+                else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
+            }
+            uint32_t c = 0xFFFFFFFFu; bool fresh = false;
+            if (lane < deg) {
+                c = links[lane];
+                fresh = alive(c) && vis[c] != epoch;                   // :539-543
+            }
+            // a list may hold the same node twice (the self-link quirk): only its first occurrence is new
+            for (uint32_t j = 0; j + 1 < deg; j++) {
+                uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                if (lane > j && c == cj) fresh = false;
+            }
+            const uint64_t fm = __ballot(fresh);
+            const uint32_t n = (uint32_t)__builtin_popcountll(fm);
+            if (fresh) { vis[c] = epoch; batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c; }   // :544, adjacency order kept
+            __syncthreads();
+            if (n == 0) continue;
+            eval(n); n_eval += n;                                      // :548 (batched)
+            if (lane == 0) {
+                int nc = s_ncand, nr = s_nres;
+                for (uint32_t i = 0; i < n; i++) {
+                    const float cd = bd[i];
+                    if (nr < ef || cd < res[0].dist) {                 // :553
+                        if (nc >= kHnswCandCap) { s_state = 2; break; }
+                        cand[nc] = {cd, batch[i]}; h_min_up(cand, nc); nc++;          // :554
+                        res[nr] = {cd, batch[i]}; h_max_up(res, nr); nr++;            // :555
+                        if (nr > ef) { nr--; HRes t = res[0]; res[0] = res[nr]; res[nr] = t; h_max_down(res, 0, nr); }   // :558-560
+                    }
+                }
+                s_ncand = nc; s_nres = nr;
+            }
+            __syncthreads();
+            if (s_state == 2) return false;
+        }
+        if (lane == 0) {                                               // :566-577 heap -> ascending slice, in place
+            int nr = s_nres;
+            for (int m = nr; m > 1; m--) { HRes t = res[0]; res[0] = res[m - 1]; res[m - 1] = t; h_max_down(res, 0, m - 1); }
+        }
+        __syncthreads();
+        return true;
+    };
+
+    for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        q_g = qblk + (size_t)qi * v.dim4 * 4;
+        qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
+        n_eval = 0;
+        uint32_t entry = g.entry;
+        bool ok = true;
+        for (int level = g.cur_level; level > 0 && ok; level--) {       // :649-657
+            ok = search_layer(entry, 1, level);
+            if (ok && s_nres > 0) entry = res[0].idx;
+            __syncthreads();
+        }
+        const int ef = (int)ef_search > (int)k ? (int)ef_search : (int)k;   // :660-663
+        if (ok) ok = search_layer(entry, ef, 0);                        // :664
+        uint32_t cnt = 0xFFFFFFFFu;                                     // overflow marker
+        if (ok) {
+            cnt = (uint32_t)s_nres < k ? (uint32_t)s_nres : k;          // :670-672 (under-filled: the caller tops up, :676-710)
+            for (uint32_t i = lane; i < k; i += 64) {
+                rows_out[(size_t)qi * k + i] = i < cnt ? res[i].idx : 0xFFFFFFFFu;
+                dist_out[(size_t)qi * k + i] = i < cnt ? res[i].dist : __uint_as_float(0x7F800000u);
+            }
+        }
+        if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
+        __syncthreads();
+        epoch += 64;                                                    // distinct epochs for the next query of this wave
+    }
+}
+
 
 template <int M, int U, int S>
 __global__ void __launch_bounds__(64)
@@ -314,7 +351,6 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     const uint32_t lane = threadIdx.x;
     uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
     uint32_t epoch = epoch0;
-    const bool use_rm = v.rowmaj != nullptr && (v.dim & 3) == 0;
     auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
 #ifdef QV_HNSW_PROF
     uint64_t T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_last = __builtin_readcyclecounter(); const uint64_t wc0 = wall_clock64(); uint64_t hops = 0;
@@ -329,44 +365,8 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
 
     // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n)
     auto eval_keys = [&](uint32_t n) -> uint64_t {
-        uint64_t kx = kDeadKey;
-        if (use_rm) {
-            const uint32_t nslab = (v.dim4 + kHnswSlab - 1) / kHnswSlab;
-            for (uint32_t base = 0; base < n; base += kHnswRound) {
-                const uint32_t cnt = n - base < (uint32_t)kHnswRound ? n - base : (uint32_t)kHnswRound;
-                const bool me = lane >= base && lane < base + cnt;       // row r of this round sits on lane base + r of kx
-                const uint32_t myrow = me ? batch_l[lane] : 0u;
-                double rn = 0.0;
-                if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[myrow]; }
-                DmaRole role;
-                dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
-                typename MT<M>::A acc = 0;
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                dma_issue_slab(role, 0, v.dim4, slabs_l);
-                for (uint32_t sl = 0; sl < nslab; sl++) {
-                    HTICK(5);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl has landed
-                    HTICK(2);
-                    if (sl + 1 < nslab) dma_issue_slab(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);   // lands while slab sl is consumed
-                    __builtin_amdgcn_sched_barrier(0);
-                    HTICK(6);
-                    if (me) slab_accumulate<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, (lane - base) & 31u, q_g, sl, v.dim4);
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this buffer's reads are done before it is refilled
-                    HTICK(3);
-                }
-                if (me) kx = make_key(finalize<M>(acc, qc, rn), myrow);
-            }
-            return kx;
-        }
-        if (lane < n) {
-            const uint32_t row = batch[lane];
-            typename MT<M>::A acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_g, v.dim4);
-            double rn = 0.0;
-            if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
-            kx = make_key(finalize<M>(acc, qc, rn), row);
-        }
-        return kx;
+        const float dd = hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
+        return lane < n ? make_key(dd, batch_l[lane]) : kDeadKey;
     };
     // sorted insert of x (distance part xd), list capacity ef
     auto insert = [&](uint64_t x, uint32_t ef) {
@@ -501,31 +501,6 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
 }
 
 // ---- HNSW traversal ------------------------------------------------------------------
-size_t hnsw_lds_bytes(int metric, uint32_t dim4) {
-    return query_lds_bytes(metric, dim4) + (size_t)(kHnswCandCap + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 8 + 64;
-}
-uint32_t hnsw_grid(int cus, int metric, uint32_t dim4, uint32_t nq) {
-    const size_t lds = hnsw_lds_bytes(metric, dim4);
-    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
-    return std::max(1u, std::min(nq, (uint32_t)cus * per_cu));
-}
-hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef,
-                              uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
-                              uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s) {
-    if (nq == 0) return hipSuccess;
-    if (k == 0 || k > (uint32_t)kHnswEfMax || ef > (uint32_t)kHnswEfMax || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
-    const size_t lds = hnsw_lds_bytes(v.metric, v.dim4);
-    hipError_t e = hipSuccess;
-    QV_DISPATCH_METRIC(v.metric, {
-        e = set_lds(k_hnsw_search<MM, 16>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_hnsw_search<MM, 16>), dim3(grid), dim3(64), lds, s, v, g, d_queries, nq, k, ef, d_visited, epoch0,
-                           d_rows_out, d_dist_out, d_count_out, d_evals_out);
-    });
-    return hipGetLastError();
-}
-
-// wave-resident form: the list in registers, the LDS for the row slabs; tie-flagged queries report kHnswTieFlag
 // the wave kernel keeps no query in LDS: queries are pre-converted to the metric's Q type (zero-padded to dim4*4)
 // in global memory and read at wave-uniform addresses, i.e. by scalar loads into SGPR operands of v_fma_f64
 template <int M>
@@ -540,6 +515,34 @@ __global__ void k_hnsw_prep_queries(const float* __restrict__ queries, uint32_t 
     }
 }
 size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4) { return (size_t)nq * dim4 * 4 * sizeof(double) + (size_t)nq * 2 * sizeof(double); }
+size_t hnsw_lds_bytes(int metric, uint32_t dim4) {
+    (void)metric; (void)dim4;                                         // the query is read by scalar loads, not staged
+    return 2 * (size_t)kHnswSlabBytes + (size_t)(kHnswCandCap + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 8 + 64;
+}
+uint32_t hnsw_grid(int cus, int metric, uint32_t dim4, uint32_t nq) {
+    const size_t lds = hnsw_lds_bytes(metric, dim4);
+    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
+    return std::max(1u, std::min(nq, (uint32_t)cus * per_cu));
+}
+hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
+                              uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                              uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (k == 0 || k > (uint32_t)kHnswEfMax || ef > (uint32_t)kHnswEfMax || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
+    const size_t lds = hnsw_lds_bytes(v.metric, v.dim4);
+    hipError_t e = hipSuccess;
+    double* d_qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qblk) + (size_t)nq * v.dim4 * 4 * sizeof(double));
+    QV_DISPATCH_METRIC(v.metric, {
+        hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
+        e = set_lds(k_hnsw_search<MM, 16>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_hnsw_search<MM, 16>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk),
+                           static_cast<const double*>(d_qconst), nq, k, ef, d_visited, epoch0, d_rows_out, d_dist_out, d_count_out, d_evals_out);
+    });
+    return hipGetLastError();
+}
+
+// wave-resident form: the list in registers, the LDS for the row slabs; tie-flagged queries report kHnswTieFlag
 size_t hnsw_wave_lds_bytes(int /*metric*/, uint32_t /*dim4*/) { return 64 * sizeof(uint32_t) + 2 * (size_t)kHnswSlabBytes + 64; }
 uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4) {
     const size_t lds = hnsw_wave_lds_bytes(metric, dim4);
