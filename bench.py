@@ -328,7 +328,7 @@ def main():
                                     "gathered_GBps": float(hev.sum()) * dim * 4 / dthd / 1e9},
                 "gathered_GBps": float(hev.sum()) * dim * 4 / dth / 1e9, "underfilled_queries": int((hcnt < k).sum()), "knn_graph_build_s": t_knn,
                 "parity": "tests/test_gpu_graph.py, tests/test_gpu_host.py: rows, float32 bits and evaluation counts equal the CPU traversal of the same graph",
-                "larger": "profiles/r01_hnsw_knn_1Mx768.json (1Mx768: 223k QPS), profiles/r01_hnsw_20kx768.jsonl (reference-built graph: 378k QPS)"}
+                "larger": "profiles/r01_hnsw_knn_1Mx768.json (1Mx768: 314k QPS device-resident), profiles/r01_hnsw_20kx768.jsonl (reference-built graph: 441k QPS)"}
             graph.close(); hidx.close()
         except Exception as ex:                                   # a measurement beside the headline; never fail the bench line over it
             also["hnsw_traversal_100kx768"] = {"error": str(ex)}
