@@ -334,7 +334,7 @@ def main():
             also["hnsw_traversal_100kx768"] = {"error": str(ex)}
 
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and G == 1 and not a.no_cpu_baseline:          # the CPU baseline is a single-GPU-run artefact (rank 0, N=1 only)
         cpu = cpu_baseline(dim, k, a.cpu_sample_rows, a.cpu_sample_queries, a.rows)
 
     if rank == 0:
