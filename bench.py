@@ -9,7 +9,7 @@ Workload (config.workload): exact flat cosine top-10 over a synthetic unit-vecto
 star's roofline target is quoted on; it fits one GPU, so the same corpus is used at every N and
 the curve is strong scaling).  One STEP = one query against the whole corpus: every rank scans
 its contiguous row shard (qv_index_search_device: HIP flat scan + fused top-k), the per-shard
-top-k are all-gathered over RCCL and merged deterministically (qv_merge_topk_device) — the
+top-k are all-gathered over RCCL and merged deterministically (qv_merge_topk_shards_device) — the
 orchestration is quiver_amd.sharded.ShardedFlatSearch, the same code the gloo tests cover; the
 exchange of step i overlaps the scan of step i+1.  Corpus and queries are resident in HBM
 before the timed region.

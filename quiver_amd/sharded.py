@@ -3,16 +3,18 @@
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box,
 "gloo" in the CPU tests).  Rank g owns the contiguous row shard [g*N/G, (g+1)*N/G); a
 query goes to every rank, each rank scans its shard for its local top-k, the k
-(distance, global row) pairs per rank are all-gathered (k*8 bytes per rank — a latency,
-not a bandwidth, collective) and merged on every rank under the same (distance, row)
-order the single-GPU scan uses, so the sharded result is identical to the unsharded one.
+(shard-local row, distance) pairs per rank are all-gathered in ONE collective (the scan
+writes rows and distances into one [2][k] buffer that goes into the all-gather as it is:
+k*8 bytes per rank — a latency, not a bandwidth, collective) and merged on every rank under
+the same (distance, global row) order the single-GPU scan uses — the merge adds each shard's
+base row — so the sharded result is identical to the unsharded one.
 
 The reference has no counterpart (single process); this is the one
 exchange step the path has.
 
 The shard backend and the merge are injected so the orchestration can be exercised on
 CPU with gloo: on the GPU they are `DeviceShard` (qv_index_search_device) and
-`qv_merge_topk_device`; the CPU tests plug in test-only stand-ins.
+`qv_merge_topk_shards_device`; the CPU tests plug in test-only stand-ins.
 """
 from __future__ import annotations
 
@@ -39,10 +41,11 @@ class DeviceShard:
         self.index.search_device(d_query.data_ptr(), 1, k, rows_out.data_ptr(), dist_out.data_ptr(), s)
 
 
-def device_merge(g_dist: torch.Tensor, g_rows: torch.Tensor, k: int, rows_out: torch.Tensor, dist_out: torch.Tensor):
-    from .device_index import merge_topk_device
+def device_merge(g_pack: torch.Tensor, bases: torch.Tensor, k: int, rows_out: torch.Tensor, dist_out: torch.Tensor):
+    """g_pack [G, 2, k] int32: per shard k local rows then k distance bit patterns; bases [G] int32"""
+    from .device_index import merge_topk_shards_device
     s = torch.cuda.current_stream().cuda_stream
-    merge_topk_device(g_dist.data_ptr(), g_rows.data_ptr(), g_dist.shape[0], k, rows_out.data_ptr(), dist_out.data_ptr(), s)
+    merge_topk_shards_device(g_pack.data_ptr(), bases.data_ptr(), g_pack.shape[0], k, rows_out.data_ptr(), dist_out.data_ptr(), s)
 
 
 class ShardedFlatSearch:
@@ -57,11 +60,22 @@ class ShardedFlatSearch:
         # pipelined one deep, any ring >= 3 is safe (stream order: merge(i) precedes scan(i+ring))
         self._ring = [self._buffers() for _ in range(max(3, ring))]
         self._n = 0
+        # on the GPU the merge runs on a side stream (after the collective it depends on), so the scan stream never has a
+        # merge between two scans; the caller's stream only waits for an event that fired long before it gets there
+        self._side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # every shard's first global row, for the merge
+        self.bases = torch.zeros(self.world, dtype=torch.int32, device=device)
+        if self.world > 1:
+            mine = torch.tensor([self.base], dtype=torch.int32, device=device)
+            dist.all_gather_into_tensor(self.bases, mine, group=self.group)
+        else:
+            self.bases[0] = self.base
 
     def _buffers(self):
         k, G, dev = self.k, self.world, self.device
-        return dict(rows=torch.empty(k, dtype=torch.int32, device=dev), dist=torch.empty(k, dtype=torch.float32, device=dev),
-                    g_rows=torch.empty((G, k), dtype=torch.int32, device=dev), g_dist=torch.empty((G, k), dtype=torch.float32, device=dev),
+        pack = torch.empty((2, k), dtype=torch.int32, device=dev)        # [0] shard-local rows, [1] distance bits: one buffer, one collective
+        return dict(pack=pack, rows=pack[0], dist=pack[1].view(torch.float32),
+                    g_pack=torch.empty((G, 2, k), dtype=torch.int32, device=dev),
                     out_rows=torch.empty(k, dtype=torch.int32, device=dev), out_dist=torch.empty(k, dtype=torch.float32, device=dev))
 
     def submit(self, d_query: torch.Tensor):
@@ -73,21 +87,28 @@ class ShardedFlatSearch:
         self.shard.search(d_query, self.k, b["rows"], b["dist"])
         if self.world == 1 and not self.force_exchange:
             return b, None
-        # shard-local rows -> global rows; 0xFFFFFFFF (no result) stays put
-        if self.base:
-            b["rows"].copy_(torch.where(b["rows"] != -1, b["rows"] + self.base, b["rows"]))
-        w1 = dist.all_gather_into_tensor(b["g_dist"].view(-1), b["dist"], group=self.group, async_op=True)
-        w2 = dist.all_gather_into_tensor(b["g_rows"].view(-1), b["rows"], group=self.group, async_op=True)
-        return b, (w1, w2)
+        w = dist.all_gather_into_tensor(b["g_pack"].view(-1), b["pack"].view(-1), group=self.group, async_op=True)
+        return b, (w,)
 
     def finish(self, ticket):
         """-> (rows[k] int32 view of uint32 global rows, dist[k]); valid until the slot is reused"""
         b, works = ticket
         if works is None:
+            if self.base:                                   # one rank, rows offset: local -> global (0xFFFFFFFF stays put)
+                b["out_rows"].copy_(torch.where(b["rows"] != -1, b["rows"] + self.base, b["rows"]))
+                return b["out_rows"], b["dist"]
             return b["rows"], b["dist"]
-        works[0].wait()
-        works[1].wait()
-        self.merge(b["g_dist"], b["g_rows"], self.k, b["out_rows"], b["out_dist"])
+        if self._side is None:
+            works[0].wait()
+            self.merge(b["g_pack"], self.bases, self.k, b["out_rows"], b["out_dist"])
+            return b["out_rows"], b["out_dist"]
+        with torch.cuda.stream(self._side):
+            works[0].wait()                                 # the side stream waits for the collective
+            self.merge(b["g_pack"], self.bases, self.k, b["out_rows"], b["out_dist"])
+            ev = b.get("ev") or torch.cuda.Event()
+            ev.record(self._side)
+            b["ev"] = ev
+        torch.cuda.current_stream().wait_event(ev)          # results (and this slot's buffers) are ordered after the merge
         return b["out_rows"], b["out_dist"]
 
     def search(self, d_query: torch.Tensor):

@@ -1,6 +1,6 @@
 """Two ranks sharing the one GPU of the test box (gloo for the exchange, since RCCL refuses two
 ranks on one device): every device piece of the multi-GPU path is the real one — per-rank
-DeviceIndex shards, qv_index_search_device, the all-gather layout, qv_merge_topk_device — and
+DeviceIndex shards, qv_index_search_device, the packed all-gather layout, qv_merge_topk_shards_device — and
 the sharded result must equal the unsharded scan and the oracle."""
 import os
 import socket

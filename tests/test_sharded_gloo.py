@@ -2,7 +2,7 @@
 bounds, local->global row offset, all-gather layout, pipelined submit/finish order and
 the (distance,row) merge must reproduce the unsharded oracle result exactly.  The shard
 backend and the merge are TEST-ONLY stand-ins built on the oracle (on the GPU box they
-are qv_index_search_device / qv_merge_topk_device, covered by tests/test_gpu_flat.py)."""
+are qv_index_search_device / qv_merge_topk_shards_device, covered by tests/test_gpu_flat.py)."""
 import os
 import socket
 import sys
@@ -43,11 +43,15 @@ class OracleShard:
         dist_out.copy_(torch.from_numpy(dd))
 
 
-def oracle_merge(g_dist, g_rows, k, rows_out, dist_out):
-    """test stand-in for qv_merge_topk_device: k smallest by (distance, row)"""
-    d = g_dist.numpy().ravel()
-    r = g_rows.numpy().ravel().view(np.uint32)
-    keep = r != 0xFFFFFFFF
+def oracle_merge(g_pack, bases, k, rows_out, dist_out):
+    """test stand-in for qv_merge_topk_shards_device: g_pack [G, 2, k] (shard-local rows, distance bits), bases [G];
+    k smallest by (distance, global row)"""
+    gp = g_pack.numpy()
+    local = gp[:, 0, :].copy().view(np.uint32)
+    d = gp[:, 1, :].copy().view(np.float32).ravel()
+    glob = (local.astype(np.uint64) + bases.numpy().astype(np.uint64)[:, None]).astype(np.uint32)
+    keep = (local != 0xFFFFFFFF).ravel()
+    r = glob.ravel()
     d, r = d[keep], r[keep]
     order = np.lexsort((r, d))[:k]
     rr = np.full(k, 0xFFFFFFFF, np.uint32)
