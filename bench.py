@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs measured at N=1")
     ap.add_argument("--force-exchange", action="store_true",
                     help="with one rank, still run the RCCL all-gather + merge per step (exercises the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--scan-streams", type=int, default=0, help="scan streams alternated between consecutive queries; 0 = auto")
     ap.add_argument("--cpu-sample-rows", type=int, default=500_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=30)
     return ap.parse_args()
@@ -144,13 +145,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     search = ShardedFlatSearch(DeviceShard(idx), base, k, dev, world=G, ring=total_steps + 2, force_exchange=a.force_exchange)
 
+    # consecutive queries are independent: alternating between scan streams lets the ramp-up of scan i+1 fill the tail of scan i
+    # Measured (profiles/r01_sweep.txt): 1.25M rows per GPU 0.5525 -> 0.5360 ms per query with two streams; from 2.5M rows up one
+    # stream is faster (two long scans interleaving cost 0.7-3 %), so the second stream is used for short shards only.
+    n_scan_streams = a.scan_streams if a.scan_streams > 0 else (2 if n_local <= 1_500_000 else 1)
+    scan_streams = [torch.cuda.Stream(device=dev) for _ in range(n_scan_streams)]
+
     def run(first, count):
         """`count` steps; the exchange+merge of step i is issued after the scan of step i+1"""
         pending = None
         for i in range(first, first + count):
-            t = search.submit(d_q[i % nq_pool])
-            if pending is not None:
-                search.finish(pending)
+            with torch.cuda.stream(scan_streams[i % len(scan_streams)]):
+                t = search.submit(d_q[i % nq_pool])
+                if pending is not None:
+                    search.finish(pending)
             pending = t
         if pending is not None:
             search.finish(pending)
@@ -347,7 +355,7 @@ def main():
             "config": {"workload": "flat %s scan %dx%d fp32, k=%d, single query per step, recall 1.0 (exact, bit-identical to the CPU oracle)" % (a.metric, a.rows, dim, k),
                        "rows_total": a.rows, "rows_per_gpu": n_local, "dim": dim, "k": k,
                        "arithmetic": "float64 accumulation over float32 rows, one rounding to float32 (the reference's arithmetic)",
-                       "sharding": "contiguous row shards, per-shard top-k + RCCL all-gather (k*8 B/rank) + deterministic merge; exchange of step i overlaps scan of step i+1" if G > 1 else "single shard",
+                       "scan_streams": n_scan_streams, "sharding": "contiguous row shards, per-shard top-k + RCCL all-gather (k*8 B/rank) + deterministic merge; exchange of step i overlaps scan of step i+1" if G > 1 else "single shard",
                        "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_local, dim),
