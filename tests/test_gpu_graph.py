@@ -88,3 +88,29 @@ def test_device_pointer_form_equals_host_pointer_form():
     assert np.array_equal(dr.cpu().numpy().view(np.uint32)[ok], r[ok])
     assert np.array_equal(dd.cpu().numpy().view(np.uint32)[ok], d.view(np.uint32)[ok])
     assert np.array_equal(de.cpu().numpy().view(np.uint32)[ok], ev[ok])
+
+
+def test_committed_hnsw_fixture_multi_level_graph():
+    """tests/golden/hnsw_3kx32_cosine.npz: a graph built by Insert with upper levels (and the reference's self-link quirk,
+    so many level-0 searches under-fill).  Device traversal == fixture where the graph search filled k; elsewhere the
+    reference tops up by brute force (hnsw.go:676-710), i.e. the fixture holds the exact top-k."""
+    import os
+    g = np.load(os.path.join(O.ROOT, "tests", "golden", "hnsw_3kx32_cosine.npz"))
+    n, dim, k, ef = int(g["n"]), int(g["dim"]), 10, int(g["efSearch"])
+    rows = O.gen_rows(int(g["corpus_seed"]), 0, n, dim)
+    idx = quiver_amd.DeviceIndex(dim, "cosine", rowmajor=True)
+    idx.add(rows)
+    dg = quiver_amd.DeviceGraph(idx, g["levels"], g["l0_deg"], g["l0_links"], entry=int(g["entry"]), cur_level=int(g["cur_level"]),
+                                up_off=g["up_off"], up_links=g["up_links"])
+    qs = O.gen_rows(int(g["query_seed"]), 0, g["rows"].shape[0], dim)
+    r, d, c, ev = dg.search(qs, k, ef, with_evals=True)
+    filled = 0
+    for i in range(qs.shape[0]):
+        if c[i] == k:
+            filled += 1
+            assert np.array_equal(r[i], g["rows"][i]) and np.array_equal(d[i].view(np.uint32), g["dist"][i].view(np.uint32)), i
+            assert int(ev[i]) == int(g["evals"][i]) - 1, i        # the reference evaluates the entry point once more up front (hnsw.go:637)
+        else:
+            er, ed, _ = idx.search(qs[i], k)
+            assert np.array_equal(er[0], g["rows"][i]) and np.array_equal(ed[0].view(np.uint32), g["dist"][i].view(np.uint32)), i
+    assert 0 < filled < qs.shape[0]                                # both branches exercised
