@@ -19,29 +19,41 @@ constexpr int kHnswCandCap = 2048;     // candidate min-heap slots per query (ov
 constexpr int kHnswEfMax = 512;
 constexpr int kHnswMaxDeg = 64;
 
+// The reference's container/heap sifts (hnsw.go:101-196), comparison for comparison; the moving element is held in
+// registers and only the displaced child / parent is written per level ("hole" form: same comparisons, same final array).
 __device__ __forceinline__ void h_min_up(HRes* rs, int j) {                      // hnsw.go:118-128
-    for (;;) { int i = (j - 1) / 2; if (i == j || rs[j].dist >= rs[i].dist) break; HRes t = rs[i]; rs[i] = rs[j]; rs[j] = t; j = i; }
+    const HRes x = rs[j];
+    for (;;) { int i = (j - 1) / 2; if (i == j) break; const HRes p = rs[i]; if (x.dist >= p.dist) break; rs[j] = p; j = i; }
+    rs[j] = x;
 }
 __device__ __forceinline__ void h_min_down(HRes* rs, int i0, int n) {            // hnsw.go:130-148
     int i = i0;
+    const HRes x = rs[i0];
     for (;;) {
         int j1 = 2 * i + 1; if (j1 >= n || j1 < 0) break;
-        int j = j1, j2 = j1 + 1; if (j2 < n && rs[j2].dist < rs[j1].dist) j = j2;
-        if (rs[i].dist <= rs[j].dist) break;
-        HRes t = rs[i]; rs[i] = rs[j]; rs[j] = t; i = j;
+        HRes c = rs[j1]; int j = j1;
+        if (j1 + 1 < n) { const HRes c2 = rs[j1 + 1]; if (c2.dist < c.dist) { c = c2; j = j1 + 1; } }
+        if (x.dist <= c.dist) break;
+        rs[i] = c; i = j;
     }
+    rs[i] = x;
 }
 __device__ __forceinline__ void h_max_up(HRes* rs, int j) {                      // hnsw.go:172-181
-    for (;;) { int i = (j - 1) / 2; if (i == j || rs[j].dist <= rs[i].dist) break; HRes t = rs[i]; rs[i] = rs[j]; rs[j] = t; j = i; }
+    const HRes x = rs[j];
+    for (;;) { int i = (j - 1) / 2; if (i == j) break; const HRes p = rs[i]; if (x.dist <= p.dist) break; rs[j] = p; j = i; }
+    rs[j] = x;
 }
 __device__ __forceinline__ void h_max_down(HRes* rs, int i0, int n) {            // hnsw.go:183-200
     int i = i0;
+    const HRes x = rs[i0];
     for (;;) {
         int j1 = 2 * i + 1; if (j1 >= n || j1 < 0) break;
-        int j = j1, j2 = j1 + 1; if (j2 < n && rs[j2].dist > rs[j1].dist) j = j2;
-        if (rs[i].dist >= rs[j].dist) break;
-        HRes t = rs[i]; rs[i] = rs[j]; rs[j] = t; i = j;
+        HRes c = rs[j1]; int j = j1;
+        if (j1 + 1 < n) { const HRes c2 = rs[j1 + 1]; if (c2.dist > c.dist) { c = c2; j = j1 + 1; } }
+        if (x.dist >= c.dist) break;
+        rs[i] = c; i = j;
     }
+    rs[i] = x;
 }
 
 // ---------------------------------------------------------------- HNSW traversal, wave-resident form
