@@ -114,3 +114,24 @@ def test_committed_hnsw_fixture_multi_level_graph():
             er, ed, _ = idx.search(qs[i], k)
             assert np.array_equal(er[0], g["rows"][i]) and np.array_equal(ed[0].view(np.uint32), g["dist"][i].view(np.uint32)), i
     assert 0 < filled < qs.shape[0]                                # both branches exercised
+
+
+def test_update_and_remove_reach_the_row_major_copy_the_traversal_reads():
+    """qv_index_update rewrites both layouts; the graph walk (row-major copy, LDS-DMA) must see the new vector"""
+    n, dim, m = 600, 40, 16
+    rows = O.gen_rows(99, 0, n, dim)
+    idx, deg, links = _knn_graph(rows, "cosine", m)
+    q = O.gen_rows(100, 0, 1, dim)[0]
+    far = int(np.argmax(O.all_distances(0, rows, q)))            # the row farthest from the query ...
+    idx.update(far, q)                                           # ... becomes the query itself
+    rows2 = rows.copy(); rows2[far] = q
+    g = quiver_amd.DeviceGraph(idx, np.zeros(n, np.int8), deg, links, entry=far)
+    o = O.HNSW(0, dim, M=m // 2, maxM0=m, efSearch=64, maxLevel=1, seed=1)
+    o.load_flat(rows2, deg, links, far)
+    r, d, c = g.search(q[None, :], 5, 64)
+    ro, do = o.search(q, 5)
+    assert c[0] == 5 and r[0].tolist() == ro.tolist() and d[0].tobytes() == do.tobytes()
+    assert r[0, 0] == far and d[0, 0] == np.float32(O.distance(0, q, q))
+    # the flat scan (tile layout) agrees
+    fr, fd, _ = idx.search(q, 1)
+    assert fr[0, 0] == far and fd[0, 0] == d[0, 0]
