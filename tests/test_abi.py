@@ -78,3 +78,27 @@ def test_fails_loudly_without_a_gpu():
     from quiver_amd.device_index import distance_pairs
     with pytest.raises(q.QvError):
         distance_pairs("cosine", np.ones((1, 3), np.float32), np.ones((1, 3), np.float32))
+
+
+def _build_c_smoke(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(root, "quiver_amd", "lib")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"),
+                    "-L", libdir, "-lqv", "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_header_is_plain_c_and_the_library_fails_loudly_without_a_gpu(tmp_path):
+    """include/qv.h compiled by a C11 compiler (what a cgo preamble does), linked against libqv.so alone; on a box
+    without a GPU every entry point refuses with QV_ERR_NO_DEVICE — there is no CPU path to fall back to"""
+    import subprocess
+    import quiver_amd
+    exe = _build_c_smoke(tmp_path)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    if quiver_amd.lib().qv_device_count() <= 0:
+        assert "no device" in p.stdout and "no CPU path" in p.stdout
+    else:
+        assert p.stdout.startswith("ok:")

@@ -431,3 +431,11 @@ def test_masked_search_equals_oracle_over_selected_rows(metric, n, dim, nq, k, f
         fr, fd, _ = idx.search(qs[:1], idx.size())
         first = [int(x) for x in fr[0] if mask[int(x)]][:want]
         assert first == r[0, :want].tolist()
+
+
+def test_pure_c_consumer_of_the_abi(tmp_path):
+    """tests/c/abi_smoke.c: C11 + include/qv.h + libqv.so only — create / add / search / remove / destroy on the GPU"""
+    import subprocess
+    from tests.test_abi import _build_c_smoke
+    p = subprocess.run([_build_c_smoke(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.startswith("ok:"), p.stdout + p.stderr
