@@ -183,11 +183,12 @@ int qv_distance_pairs(qv_metric metric, const float* a, const float* b, uint32_t
 int qv_merge_topk_device(const float* d_dist_lists, const uint32_t* d_row_lists, uint32_t n_lists, uint32_t k,
                          uint32_t* d_rows_out, float* d_dist_out, void* stream);
 
-/* The same merge for the PACKED exchange buffer: per shard one block of 2k 32-bit words — k shard-local rows
- * (0xFFFFFFFF = no result) followed by the k float32 distances — exactly what a shard's qv_index_search_device
- * wrote into one [2][k] buffer, so that buffer goes into a single all-gather untouched.  d_bases[n_lists] = first
- * global row of each shard; output rows are global.  n_lists * k <= 65536. */
-int qv_merge_topk_shards_device(const uint32_t* d_packed_lists, const uint32_t* d_bases, uint32_t n_lists, uint32_t k,
+/* The same merge for the PACKED exchange buffer of a batch of nq queries: d_packed_lists = [n_lists][nq][2][k] 32-bit
+ * words — per shard and query, k shard-local rows (0xFFFFFFFF = no result) followed by the k float32 distances —
+ * exactly what a shard's qv_index_search_device wrote for the batch into one [nq][2][k] buffer, so that buffer goes
+ * into a single all-gather untouched.  d_bases[n_lists] = first global row of each shard; outputs are [nq][k],
+ * rows global.  n_lists * k <= 65536. */
+int qv_merge_topk_shards_device(const uint32_t* d_packed_lists, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t k,
                                 uint32_t* d_rows_out, float* d_dist_out, void* stream);
 
 /* Measurement aid: when enabled, every flat-scan kernel launched through

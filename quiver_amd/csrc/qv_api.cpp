@@ -622,12 +622,13 @@ int qv_merge_topk_device(const float* d_dist_lists, const uint32_t* d_row_lists,
     return QV_OK;
 }
 
-int qv_merge_topk_shards_device(const uint32_t* d_packed_lists, const uint32_t* d_bases, uint32_t n_lists, uint32_t k,
+int qv_merge_topk_shards_device(const uint32_t* d_packed_lists, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t k,
                                 uint32_t* d_rows_out, float* d_dist_out, void* stream) {
     if (!d_packed_lists || !d_bases || !d_rows_out || !d_dist_out) return fail(QV_ERR_INVALID_ARG, "null device pointer");
+    if (nq == 0) return QV_OK;
     if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");
     if (k > (uint32_t)qv::kMaxFusedK || n_lists == 0 || (uint64_t)n_lists * k > 65536) return fail(QV_ERR_UNSUPPORTED, "merge supports k <= %d and n_lists*k <= 65536", qv::kMaxFusedK);
-    hipError_t e = qv::launch_merge_shards(d_packed_lists, d_bases, n_lists, k, d_rows_out, d_dist_out, static_cast<hipStream_t>(stream));
+    hipError_t e = qv::launch_merge_shards(d_packed_lists, d_bases, n_lists, nq, k, d_rows_out, d_dist_out, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "merge launch failed: %s", hipGetErrorString(e));
     return QV_OK;
 }

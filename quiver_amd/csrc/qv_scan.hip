@@ -389,15 +389,17 @@ k_merge_pairs(const float* __restrict__ dist, const uint32_t* __restrict__ rows,
     }
 }
 
-// the same merge for the packed exchange buffer of the sharded scan: per shard [k local rows][k distance bits], global row =
-// shard base + local row (so a shard's scan output goes into the all-gather as it is: one collective, no kernel in between)
+// the same merge for the packed exchange buffer of the sharded scan: per shard and query [k local rows][k distance bits], global
+// row = shard base + local row (so a shard's scan output goes into the all-gather as it is: one collective, no kernel in
+// between).  packed = [n_lists][nq][2][k]; one workgroup per query.
 __global__ void __launch_bounds__(kMergeBlock)
-k_merge_shards(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ bases, uint32_t n_lists, uint32_t k,
+k_merge_shards(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ bases, uint32_t n_lists, uint32_t nq, uint32_t k,
                uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
     __shared__ uint64_t wl[kMergeBlock / 64][64];
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nw = blockDim.x >> 6;
+    const uint32_t q = blockIdx.x;
     const uint32_t kth = k - 1, total = n_lists * k;
     uint64_t list = kDeadKey, thr = kDeadKey;
     for (uint32_t base = wave * 64; base < total; base += nw * 64) {
@@ -405,8 +407,9 @@ k_merge_shards(const uint32_t* __restrict__ packed, const uint32_t* __restrict__
         uint64_t key = kDeadKey;
         if (i < total) {
             const uint32_t g = i / k, j = i - g * k;
-            const uint32_t row = packed[(size_t)g * 2 * k + j];
-            if (row != 0xFFFFFFFFu) key = make_key(__uint_as_float(packed[(size_t)g * 2 * k + k + j]), bases[g] + row);
+            const uint32_t* blk = packed + ((size_t)g * nq + q) * 2 * k;
+            const uint32_t row = blk[j];
+            if (row != 0xFFFFFFFFu) key = make_key(__uint_as_float(blk[k + j]), bases[g] + row);
         }
         list_insert(list, thr, key, kth, lane);
     }
@@ -419,8 +422,8 @@ k_merge_shards(const uint32_t* __restrict__ packed, const uint32_t* __restrict__
         }
         if (lane < k) {
             bool dead = list == kDeadKey;
-            rows_out[lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
-            dist_out[lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+            rows_out[(size_t)q * k + lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
+            dist_out[(size_t)q * k + lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
         }
     }
 }
@@ -459,12 +462,12 @@ hipError_t launch_merge_pairs(const float* d_dist, const uint32_t* d_rows, uint3
     return hipGetLastError();
 }
 
-hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t k,
+hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t k,
                                uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
-    if (k == 0 || k > (uint32_t)kMaxFusedK || n_lists == 0) return hipErrorInvalidValue;
+    if (k == 0 || k > (uint32_t)kMaxFusedK || n_lists == 0 || nq == 0) return hipErrorInvalidValue;
     uint32_t total = n_lists * k;
     uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
-    hipLaunchKernelGGL(k_merge_shards, dim3(1), dim3(mblock), 0, s, d_packed, d_bases, n_lists, k, d_rows_out, d_dist_out);
+    hipLaunchKernelGGL(k_merge_shards, dim3(nq), dim3(mblock), 0, s, d_packed, d_bases, n_lists, nq, k, d_rows_out, d_dist_out);
     return hipGetLastError();
 }
 

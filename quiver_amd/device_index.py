@@ -212,9 +212,9 @@ def merge_topk_device(d_dist_lists: int, d_row_lists: int, n_lists: int, k: int,
     check(lib().qv_merge_topk_device(d_dist_lists, d_row_lists, n_lists, k, d_rows_out, d_dist_out, stream))
 
 
-def merge_topk_shards_device(d_packed_lists: int, d_bases: int, n_lists: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
-    """merge of the packed per-shard buffers ([k local rows][k distance bits] per shard); output rows are global"""
-    check(lib().qv_merge_topk_shards_device(d_packed_lists, d_bases, n_lists, k, d_rows_out, d_dist_out, stream or None))
+def merge_topk_shards_device(d_packed_lists: int, d_bases: int, n_lists: int, nq: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
+    """merge of the packed per-shard buffers ([n_lists][nq][2][k]: k local rows, k distance bits); outputs [nq][k], rows global"""
+    check(lib().qv_merge_topk_shards_device(d_packed_lists, d_bases, n_lists, nq, k, d_rows_out, d_dist_out, stream or None))
 
 
 def distance_pairs(metric, a, b, device: int = 0) -> np.ndarray:

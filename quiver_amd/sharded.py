@@ -37,15 +37,25 @@ class DeviceShard:
         self.index = index
 
     def search(self, d_query: torch.Tensor, k: int, rows_out: torch.Tensor, dist_out: torch.Tensor):
+        """d_query [dim] -> rows_out / dist_out [k]; d_query [nq, dim] -> [nq, k] views (may be strided slices of a packed buffer)"""
         s = torch.cuda.current_stream().cuda_stream
-        self.index.search_device(d_query.data_ptr(), 1, k, rows_out.data_ptr(), dist_out.data_ptr(), s)
+        if d_query.dim() == 1:
+            self.index.search_device(d_query.data_ptr(), 1, k, rows_out.data_ptr(), dist_out.data_ptr(), s)
+            return
+        nq = d_query.shape[0]
+        st_r = torch.empty((nq, k), dtype=torch.int32, device=d_query.device)
+        st_d = torch.empty((nq, k), dtype=torch.float32, device=d_query.device)
+        self.index.search_device(d_query.data_ptr(), nq, k, st_r.data_ptr(), st_d.data_ptr(), s)   # exact multi-query scan
+        rows_out.copy_(st_r); dist_out.copy_(st_d)
 
 
 def device_merge(g_pack: torch.Tensor, bases: torch.Tensor, k: int, rows_out: torch.Tensor, dist_out: torch.Tensor):
-    """g_pack [G, 2, k] int32: per shard k local rows then k distance bit patterns; bases [G] int32"""
+    """g_pack [G, 2, k] (one query) or [G, nq, 2, k] int32: per shard (and query) k local rows then k distance bit patterns;
+    bases [G] int32; outputs [k] or [nq, k]"""
     from .device_index import merge_topk_shards_device
     s = torch.cuda.current_stream().cuda_stream
-    merge_topk_shards_device(g_pack.data_ptr(), bases.data_ptr(), g_pack.shape[0], k, rows_out.data_ptr(), dist_out.data_ptr(), s)
+    nq = 1 if g_pack.dim() == 3 else g_pack.shape[1]
+    merge_topk_shards_device(g_pack.data_ptr(), bases.data_ptr(), g_pack.shape[0], nq, k, rows_out.data_ptr(), dist_out.data_ptr(), s)
 
 
 class ShardedFlatSearch:
@@ -114,6 +124,23 @@ class ShardedFlatSearch:
     def search(self, d_query: torch.Tensor):
         r, d = self.finish(self.submit(d_query))
         return r.clone(), d.clone()
+
+    def search_batch(self, d_queries: torch.Tensor):
+        """nq queries at once ([nq, dim]): every shard runs its multi-query scan, ONE all-gather carries all nq local top-k
+        lists, one merge launch (a workgroup per query) -> (rows [nq, k], dist [nq, k]), identical to nq single searches"""
+        nq, k, G, dev = d_queries.shape[0], self.k, self.world, self.device
+        pack = torch.empty((nq, 2, k), dtype=torch.int32, device=dev)
+        self.shard.search(d_queries, k, pack[:, 0, :], pack[:, 1, :].view(torch.float32))
+        if self.world == 1 and not self.force_exchange:
+            rows = pack[:, 0, :]
+            if self.base:
+                rows = torch.where(rows != -1, rows + self.base, rows)
+            return rows.contiguous(), pack[:, 1, :].view(torch.float32).contiguous()
+        g_pack = torch.empty((G, nq, 2, k), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(g_pack.view(-1), pack.view(-1), group=self.group)
+        out_rows = torch.empty((nq, k), dtype=torch.int32, device=dev); out_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        self.merge(g_pack, self.bases, k, out_rows, out_dist)
+        return out_rows, out_dist
 
     def search_stream(self, queries):
         """pipelined: exchange of query i overlaps the scan of query i+1"""

@@ -321,7 +321,7 @@ def test_config4_flat_cosine_10Mx768_single_gpu_properties():
     from quiver_amd.device_index import merge_topk_shards_device
     pack = np.stack([np.stack([ra[0].view(np.int32), da[0].view(np.int32)]), np.stack([rb[0].view(np.int32), db[0].view(np.int32)])])
     gp = torch.from_numpy(pack).cuda(); bases = torch.tensor([0, 600_000], dtype=torch.int32, device="cuda")
-    merge_topk_shards_device(gp.data_ptr(), bases.data_ptr(), 2, 10, orow.data_ptr(), odist.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    merge_topk_shards_device(gp.data_ptr(), bases.data_ptr(), 2, 1, 10, orow.data_ptr(), odist.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(orow.cpu().numpy().view(np.uint32), r1[0]) and np.array_equal(_bits(odist.cpu().numpy()), _bits(d1[0]))
 

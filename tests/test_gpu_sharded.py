@@ -43,7 +43,10 @@ def _worker(rank, world, port, ret):
         s = ShardedFlatSearch(DeviceShard(idx), base, K, torch.device("cuda", 0), world=world)
         qs = [torch.from_numpy(q).cuda() for q in O.gen_rows(20260425, 0, NQ, D)]
         res = s.search_stream(qs)
+        br, bd = s.search_batch(torch.stack(qs))       # the batch form: one all-gather, one merge launch
         torch.cuda.synchronize()
+        for i in range(len(qs)):
+            assert torch.equal(br[i], res[i][0]) and torch.equal(bd[i].view(torch.int32), res[i][1].view(torch.int32))
         ret[rank] = (np.stack([r.cpu().numpy().view(np.uint32) for r, _ in res]), np.stack([d.cpu().numpy() for _, d in res]), base)
     finally:
         dist.destroy_process_group()

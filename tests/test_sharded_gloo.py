@@ -35,10 +35,14 @@ class OracleShard:
 
     def search(self, q, k, rows_out, dist_out):
         from tests import _oracle as O
-        r, d = O.exact_search(0, self.rows, q.numpy(), k)
-        rr = np.full(k, 0xFFFFFFFF, np.uint32)
-        dd = np.full(k, np.inf, np.float32)
-        rr[: len(r)], dd[: len(d)] = r, d
+        qs = q.numpy() if q.dim() == 2 else q.numpy()[None, :]
+        rr = np.full((qs.shape[0], k), 0xFFFFFFFF, np.uint32)
+        dd = np.full((qs.shape[0], k), np.inf, np.float32)
+        for i in range(qs.shape[0]):
+            r, d = O.exact_search(0, self.rows, qs[i], k)
+            rr[i, : len(r)], dd[i, : len(d)] = r, d
+        if q.dim() == 1:
+            rr, dd = rr[0], dd[0]
         rows_out.copy_(torch.from_numpy(rr.view(np.int32)))
         dist_out.copy_(torch.from_numpy(dd))
 
@@ -47,6 +51,10 @@ def oracle_merge(g_pack, bases, k, rows_out, dist_out):
     """test stand-in for qv_merge_topk_shards_device: g_pack [G, 2, k] (shard-local rows, distance bits), bases [G];
     k smallest by (distance, global row)"""
     gp = g_pack.numpy()
+    if gp.ndim == 4:                                   # a batch: [G, nq, 2, k] -> one merge per query
+        for qi in range(gp.shape[1]):
+            oracle_merge(torch.from_numpy(np.ascontiguousarray(gp[:, qi])), bases, k, rows_out[qi], dist_out[qi])
+        return
     local = gp[:, 0, :].copy().view(np.uint32)
     d = gp[:, 1, :].copy().view(np.float32).ravel()
     glob = (local.astype(np.uint64) + bases.numpy().astype(np.uint64)[:, None]).astype(np.uint32)
@@ -75,6 +83,9 @@ def _worker(rank, world, port, n_rows, ret):
         res = s.search_stream(qs)                     # pipelined path
         one = s.search(qs[0])                         # unpipelined path
         assert torch.equal(one[0], res[0][0]) and torch.equal(one[1], res[0][1])
+        br, bd = s.search_batch(torch.stack(qs))       # all queries in one exchange
+        for i in range(len(qs)):
+            assert torch.equal(br[i], res[i][0]) and torch.equal(bd[i], res[i][1])
         out_r = np.stack([r.numpy().view(np.uint32) for r, _ in res])
         out_d = np.stack([d.numpy() for _, d in res])
         ret[rank] = (out_r, out_d)
