@@ -42,7 +42,7 @@ def test_mfma_batched_equals_exact_scan(metric):
         er, ed = O.exact_search(q.metric_id(metric), corpus, qs[i], 10)
         assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
     # other k, fewer queries (not a multiple of 64)
-    for k, m in ((1, 100), (64, 40), (33, 64)):
+    for k, m in ((1, 100), (64, 40), (33, 64), (10, 160), (7, 200)):      # 160 and 200 queries: padded from 3-4 to 4 blocks of 64
         assert _eq(_exact(idx, qs[:m], k), idx.search(qs[:m], k, batched=True))
 
 
