@@ -317,9 +317,14 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 }
 
 // ---- MFMA batched path --------------------------------------------------------------
-uint32_t batched_sample_rows(uint32_t n_rows) {
-    static const int s = env_int("QV_MFMA_SAMPLE_ROWS", 8192);
-    return std::min<uint32_t>(n_rows, (uint32_t)s);
+// Rows of the exact sample scan that bounds each query's k-th distance.  A sample of S of N rows lets about k*N/S rows through
+// the filter per query; the candidate buffer holds kMfmaCandCap (4096), so S grows with N and k to keep that near 1024
+// (10M rows or k = 64 with the former fixed 8192 overflowed nearly every query into the exact redo: 256 x 10M x 768 took 108 ms).
+uint32_t batched_sample_rows(uint32_t n_rows, uint32_t k) {
+    static const int forced = env_int("QV_MFMA_SAMPLE_ROWS", 0);
+    if (forced > 0) return std::min<uint32_t>(n_rows, (uint32_t)forced);
+    const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / 1024 + 63) / 64 * 64;
+    return (uint32_t)std::min<uint64_t>(n_rows, std::max<uint64_t>(8192, want));
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 262144), min_q = env_int("QV_MFMA_MIN_QUERIES", 32);
@@ -361,7 +366,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     float* sdist = reinterpret_cast<float*>(w + off); off += (size_t)nq * k * 4;
     // 1. exact top-k over a sample (first rows) -> per-query upper bound U_q of the k-th distance
     IndexView vs = v;
-    vs.n_rows = batched_sample_rows(v.n_rows);
+    vs.n_rows = batched_sample_rows(v.n_rows, k);
     vs.n_tiles = (vs.n_rows + 63) / 64;
     ScanPlan ps = plan_scan(vs.n_tiles, cus);
     hipError_t e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);

@@ -138,6 +138,14 @@ def test_batched_device_pointer_entry_point():
     assert int(fl.sum().item()) == 0
     ex = _exact(idx, qs, 10)
     assert np.array_equal(dr.cpu().numpy().view(np.uint32), ex[0]) and np.array_equal(_bits(dd.cpu().numpy()), _bits(ex[1]))
+    # k = 64: the bound sample grows with k (and N) so that the candidate buffers do not overflow into the exact redo
+    dr64 = torch.empty((96, 64), dtype=torch.int32, device="cuda"); dd64 = torch.empty((96, 64), dtype=torch.float32, device="cuda")
+    fl.fill_(1)
+    idx.search_batched_device(dq.data_ptr(), 96, 64, dr64.data_ptr(), dd64.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(fl.sum().item()) == 0
+    ex64 = _exact(idx, qs, 64)
+    assert np.array_equal(dr64.cpu().numpy().view(np.uint32), ex64[0]) and np.array_equal(_bits(dd64.cpu().numpy()), _bits(ex64[1]))
     small = q.DeviceIndex(128, "manhattan")
     small.add_synthetic(5, 0, 1000)
     with pytest.raises(q.QvError) as e:
