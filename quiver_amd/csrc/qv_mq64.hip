@@ -31,10 +31,17 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //   W  waves that share out the tiles;  H  such wave sets per workgroup, set h computing query blocks h*NB.. for the SAME tiles;
 //   NB 16-query blocks per wave;  U chunks per register block (double-buffered);  WGS workgroups per CU
 struct Mq64Shape { int h, nb, u, w, wgs; };
-static Mq64Shape mq64_shape() {
-    // Measured, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt).  0: 16 queries/pass, 2 x 4 waves per CU on distinct tiles;
-    // 1: 32 queries/pass as two 4-wave sets sharing tiles; 2: 32 queries/pass, 8 waves per CU with two blocks per wave
-    static const int mode = env_int("QV_MQ64_MODE", 3) - 1;          // env value 1..3 -> mode 0..2 (0 = unset)
+static Mq64Shape mq64_shape(uint32_t nq) {
+    // Measured, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt).  0: 16 queries/pass, 2 x 4 waves per CU on distinct tiles
+    // (0.63 ms per pass); 1: 32 queries/pass as two 4-wave sets sharing tiles; 2: 32 queries/pass, 8 waves per CU with two
+    // blocks per wave (1.1 ms per pass).  Unforced, the shape with the cheaper total for this batch is taken: 9-16 queries
+    // and e.g. 33-48 go in 16-query passes, 17-32 and large batches in 32-query passes.
+    static const int forced = env_int("QV_MQ64_MODE", 0) - 1;        // env value 1..3 -> mode 0..2 (0 = choose per batch)
+    int mode = forced;
+    if (mode < 0) {
+        const uint32_t p16 = (nq + 15) / 16, p32 = (nq + 31) / 32;
+        mode = (p16 * 63 <= p32 * 110) ? 0 : 2;
+    }
     if (mode == 0) return {1, 1, 8, 4, 2};
     if (mode == 1) return {2, 1, 8, 4, 1};
     return {1, 2, 4, 8, 1};
@@ -272,7 +279,7 @@ static size_t mq64_lds_bytes(uint32_t dim4, const Mq64Shape& sh) {
 int mq64_blocks(int metric, uint32_t dim4, uint32_t nq) {
     static const int enabled = env_int("QV_MQ64", 1);
     if (enabled != 1 || (metric != QV_COSINE && metric != QV_DOT)) return 0;
-    const Mq64Shape sh = mq64_shape();
+    const Mq64Shape sh = mq64_shape(nq);
     if (mq64_lds_bytes(dim4, sh) * sh.wgs > 158 * 1024) return 0;
     return 16 * sh.h * sh.nb;
 }
@@ -282,7 +289,7 @@ size_t mq64_workspace_bytes(uint32_t nq, uint32_t dim4) { return (size_t)(nq + 3
 hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_queries, uint32_t nq, uint32_t k, void* d_qws, uint64_t* partial,
                                  uint32_t* grid_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (mq64_blocks(v.metric, v.dim4, nq) == 0) return hipErrorInvalidValue;
-    const Mq64Shape sh = mq64_shape();
+    const Mq64Shape sh = mq64_shape(nq);
     const uint32_t B = (uint32_t)(sh.h * sh.nb), Q = 16u * B, groups = (nq + Q - 1) / Q;
     float* qfrag = static_cast<float*>(d_qws);
     double* qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qws) + (((size_t)groups * Q * v.dim4 * 4 * sizeof(float)) + 255) / 256 * 256);
