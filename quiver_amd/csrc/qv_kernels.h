@@ -201,6 +201,12 @@ __device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict
         f4 v[U];
 #pragma unroll
         for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * stride4]);
+        // Keep all U loads ahead of the arithmetic: left alone, hipcc (ROCm 7.2) sinks them next to their uses for every
+        // metric but cosine — 2 loads in flight instead of 16: dot / Euclidean 78 %, squared Euclidean / Manhattan 52 % of
+        // the HBM peak instead of 88 %.  For cosine its own schedule (a rolling window of ~8 loads) beats the hard barrier
+        // (89.7 vs 86.6-87.9 % at any batch size 8..32), so the barrier is left out there; tests/test_isa_guard.py checks the
+        // compiled loops (>= 16 loads in flight for the barriered metrics, >= 8 for cosine).
+        if constexpr (M != QV_COSINE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const Q* qq = q_lds + (size_t)(c0 + u) * 4;

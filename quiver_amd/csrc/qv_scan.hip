@@ -483,7 +483,10 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
         // QB queries per corpus pass.  Measured on MI355X, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt):
         // QB=8 is HBM-bound (0.454 ms/pass), QB=16 is f64-VALU-bound (0.75 ms/pass, 12.0 ms per 256 queries).
         static const int mq_qb_env = env_int("QV_MQ_QB", 0), mq_wg = env_int("QV_MQ_WG_PER_CU", 2);
-        const int qb = mq_qb_env ? mq_qb_env : (nq >= 9 ? 16 : (nq >= 5 ? 8 : 4));
+        // the all-float32 metrics spill ~330 SGPRs at 16 queries per pass (16 x 4 scalar query values per chunk on top of the
+        // list state): 16 queries take 1.73 ms in one pass and 1.02 ms in two passes of 8 (1M x 768) -> 8 per pass for them
+        const bool f32_acc = v.metric == QV_L2SQ || v.metric == QV_COSINE_F32 || v.metric == QV_L2_F32 || v.metric == QV_DOT_F32;
+        const int qb = mq_qb_env ? mq_qb_env : (nq >= 9 ? (f32_acc ? 8 : 16) : (nq >= 5 ? 8 : 4));
         const uint32_t want = (v.n_tiles + kScanWaves - 1) / kScanWaves;
         const uint32_t grid = std::max(1u, std::min(want, (uint32_t)mq_wg * (p.grid / 2 ? p.grid / 2 : 1)));   // p.grid = 2 WG/CU * CUs
         void* qblk = static_cast<char*>(d_ws) + scan_workspace_bytes(p, nq, k);   // tail of the workspace
