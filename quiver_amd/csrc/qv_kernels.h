@@ -27,6 +27,7 @@
 #include "../../include/qv.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace qv {
 
@@ -196,30 +197,32 @@ __device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict
         if constexpr (QN && M == QV_COSINE) qa = __builtin_fma(a, a, qa);
         else if constexpr (QN && M == QV_COSINE_F32) { float pp = a * a; qa = qa + pp; }
     };
-    uint32_t c0 = 0;
-    for (; c0 + U <= dim4; c0 += U) {
-        f4 v[U];
+    // one block of B chunks: all B loads issued together, then consumed in order
+    auto block = [&](auto Bc, uint32_t c0) {
+        constexpr int B = decltype(Bc)::value;
+        f4 v[B];
 #pragma unroll
-        for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * stride4]);
-        // Keep all U loads ahead of the arithmetic: left alone, hipcc (ROCm 7.2) sinks them next to their uses for every
-        // metric but cosine — 2 loads in flight instead of 16: dot / Euclidean 78 %, squared Euclidean / Manhattan 52 % of
+        for (int u = 0; u < B; u++) v[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * stride4]);
+        // Keep all loads of the block ahead of the arithmetic: left alone, hipcc (ROCm 7.2) sinks them next to their uses for
+        // every metric but cosine — 2 loads in flight instead of 16: dot / Euclidean 78 %, squared Euclidean / Manhattan 52 % of
         // the HBM peak instead of 88 %.  For cosine its own schedule (a rolling window of ~8 loads) beats the hard barrier
         // (89.7 vs 86.6-87.9 % at any batch size 8..32), so the barrier is left out there; tests/test_isa_guard.py checks the
         // compiled loops (>= 16 loads in flight for the barriered metrics, >= 8 for cosine).
         if constexpr (M != QV_COSINE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
+        for (int u = 0; u < B; u++) {
             const Q* qq = q_lds + (size_t)(c0 + u) * 4;
             acc1<M>(acc, qq[0], v[u].x); qn1(qq[0]); acc1<M>(acc, qq[1], v[u].y); qn1(qq[1]);
             acc1<M>(acc, qq[2], v[u].z); qn1(qq[2]); acc1<M>(acc, qq[3], v[u].w); qn1(qq[3]);
         }
-    }
-    for (; c0 < dim4; c0++) {
-        f4 v = __builtin_nontemporal_load(&p[(size_t)c0 * stride4]);
-        const Q* qq = q_lds + (size_t)c0 * 4;
-        acc1<M>(acc, qq[0], v.x); qn1(qq[0]); acc1<M>(acc, qq[1], v.y); qn1(qq[1]);
-        acc1<M>(acc, qq[2], v.z); qn1(qq[2]); acc1<M>(acc, qq[3], v.w); qn1(qq[3]);
-    }
+    };
+    uint32_t c0 = 0;
+    for (; c0 + U <= dim4; c0 += U) block(std::integral_constant<int, U>{}, c0);
+    // the remainder in blocks of 8, 4, 2, 1 loads (a chunk-at-a-time tail ran dim 16-48 at 40-45 % and dim 100 at 69 % of the HBM peak)
+    if constexpr (U > 8) { for (; c0 + 8 <= dim4; c0 += 8) block(std::integral_constant<int, 8>{}, c0); }
+    if constexpr (U > 4) { if (c0 + 4 <= dim4) { block(std::integral_constant<int, 4>{}, c0); c0 += 4; } }
+    if (c0 + 2 <= dim4) { block(std::integral_constant<int, 2>{}, c0); c0 += 2; }
+    if (c0 < dim4) block(std::integral_constant<int, 1>{}, c0);
     if constexpr (QN) *qnorm2 = qa;       // zero padding of the query adds +0 terms: exact
     return acc;
 }
