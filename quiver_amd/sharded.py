@@ -45,7 +45,21 @@ class DeviceShard:
         nq = d_query.shape[0]
         st_r = torch.empty((nq, k), dtype=torch.int32, device=d_query.device)
         st_d = torch.empty((nq, k), dtype=torch.float32, device=d_query.device)
-        self.index.search_device(d_query.data_ptr(), nq, k, st_r.data_ptr(), st_d.data_ptr(), s)   # exact multi-query scan
+        done = False
+        if nq >= 32:
+            # big batches: fp32-MFMA filter + exact re-score (same results); queries it flags are redone by the exact scan
+            from ._lib import QvError
+            flags = torch.zeros(nq, dtype=torch.int32, device=d_query.device)
+            try:
+                self.index.search_batched_device(d_query.data_ptr(), nq, k, st_r.data_ptr(), st_d.data_ptr(), flags.data_ptr(), s)
+                done = True
+                for qi in flags.nonzero().flatten().tolist():
+                    self.index.search_device(d_query[qi].data_ptr(), 1, k, st_r[qi].data_ptr(), st_d[qi].data_ptr(), s)
+            except QvError as e:
+                if e.code != -8:                          # QV_ERR_UNSUPPORTED: metric / corpus size / k -> exact scan below
+                    raise
+        if not done:
+            self.index.search_device(d_query.data_ptr(), nq, k, st_r.data_ptr(), st_d.data_ptr(), s)   # exact multi-query scan
         rows_out.copy_(st_r); dist_out.copy_(st_d)
 
 

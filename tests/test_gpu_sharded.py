@@ -70,3 +70,44 @@ def test_two_ranks_one_gpu_equal_unsharded(world):
             er, ed = O.exact_search(0, corpus, qs[i], K, alive=alive)
             assert np.array_equal(rr[i], er), (world, rank, i)
             assert np.array_equal(dd[i].view(np.uint32), ed.view(np.uint32))
+
+
+def _worker_big_batch(rank, world, port, n, d, nq, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import quiver_amd
+        from quiver_amd.sharded import DeviceShard, ShardedFlatSearch, shard_bounds
+        from tests import _oracle as O
+        torch.cuda.set_device(0)
+        base, n_local = shard_bounds(n, world, rank)
+        idx = quiver_amd.DeviceIndex(d, "cosine", device=0)
+        idx.add_synthetic(20260424, base, n_local)
+        s = ShardedFlatSearch(DeviceShard(idx), base, K, torch.device("cuda", 0), world=world)
+        qs = torch.from_numpy(O.gen_rows(20260425, 0, nq, d)).cuda()
+        br, bd = s.search_batch(qs)                      # >= 32 queries over >= 262144 rows per shard: the fp32-MFMA path per shard
+        torch.cuda.synchronize()
+        ret[rank] = (br.cpu().numpy().view(np.uint32), bd.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_big_batch_goes_through_the_mfma_path_and_equals_the_oracle():
+    import torch.multiprocessing as mp
+    from tests import _oracle as O
+    n, d, nq, world = 600_000, 64, 40, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_big_batch, args=(world, _free_port(), n, d, nq, ret), nprocs=world, join=True)
+    corpus = O.gen_rows(20260424, 0, n, d)
+    qs = O.gen_rows(20260425, 0, nq, d)
+    for rank in range(world):
+        rr, dd = ret[rank]
+        for i in range(0, nq, 3):
+            er, ed = O.exact_search(0, corpus, qs[i], K)
+            assert np.array_equal(rr[i], er), (rank, i)
+            assert np.array_equal(dd[i].view(np.uint32), ed.view(np.uint32))
