@@ -318,12 +318,14 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 
 // ---- MFMA batched path --------------------------------------------------------------
 // Rows of the exact sample scan that bounds each query's k-th distance.  A sample of S of N rows lets about k*N/S rows through
-// the filter per query; the candidate buffer holds kMfmaCandCap (4096), so S grows with N and k to keep that near 1024
+// the filter per query; the candidate buffer holds kMfmaCandCap (4096), so S grows with N and k to keep that near 1536
 // (10M rows or k = 64 with the former fixed 8192 overflowed nearly every query into the exact redo: 256 x 10M x 768 took 108 ms).
 uint32_t batched_sample_rows(uint32_t n_rows, uint32_t k) {
     static const int forced = env_int("QV_MFMA_SAMPLE_ROWS", 0);
     if (forced > 0) return std::min<uint32_t>(n_rows, (uint32_t)forced);
-    const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / 1024 + 63) / 64 * 64;
+    // ~1536 expected candidates (3 sigma of the k-th order statistic at k = 10 stays under the 4096 slots), in whole multiples
+    // of 8192 rows = 128 tiles: with 16 query groups that is one full round of the 2048 scan waves per multiple
+    const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / 1536 + 8191) / 8192 * 8192;
     return (uint32_t)std::min<uint64_t>(n_rows, std::max<uint64_t>(8192, want));
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
