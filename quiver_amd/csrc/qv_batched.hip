@@ -329,8 +329,13 @@ uint32_t batched_sample_rows(uint32_t n_rows, uint32_t k) {
     return (uint32_t)std::min<uint64_t>(n_rows, std::max<uint64_t>(8192, want));
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
-    static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 262144), min_q = env_int("QV_MFMA_MIN_QUERIES", 32);
-    return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxFusedK && nq >= (uint32_t)min_q && v.n_rows >= (uint32_t)min_rows;
+    // Measured crossover against the exact multi-query scans (256 queries x 768 dims, host pointers for the filter): 12k-16k
+    // rows 0.49-0.50 vs 0.36-0.40 ms, 32k 0.51 vs 0.67, 64k 0.64 vs 1.34, 128k 0.85 vs 2.44, 200k 1.19 vs 3.16 — the filter's
+    // fixed cost (sample scan, prep, re-score: ~0.4 ms) pays off from about 8M query-rows.
+    static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 32768), min_q = env_int("QV_MFMA_MIN_QUERIES", 32);
+    static const int min_work_m = env_int("QV_MFMA_MIN_MROWS", 8);                       // millions of query-rows
+    return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxFusedK && nq >= (uint32_t)min_q &&
+           v.n_rows >= (uint32_t)min_rows && (uint64_t)nq * v.n_rows >= (uint64_t)min_work_m * 1000000ull;
 }
 // queries are padded (zero vector, +inf threshold: nothing passes) to 1, 2 or a multiple of 4 blocks of 64: the four waves of a
 // workgroup then work on the same row group (its tiles are fetched once and hit L1/L2 for the other three) and the wave count

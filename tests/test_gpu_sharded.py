@@ -89,7 +89,7 @@ def _worker_big_batch(rank, world, port, n, d, nq, ret):
         idx.add_synthetic(20260424, base, n_local)
         s = ShardedFlatSearch(DeviceShard(idx), base, K, torch.device("cuda", 0), world=world)
         qs = torch.from_numpy(O.gen_rows(20260425, 0, nq, d)).cuda()
-        br, bd = s.search_batch(qs)                      # >= 32 queries over >= 262144 rows per shard: the fp32-MFMA path per shard
+        br, bd = s.search_batch(qs)                      # 40 queries x 300k rows per shard (>= 8M query-rows): the fp32-MFMA path per shard
         torch.cuda.synchronize()
         ret[rank] = (br.cpu().numpy().view(np.uint32), bd.cpu().numpy())
     finally:
