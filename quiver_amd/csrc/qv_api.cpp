@@ -758,12 +758,12 @@ int qv_distance_rows(qv_index* idx, const float* query, const uint32_t* rows, ui
         return rc;
     memcpy(c->h_q.p, query, qbytes);
     memcpy(c->h_ids.p, rows, ibytes);
-    HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_ids.p, c->h_ids.p, ibytes, hipMemcpyHostToDevice, c->stream));
-    hipError_t e = qv::launch_distance_rows(idx->view(), static_cast<const float*>(c->d_q.p), static_cast<const uint32_t*>(c->d_ids.p), n,
-                                            static_cast<float*>(c->d_dist.p), c->stream);
+    // This call is a latency path (one searchLayer hop: a 3 KB query, <= 64 row ids, <= 64 floats back).  The pinned staging
+    // buffers are device-visible, so the kernel reads the query and the ids from them and writes the distances into one
+    // directly: one launch and one stream sync, no copy commands in between.
+    hipError_t e = qv::launch_distance_rows(idx->view(), static_cast<const float*>(c->h_q.p), static_cast<const uint32_t*>(c->h_ids.p), n,
+                                            static_cast<float*>(c->h_dist.p), c->stream);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_rows launch failed: %s", hipGetErrorString(e));
-    HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(dist_out, c->h_dist.p, obytes);
     return QV_OK;

@@ -19,8 +19,11 @@ k_distance_rows(IndexView v, const float* __restrict__ query, const uint32_t* __
     if (i >= n) return;
     const uint32_t row = rows[i];
     if (row >= v.n_rows) { out[i] = __uint_as_float(0x7FC00000u); return; }
-    const f4* p = reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63);
-    typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
+    // a lane walks ITS row: from the row-major copy when the index keeps one (consecutive 16-byte chunks share cache lines:
+    // a quarter of the line transactions of the tile layout, where every chunk of a row sits in its own line)
+    typename MT<M>::A acc;
+    if (v.rowmaj != nullptr && (v.dim & 3) == 0) acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
+    else acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
     double rn = 0.0;
     if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
     out[i] = finalize<M>(acc, qc, rn);
