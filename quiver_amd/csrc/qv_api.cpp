@@ -480,11 +480,16 @@ static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, u
         return rc;
     memcpy(c->h_q.p, queries, qbytes);
     HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
+    // small result sets are written by the last kernel straight into the (device-visible) pinned buffers: two copy commands less
+    // on the latency path of a single query; large ones go through device buffers and DMA
+    const bool direct = (size_t)nq * kk <= 1024;
     rc = enqueue_search(idx, static_cast<const float*>(c->d_q.p), nq, kk, kk, c->ws.p, c->ws.cap,
-                        static_cast<uint32_t*>(c->d_rows.p), static_cast<float*>(c->d_dist.p), c->stream);
+                        static_cast<uint32_t*>(direct ? c->h_rows.p : c->d_rows.p), static_cast<float*>(direct ? c->h_dist.p : c->d_dist.p), c->stream);
     if (rc != QV_OK) return rc;
-    HIPCHK(hipMemcpyAsync(c->h_rows.p, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    if (!direct) {
+        HIPCHK(hipMemcpyAsync(c->h_rows.p, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint32_t* hr = static_cast<const uint32_t*>(c->h_rows.p);
     const float* hd = static_cast<const float*>(c->h_dist.p);
