@@ -292,6 +292,39 @@ def main():
                          "pmc": "profiles/r01_sweep_mq.txt: SQ_VALU_MFMA_BUSY_CYCLES = 81.8 % of kernel cycles at an effective 1.99 GHz"}}
         if idx1 is not idx:
             idx1.close()
+        # configs[0]: the reference's own CPU-runnable case, 10k x 128 cosine k=10, one query at a time through the host-pointer
+        # C ABI (query up, results down, one sync per call) — latency, not bandwidth; the CPU port beside it on the same rows
+        try:
+            c0 = quiver_amd.DeviceIndex(128, a.metric, device=local_rank)
+            c0.add_synthetic(CORPUS_SEED, 0, 10_000)
+            q0g = quiver_amd.DeviceIndex(128, a.metric, device=local_rank); q0g.add_synthetic(QUERY_SEED, 0, 64)
+            q0 = np.stack([q0g.get_row(i) for i in range(64)]); q0g.close()
+            for j in range(50):
+                c0.search(q0[j % 64], k)
+            t1 = time.perf_counter()
+            for j in range(1000):
+                r0, d0, _ = c0.search(q0[j % 64], k)
+            dt0 = (time.perf_counter() - t1) / 1000
+            entry = {"workload": "pkg/hybrid exact flat scan 10k x 128 fp32 cosine, k=10 (BASELINE configs[0]), one query per call, host pointers",
+                     "latency_us": dt0 * 1e6, "qps_one_caller": 1.0 / dt0}
+            if not a.no_cpu_baseline:
+                from tests import _oracle as O
+                rows0 = O.gen_rows(CORPUS_SEED, 0, 10_000, 128)
+                f0 = O.Faithful(0, 128)
+                for i in range(10_000):
+                    f0.insert("v%d" % i, rows0[i])
+                f0.search(q0[0], k)
+                t1 = time.perf_counter()
+                for j in range(200):
+                    ids0, dd0 = f0.search(q0[j % 64], k)
+                dtc = (time.perf_counter() - t1) / 200
+                er0, ed0 = O.exact_search(0, rows0, q0[199 % 64], k)
+                entry["cpu_port_latency_us_1core"] = dtc * 1e6
+                entry["identical_to_oracle"] = bool(np.array_equal(r0[0], O.exact_search(0, rows0, q0[999 % 64], k)[0]))
+            also["config0_10kx128_single_query"] = entry
+            c0.close()
+        except Exception as ex:
+            also["config0_10kx128_single_query"] = {"error": str(ex)}
         # configs[3] shape at reduced N: HNSW traversal (efSearch=128, MaxM0=32) on an exact 32-NN graph over 100k rows,
         # built here by the product's own scan (the reference's sequential Insert build is not a data-parallel path)
         try:
