@@ -479,11 +479,13 @@ static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, u
         (rc = c->h_rows.ensure(obytes)) || (rc = c->h_dist.ensure(obytes)) || (rc = c->ws.ensure(search_ws_bytes(idx, nq, kk, kk))))
         return rc;
     memcpy(c->h_q.p, queries, qbytes);
-    HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
     // small result sets are written by the last kernel straight into the (device-visible) pinned buffers: two copy commands less
-    // on the latency path of a single query; large ones go through device buffers and DMA
+    // on the latency path of a single query; large ones go through device buffers and DMA.  On a small corpus (few workgroups,
+    // each staging the query once) the query is read from the pinned buffer too: no copy command at all.
     const bool direct = (size_t)nq * kk <= 1024;
-    rc = enqueue_search(idx, static_cast<const float*>(c->d_q.p), nq, kk, kk, c->ws.p, c->ws.cap,
+    const bool q_direct = direct && nq <= 4 && idx->n_rows <= 262144;
+    if (!q_direct) HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
+    rc = enqueue_search(idx, static_cast<const float*>(q_direct ? c->h_q.p : c->d_q.p), nq, kk, kk, c->ws.p, c->ws.cap,
                         static_cast<uint32_t*>(direct ? c->h_rows.p : c->d_rows.p), static_cast<float*>(direct ? c->h_dist.p : c->d_dist.p), c->stream);
     if (rc != QV_OK) return rc;
     if (!direct) {
