@@ -90,6 +90,8 @@ struct qv_index {
     uint64_t* d_alive = nullptr;
     float* d_rowmaj = nullptr;
     std::vector<uint64_t> alive_host;          // mirror of d_alive, for size bookkeeping and validation
+    Buf mut_stage;                             // grow-only staging buffer of the mutating calls (add / remove / update run under the
+                                               // caller's exclusion, so one buffer serves them all: no hipMalloc per single-row Insert)
 
     std::mutex ctx_mu;
     std::vector<SearchCtx*> free_ctx;
@@ -271,6 +273,7 @@ void qv_index_destroy(qv_index* idx) {
     for (SearchCtx* c : idx->all_ctx) { c->release(); delete c; }
     for (auto& kv : idx->stream_ws) { kv.second->ws.release(); delete kv.second; }
     (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rowmaj);
+    idx->mut_stage.release();
     delete idx;
 }
 
@@ -315,8 +318,8 @@ int qv_index_add(qv_index* idx, const float* rows, uint32_t n, uint32_t* first_r
     // stage in chunks of <= 256 MiB so a 30 GB corpus never needs a second full-size buffer
     const size_t row_bytes = (size_t)idx->dim * sizeof(float);
     const uint32_t chunk_rows = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, ((size_t)256 << 20) / row_bytes));
-    float* d_stage = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d_stage), (size_t)chunk_rows * row_bytes));
+    if ((rc = idx->mut_stage.ensure((size_t)chunk_rows * row_bytes))) return rc;
+    float* d_stage = static_cast<float*>(idx->mut_stage.p);
     uint32_t done = 0;
     const uint32_t base_rows = idx->n_rows, base_live = idx->n_live;
     while (done < n) {
@@ -326,13 +329,12 @@ int qv_index_add(qv_index* idx, const float* rows, uint32_t n, uint32_t* first_r
         uint32_t fr = 0;
         if (rc == QV_OK) rc = qv_index_add_device(idx, d_stage, m, &fr, nullptr);
         if (rc != QV_OK) {                      // all-or-nothing (InsertBatch rolls back, hybrid_index.go:175-216)
-            (void)hipFree(d_stage);
             rollback_rows(idx, base_rows, base_live);
             return rc;
         }
         done += m;
     }
-    (void)hipFree(d_stage);
+    if (idx->mut_stage.cap > ((size_t)64 << 20)) idx->mut_stage.release();     // do not keep a bulk-load buffer around
     if (first_row_out) *first_row_out = base_rows;
     return QV_OK;
 }
@@ -361,12 +363,11 @@ int qv_index_remove(qv_index* idx, const uint32_t* rows, uint32_t n) {
     for (uint32_t i = 0; i < n; i++)
         if (rows[i] >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", rows[i], idx->n_rows);
     HIPCHK(hipSetDevice(idx->device));
-    uint32_t* d = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * sizeof(uint32_t)));
+    { const int rc0 = idx->mut_stage.ensure((size_t)n * sizeof(uint32_t)); if (rc0 != QV_OK) return rc0; }
+    uint32_t* d = static_cast<uint32_t*>(idx->mut_stage.p);
     hipError_t e = hipMemcpy(d, rows, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = qv::launch_set_alive(idx->view(), d, n, 0, nullptr);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "remove failed: %s", hipGetErrorString(e));
     for (uint32_t i = 0; i < n; i++) {
         uint64_t bit = 1ull << (rows[i] & 63);
@@ -380,12 +381,11 @@ int qv_index_update(qv_index* idx, uint32_t row, const float* vec) {
     if (!vec) return fail(QV_ERR_INVALID_ARG, "vector is null");
     if (row >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", row, idx->n_rows);
     HIPCHK(hipSetDevice(idx->device));
-    float* d = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)idx->dim * sizeof(float)));
+    { const int rc0 = idx->mut_stage.ensure((size_t)idx->dim * sizeof(float)); if (rc0 != QV_OK) return rc0; }
+    float* d = static_cast<float*>(idx->mut_stage.p);
     hipError_t e = hipMemcpy(d, vec, (size_t)idx->dim * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = qv::launch_ingest(idx->view(), d, row, 1, nullptr);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "update failed: %s", hipGetErrorString(e));
     uint64_t bit = 1ull << (row & 63);
     if (!(idx->alive_host[row >> 6] & bit)) { idx->alive_host[row >> 6] |= bit; idx->n_live++; }
