@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define QV_ABI_VERSION 1
+#define QV_ABI_VERSION 2
 
 typedef struct qv_index qv_index; /* opaque; owns device memory */
 
@@ -221,12 +221,45 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out);
 /* Device-pointer form: queries, results, counts (and optional evals) live on the device; the traversal is
  * enqueued on `stream` (0 = the graph's own stream) with no synchronisation.  One pass only: a query that
- * met two equal distances or a NaN on its way reports count 0xFFFFFFFE and must be redone through
- * qv_graph_search (which runs the exact-heap kernel for those); everything else is final.  Traversals on one
- * graph are ordered one after another whatever their streams (they share the visited stamps). */
+ * met two equal distances or a NaN on its way (or visited more nodes than its visited table holds: ~48 x ef)
+ * reports count 0xFFFFFFFE and must be redone through qv_graph_search (which runs the exact-heap kernel for
+ * those); everything else is final.  Traversals on one graph are ordered one after another whatever their
+ * streams (they share the per-wave visited tables). */
 int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef_search,
                            uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_count_out, uint32_t* d_evals_out, void* stream);
 void qv_graph_destroy(qv_graph* g);
+
+/* ---- device-resident HNSW construction ----------------------------------------------
+ * Replaces a loop of hnsw.HNSW.Insert (pkg/hnsw/hnsw.go:266-334: connectNode :337-468, selectNeighbors :583-599)
+ * over rows that are already in `idx` (node index == row; the index must have been created with QV_FLAG_ROWMAJOR).
+ * The reference connects concurrently (it releases its lock before connectNode, hnsw.go:313-315); the device build
+ * inserts in BATCHES with the deterministic form of that: every node of a batch runs connectNode's searches
+ * (greedy descent :367-380, then searchLayer(efConstruction) :385 on level min(level, CurrentLevel)) against the
+ * graph as it was before the batch — one wavefront per node, the same traversal kernels as qv_graph_search — and
+ * forward links, the self-links below the connected level (:463-467) and the back-links with their prune
+ * (:413-460) are then applied as if node by node in index order.  A batch of ONE node is exactly Insert, so
+ * batch_max = 1 reproduces the reference's sequential graph (the oracle's, tests/test_gpu_build.py).
+ *   levels[i]   level of row first_row + i: the caller draws them in node order (randomLevel, hnsw.go:716-738),
+ *               which keeps the RNG — seeded from the wall clock in the reference, hnsw.go:248 — on the host side
+ *   m, max_m0, ef_construction   0 = the reference's defaults 16 / 2m / 200 (hnsw.go:223-231); <= 64 / 64 / 512
+ *   batch_max   largest batch (0 = 4096);  ramp_div: a batch never exceeds (nodes already linked) / ramp_div, so
+ *               early nodes are inserted nearly one by one (0 = no ramp).  qv_graph_batch_size is the rule.
+ * qv_graph_insert appends rows [first_row, first_row + n) (first_row must equal the graph's node count) and returns
+ * when they are linked; the graph can be searched (qv_graph_search*) between and after calls. */
+uint32_t qv_graph_batch_size(uint32_t nodes_linked, uint32_t batch_max, uint32_t ramp_div);
+int qv_graph_create_empty(qv_graph** out, qv_index* idx, uint32_t capacity_nodes, uint32_t m, uint32_t max_m0, uint32_t ef_construction);
+int qv_graph_insert(qv_graph* g, uint32_t first_row, uint32_t n, const int8_t* levels, uint32_t batch_max, uint32_t ramp_div);
+/* create_empty + insert of rows [0, n_nodes) */
+int qv_graph_build(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_t* levels, uint32_t m, uint32_t max_m0,
+                   uint32_t ef_construction, uint32_t batch_max, uint32_t ramp_div);
+/* Shape of a graph (any output may be null), and a copy of it in the flat form qv_graph_create takes:
+ * levels [n_nodes], l0_deg [n_nodes], l0_links [n_nodes][max_m0], up_off [n_nodes], up_links [n_up_blocks][1 + max_m]
+ * (any output may be null).  What HNSW.Nodes[i].Connections holds (hnsw.go:44-56), for the host side to keep. */
+int qv_graph_info(const qv_graph* g, uint32_t* n_nodes, uint32_t* n_up_blocks, uint32_t* max_m0, uint32_t* max_m, uint32_t* entry, int* cur_level);
+int qv_graph_export(qv_graph* g, int8_t* levels, uint32_t* l0_deg, uint32_t* l0_links, uint32_t* up_off, uint32_t* up_links);
+/* Counters for reports: seconds spent in qv_graph_insert, batches, construction searches redone by the exact-heap
+ * kernel (equal distances), qv_graph_search queries redone for the same reason. */
+int qv_graph_stats(const qv_graph* g, double* build_seconds, uint64_t* build_batches, uint64_t* build_redo, uint64_t* search_redo);
 
 /* Copy row `row` back to the host (ExactIndex keeps vectors readable,
  * hybrid_index.go:537 reads idx.vectors[id] for the re-rank). */

@@ -81,6 +81,15 @@ int       qvo_hnsw_entry_point(const qvo_hnsw*, uint32_t* ep_out, int* cur_level
 int       qvo_hnsw_node_level(const qvo_hnsw*, uint32_t node); /* -1 if deleted */
 /* copy out node's links at `level`; returns count (<= cap) or -1 */
 int       qvo_hnsw_links(const qvo_hnsw*, uint32_t node, int level, uint32_t* out, uint32_t cap);
+/* n Inserts "at once" (the reference connects concurrently, hnsw.go:313-315): levels drawn in node order, every node's
+ * searches see the graph as it was before the batch, links applied node by node in index order with the reference's
+ * append / re-scoring prune.  n == 1 is qvo_hnsw_insert.  This is the CPU statement of what qv_graph_insert does on the
+ * device.  Returns the index of the first node, -1 on error. */
+int64_t   qvo_hnsw_insert_batch(qvo_hnsw*, const float* vecs, uint32_t n);
+/* test scaffolding: install a multi-level graph in include/qv.h's flat form (qv_graph_export); rows are borrowed */
+int       qvo_hnsw_load_graph(qvo_hnsw*, uint32_t n, const float* rows, const int8_t* levels, uint32_t max_m0, uint32_t max_m,
+                              const uint32_t* l0_deg, const uint32_t* l0_links, const uint32_t* up_off, const uint32_t* up_links,
+                              uint32_t entry, int cur_level);
 /* test scaffolding (not a reference function): install a ready-made single-layer graph; rows are borrowed */
 int       qvo_hnsw_load_flat(qvo_hnsw*, uint32_t n, const float* rows, const uint32_t* deg, const uint32_t* links,
                              uint32_t stride, uint32_t entry);

@@ -266,6 +266,151 @@ int64_t qvo_hnsw_insert(qvo_hnsw* h, const float* vec) {
     return idx;
 }
 
+/* ---- batched insertion ------------------------------------------------------------
+ * The reference's Insert releases the index lock BEFORE connectNode ("Connect the new node to the graph
+ * concurrently", hnsw.go:313-315), so n goroutines calling Insert at once is part of its contract: every one of them
+ * searches a graph in which the others are not linked yet.  qvo_hnsw_insert_batch is the deterministic member of that
+ * family which the device build (qv_graph_insert) implements:
+ *   1. levels are drawn in node order (:275) and the nodes appended (:279-303);
+ *   2. every node of the batch runs connectNode's searches (:367-385) against the graph AS IT WAS BEFORE THE BATCH
+ *      (snapshot entry point / CurrentLevel; batch nodes are unreachable: nothing links to them yet);
+ *   3. links are applied node by node, in index order, with the reference's own statements: forward links :404-409,
+ *      back-links with the re-scoring prune :413-460, then the entry-point update :325-332.
+ * A batch of ONE node is exactly qvo_hnsw_insert (tests/test_oracle_hnsw.py asserts graph equality). */
+typedef struct { int top; int n_lv; uint32_t** sel; int* nsel; } plan_t;
+
+static int connect_search(qvo_hnsw* h, uint32_t nodeIdx, const float* vec, int level, int graphLevel, uint32_t entry, plan_t* pl) {
+    if (level >= h->maxLevel) level = h->maxLevel - 1;                /* :342-344 */
+    res_t* buf = NULL; int buf_cap = 0;
+    for (int lc = graphLevel; lc > level; lc--) {                     /* :367-380 */
+        if (!node_ok(h, entry)) break;
+        if (lc >= h->nodes[entry].level + 1) continue;
+        int n = search_layer(h, vec, entry, 1, lc, &buf, &buf_cap);
+        if (n < 0) { free(buf); return -1; }
+        if (n > 0) entry = buf[0].idx;
+    }
+    int top = level < graphLevel ? level : graphLevel;
+    pl->top = top; pl->n_lv = top + 1;
+    pl->sel = (uint32_t**)calloc((size_t)(top + 1 > 0 ? top + 1 : 1), sizeof(uint32_t*));
+    pl->nsel = (int*)calloc((size_t)(top + 1 > 0 ? top + 1 : 1), sizeof(int));
+    for (int lc = top; lc >= 0; lc--) {                               /* :383 */
+        if (!node_ok(h, entry)) break;
+        int n = search_layer(h, vec, entry, h->efC, lc, &buf, &buf_cap);   /* :385 */
+        if (n < 0) { free(buf); return -1; }
+        if (n == 0) continue;
+        int maxConn = lc == 0 ? h->maxM0 : h->M;
+        int nsel = select_neighbors(buf, n, maxConn < n ? maxConn : n);    /* :401 */
+        pl->sel[lc] = (uint32_t*)malloc((size_t)(nsel ? nsel : 1) * sizeof(uint32_t));
+        for (int i = 0; i < nsel; i++) pl->sel[lc][i] = buf[i].idx;
+        pl->nsel[lc] = nsel;
+        if (nsel > 0) entry = nodeIdx;                                /* :463-465: the node's lower-level lists are still empty,
+                                                                         so the next search returns the node itself */
+    }
+    free(buf);
+    return 0;
+}
+
+static void connect_apply(qvo_hnsw* h, uint32_t nodeIdx, const plan_t* pl) {
+    for (int lc = pl->top; lc >= 0; lc--) {
+        int nsel = pl->nsel[lc];
+        if (nsel == 0) continue;
+        int maxConn = lc == 0 ? h->maxM0 : h->M;
+        node_t* nn = &h->nodes[nodeIdx];
+        for (int i = 0; i < nsel; i++) conn_append(nn, lc, pl->sel[lc][i]);      /* :407-409 */
+        for (int i = 0; i < nsel; i++) {                              /* :413 */
+            uint32_t nb = pl->sel[lc][i];
+            if (!node_ok(h, nb)) continue;
+            node_t* nbn = &h->nodes[nb];
+            if (lc > nbn->level) continue;                            /* :420-422 */
+            conn_append(nbn, lc, nodeIdx);                            /* :426 */
+            if ((int)nbn->conn_len[lc] > maxConn) {                   /* :429 */
+                int cn = (int)nbn->conn_len[lc];
+                res_t* nd = (res_t*)malloc((size_t)cn * sizeof(res_t)); int m = 0;
+                for (int j = 0; j < cn; j++) {
+                    uint32_t ci = nbn->conn[lc][j];
+                    if (!node_ok(h, ci)) continue;
+                    nd[m].dist = dist(h, nbn->vec, h->nodes[ci].vec); nd[m].idx = ci; m++;   /* :438 */
+                }
+                int keep = select_neighbors(nd, m, maxConn);          /* :451 */
+                nbn->conn_len[lc] = 0;
+                for (int j = 0; j < keep; j++) conn_append(nbn, lc, nd[j].idx);
+                free(nd);
+            }
+        }
+    }
+}
+
+int64_t qvo_hnsw_insert_batch(qvo_hnsw* h, const float* vecs, uint32_t n) {
+    if (n == 0) return (int64_t)h->n_nodes;
+    if (h->n_nodes == 0) {                                            /* the first node has nothing to search (:306-311) */
+        if (qvo_hnsw_insert(h, vecs) < 0) return -1;
+        if (n == 1) return 0;
+        int64_t r = qvo_hnsw_insert_batch(h, vecs + h->dim, n - 1);
+        return r < 0 ? r : 0;
+    }
+    const uint32_t first = h->n_nodes;
+    const int snapLevel = h->cur_level;                               /* every batch node's oldCurrentLevel (:276) */
+    uint32_t snapEntry = h->entry;
+    if (!node_ok(h, snapEntry)) {                                     /* :356-364 */
+        for (uint32_t i = 0; i < first; i++) if (h->nodes[i].alive) { snapEntry = i; break; }
+    }
+    while (h->n_nodes + n > h->cap_nodes) { h->cap_nodes = h->cap_nodes ? h->cap_nodes * 2 : 1024; h->nodes = (node_t*)realloc(h->nodes, (size_t)h->cap_nodes * sizeof(node_t)); }
+    for (uint32_t i = 0; i < n; i++) {                                /* :275-303, in node order */
+        int level = qvo_hnsw_random_level(h);
+        node_t* nd = &h->nodes[first + i];
+        nd->vec = (float*)malloc(h->dim * sizeof(float)); memcpy(nd->vec, vecs + (size_t)i * h->dim, h->dim * sizeof(float));
+        nd->level = level; nd->alive = 1; nd->borrowed = 0;
+        nd->conn = (uint32_t**)calloc((size_t)level + 1, sizeof(uint32_t*));
+        nd->conn_len = (uint32_t*)calloc((size_t)level + 1, sizeof(uint32_t));
+        nd->conn_cap = (uint32_t*)calloc((size_t)level + 1, sizeof(uint32_t));
+    }
+    h->n_nodes += n; h->size += n;
+    plan_t* plans = (plan_t*)calloc(n, sizeof(plan_t));
+    int rc = 0;
+    for (uint32_t i = 0; i < n && rc == 0; i++)                       /* searches: the graph before the batch */
+        rc = connect_search(h, first + i, h->nodes[first + i].vec, h->nodes[first + i].level, snapLevel, snapEntry, &plans[i]);
+    for (uint32_t i = 0; i < n && rc == 0; i++) {                     /* links: node by node */
+        connect_apply(h, first + i, &plans[i]);
+        int level = h->nodes[first + i].level;
+        if (level > snapLevel && level > h->cur_level) { h->entry = first + i; h->cur_level = level; }   /* :325-332 */
+    }
+    for (uint32_t i = 0; i < n; i++) { for (int l = 0; l < plans[i].n_lv; l++) free(plans[i].sel[l]); free(plans[i].sel); free(plans[i].nsel); }
+    free(plans);
+    return rc == 0 ? (int64_t)first : -1;
+}
+
+/* Test scaffolding, not a reference function: install a ready-made MULTI-level graph in the flat form of
+ * include/qv.h (qv_graph_export): levels[n], level-0 degree/links, and per (node, level >= 1) blocks of
+ * (1 + max_m) words — so the CPU traversal can walk the very graph the device built.  `rows` is BORROWED. */
+int qvo_hnsw_load_graph(qvo_hnsw* h, uint32_t n, const float* rows, const int8_t* levels, uint32_t max_m0, uint32_t max_m,
+                        const uint32_t* l0_deg, const uint32_t* l0_links, const uint32_t* up_off, const uint32_t* up_links,
+                        uint32_t entry, int cur_level) {
+    if (!h || h->n_nodes != 0 || n == 0 || entry >= n) return -1;
+    h->nodes = (node_t*)calloc(n, sizeof(node_t)); h->cap_nodes = n;
+    uint32_t live = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        node_t* nd = &h->nodes[i];
+        nd->vec = (float*)(rows + (size_t)i * h->dim); nd->borrowed = 1;
+        int lv = levels[i];
+        nd->alive = lv >= 0; if (lv < 0) lv = 0; else live++;
+        nd->level = lv;
+        nd->conn = (uint32_t**)calloc((size_t)lv + 1, sizeof(uint32_t*));
+        nd->conn_len = (uint32_t*)calloc((size_t)lv + 1, sizeof(uint32_t));
+        nd->conn_cap = (uint32_t*)calloc((size_t)lv + 1, sizeof(uint32_t));
+        for (int l = 0; l <= lv; l++) {
+            uint32_t d; const uint32_t* src;
+            if (l == 0) { d = l0_deg[i] < max_m0 ? l0_deg[i] : max_m0; src = l0_links + (size_t)i * max_m0; }
+            else { const uint32_t* blk = up_links + (size_t)(up_off[i] + (uint32_t)(l - 1)) * (1 + max_m); d = blk[0] < max_m ? blk[0] : max_m; src = blk + 1; }
+            if (!nd->alive) d = 0;
+            nd->conn[l] = (uint32_t*)malloc((d ? d : 1) * sizeof(uint32_t));
+            memcpy(nd->conn[l], src, d * sizeof(uint32_t));
+            nd->conn_len[l] = d; nd->conn_cap[l] = d ? d : 1;
+        }
+    }
+    h->n_nodes = n; h->size = live; h->entry = entry; h->cur_level = cur_level;
+    return 0;
+}
+
 /* Test scaffolding, not a reference function: install a ready-made single-layer graph (every node at
  * level 0, links as given) so that Search (hnsw.go:602-713) can be run on graphs that were not built by
  * Insert — e.g. an exact k-NN graph at a size where the sequential reference build is impractical.

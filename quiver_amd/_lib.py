@@ -17,6 +17,8 @@ QV_FLAG_ROWMAJOR = 1
 METRICS = {
     "cosine": 0, "euclidean": 1, "squared_euclidean": 2, "dot_product": 3, "manhattan": 4,
     "hnsw_cosine": 5, "hnsw_euclidean": 6, "hnsw_dot_product": 7, "arrow_squared_euclidean": 8,
+    # short names (the qv_metric enumerators of include/qv.h)
+    "l2": 1, "l2sq": 2, "dot": 3, "l1": 4, "cosine_f32": 5, "l2_f32": 6, "dot_f32": 7, "l2sq_f64": 8,
 }
 
 
@@ -67,6 +69,13 @@ PROTOTYPES = {
     "qv_graph_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_graph_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_graph_destroy": (None, [C.c_void_p]),
+    "qv_graph_batch_size": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "qv_graph_create_empty": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "qv_graph_insert": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "qv_graph_build": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "qv_graph_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p, _u32p, _u32p, C.POINTER(C.c_int)]),
+    "qv_graph_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qv_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "qv_index_get_row": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "qv_last_error": (C.c_char_p, []),
     "qv_abi_version": (C.c_int, []),

@@ -7,126 +7,18 @@
 // not serialise, and per-stream workspaces for the *_device entry points.
 // There is NO CPU compute path here: every distance and every selection runs in
 // a HIP kernel, and a missing/failed HIP runtime is a loud error, never a fallback.
-#include "../../include/qv.h"
-#include "qv_device.h"
-
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <chrono>
-#include <mutex>
-#include <new>
-#include <vector>
+#include "qv_api_internal.h"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
-int fail(int code, const char* fmt, ...) {
+int qv_fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-
-#define HIPCHK(call)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(e_ == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
-    } while (0)
-
-struct Buf {            // growable device buffer
-    void* p = nullptr; size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return QV_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = std::max(bytes, (size_t)4096);
-        HIPCHK(hipMalloc(&p, want));
-        cap = want; return QV_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-struct PinBuf {         // growable pinned host buffer
-    void* p = nullptr; size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return QV_OK;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        size_t want = std::max(bytes, (size_t)4096);
-        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
-        cap = want; return QV_OK;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct Workspace { Buf ws; };
-
-struct SearchCtx {
-    hipStream_t stream = nullptr;
-    Buf d_q, d_rows, d_dist, d_ids, d_mask, ws;
-    PinBuf h_q, h_rows, h_dist, h_ids, h_mask;
-    void release() {
-        d_q.release(); d_rows.release(); d_dist.release(); d_ids.release(); d_mask.release(); ws.release();
-        h_q.release(); h_rows.release(); h_dist.release(); h_ids.release(); h_mask.release();
-        if (stream) (void)hipStreamDestroy(stream);
-        stream = nullptr;
-    }
-};
-
-}  // namespace
-
-struct qv_index {
-    int device = 0;
-    int cus = 256;
-    uint32_t dim = 0, dim4 = 0;
-    int metric = QV_COSINE;
-    uint64_t flags = 0;
-    uint32_t n_rows = 0, n_live = 0;
-    uint64_t cap_tiles = 0;
-    float* d_tiles = nullptr;
-    double* d_rnorm = nullptr;
-    uint64_t* d_alive = nullptr;
-    float* d_rowmaj = nullptr;
-    std::vector<uint64_t> alive_host;          // mirror of d_alive, for size bookkeeping and validation
-    Buf mut_stage;                             // grow-only staging buffer of the mutating calls (add / remove / update run under the
-                                               // caller's exclusion, so one buffer serves them all: no hipMalloc per single-row Insert)
-
-    std::mutex ctx_mu;
-    std::vector<SearchCtx*> free_ctx;
-    std::vector<SearchCtx*> all_ctx;
-    uint64_t batched_redo = 0;                 // queries the MFMA path handed back to the exact scan
-    bool profiling = false;                    // qv_index_profile: event pairs around scan kernels
-    std::mutex prof_mu;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-    std::mutex ws_mu;
-    std::map<hipStream_t, Workspace*> stream_ws;   // workspaces of the *_device entry points, one per caller stream
-
-    qv::IndexView view() const {
-        qv::IndexView v;
-        v.tiles = d_tiles; v.rnorm = d_rnorm; v.alive = d_alive; v.rowmaj = d_rowmaj;
-        v.dim = dim; v.dim4 = dim4; v.n_rows = n_rows; v.n_tiles = (n_rows + 63) / 64; v.metric = metric;
-        return v;
-    }
-    size_t tile_bytes() const { return (size_t)dim4 * 64 * 16; }
-};
-
-struct qv_graph {
-    qv_index* idx = nullptr;
-    qv::GraphView g{};
-    void *d_level = nullptr, *d_l0deg = nullptr, *d_l0links = nullptr, *d_upoff = nullptr, *d_uplinks = nullptr;
-    uint32_t* d_visited = nullptr;
-    uint32_t grid = 0, heap_grid = 0;           // wave slots: the wave-resident kernel / the exact-heap kernel
-    uint32_t epoch = 0;
-    uint64_t tie_reruns = 0;
-    std::mutex mu;                              // one batch at a time (the visited stamps are per wave slot)
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_last = nullptr;               // end of the most recent traversal: the next one (on any stream) waits for it
-    Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev;
-    PinBuf h_stage[2];                          // pinned bounce buffers for the query upload (pageable callers)
-    hipEvent_t ev_stage[2] = {nullptr, nullptr};
-};
 
 namespace {
 
@@ -773,179 +665,6 @@ int qv_distance_rows(qv_index* idx, const float* query, const uint32_t* rows, ui
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_rows launch failed: %s", hipGetErrorString(e));
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(dist_out, c->h_dist.p, obytes);
-    return QV_OK;
-}
-
-int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_t* levels, uint32_t max_m0, uint32_t max_m,
-                    const uint32_t* l0_deg, const uint32_t* l0_links, const uint32_t* up_off, const uint32_t* up_links,
-                    uint32_t n_up_blocks, uint32_t entry, int cur_level) {
-    if (!out) return fail(QV_ERR_INVALID_ARG, "out is null");
-    *out = nullptr;
-    if (!idx || !levels || !l0_deg || !l0_links || !up_off) return fail(QV_ERR_INVALID_ARG, "null argument");
-    if (n_nodes == 0 || n_nodes > idx->n_rows) return fail(QV_ERR_INVALID_ARG, "graph has %u nodes but the index holds %u rows", n_nodes, idx->n_rows);
-    if (max_m0 == 0 || max_m0 > 64 || max_m > 64) return fail(QV_ERR_UNSUPPORTED, "degree bounds above 64 are not supported (MaxM0=%u, M=%u)", max_m0, max_m);
-    if (entry >= n_nodes || levels[entry] < 0) return fail(QV_ERR_INVALID_ARG, "entry point %u is not a live node", entry);
-    HIPCHK(hipSetDevice(idx->device));
-    qv_graph* g = new (std::nothrow) qv_graph();
-    if (!g) return fail(QV_ERR_OOM, "out of host memory");
-    g->idx = idx;
-    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
-        if (e == hipSuccess && bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
-        return e;
-    };
-    hipError_t e = up(&g->d_level, levels, (size_t)n_nodes);
-    if (e == hipSuccess) e = up(&g->d_l0deg, l0_deg, (size_t)n_nodes * 4);
-    if (e == hipSuccess) e = up(&g->d_l0links, l0_links, (size_t)n_nodes * max_m0 * 4);
-    if (e == hipSuccess) e = up(&g->d_upoff, up_off, (size_t)n_nodes * 4);
-    if (e == hipSuccess) e = up(&g->d_uplinks, up_links, (size_t)n_up_blocks * (1 + max_m) * 4);
-    // visited stamps: one uint32 per (wave slot, node) — sized for 288 GB HBM: 16 GB at 1M nodes x 4096 slots;
-    // never more than half of what is free (fewer resident queries instead)
-    g->heap_grid = qv::hnsw_grid(idx->cus, idx->metric, idx->dim4, 0xFFFFFFFFu);
-    g->grid = std::max(g->heap_grid, qv::hnsw_wave_grid(idx->cus, idx->metric, idx->dim4));
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)32 << 30;
-    while (g->grid > 64 && (size_t)g->grid * n_nodes * 4 > free_b / 2) g->grid /= 2;
-    g->heap_grid = std::min(g->heap_grid, g->grid);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_visited), (size_t)g->grid * n_nodes * 4);
-    if (e == hipSuccess) e = hipMemset(g->d_visited, 0, (size_t)g->grid * n_nodes * 4);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_last, hipEventDisableTiming);
-    if (e != hipSuccess) { qv_graph_destroy(g); return fail(e == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "graph upload failed: %s", hipGetErrorString(e)); }
-    g->g.level = static_cast<const int8_t*>(g->d_level); g->g.l0_deg = static_cast<const uint32_t*>(g->d_l0deg);
-    g->g.l0_links = static_cast<const uint32_t*>(g->d_l0links); g->g.up_off = static_cast<const uint32_t*>(g->d_upoff);
-    g->g.up_links = static_cast<const uint32_t*>(g->d_uplinks);
-    g->g.n_nodes = n_nodes; g->g.max_m0 = max_m0; g->g.max_m = max_m ? max_m : 1; g->g.entry = entry; g->g.cur_level = cur_level;
-    *out = g;
-    return QV_OK;
-}
-
-void qv_graph_destroy(qv_graph* g) {
-    if (!g) return;
-    if (g->idx) (void)hipSetDevice(g->idx->device);
-    if (g->ev_last) { (void)hipEventSynchronize(g->ev_last); (void)hipEventDestroy(g->ev_last); }
-    for (int i = 0; i < 2; i++) { if (g->ev_stage[i]) (void)hipEventDestroy(g->ev_stage[i]); g->h_stage[i].release(); }
-    if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
-    (void)hipFree(g->d_level); (void)hipFree(g->d_l0deg); (void)hipFree(g->d_l0links); (void)hipFree(g->d_upoff); (void)hipFree(g->d_uplinks);
-    (void)hipFree(g->d_visited);
-    g->d_q.release(); g->d_qblk.release(); g->d_rows.release(); g->d_dist.release(); g->d_cnt.release(); g->d_ev.release();
-    delete g;
-}
-
-int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
-                    uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out) {
-    if (!g) return fail(QV_ERR_INVALID_ARG, "graph is null");
-    if (nq == 0) return QV_OK;
-    if (!queries || !rows_out || !dist_out || !count_out) return fail(QV_ERR_INVALID_ARG, "null argument");
-    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");                      // hnsw.go:610-612
-    if (k > 512 || ef_search > 512) return fail(QV_ERR_UNSUPPORTED, "k and efSearch above 512 are not supported on the device path");
-    qv_index* idx = g->idx;
-    HIPCHK(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> lock(g->mu);
-    const size_t qbytes = (size_t)nq * idx->dim * sizeof(float), obytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
-    int rc;
-    if ((rc = g->d_q.ensure(qbytes)) || (rc = g->d_rows.ensure(obytes)) || (rc = g->d_dist.ensure(obytes)) || (rc = g->d_cnt.ensure(cbytes)) ||
-        (rc = g->d_ev.ensure(cbytes)) || (rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4))))
-        return rc;
-    const uint32_t grid = std::min(g->grid, nq);
-    const uint32_t per_wave = (nq + std::min(grid, std::max(1u, g->heap_grid)) - 1) / std::min(grid, std::max(1u, g->heap_grid));
-    const uint64_t need = (uint64_t)per_wave * 256 + 256;                 // stamps consumed by this batch per wave slot (both passes)
-    if ((uint64_t)g->epoch + need >= 0xFFFFFF00ull) {                      // wrap: clear and restart
-        HIPCHK(hipMemsetAsync(g->d_visited, 0, (size_t)g->grid * g->g.n_nodes * 4, g->stream));
-        g->epoch = 0;
-    }
-    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_last, 0));               // after any device-form traversal still running on another stream
-    static const bool trace = getenv("QV_TRACE") && atoi(getenv("QV_TRACE")) > 0;
-    const auto t_begin = std::chrono::steady_clock::now();
-    {   // upload through two pinned bounce buffers: the CPU copy of slice i+1 overlaps the DMA of slice i
-        // (a single hipMemcpyAsync from pageable memory ran at 2.5-5 GB/s: a third of a 16k-query batch's time)
-        const size_t slice = (size_t)8 << 20;
-        size_t off = 0; int slot = 0;
-        while (off < qbytes) {
-            const size_t n = std::min(slice, qbytes - off);
-            if ((rc = g->h_stage[slot].ensure(slice))) return rc;
-            if (!g->ev_stage[slot]) HIPCHK(hipEventCreateWithFlags(&g->ev_stage[slot], hipEventDisableTiming));
-            else HIPCHK(hipEventSynchronize(g->ev_stage[slot]));        // the DMA that last read this buffer is done
-            memcpy(g->h_stage[slot].p, reinterpret_cast<const unsigned char*>(queries) + off, n);
-            HIPCHK(hipMemcpyAsync(static_cast<unsigned char*>(g->d_q.p) + off, g->h_stage[slot].p, n, hipMemcpyHostToDevice, g->stream));
-            HIPCHK(hipEventRecord(g->ev_stage[slot], g->stream));
-            off += n; slot ^= 1;
-        }
-    }
-    if (trace) { (void)hipStreamSynchronize(g->stream); fprintf(stderr, "qv: graph search upload %.3f ms (%zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), qbytes); }
-    const auto t_p1 = std::chrono::steady_clock::now();
-    // pass 1: wave-resident traversal (list in registers, rows streamed through LDS); queries that meet equal distances / NaN report 0xFFFFFFFE
-    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, static_cast<const float*>(g->d_q.p), g->d_qblk.p, nq, k, ef_search, g->d_visited, grid, g->epoch,
-                                               static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
-                                               static_cast<uint32_t*>(g->d_ev.p), g->stream);
-    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
-    g->epoch += (uint32_t)need / 2;
-    HIPCHK(hipMemcpyAsync(rows_out, g->d_rows.p, obytes, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipMemcpyAsync(dist_out, g->d_dist.p, obytes, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipMemcpyAsync(count_out, g->d_cnt.p, cbytes, hipMemcpyDeviceToHost, g->stream));
-    if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, g->d_ev.p, cbytes, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
-    if (trace) fprintf(stderr, "qv: graph search pass 1 + download %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p1).count());
-    const auto t_p2 = std::chrono::steady_clock::now();
-    // pass 2: the exact-heap kernel for the flagged queries (heap pop order under ties depends on the heap layout)
-    std::vector<uint32_t> redo;
-    for (uint32_t q = 0; q < nq; q++) if (count_out[q] == 0xFFFFFFFEu) redo.push_back(q);
-    if (!redo.empty()) {
-        g->tie_reruns += redo.size();
-        const uint32_t m = (uint32_t)redo.size();
-        std::vector<float> rq((size_t)m * idx->dim);
-        for (uint32_t i = 0; i < m; i++) memcpy(&rq[(size_t)i * idx->dim], queries + (size_t)redo[i] * idx->dim, idx->dim * sizeof(float));
-        std::vector<uint32_t> rr((size_t)m * k), rc(m), rev(m);
-        std::vector<float> rd((size_t)m * k);
-        HIPCHK(hipMemcpyAsync(g->d_q.p, rq.data(), rq.size() * sizeof(float), hipMemcpyHostToDevice, g->stream));
-        e = qv::launch_hnsw_search(idx->view(), g->g, static_cast<const float*>(g->d_q.p), g->d_qblk.p, m, k, ef_search, g->d_visited, std::min(g->heap_grid, m), g->epoch,
-                                   static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
-                                   static_cast<uint32_t*>(g->d_ev.p), g->stream);
-        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
-        g->epoch += (uint32_t)need / 2;
-        HIPCHK(hipMemcpyAsync(rr.data(), g->d_rows.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipMemcpyAsync(rd.data(), g->d_dist.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipMemcpyAsync(rc.data(), g->d_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipMemcpyAsync(rev.data(), g->d_ev.p, (size_t)m * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipStreamSynchronize(g->stream));
-        for (uint32_t i = 0; i < m; i++) {
-            memcpy(rows_out + (size_t)redo[i] * k, &rr[(size_t)i * k], (size_t)k * 4);
-            memcpy(dist_out + (size_t)redo[i] * k, &rd[(size_t)i * k], (size_t)k * 4);
-            count_out[redo[i]] = rc[i];
-            if (evals_out) evals_out[redo[i]] = rev[i];
-        }
-    }
-    if (trace) fprintf(stderr, "qv: graph search pass 2 (%zu tie-flagged queries) %.3f ms\n", redo.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p2).count());
-    return QV_OK;
-}
-
-int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef_search,
-                           uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_count_out, uint32_t* d_evals_out, void* stream) {
-    if (!g) return fail(QV_ERR_INVALID_ARG, "graph is null");
-    if (nq == 0) return QV_OK;
-    if (!d_queries || !d_rows_out || !d_dist_out || !d_count_out) return fail(QV_ERR_INVALID_ARG, "null device pointer");
-    if (k == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive");                      // hnsw.go:610-612
-    if (k > 512 || ef_search > 512) return fail(QV_ERR_UNSUPPORTED, "k and efSearch above 512 are not supported on the device path");
-    qv_index* idx = g->idx;
-    HIPCHK(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> lock(g->mu);
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : g->stream;
-    // the visited stamps and the converted-query workspace belong to one traversal at a time: order this one after the last
-    HIPCHK(hipStreamWaitEvent(s, g->ev_last, 0));
-    int rc;
-    if ((rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4)))) return rc;
-    const uint32_t grid = std::min(g->grid, nq);
-    const uint32_t per_wave = (nq + grid - 1) / grid;
-    const uint64_t need = (uint64_t)per_wave * 128 + 128;                  // stamps consumed by this batch per wave slot
-    if ((uint64_t)g->epoch + need >= 0xFFFFFF00ull) {
-        HIPCHK(hipMemsetAsync(g->d_visited, 0, (size_t)g->grid * g->g.n_nodes * 4, s));
-        g->epoch = 0;
-    }
-    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, d_queries, g->d_qblk.p, nq, k, ef_search, g->d_visited, grid, g->epoch,
-                                               d_rows_out, d_dist_out, d_count_out, d_evals_out, s);
-    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
-    g->epoch += (uint32_t)need;
-    HIPCHK(hipEventRecord(g->ev_last, s));
     return QV_OK;
 }
 

@@ -1,0 +1,99 @@
+// qv_api_internal.h — shared by the C-ABI translation units (qv_api.cpp: indexes; qv_graph_api.cpp: HNSW graphs;
+// qv_sharded_api.cpp: multi-GPU shards).  Not installed.
+#pragma once
+#include "../../include/qv.h"
+#include "qv_device.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <chrono>
+#include <mutex>
+#include <new>
+#include <vector>
+
+int qv_fail(int code, const char* fmt, ...);      // sets the thread-local message, returns code
+#define fail qv_fail
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Buf {            // growable device buffer
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return QV_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(bytes, (size_t)4096);
+        HIPCHK(hipMalloc(&p, want));
+        cap = want; return QV_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct PinBuf {         // growable pinned host buffer
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return QV_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(bytes, (size_t)4096);
+        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want; return QV_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct Workspace { Buf ws; };
+
+struct SearchCtx {
+    hipStream_t stream = nullptr;
+    Buf d_q, d_rows, d_dist, d_ids, d_mask, ws;
+    PinBuf h_q, h_rows, h_dist, h_ids, h_mask;
+    void release() {
+        d_q.release(); d_rows.release(); d_dist.release(); d_ids.release(); d_mask.release(); ws.release();
+        h_q.release(); h_rows.release(); h_dist.release(); h_ids.release(); h_mask.release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
+
+struct qv_index {
+    int device = 0;
+    int cus = 256;
+    uint32_t dim = 0, dim4 = 0;
+    int metric = QV_COSINE;
+    uint64_t flags = 0;
+    uint32_t n_rows = 0, n_live = 0;
+    uint64_t cap_tiles = 0;
+    float* d_tiles = nullptr;
+    double* d_rnorm = nullptr;
+    uint64_t* d_alive = nullptr;
+    float* d_rowmaj = nullptr;
+    std::vector<uint64_t> alive_host;          // mirror of d_alive, for size bookkeeping and validation
+    Buf mut_stage;                             // grow-only staging buffer of the mutating calls (add / remove / update run under the
+                                               // caller's exclusion, so one buffer serves them all: no hipMalloc per single-row Insert)
+
+    std::mutex ctx_mu;
+    std::vector<SearchCtx*> free_ctx;
+    std::vector<SearchCtx*> all_ctx;
+    uint64_t batched_redo = 0;                 // queries the MFMA path handed back to the exact scan
+    bool profiling = false;                    // qv_index_profile: event pairs around scan kernels
+    std::mutex prof_mu;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::mutex ws_mu;
+    std::map<hipStream_t, Workspace*> stream_ws;   // workspaces of the *_device entry points, one per caller stream
+
+    qv::IndexView view() const {
+        qv::IndexView v;
+        v.tiles = d_tiles; v.rnorm = d_rnorm; v.alive = d_alive; v.rowmaj = d_rowmaj;
+        v.dim = dim; v.dim4 = dim4; v.n_rows = n_rows; v.n_tiles = (n_rows + 63) / 64; v.metric = metric;
+        return v;
+    }
+    size_t tile_bytes() const { return (size_t)dim4 * 64 * 16; }
+};
+

@@ -45,6 +45,31 @@ struct GraphView {
     uint32_t entry; int cur_level;
 };
 
+// Extras of the traversal kernels beyond a plain Search: the build's per-query stop level, the device-side redo list of
+// the exact-heap pass, and the visited-set storage (qv_hnsw.hip).
+struct HnswOpts {
+    const int8_t*   qlevel    = nullptr;  // build: level of the node query i stands for; the query stops at
+                                          // min(qlevel[i], cur_level) and searches THAT level with ef (hnsw.go:383-385)
+    uint32_t        qnode0    = 0;        // build: node index of query 0 (query i is node qnode0 + i)
+    float*          self_dist = nullptr;  // build: [nq] distance(node, node), written when the stop level is >= 1
+    const uint32_t* redo_idx  = nullptr;  // heap kernel: the queries to run (null = all nq)
+    const uint32_t* redo_n    = nullptr;  // heap kernel: how many of them (device word)
+    uint32_t*       vis       = nullptr;  // visited storage: [slots][vis_cap] hash entries / [slots][vis_cap] bitmap words
+    uint32_t        vis_cap   = 0;        // per slot: hash entries (power of two) / bitmap words
+};
+
+// the mutable arrays of a graph under construction (qv_build.hip); every link carries its distance
+struct BuildView {
+    int8_t*   level;      // [cap_nodes]
+    uint32_t* l0_deg;     // [cap_nodes]
+    uint32_t* l0_links;   // [cap_nodes][max_m0]
+    float*    l0_dist;    // [cap_nodes][max_m0]
+    uint32_t* up_off;     // [cap_nodes]
+    uint32_t* up_links;   // [blocks][1 + max_m]
+    float*    up_dist;    // [blocks][max_m]
+    uint32_t  cap_nodes, max_m0, max_m;
+};
+
 struct ScanPlan {
     uint32_t grid;        // workgroups
     uint32_t block;       // threads (multiple of 64)
@@ -98,17 +123,19 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
                           hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // Device-resident HNSW traversal (hnsw.go:471-713), one wave per query.
-size_t   hnsw_lds_bytes(int metric, uint32_t dim4);
-uint32_t hnsw_grid(int cus, int metric, uint32_t dim4, uint32_t nq);
+size_t   hnsw_lds_bytes(uint32_t ef);
+uint32_t hnsw_grid(int cus, uint32_t ef, uint32_t nq);
+// prep = also convert the queries into d_qblk (false: d_qblk already holds them, e.g. the redo pass of the same batch)
 hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
-                              uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                              const HnswOpts& o, uint32_t grid, bool prep, uint32_t* d_rows_out, float* d_dist_out,
                               uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s);
+uint32_t hnsw_vis_hash_cap(uint32_t ef);                 // hash entries per wave slot for a search with this ef
 
 // wave-resident form (no LDS heaps); count_out = 0xFFFFFFFE for queries that met equal distances / NaN
 uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4);
 size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4);   // workspace for the converted queries + per-query constants
 hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
-                                   uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                                   const HnswOpts& o, uint32_t grid, uint32_t* d_rows_out, float* d_dist_out,
                                    uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s);
 
 // Full ranking path (any k): all distances -> 64-bit keys -> stable radix sort -> first k.
@@ -116,6 +143,16 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
 size_t  full_sort_workspace_bytes(uint32_t n_tiles);
 hipError_t launch_flat_fullsort(const IndexView& v, const ScanPlan& p, const float* d_query, uint32_t k,
                                 void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
+
+// stable sort of n 64-bit keys by their upper 32 bits; hist: radix_hist_words(n) words; *sorted_out = a or b
+size_t radix_hist_words(uint32_t n);
+hipError_t launch_radix_sort_hi32(uint64_t* a, uint64_t* b, uint32_t n, uint32_t* hist, uint64_t** sorted_out, hipStream_t s);
+
+// HNSW construction, link phase of one batch (qv_build.hip).  d_counters: [0] redo count, [1] segment count, [2] status bits
+hipError_t launch_build_compact_redo(const uint32_t* d_count, uint32_t n, uint32_t* d_redo_idx, uint32_t* d_redo_n, hipStream_t s);
+hipError_t launch_build_links(const BuildView& b, uint32_t first, uint32_t n, int cur_level, const uint32_t* d_rows, const float* d_dist,
+                              const uint32_t* d_count, const float* d_self, uint64_t* d_keys_a, uint64_t* d_keys_b, uint32_t* d_hist,
+                              uint32_t* d_seg_start, uint32_t* d_counters, uint32_t merge_grid, hipStream_t s);
 
 // distance of one query to n listed rows (lane == listed row, sequential accumulation)
 hipError_t launch_distance_rows(const IndexView& v, const float* d_query, const uint32_t* d_rows, uint32_t n,

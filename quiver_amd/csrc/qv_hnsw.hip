@@ -19,6 +19,44 @@ constexpr int kHnswCandCap = 2048;     // candidate min-heap slots per query (ov
 constexpr int kHnswEfMax = 512;
 constexpr int kHnswMaxDeg = 64;
 
+// ---- visited sets ---------------------------------------------------------------------------------------------------
+// searchLayer's visited map (hnsw.go:483-488) is per call and holds only the nodes the call evaluated, so its device form
+// is sized by the SEARCH, not by the graph:
+//   wave kernel  : an open-addressed hash table of `vis_cap` node ids per wave slot in global memory (L2/MALL-resident:
+//                  32-64 KiB per slot), test-and-set by one atomicCAS per probe — lanes of a hop insert their neighbours
+//                  concurrently, a duplicate inside one adjacency list (the self-link quirk) resolves itself: one lane
+//                  gets EMPTY back, the other the node id.  Cleared by the wave at the start of every searchLayer.  A
+//                  search that fills 3/4 of the table is flagged for the exact-heap kernel like a tie.
+//   heap kernel  : one bit per node per slot (n/8 bytes), atomicOr test-and-set: never overflows, and the few slots of this
+//                  kernel keep it small (1.25 MB per slot at 10M nodes).
+// (Round 1 kept a uint32 stamp per (slot, node): 16 GB at 1M nodes x 4096 slots, unusable at 10M.)
+constexpr uint32_t kVisEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kVisGreedyCap = 1024;   // table entries used by an ef = 1 (greedy, upper-level) search
+__device__ __forceinline__ void vis_hash_clear(uint32_t* tab, uint32_t cap, uint32_t lane) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 e = {kVisEmpty, kVisEmpty, kVisEmpty, kVisEmpty};
+    for (uint32_t i = lane * 4; i < cap; i += 256) *reinterpret_cast<u4*>(tab + i) = e;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clears are in L2 before the first atomic probes it
+}
+// true if `node` was not in the table (and now is)
+__device__ __forceinline__ bool vis_hash_insert(uint32_t* tab, uint32_t mask, uint32_t shift, uint32_t node) {
+    uint32_t h = (node * 0x9E3779B1u) >> shift;
+    for (;;) {
+        const uint32_t old = atomicCAS(&tab[h], kVisEmpty, node);
+        if (old == kVisEmpty) return true;
+        if (old == node) return false;
+        h = (h + 1) & mask;
+    }
+}
+__device__ __forceinline__ void vis_bits_clear(uint32_t* bm, uint32_t words, uint32_t lane) {
+    for (uint32_t i = lane; i < words; i += 64) bm[i] = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ bool vis_bits_insert(uint32_t* bm, uint32_t node) {
+    const uint32_t bit = 1u << (node & 31);
+    return (atomicOr(&bm[node >> 5], bit) & bit) == 0;
+}
+
 // The reference's container/heap sifts (hnsw.go:101-196), comparison for comparison; the moving element is held in
 // registers and only the displaced child / parent is written per level ("hole" form: same comparisons, same final array).
 __device__ __forceinline__ void h_min_up(HRes* rs, int j) {                      // hnsw.go:118-128
@@ -218,27 +256,31 @@ __device__ __forceinline__ float hnsw_eval_rows(const IndexView& v, const lds_u3
 #endif
 
 // one wave (64-thread workgroup) per query stream
+// Build mode (o.qlevel != null, connectNode's searches hnsw.go:367-385): query i stands for node o.qnode0 + i, descends
+// greedily to min(level, cur_level) and searches THAT level with ef exactly; the ascending result is re-ordered inside
+// equal-distance runs by node index (selectNeighbors' order, hnsw.go:589-594) and cut to the level's degree bound.
 template <int M, int U>
 __global__ void __launch_bounds__(64)
 k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t nq, uint32_t k, uint32_t ef_search,
-              uint32_t* __restrict__ visited /*[gridDim.x][n_nodes]*/, uint32_t epoch0,
+              HnswOpts o, uint32_t cand_cap,
               uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     // LDS: two row slabs (hnsw_eval_rows) | candidate heap | result heap | the hop's batch | its distances
     lds_u8* slabs_l = (lds_u8*)smem;
     unsigned char* base = smem + 2 * kHnswSlabBytes;
-    HRes* cand = reinterpret_cast<HRes*>(base);                       // [kHnswCandCap]
-    HRes* res = cand + kHnswCandCap;                                  // [kHnswEfMax + 1]
+    HRes* cand = reinterpret_cast<HRes*>(base);                       // [cand_cap]
+    HRes* res = cand + cand_cap;                                      // [kHnswEfMax + 1]
     uint32_t* batch = reinterpret_cast<uint32_t*>(res + kHnswEfMax + 1);   // [kHnswMaxDeg]
     float* bd = reinterpret_cast<float*>(batch + kHnswMaxDeg);        // [kHnswMaxDeg]
-    const lds_u32* batch_l = (const lds_u32*)((lds_u8*)smem + 2 * kHnswSlabBytes + (size_t)(kHnswCandCap + kHnswEfMax + 1) * sizeof(HRes));
+    const lds_u32* batch_l = (const lds_u32*)((lds_u8*)smem + 2 * kHnswSlabBytes + (size_t)(cand_cap + kHnswEfMax + 1) * sizeof(HRes));
     const Q* q_g = qblk;
     __shared__ int s_ncand, s_nres, s_state;                           // state: 0 run, 1 done, 2 overflow
     __shared__ uint32_t s_cur;
     const uint32_t lane = threadIdx.x;
-    uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
-    uint32_t epoch = epoch0;
+    uint32_t* bm = o.vis + (size_t)blockIdx.x * o.vis_cap;            // one bit per node
+    const uint32_t bm_words = (g.n_nodes + 31) >> 5;
+    const bool build = o.qlevel != nullptr;
 
     auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
     // distances of batch[0..n) -> bd[0..n); lane i scores batch[i]
@@ -251,8 +293,8 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
     // searchLayer (hnsw.go:471-580); result: res[0..s_nres) ascending; returns false on overflow
     uint32_t n_eval = 0;
     auto search_layer = [&](uint32_t entry, int ef, int level) -> bool {
-        epoch++;
-        if (lane == 0) { vis[entry] = epoch; batch[0] = entry; }
+        vis_bits_clear(bm, bm_words, lane);                            // :483-488
+        if (lane == 0) { (void)vis_bits_insert(bm, entry); batch[0] = entry; }
         __syncthreads();
         eval(1); n_eval += 1;                                          // :492
         if (lane == 0) {
@@ -281,18 +323,16 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                 else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
             }
             uint32_t c = 0xFFFFFFFFu; bool fresh = false;
-            if (lane < deg) {
-                c = links[lane];
-                fresh = alive(c) && vis[c] != epoch;                   // :539-543
-            }
+            if (lane < deg) { c = links[lane]; fresh = alive(c); }     // :539-541
             // a list may hold the same node twice (the self-link quirk): only its first occurrence is new
             for (uint32_t j = 0; j + 1 < deg; j++) {
                 uint32_t cj = __builtin_amdgcn_readlane(c, j);
                 if (lane > j && c == cj) fresh = false;
             }
+            if (fresh) fresh = vis_bits_insert(bm, c);                 // :543-544
             const uint64_t fm = __ballot(fresh);
             const uint32_t n = (uint32_t)__builtin_popcountll(fm);
-            if (fresh) { vis[c] = epoch; batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c; }   // :544, adjacency order kept
+            if (fresh) batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c;   // adjacency order kept
             __syncthreads();
             if (n == 0) continue;
             eval(n); n_eval += n;                                      // :548 (batched)
@@ -301,7 +341,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                 for (uint32_t i = 0; i < n; i++) {
                     const float cd = bd[i];
                     if (nr < ef || cd < res[0].dist) {                 // :553
-                        if (nc >= kHnswCandCap) { s_state = 2; break; }
+                        if (nc >= (int)cand_cap) { s_state = 2; break; }
                         cand[nc] = {cd, batch[i]}; h_min_up(cand, nc); nc++;          // :554
                         res[nr] = {cd, batch[i]}; h_max_up(res, nr); nr++;            // :555
                         if (nr > ef) { nr--; HRes t = res[0]; res[0] = res[nr]; res[nr] = t; h_max_down(res, 0, nr); }   // :558-560
@@ -320,30 +360,53 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
         return true;
     };
 
-    for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+    const uint32_t n_run = o.redo_n ? *o.redo_n : nq;
+    for (uint32_t ri = blockIdx.x; ri < n_run; ri += gridDim.x) {
+        const uint32_t qi = o.redo_idx ? o.redo_idx[ri] : ri;
         q_g = qblk + (size_t)qi * v.dim4 * 4;
         qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
         n_eval = 0;
         uint32_t entry = g.entry;
         bool ok = true;
-        for (int level = g.cur_level; level > 0 && ok; level--) {       // :649-657
+        int stop = 0;
+        if (build) { stop = (int)o.qlevel[qi]; if (stop > g.cur_level) stop = g.cur_level; }
+        for (int level = g.cur_level; level > stop && ok; level--) {    // :649-657 / :367-380
             ok = search_layer(entry, 1, level);
             if (ok && s_nres > 0) entry = res[0].idx;
             __syncthreads();
         }
-        const int ef = (int)ef_search > (int)k ? (int)ef_search : (int)k;   // :660-663
-        if (ok) ok = search_layer(entry, ef, 0);                        // :664
+        const int ef = build ? (int)ef_search : ((int)ef_search > (int)k ? (int)ef_search : (int)k);   // :660-663 / :385
+        if (ok) ok = search_layer(entry, ef, stop);                     // :664
         uint32_t cnt = 0xFFFFFFFFu;                                     // overflow marker
         if (ok) {
-            cnt = (uint32_t)s_nres < k ? (uint32_t)s_nres : k;          // :670-672 (under-filled: the caller tops up, :676-710)
+            uint32_t kq = k;
+            if (build) {
+                kq = stop == 0 ? g.max_m0 : g.max_m;                    // :395-398
+                if (lane == 0) {                                        // selectNeighbors' (Distance, VectorIndex) order, :589-594
+                    const int nr = s_nres;
+                    for (int i = 1; i < nr; i++) {
+                        const HRes x = res[i]; int j = i;
+                        while (j > 0 && res[j - 1].dist == x.dist && res[j - 1].idx > x.idx) { res[j] = res[j - 1]; j--; }
+                        res[j] = x;
+                    }
+                }
+                __syncthreads();
+            }
+            cnt = (uint32_t)s_nres < kq ? (uint32_t)s_nres : kq;        // :670-672 (under-filled: the caller tops up, :676-710)
             for (uint32_t i = lane; i < k; i += 64) {
                 rows_out[(size_t)qi * k + i] = i < cnt ? res[i].idx : 0xFFFFFFFFu;
                 dist_out[(size_t)qi * k + i] = i < cnt ? res[i].dist : __uint_as_float(0x7F800000u);
             }
+            if (build && stop >= 1 && o.self_dist) {                    // the node's lower levels link to itself (:463-467): d(node, node)
+                __syncthreads();
+                if (lane == 0) batch[0] = o.qnode0 + qi;
+                __syncthreads();
+                eval(1);
+                if (lane == 0) o.self_dist[qi] = bd[0];
+            }
         }
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
         __syncthreads();
-        epoch += 64;                                                    // distinct epochs for the next query of this wave
     }
 }
 
@@ -351,7 +414,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
 template <int M, int U, int S>
 __global__ void __launch_bounds__(64)
 k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t nq, uint32_t k, uint32_t ef_search,
-                   uint32_t* __restrict__ visited, uint32_t epoch0,
+                   HnswOpts o,
                    uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -361,8 +424,8 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     lds_u8* slabs_l = (lds_u8*)(batch_l + 64);                             // 2 x kHnswSlabBytes (row-major index only)
     const Q* q_g = qblk;                                                   // this wave's query, zero-padded to dim4*4, in the metric's Q type
     const uint32_t lane = threadIdx.x;
-    uint32_t* vis = visited + (size_t)blockIdx.x * g.n_nodes;
-    uint32_t epoch = epoch0;
+    uint32_t* tab = o.vis + (size_t)blockIdx.x * o.vis_cap;               // this wave slot's visited hash table
+    const bool build = o.qlevel != nullptr;
     auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
 #ifdef QV_HNSW_PROF
     uint64_t T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_last = __builtin_readcyclecounter(); const uint64_t wc0 = wall_clock64(); uint64_t hops = 0;
@@ -430,13 +493,19 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
         n_eval = 0; tie = false;
         uint32_t entry = g.entry;
+        int stop = 0;                                                   // build: connectNode stops at min(level, graphLevel), hnsw.go:383
+        if (build) { stop = (int)o.qlevel[qi]; if (stop > g.cur_level) stop = g.cur_level; }
         // Search (hnsw.go:649-664): ef = 1 on the upper levels, max(efSearch, k) on level 0.  One loop body serves every
         // level and the entry-point evaluation (a "hop" whose only neighbour is the entry), so each piece of the
         // traversal is instantiated once.
-        for (int level = g.cur_level; level >= 0; level--) {
-            const uint32_t ef = level > 0 ? 1u : (ef_search > k ? ef_search : k);
+        for (int level = g.cur_level; level >= stop && !tie; level--) {
+            const uint32_t ef = level > stop ? 1u : (build ? ef_search : (ef_search > k ? ef_search : k));
             // searchLayer (hnsw.go:471-580)
-            epoch++;
+            const uint32_t hcap = level > stop && o.vis_cap > kVisGreedyCap ? kVisGreedyCap : o.vis_cap;
+            const uint32_t hmask = hcap - 1, hshift = (uint32_t)__builtin_clz(hcap) + 1;   // 32 - log2(hcap)
+            const uint32_t hlimit = hcap - (hcap >> 2);
+            uint32_t n_vis = 1;
+            vis_hash_clear(tab, hcap, lane);                               // :483-488
 #pragma unroll
             for (int s2 = 0; s2 < S; s2++) { key[s2] = kDeadKey; expd[s2] = 0; }
             n_list = 0;
@@ -446,7 +515,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                 if (first) {                                                 // :492-506: the entry point itself
                     first = false;
                     __syncthreads();
-                    if (lane == 0) { vis[entry] = epoch; batch[0] = entry; }
+                    if (lane == 0) { (void)vis_hash_insert(tab, hmask, hshift, entry); batch[0] = entry; }
                     __syncthreads();
                     nb = 1;
                 } else {
@@ -466,15 +535,16 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                         else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
                     }
                     uint32_t c = 0xFFFFFFFFu; bool fresh = false;
-                    if (lane < deg) { c = links[lane]; fresh = alive(c) && vis[c] != epoch; }
-                    for (uint32_t j = 0; j + 1 < deg; j++) {                 // repeated node in one list: first occurrence only
-                        uint32_t cj = __builtin_amdgcn_readlane(c, j);
-                        if (lane > j && c == cj) fresh = false;
-                    }
+                    if (lane < deg) { c = links[lane]; fresh = alive(c); }
+                    // test-and-set in the hash: a node repeated inside one list is new for exactly one of its lanes (which one
+                    // does not matter here: without equal distances the admission order of a hop is immaterial)
+                    if (fresh) fresh = vis_hash_insert(tab, hmask, hshift, c);
                     const uint64_t fm = __ballot(fresh);
                     nb = (uint32_t)__builtin_popcountll(fm);
+                    n_vis += nb;
+                    if (n_vis > hlimit) { tie = true; break; }               // table 3/4 full: hand the query to the exact-heap kernel
                     __syncthreads();                                         // previous hop's batch[] reads are done
-                    if (fresh) { vis[c] = epoch; batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c; }
+                    if (fresh) batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c;
                     __syncthreads();
                     HTICK(1);
                     if (nb == 0) continue;
@@ -483,13 +553,15 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                 HTICK(7);
                 for (uint32_t i = 0; i < nb; i++) insert(readlane64(kx, i), ef);
                 HTICK(4);
+                if (tie) break;                                              // flagged: the exact-heap kernel redoes it from scratch
 #ifdef QV_HNSW_PROF
                 hops++;
 #endif
             }
-            if (level > 0 && n_list > 0) entry = (uint32_t)readlane64(key[0], 0);   // :649-657
+            if (level > stop && n_list > 0) entry = (uint32_t)readlane64(key[0], 0);   // :649-657
         }
-        uint32_t cnt = n_list < k ? n_list : k;                         // :670-672
+        const uint32_t kq = build ? (stop == 0 ? g.max_m0 : g.max_m) : k;   // build: the level's degree bound (:395-398)
+        uint32_t cnt = n_list < kq ? n_list : kq;                       // :670-672
         if (tie) cnt = kHnswTieFlag;
         else {
 #pragma unroll
@@ -501,6 +573,13 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     dist_out[(size_t)qi * k + e] = has ? unord_f32((uint32_t)(key[s2] >> 32)) : __uint_as_float(0x7F800000u);
                 }
             }
+            if (build && stop >= 1 && o.self_dist) {                    // lower levels link the node to itself (:463-467): d(node, node)
+                __syncthreads();
+                if (lane == 0) batch[0] = o.qnode0 + qi;
+                __syncthreads();
+                const uint64_t ks = eval_keys(1);
+                if (lane == 0) o.self_dist[qi] = unord_f32((uint32_t)(ks >> 32));
+            }
         }
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
 #ifdef QV_HNSW_PROF
@@ -508,7 +587,6 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             printf("blk %u: pop %llu links+vis %llu dma-wait %llu issue %llu compute %llu insert %llu other %llu/%llu hops %llu evals(last q) %u wall(10ns) %llu cyc %llu\n", blockIdx.x, T[0], T[1], T[2], T[6], T[3], T[4], T[5], T[7], hops, n_eval,
                    (unsigned long long)(wall_clock64() - wc0), (unsigned long long)(T[0]+T[1]+T[2]+T[3]+T[4]+T[5]+T[6]+T[7]));
 #endif
-        epoch += 64;
     }
 }
 
@@ -527,29 +605,39 @@ __global__ void k_hnsw_prep_queries(const float* __restrict__ queries, uint32_t 
     }
 }
 size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4) { return (size_t)nq * dim4 * 4 * sizeof(double) + (size_t)nq * 2 * sizeof(double); }
-size_t hnsw_lds_bytes(int metric, uint32_t dim4) {
-    (void)metric; (void)dim4;                                         // the query is read by scalar loads, not staged
-    return 2 * (size_t)kHnswSlabBytes + (size_t)(kHnswCandCap + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 8 + 64;
+// candidate min-heap slots of the exact-heap kernel: admissions of one searchLayer grow like ef * (1 + ln(visited / ef))
+static uint32_t hnsw_cand_cap(uint32_t ef) { return ef > 256 ? 2 * (uint32_t)kHnswCandCap : (uint32_t)kHnswCandCap; }
+size_t hnsw_lds_bytes(uint32_t ef) {
+    return 2 * (size_t)kHnswSlabBytes + (size_t)(hnsw_cand_cap(ef) + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 8 + 64;
 }
-uint32_t hnsw_grid(int cus, int metric, uint32_t dim4, uint32_t nq) {
-    const size_t lds = hnsw_lds_bytes(metric, dim4);
+uint32_t hnsw_grid(int cus, uint32_t ef, uint32_t nq) {
+    const size_t lds = hnsw_lds_bytes(ef);
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
     return std::max(1u, std::min(nq, (uint32_t)cus * per_cu));
 }
+// visited hash entries per wave slot: ~64 x ef (a search with ef = 128 evaluates ~4-5 k nodes of a 1M-node graph), 3/4 usable
+uint32_t hnsw_vis_hash_cap(uint32_t ef) {
+    uint32_t cap = 4096;
+    while (cap < 64u * ef && cap < 65536u) cap <<= 1;
+    return cap;
+}
 hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
-                              uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                              const HnswOpts& o, uint32_t grid, bool prep, uint32_t* d_rows_out, float* d_dist_out,
                               uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s) {
     if (nq == 0) return hipSuccess;
     if (k == 0 || k > (uint32_t)kHnswEfMax || ef > (uint32_t)kHnswEfMax || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
-    const size_t lds = hnsw_lds_bytes(v.metric, v.dim4);
+    if (!o.vis || (size_t)o.vis_cap * 32 < g.n_nodes) return hipErrorInvalidValue;
+    const uint32_t efx = o.qlevel ? ef : std::max(ef, k);
+    const size_t lds = hnsw_lds_bytes(efx);
+    const uint32_t cand_cap = hnsw_cand_cap(efx);
     hipError_t e = hipSuccess;
     double* d_qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qblk) + (size_t)nq * v.dim4 * 4 * sizeof(double));
     QV_DISPATCH_METRIC(v.metric, {
-        hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
+        if (prep) hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
         e = set_lds(k_hnsw_search<MM, 16>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_hnsw_search<MM, 16>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk),
-                           static_cast<const double*>(d_qconst), nq, k, ef, d_visited, epoch0, d_rows_out, d_dist_out, d_count_out, d_evals_out);
+                           static_cast<const double*>(d_qconst), nq, k, ef, o, cand_cap, d_rows_out, d_dist_out, d_count_out, d_evals_out);
     });
     return hipGetLastError();
 }
@@ -564,11 +652,12 @@ uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4) {
     return (uint32_t)cus * per_cu;
 }
 hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
-                                   uint32_t* d_visited, uint32_t grid, uint32_t epoch0, uint32_t* d_rows_out, float* d_dist_out,
+                                   const HnswOpts& o, uint32_t grid, uint32_t* d_rows_out, float* d_dist_out,
                                    uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s) {
     if (nq == 0) return hipSuccess;
-    const uint32_t efx = ef > k ? ef : k;
-    if (k == 0 || efx > (uint32_t)kHnswEfMax || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
+    const uint32_t efx = o.qlevel ? std::max(ef, 64u) : (ef > k ? ef : k);       // build: the list must also hold the k = MaxM0 outputs
+    if (k == 0 || efx > (uint32_t)kHnswEfMax || k > (uint32_t)kHnswEfMax || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
+    if (!o.vis || o.vis_cap < 1024 || (o.vis_cap & (o.vis_cap - 1))) return hipErrorInvalidValue;
     const size_t lds = hnsw_wave_lds_bytes(v.metric, v.dim4);
     hipError_t e = hipSuccess;
     double* d_qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qblk) + (size_t)nq * v.dim4 * 4 * sizeof(double));
@@ -579,7 +668,7 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
         e = set_lds(k_hnsw_search_wave<MM, 8, SS>, lds);                                                              \
         if (e != hipSuccess) return e;                                                                                \
         hipLaunchKernelGGL((k_hnsw_search_wave<MM, 8, SS>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
-                           static_cast<const double*>(d_qconst), nq, k, ef, d_visited, epoch0,                       \
+                           static_cast<const double*>(d_qconst), nq, k, ef, o,                                       \
                            d_rows_out, d_dist_out, d_count_out, d_evals_out);                                         \
     })
     if (efx <= 64) { QV_HW(1); } else if (efx <= 128) { QV_HW(2); } else if (efx <= 256) { QV_HW(4); } else { QV_HW(8); }

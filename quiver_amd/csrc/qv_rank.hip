@@ -148,6 +148,24 @@ __global__ void k_emit_topk(const uint64_t* __restrict__ keys, uint32_t n, uint3
     dist_out[i] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(key >> 32));
 }
 
+// stable sort of n 64-bit keys by their upper 32 bits (4 passes); *sorted_out = the buffer holding the result (a)
+size_t radix_hist_words(uint32_t n) { return (size_t)256 * ((n + kRadixTile - 1) / kRadixTile) + 512; }
+hipError_t launch_radix_sort_hi32(uint64_t* a, uint64_t* b, uint32_t n, uint32_t* hist, uint64_t** sorted_out, hipStream_t s) {
+    const uint32_t nblocks = (n + kRadixTile - 1) / kRadixTile;
+    uint32_t* dtot = hist + (size_t)256 * nblocks;
+    uint32_t* dbase = dtot + 256;
+    uint64_t* in = a; uint64_t* out = b;
+    for (uint32_t shift = 32; shift < 64; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kRadixBlock), 0, s, in, n, shift, hist);
+        hipLaunchKernelGGL(k_radix_scan_digits, dim3(256), dim3(256), 0, s, hist, nblocks, dtot);
+        hipLaunchKernelGGL(k_radix_scan_totals, dim3(1), dim3(256), 0, s, dtot, dbase);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(kRadixBlock), 0, s, in, out, n, shift, hist, dbase);
+        uint64_t* t = in; in = out; out = t;
+    }
+    *sorted_out = in;
+    return hipGetLastError();
+}
+
 size_t full_sort_workspace_bytes(uint32_t n_tiles) {
     size_t n = (size_t)n_tiles * 64;
     size_t nblocks = (n + kRadixTile - 1) / kRadixTile;
@@ -160,9 +178,6 @@ hipError_t launch_flat_fullsort(const IndexView& v, const ScanPlan& p, const flo
     uint64_t* ka = static_cast<uint64_t*>(d_ws);
     uint64_t* kb = ka + n;
     uint32_t* hist = reinterpret_cast<uint32_t*>(kb + n);
-    const uint32_t nblocks = (n + kRadixTile - 1) / kRadixTile;
-    uint32_t* dtot = hist + (size_t)256 * nblocks;
-    uint32_t* dbase = dtot + 256;
     const size_t lds = query_lds_bytes(v.metric, v.dim4);
     hipError_t e = hipSuccess;
     QV_DISPATCH_METRIC(v.metric, {
@@ -172,15 +187,8 @@ hipError_t launch_flat_fullsort(const IndexView& v, const ScanPlan& p, const flo
     });
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    uint64_t* in = ka; uint64_t* out = kb;
-    for (uint32_t shift = 32; shift < 64; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(kRadixBlock), 0, s, in, n, shift, hist);
-        hipLaunchKernelGGL(k_radix_scan_digits, dim3(256), dim3(256), 0, s, hist, nblocks, dtot);
-        hipLaunchKernelGGL(k_radix_scan_totals, dim3(1), dim3(256), 0, s, dtot, dbase);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblocks), dim3(kRadixBlock), 0, s, in, out, n, shift, hist, dbase);
-        uint64_t* t = in; in = out; out = t;
-    }
-    e = hipGetLastError();
+    uint64_t* in = nullptr;
+    e = launch_radix_sort_hi32(ka, kb, n, hist, &in, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_emit_topk, dim3((k + 255) / 256), dim3(256), 0, s, in, n, k, d_rows_out, d_dist_out);
     return hipGetLastError();

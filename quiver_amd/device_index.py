@@ -162,6 +162,7 @@ class DeviceGraph:
 
     def __init__(self, index: DeviceIndex, levels, l0_deg, l0_links, entry: int, cur_level: int = 0, up_off=None, up_links=None, max_m: int = 0):
         self.index = index
+        self._g = C.c_void_p()
         levels = np.ascontiguousarray(levels, dtype=np.int8)
         l0_deg = np.ascontiguousarray(l0_deg, dtype=np.uint32)
         l0_links = np.ascontiguousarray(l0_links, dtype=np.uint32)
@@ -196,6 +197,49 @@ class DeviceGraph:
         """device pointers in and out, enqueued on `stream`, no sync; count 0xFFFFFFFE = redo that query through search()"""
         check(lib().qv_graph_search_device(self._g, d_queries, nq, k, ef_search, d_rows_out, d_dist_out, d_count_out, d_evals_out or None, stream or None))
 
+    # ---- device-resident construction (qv_graph_create_empty / qv_graph_insert / qv_graph_export) ----
+    @classmethod
+    def empty(cls, index: DeviceIndex, capacity: int, m: int = 16, max_m0: int = 0, ef_construction: int = 200) -> "DeviceGraph":
+        """a graph to be built on the device over the rows of `index` (which must keep a row-major copy)"""
+        self = cls.__new__(cls)
+        self.index = index
+        self._g = C.c_void_p()
+        check(lib().qv_graph_create_empty(C.byref(self._g), index.handle, capacity, m, max_m0, ef_construction))
+        return self
+
+    @classmethod
+    def build(cls, index: DeviceIndex, levels, m: int = 16, max_m0: int = 0, ef_construction: int = 200, batch_max: int = 4096,
+              ramp_div: int = 16) -> "DeviceGraph":
+        """hnsw.HNSW.Insert (hnsw.go:266-468) for rows 0..len(levels)-1 of `index`, in batches on the device"""
+        levels = np.ascontiguousarray(levels, dtype=np.int8)
+        self = cls.empty(index, levels.size, m, max_m0, ef_construction)
+        self.insert(0, levels, batch_max, ramp_div)
+        return self
+
+    def insert(self, first_row: int, levels, batch_max: int = 4096, ramp_div: int = 16):
+        levels = np.ascontiguousarray(levels, dtype=np.int8)
+        check(lib().qv_graph_insert(self._g, first_row, levels.size, levels.ctypes.data, batch_max, ramp_div))
+
+    def info(self) -> dict:
+        v = [C.c_uint32(0) for _ in range(5)]; lv = C.c_int(0)
+        check(lib().qv_graph_info(self._g, *[C.byref(x) for x in v], C.byref(lv)))
+        return {"n_nodes": v[0].value, "n_up_blocks": v[1].value, "max_m0": v[2].value, "max_m": v[3].value, "entry": v[4].value, "cur_level": lv.value}
+
+    def stats(self) -> dict:
+        sec = C.c_double(0); a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib().qv_graph_stats(self._g, C.byref(sec), C.byref(a), C.byref(b), C.byref(c)))
+        return {"build_seconds": sec.value, "build_batches": a.value, "build_redo": b.value, "search_redo": c.value}
+
+    def export(self):
+        """(levels, l0_deg, l0_links [n, max_m0], up_off, up_links [blocks, 1 + max_m]) — the form qv_graph_create takes"""
+        i = self.info()
+        n, nb = i["n_nodes"], i["n_up_blocks"]
+        levels = np.empty(n, dtype=np.int8); l0_deg = np.empty(n, dtype=np.uint32); l0_links = np.empty((n, i["max_m0"]), dtype=np.uint32)
+        up_off = np.empty(n, dtype=np.uint32); up_links = np.zeros((nb, 1 + i["max_m"]), dtype=np.uint32)
+        check(lib().qv_graph_export(self._g, levels.ctypes.data, l0_deg.ctypes.data, l0_links.ctypes.data, up_off.ctypes.data,
+                                    up_links.ctypes.data if nb else None))
+        return levels, l0_deg, l0_links, up_off, up_links
+
     def close(self):
         if getattr(self, "_g", None) is not None and self._g.value:
             lib().qv_graph_destroy(self._g)
@@ -206,6 +250,53 @@ class DeviceGraph:
             self.close()
         except Exception:
             pass
+
+
+def graph_batch_size(nodes_linked: int, batch_max: int, ramp_div: int) -> int:
+    return int(lib().qv_graph_batch_size(nodes_linked, batch_max, ramp_div))
+
+
+def random_levels(n: int, max_level: int = 16, seed: int = 1) -> np.ndarray:
+    """n draws of randomLevel (hnsw.go:716-738: p = 0.25 per extra level, at most min(MaxLevel, 10) draws, < MaxLevel) from a
+    SplitMix64 stream — the level law stays on the host side of the boundary, where the reference keeps its RNG
+    (hnsw.go:248 seeds it from the wall clock; a seed here makes builds repeatable)."""
+    attempts = min(max_level, 10)
+    out = np.empty(n, dtype=np.int8)
+    filled, draw0 = 0, 0
+    while filled < n:
+        # a block of the draw stream u_j = f(seed + (j+1) * gamma); a node consumes draws up to its first failure (u >= 0.25)
+        # or `attempts` successes, whichever comes first
+        m = max(2 * (n - filled), 1024)
+        j = np.arange(draw0 + 1, draw0 + m + 1, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            x = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + j * np.uint64(0x9E3779B97F4A7C15)
+            x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            x = x ^ (x >> np.uint64(31))
+        ok = ((x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)) < 0.25
+        fails = np.flatnonzero(~ok)
+        if fails.size == 0:
+            raise RuntimeError("level draw stream has no failure in a block")
+        runs = np.diff(np.concatenate(([-1], fails))) - 1          # successes before each failure
+        if (runs >= attempts).any():                                # a run of >= `attempts` successes: walk the block draw by draw
+            pos = 0
+            while filled < n and pos < m:
+                level = 0
+                while level < attempts and pos < m and ok[pos]:
+                    level += 1; pos += 1
+                if level < attempts:
+                    if pos >= m:
+                        break                                       # node straddles the block: redo it in the next one
+                    pos += 1                                        # the failing draw
+                out[filled] = min(level, max_level - 1); filled += 1
+                last_end = pos
+            draw0 += last_end
+            continue
+        take = min(runs.size, n - filled)
+        out[filled:filled + take] = np.minimum(runs[:take], max_level - 1)
+        filled += take
+        draw0 += int(fails[take - 1]) + 1
+    return out
 
 
 def merge_topk_device(d_dist_lists: int, d_row_lists: int, n_lists: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):

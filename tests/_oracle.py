@@ -64,6 +64,12 @@ def _load():
     lib.qvo_hnsw_random_level.argtypes = [C.c_void_p]
     lib.qvo_hnsw_load_flat.argtypes = [C.c_void_p, C.c_uint32, _f32p, _u32p, _u32p, C.c_uint32, C.c_uint32]
     lib.qvo_hnsw_load_flat.restype = C.c_int
+    lib.qvo_hnsw_insert_batch.restype = C.c_int64
+    lib.qvo_hnsw_insert_batch.argtypes = [C.c_void_p, _f32p, C.c_uint32]
+    _i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+    lib.qvo_hnsw_load_graph.restype = C.c_int
+    lib.qvo_hnsw_load_graph.argtypes = [C.c_void_p, C.c_uint32, _f32p, _i8p, C.c_uint32, C.c_uint32, _u32p, _u32p, _u32p, _u32p,
+                                        C.c_uint32, C.c_int]
     return lib
 
 
@@ -179,6 +185,15 @@ class HNSW:
     def insert(self, vec) -> int:
         return int(lib().qvo_hnsw_insert(self._h, _f32(vec)))
 
+    def insert_batch(self, vecs) -> int:
+        """n Inserts at once: searches against the graph before the batch, links applied in node order"""
+        vecs = _f32(vecs)
+        assert vecs.ndim == 2 and vecs.shape[1] == self.dim
+        r = int(lib().qvo_hnsw_insert_batch(self._h, vecs, vecs.shape[0]))
+        if r < 0:
+            raise RuntimeError("insert_batch failed")
+        return r
+
     def delete(self, node: int) -> int:
         return lib().qvo_hnsw_delete(self._h, node)
 
@@ -229,6 +244,38 @@ class HNSW:
         assert self._rows.shape == (deg.size, self.dim) and links.shape[0] == deg.size
         if lib().qvo_hnsw_load_flat(self._h, deg.size, self._rows, deg, links, links.shape[1], entry) != 0:
             raise RuntimeError("load_flat failed (index not empty / bad entry)")
+
+    def load_graph(self, rows, levels, max_m0, max_m, l0_deg, l0_links, up_off, up_links, entry: int, cur_level: int):
+        """test scaffolding: install a multi-level graph in qv_graph_export's flat form (rows borrowed, kept alive here)"""
+        self._rows = np.ascontiguousarray(rows, dtype=np.float32)
+        levels = np.ascontiguousarray(levels, dtype=np.int8)
+        l0_deg = np.ascontiguousarray(l0_deg, dtype=np.uint32); l0_links = np.ascontiguousarray(l0_links, dtype=np.uint32)
+        up_off = np.ascontiguousarray(up_off, dtype=np.uint32); up_links = np.ascontiguousarray(up_links, dtype=np.uint32)
+        if up_links.size == 0:
+            up_links = np.zeros(1 + max_m, dtype=np.uint32)
+        n = levels.size
+        assert self._rows.shape == (n, self.dim) and l0_deg.size == n and l0_links.size == n * max_m0 and up_off.size == n
+        if lib().qvo_hnsw_load_graph(self._h, n, self._rows, levels, max_m0, max_m, l0_deg, l0_links.reshape(-1), up_off,
+                                     up_links.reshape(-1), entry, cur_level) != 0:
+            raise RuntimeError("load_graph failed (index not empty / bad entry)")
+
+    def export_flat(self, max_m0: int, max_m: int):
+        """the graph in qv_graph_export's flat form: (levels, l0_deg, l0_links[n][max_m0], up_off, up_links[blocks][1+max_m])"""
+        n = self.nodes()
+        levels = np.array([self.node_level(i) for i in range(n)], dtype=np.int8)
+        l0_deg = np.zeros(n, dtype=np.uint32); l0_links = np.zeros((n, max_m0), dtype=np.uint32)
+        up_off = np.zeros(n, dtype=np.uint32); blocks = []
+        for i in range(n):
+            if levels[i] < 0:
+                continue
+            l = self.links(i, 0); l0_deg[i] = l.size; l0_links[i, :l.size] = l
+            if levels[i] >= 1:
+                up_off[i] = len(blocks)
+                for lv in range(1, levels[i] + 1):
+                    l = self.links(i, lv); b = np.zeros(1 + max_m, dtype=np.uint32); b[0] = l.size; b[1:1 + l.size] = l
+                    blocks.append(b)
+        up_links = np.stack(blocks) if blocks else np.zeros((0, 1 + max_m), dtype=np.uint32)
+        return levels, l0_deg, l0_links, up_off, up_links
 
     def __del__(self):
         try:

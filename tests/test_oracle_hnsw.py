@@ -182,3 +182,67 @@ def test_load_flat_reproduces_a_built_single_layer_graph():
         assert ra.tolist() == rb.tolist() and da.tobytes() == db.tobytes() and ea == eb
     with pytest.raises(RuntimeError):
         b.load_flat(rows, deg, links, ep)          # not empty any more
+
+
+# ---- batched insertion (what qv_graph_insert does on the device) ----------------------------
+def _graph(h):
+    n = h.nodes()
+    return [(h.node_level(i), [h.links(i, l).tolist() for l in range(h.node_level(i) + 1)]) for i in range(n)], h.entry_point()
+
+
+def batch_schedule(n_total, batch_max, ramp_div):
+    """batch sizes of a bulk build: node 0 alone, then min(batch_max, max(1, inserted // ramp_div)) — the rule
+    libqv exports as qv_graph_batch_size (tests/test_gpu_build.py asserts the two agree)"""
+    out, done = [], 0
+    while done < n_total:
+        b = 1 if done == 0 else min(batch_max, max(1, done // ramp_div) if ramp_div else batch_max, n_total - done)
+        out.append(b); done += b
+    return out
+
+
+@pytest.mark.parametrize("metric", [0, 1, 6])
+def test_batch_of_one_is_insert(metric):
+    rows = O.gen_rows(5, 0, 400, 24)
+    a = _build(metric, rows, seed=3, M=6, efConstruction=40, maxLevel=8)
+    b = O.HNSW(metric, 24, seed=3, M=6, efConstruction=40, maxLevel=8)
+    for r in rows:
+        b.insert_batch(r[None, :])
+    assert _graph(a) == _graph(b)
+
+
+def test_batched_build_properties():
+    """snapshot semantics: nodes of one batch never link to each other, every list respects its degree bound, links are
+    symmetric-or-pruned, and searching the batched graph still finds an inserted vector when every node is level 0"""
+    rows = O.gen_rows(11, 0, 1500, 16)
+    h = O.HNSW(1, 16, seed=9, M=8, efConstruction=60, maxLevel=1)
+    done = 0
+    bounds = []
+    for b in batch_schedule(len(rows), 64, 8):
+        h.insert_batch(rows[done:done + b]); bounds.append((done, done + b)); done += b
+    g, (ep, lvl) = _graph(h)
+    assert lvl == 0 and len(g) == len(rows)
+    for lo, hi in bounds:
+        for x in range(lo, hi):
+            lv, conn = g[x]
+            assert len(conn[0]) <= 16
+            assert not [c for c in conn[0] if lo <= c < hi and c != x]      # batch mates were invisible to each other
+    hits = 0
+    for i in range(0, 1500, 50):
+        r, d = h.search(rows[i], 5)
+        hits += int(i in r.tolist())
+    assert hits >= 27
+
+
+def test_load_graph_round_trip():
+    rows = O.gen_rows(2, 0, 600, 12)
+    a = _build(0, rows, seed=4, M=5, efConstruction=30, maxLevel=6)
+    flat = a.export_flat(10, 5)
+    b = O.HNSW(0, 12, seed=4, M=5, efConstruction=30, maxLevel=6)
+    ep, lvl = a.entry_point()
+    b.load_graph(rows, flat[0], 10, 5, flat[1], flat[2], flat[3], flat[4], ep, lvl)
+    assert _graph(a) == _graph(b)
+    qs = O.gen_rows(3, 0, 20, 12)
+    for q in qs:
+        ra, da, ea = a.search(q, 7, with_evals=True)
+        rb, db, eb = b.search(q, 7, with_evals=True)
+        assert ra.tolist() == rb.tolist() and da.tobytes() == db.tobytes() and ea == eb
