@@ -21,7 +21,9 @@ _SIGS = {
     "qvh_results_many_strategy": (_cp, [_vp, _i]),
     "qvh_exact_new": (_vp, [_i, _i]), "qvh_exact_free": (None, [_vp]),
     "qvh_exact_insert": (_i, [_vp, _cp, _vp, _u32]), "qvh_exact_delete": (_i, [_vp, _cp]),
-    "qvh_exact_search": (_i, [_vp, _vp, _u32, _i, _vp]), "qvh_exact_size": (_i, [_vp]),
+    "qvh_exact_search": (_i, [_vp, _vp, _u32, _i, _vp]), "qvh_exact_size": (_i, [_vp]), "qvh_exact_device_rows": (_u32, [_vp]),
+    "qvh_hnsw_insert_batch": (_i, [_vp, C.POINTER(_cp), _vp, _u32, _u32, _u32, _u32]), "qvh_hnsw_built_on_device": (_i, [_vp]),
+    "qvh_hybrid_exact_device_rows": (_u32, [_vp]), "qvh_hybrid_hnsw_built_on_device": (_i, [_vp]),
     "qvh_hnsw_new": (_vp, [_i, _i, _i, _i, _i, _i, _i, C.c_uint64]), "qvh_hnsw_free": (None, [_vp]),
     "qvh_hnsw_insert": (_i, [_vp, _cp, _vp, _u32]), "qvh_hnsw_delete": (_i, [_vp, _cp]),
     "qvh_hnsw_search": (_i, [_vp, _vp, _u32, _i, _vp, _vp]),

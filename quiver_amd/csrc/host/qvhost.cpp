@@ -34,7 +34,7 @@ inline double rng_float64(uint64_t* s) { return (double)(sm64_next(s) >> 11) * (
 ExactIndex::ExactIndex(qv_metric metric, int device) : metric_(metric), device_(device) {}
 ExactIndex::~ExactIndex() { if (h_) qv_index_destroy(h_); }
 
-Error ExactIndex::Insert(const std::string& id, const float* v, uint32_t len) {
+Error ExactIndex::insertLocked(const std::string& id, const float* v, uint32_t len) {
     if (dim_ == 0) {                                                   // exact.go:43-44 dimension lock-in
         if (len == 0) return "vector dimension mismatch: expected >0, got 0";
         if (qv_index_create(&h_, len, metric_, device_, 0) != QV_OK) return qv_err();
@@ -44,29 +44,77 @@ Error ExactIndex::Insert(const std::string& id, const float* v, uint32_t len) {
     }
     if (row_of_.count(id)) return fmt("vector with ID %s already exists", id.c_str());   // exact.go:48-50
     uint32_t row = 0;
-    if (qv_index_add(h_, v, 1, &row) != QV_OK) return qv_err();        // copies (exact.go:53-56)
+    if (!free_rows_.empty()) {                                         // a deleted entry's slot is reused (the reference's map frees it, exact.go:65):
+        row = free_rows_.back();                                       // storage, HBM and scan time stay bounded under insert/delete churn
+        if (qv_index_update(h_, row, v) != QV_OK) return qv_err();     // overwrites the row in place and marks it live
+        free_rows_.pop_back();
+    } else if (qv_index_add(h_, v, 1, &row) != QV_OK) return qv_err(); // copies (exact.go:53-56)
     row_of_[id] = row;
     if (id_of_.size() <= row) id_of_.resize(row + 1);
     id_of_[row] = id;
     return "";
 }
 
-Error ExactIndex::Delete(const std::string& id) {
+Error ExactIndex::Insert(const std::string& id, const float* v, uint32_t len) {
+    std::unique_lock<std::shared_mutex> l(mu_);                        // exact.go:39-40
+    return insertLocked(id, v, len);
+}
+
+Error ExactIndex::InsertMany(const std::vector<std::string>& ids, const float* packed, uint32_t len, std::string* failed_id) {
+    std::unique_lock<std::shared_mutex> l(mu_);
+    if (ids.empty()) return "";
+    // every check of every Insert first: nothing is inserted unless all of them pass
+    auto failed = [&](const std::string& id, Error e) { if (failed_id) *failed_id = id; return e; };
+    if (dim_ == 0 ? len == 0 : (int)len != dim_)
+        return failed(ids[0], dim_ == 0 ? Error("vector dimension mismatch: expected >0, got 0") : fmt("vector dimension mismatch: expected %d, got %u", dim_, len));
+    {
+        std::unordered_map<std::string, int> seen;
+        for (auto& id : ids) if (row_of_.count(id) || seen[id]++) return failed(id, fmt("vector with ID %s already exists", id.c_str()));
+    }
+    size_t i = 0;
+    for (; i < ids.size() && (!free_rows_.empty() || dim_ == 0); i++) {    // reuse tombstoned rows first (and create the index on the first insert)
+        Error e = insertLocked(ids[i], packed + i * (size_t)len, len);
+        if (!e.empty()) { for (size_t j = 0; j < i; j++) (void)deleteLocked(ids[j]); return failed(ids[i], e); }
+    }
+    if (i < ids.size()) {                                              // the rest: one device copy
+        const uint32_t n = (uint32_t)(ids.size() - i);
+        uint32_t first = 0;
+        if (qv_index_add(h_, packed + i * (size_t)len, n, &first) != QV_OK) {
+            Error e = qv_err();
+            for (size_t j = 0; j < i; j++) (void)deleteLocked(ids[j]);
+            return failed(ids[i], e);
+        }
+        if (id_of_.size() < (size_t)first + n) id_of_.resize((size_t)first + n);
+        for (uint32_t j = 0; j < n; j++) { row_of_[ids[i + j]] = first + j; id_of_[first + j] = ids[i + j]; }
+    }
+    return "";
+}
+
+Error ExactIndex::deleteLocked(const std::string& id) {
     auto it = row_of_.find(id);
     if (it != row_of_.end()) {                                         // exact.go:65 delete(map, id): absent id is not an error
         uint32_t row = it->second;
         if (qv_index_remove(h_, &row, 1) != QV_OK) return qv_err();
         id_of_[row].clear();
         row_of_.erase(it);
+        free_rows_.push_back(row);
     }
     if (row_of_.empty() && h_) {                                       // exact.go:66-68 reset the dimension when empty
-        qv_index_destroy(h_); h_ = nullptr; dim_ = 0; id_of_.clear();
+        qv_index_destroy(h_); h_ = nullptr; dim_ = 0; id_of_.clear(); free_rows_.clear();
     }
     return "";
 }
 
+Error ExactIndex::Delete(const std::string& id) {
+    std::unique_lock<std::shared_mutex> l(mu_);                        // exact.go:62-63
+    return deleteLocked(id);
+}
+
+uint32_t ExactIndex::DeviceRows() const { std::shared_lock<std::shared_mutex> l(mu_); return h_ ? qv_index_rows(h_) : 0; }
+
 Error ExactIndex::SearchMany(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<BasicSearchResult>>* out) {
     out->assign(nq, {});
+    std::shared_lock<std::shared_mutex> l(mu_);                        // exact.go:93-94
     if (row_of_.empty()) return "";                                    // exact.go:96-98
     if (dim_ > 0 && (int)len != dim_) return fmt("query dimension mismatch: expected %d, got %u", dim_, len);   // :100-102
     if (k <= 0) return "k must be positive";                           // :104-106
@@ -95,6 +143,7 @@ Error ExactIndex::Search(const float* q, uint32_t len, int k, std::vector<BasicS
 Error ExactIndex::DistancesTo(const float* other, uint32_t len, const std::vector<std::string>& ids, std::vector<float>* out) {
     out->assign(ids.size(), 0.f);
     if (ids.empty()) return "";
+    std::shared_lock<std::shared_mutex> l(mu_);
     if ((int)len != dim_) return fmt("negative example dimension mismatch: expected %d, got %u", dim_, len);
     std::vector<uint32_t> rows(ids.size());
     for (size_t i = 0; i < ids.size(); i++) {
@@ -118,7 +167,7 @@ HNSW::HNSW(qv_metric metric, int device, const HNSWConfig& c) : metric_(metric),
     maxLevel_ = c.MaxLevel > 0 ? c.MaxLevel : 16;                      // :235-237
     rng_ = c.seed;
 }
-HNSW::~HNSW() { if (dg_) qv_graph_destroy(dg_); if (h_) qv_index_destroy(h_); }
+HNSW::~HNSW() { if (dg_ && dg_ != bg_) qv_graph_destroy(dg_); if (bg_) qv_graph_destroy(bg_); if (h_) qv_index_destroy(h_); }
 
 const std::vector<uint32_t>* HNSW::Links(uint32_t n, int level) const {
     if (!ok(n) || level < 0 || level > nodes_[n].level) return nullptr;
@@ -139,6 +188,10 @@ int HNSW::RandomLevel() {                                              // hnsw.g
 }
 
 Error HNSW::Distances(const float* query, const std::vector<uint32_t>& nodes, std::vector<float>* out) {
+    std::shared_lock<std::shared_mutex> l(mu_);
+    return distancesLocked(query, nodes, out);
+}
+Error HNSW::distancesLocked(const float* query, const std::vector<uint32_t>& nodes, std::vector<float>* out) {
     out->resize(nodes.size());
     if (nodes.empty()) return "";
     n_calls_++; n_evals_ += nodes.size();
@@ -190,12 +243,18 @@ Error HNSW::searchLayer(const float* q, uint32_t entry, int ef, int level, std::
     out->clear();
     if (nodes_.empty()) return "";                                     // :473-475
     if (!ok(entry)) return fmt("invalid entry point ID: %u", entry);   // :478-480
-    if (visited_.size() < nodes_.size()) visited_.resize(nodes_.size() * 2 + 16, 0);
-    if (++epoch_ == 0) { std::fill(visited_.begin(), visited_.end(), 0); epoch_ = 1; }
-    visited_[entry] = epoch_;                                          // :483-488
+    // the reference takes a cleared map from a sync.Pool per call (:483-488): searches run concurrently under the read
+    // lock, so the stamps are per thread (re-zeroed when another index used this thread's array last)
+    struct Visited { const void* owner = nullptr; std::vector<uint32_t> stamp; uint32_t epoch = 0; };
+    static thread_local Visited tv;
+    if (tv.owner != this) { tv.owner = this; std::fill(tv.stamp.begin(), tv.stamp.end(), 0); tv.epoch = 0; }
+    if (tv.stamp.size() < nodes_.size()) tv.stamp.resize(nodes_.size() * 2 + 16, 0);
+    if (++tv.epoch == 0) { std::fill(tv.stamp.begin(), tv.stamp.end(), 0); tv.epoch = 1; }
+    std::vector<uint32_t>& visited_ = tv.stamp; const uint32_t epoch_ = tv.epoch;
+    visited_[entry] = epoch_;
     std::vector<uint32_t> batch; std::vector<float> bd;
     batch.push_back(entry);
-    Error e = Distances(q, batch, &bd);                                // :492
+    Error e = distancesLocked(q, batch, &bd);                                // :492
     if (!e.empty()) return e;
     std::vector<R> cand, res;
     min_push(cand, {bd[0], entry}); max_push(res, {bd[0], entry});     // :498-506
@@ -211,7 +270,7 @@ Error HNSW::searchLayer(const float* q, uint32_t entry, int ef, int level, std::
             if (visited_[c] != epoch_) { visited_[c] = epoch_; batch.push_back(c); }   // :543-544
         }
         if (batch.empty()) continue;
-        e = Distances(q, batch, &bd);                                  // :548, batched
+        e = distancesLocked(q, batch, &bd);                                  // :548, batched
         if (!e.empty()) return e;
         for (size_t i = 0; i < batch.size(); i++) {
             float cd = bd[i];
@@ -270,7 +329,7 @@ Error HNSW::connectNode(uint32_t nodeIdx, const float* v, int level, int graphLe
                 std::vector<uint32_t> ids;
                 for (uint32_t ci : nbn.conn[lc]) if (ok(ci)) ids.push_back(ci);   // :432-436
                 std::vector<float> d;
-                Error e2 = Distances(nbn.vec.data(), ids, &d);         // :438 computeDistance(neighborNode.Vector, conn.Vector)
+                Error e2 = distancesLocked(nbn.vec.data(), ids, &d);         // :438 computeDistance(neighborNode.Vector, conn.Vector)
                 if (!e2.empty()) return e2;
                 std::vector<Res> nd(ids.size());
                 for (size_t j = 0; j < ids.size(); j++) nd[j] = {d[j], ids[j]};
@@ -284,8 +343,9 @@ Error HNSW::connectNode(uint32_t nodeIdx, const float* v, int level, int graphLe
     return "";
 }
 
-Error HNSW::Insert(const std::string& id, const float* v, uint32_t len) {   // hnsw.go:266-334
-    if (by_id_.count(id)) return fmt("vector with ID %s already exists", id.c_str());   // :269-272
+// the device index behind the nodes (row == node index); created at the first insert, rebuilt when every node is a
+// tombstone and a vector of another dimension arrives
+Error HNSW::ensureIndex(uint32_t len) {
     if (!h_) {
         if (len == 0) return "vector dimensions do not match";
         if (qv_index_create(&h_, len, metric_, device_, QV_FLAG_ROWMAJOR) != QV_OK) return qv_err();   // row gathers are this index's hot path
@@ -295,7 +355,9 @@ Error HNSW::Insert(const std::string& id, const float* v, uint32_t len) {   // h
         // every node is a tombstone: Go slices carry no dimension, so a new one is fine.
         // Rebuild the device index at the new dimension, keeping row == node index.
         if (len == 0) return "vector dimensions do not match";
-        if (dg_) { qv_graph_destroy(dg_); dg_ = nullptr; }
+        if (dg_ && dg_ != bg_) qv_graph_destroy(dg_);
+        if (bg_) qv_graph_destroy(bg_);
+        dg_ = nullptr; bg_ = nullptr; dg_dirty_ = true; bg_synced_ = false;
         qv_index_destroy(h_); h_ = nullptr;
         if (qv_index_create(&h_, len, metric_, device_, QV_FLAG_ROWMAJOR) != QV_OK) return qv_err();
         dim_ = (int)len;
@@ -308,7 +370,19 @@ Error HNSW::Insert(const std::string& id, const float* v, uint32_t len) {   // h
             if (qv_index_remove(h_, dead.data(), (uint32_t)dead.size()) != QV_OK) return qv_err();
         }
     }
-    dg_dirty_ = true;
+    return "";
+}
+
+Error HNSW::Insert(const std::string& id, const float* v, uint32_t len) {   // hnsw.go:266-334
+    std::unique_lock<std::shared_mutex> l(mu_);                        // :267 (the reference drops it before connectNode; one writer here)
+    return insertLocked(id, v, len);
+}
+
+Error HNSW::insertLocked(const std::string& id, const float* v, uint32_t len) {
+    if (by_id_.count(id)) return fmt("vector with ID %s already exists", id.c_str());   // :269-272
+    Error ei = ensureIndex(len);
+    if (!ei.empty()) return ei;
+    dg_dirty_ = true; bg_synced_ = false;                              // the host graph moves on without the device graph's link distances
     int level = RandomLevel();                                         // :275
     int oldLevel = cur_level_;                                         // :276
     uint32_t row = 0;
@@ -331,12 +405,89 @@ Error HNSW::Insert(const std::string& id, const float* v, uint32_t len) {   // h
     return "";
 }
 
+// n Inserts connected on the device.  Same checks and bookkeeping as Insert; the connectNode work of all n nodes is
+// qv_graph_insert (searches: the traversal kernels in build mode; links: qv_build.hip), and the adjacency comes back
+// with qv_graph_export so that Links / the host-driven Search / Delete keep working on nodes_.
+Error HNSW::InsertBatch(const std::vector<std::string>& ids, const float* packed, uint32_t len, uint32_t batch_max, uint32_t ramp_div) {
+    std::unique_lock<std::shared_mutex> l(mu_);
+    if (ids.empty()) return "";
+    const bool device_ok = bg_synced_ && (bg_ != nullptr || nodes_.empty()) && M_ <= 64 && maxM0_ <= 64 && efC_ <= 512 && maxLevel_ <= 64;
+    if (!device_ok) {                                                  // the host graph has moved on without link distances: plain Inserts
+        for (size_t i = 0; i < ids.size(); i++) {
+            Error e = insertLocked(ids[i], packed + i * (size_t)len, len);
+            if (!e.empty()) return e;
+        }
+        return "";
+    }
+    {
+        std::unordered_map<std::string, int> seen;
+        for (auto& id : ids) if (by_id_.count(id) || seen[id]++) return fmt("vector with ID %s already exists", id.c_str());   // :269-272
+    }
+    Error e = ensureIndex(len);
+    if (!e.empty()) return e;
+    const uint32_t n = (uint32_t)ids.size(), first = (uint32_t)nodes_.size();
+    uint32_t row0 = 0;
+    if (qv_index_add(h_, packed, n, &row0) != QV_OK) return qv_err();  // :281-282 copies; device row == node index
+    if (row0 != first) return "internal: device row and node index diverged";
+    std::vector<int8_t> levels(n);
+    for (uint32_t i = 0; i < n; i++) levels[i] = (int8_t)RandomLevel();    // :275, in node order
+    if (!bg_ && qv_graph_create_empty(&bg_, h_, std::max<uint32_t>(first + n, 1024u), (uint32_t)M_, (uint32_t)maxM0_, (uint32_t)efC_) != QV_OK) {
+        Error ge = qv_err();
+        std::vector<uint32_t> rows(n); for (uint32_t i = 0; i < n; i++) rows[i] = first + i;
+        (void)qv_index_remove(h_, rows.data(), n);
+        bg_synced_ = false;
+        return ge;
+    }
+    if (qv_graph_insert(bg_, first, n, levels.data(), batch_max, ramp_div) != QV_OK) {
+        Error ge = qv_err();                                           // :316-322 rollback keeps the slots (tombstones)
+        std::vector<uint32_t> rows(n); for (uint32_t i = 0; i < n; i++) rows[i] = first + i;
+        (void)qv_index_remove(h_, rows.data(), n);
+        for (uint32_t i = 0; i < n; i++) { nodes_.emplace_back(); nodes_.back().alive = false; }
+        if (dg_ == bg_) dg_ = nullptr;
+        qv_graph_destroy(bg_); bg_ = nullptr; bg_synced_ = false; dg_dirty_ = true;
+        return ge;
+    }
+    for (uint32_t i = 0; i < n; i++) {                                 // :287-303
+        nodes_.emplace_back();
+        Node& nd = nodes_.back();
+        nd.id = ids[i]; nd.vec.assign(packed + i * (size_t)len, packed + (i + 1) * (size_t)len); nd.level = levels[i]; nd.alive = true;
+        by_id_[ids[i]] = first + i;
+    }
+    size_ += n;
+    e = pullGraphFromDevice();
+    if (!e.empty()) return e;
+    if (dg_ && dg_ != bg_) qv_graph_destroy(dg_);
+    dg_ = bg_; dg_dirty_ = false;                                      // the graph just built is the one SearchBatch walks
+    return "";
+}
+
+Error HNSW::pullGraphFromDevice() {
+    uint32_t n = 0, nb = 0, m0 = 0, m = 0, ep = 0; int lvl = -1;
+    if (qv_graph_info(bg_, &n, &nb, &m0, &m, &ep, &lvl) != QV_OK) return qv_err();
+    if (n != nodes_.size()) return "internal: device graph and node list diverged";
+    std::vector<uint32_t> l0deg(n), l0links((size_t)n * m0), upoff(n), uplinks((size_t)std::max(nb, 1u) * (1 + m));
+    if (qv_graph_export(bg_, nullptr, l0deg.data(), l0links.data(), upoff.data(), nb ? uplinks.data() : nullptr) != QV_OK) return qv_err();
+    for (uint32_t i = 0; i < n; i++) {
+        Node& nd = nodes_[i];
+        if (!nd.alive) continue;
+        nd.conn.assign((size_t)nd.level + 1, {});
+        nd.conn[0].assign(l0links.begin() + (size_t)i * m0, l0links.begin() + (size_t)i * m0 + std::min(l0deg[i], m0));
+        for (int l = 1; l <= nd.level; l++) {
+            const uint32_t* blk = &uplinks[(size_t)(upoff[i] + (uint32_t)(l - 1)) * (1 + m)];
+            nd.conn[l].assign(blk + 1, blk + 1 + std::min(blk[0], m));
+        }
+    }
+    entry_ = ep; cur_level_ = lvl;                                     // :325-332, replayed per batch by qv_graph_insert
+    return "";
+}
+
 Error HNSW::Delete(const std::string& id) {                            // hnsw.go:741-842
+    std::unique_lock<std::shared_mutex> l(mu_);                        // :742-743
     auto it = by_id_.find(id);
     if (it == by_id_.end()) return fmt("vector with ID %s not found", id.c_str());   // :745-749
     uint32_t idx = it->second;
     if (!ok(idx)) return fmt("vector index %u is invalid", idx);       // :752-755
-    dg_dirty_ = true;
+    dg_dirty_ = true; bg_synced_ = false;
     Node& nd = nodes_[idx];
     for (int level = 0; level <= nd.level; level++) {                  // :762
         if (level >= (int)nd.conn.size()) continue;
@@ -372,6 +523,11 @@ Error HNSW::Delete(const std::string& id) {                            // hnsw.g
 }
 
 Error HNSW::Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>* out) {   // hnsw.go:602-713
+    std::shared_lock<std::shared_mutex> l(mu_);                        // :603-604
+    return searchLocked(q, len, k, out);
+}
+
+Error HNSW::searchLocked(const float* q, uint32_t len, int k, std::vector<HNSWResult>* out) {
     out->clear();
     if (nodes_.empty()) return "";                                     // :606-608
     if (k <= 0) return "k must be positive";                           // :610-612
@@ -398,7 +554,7 @@ Error HNSW::Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>*
         std::vector<uint32_t> rest;
         for (uint32_t i = 0; i < nodes_.size(); i++) if (nodes_[i].alive && !have[i]) rest.push_back(i);   // :682-688
         std::vector<float> d;
-        e = Distances(q, rest, &d);                                    // :690
+        e = distancesLocked(q, rest, &d);                                    // :690
         if (!e.empty()) return e;
         for (size_t i = 0; i < rest.size(); i++) buf.push_back({d[i], rest[i]});
         std::sort(buf.begin(), buf.end(), [&](const Res& a, const Res& b) {   // :699-704 (Distance, VectorID)
@@ -415,8 +571,10 @@ Error HNSW::Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>*
 
 // flatten the host graph into the arrays qv_graph_create takes and upload it
 Error HNSW::syncDeviceGraph() {
+    std::lock_guard<std::mutex> lk(dg_mu_);                            // searches hold mu_ shared: one of them uploads, the others wait
     if (dg_ && !dg_dirty_) return "";
-    if (dg_) { qv_graph_destroy(dg_); dg_ = nullptr; }
+    if (M_ > 64 || maxM0_ > 64) return "device traversal unsupported: degree bounds above 64";
+    if (dg_) { if (dg_ == bg_) bg_ = nullptr; qv_graph_destroy(dg_); dg_ = nullptr; }
     const uint32_t n = (uint32_t)nodes_.size();
     uint32_t entry = entry_;
     if (!ok(entry)) {                                                  // hnsw.go:621-629
@@ -452,6 +610,7 @@ Error HNSW::syncDeviceGraph() {
 
 Error HNSW::SearchBatchRaw(const float* qs, uint32_t len, uint32_t nq, int k, uint32_t* rows, float* dist, uint32_t* count, uint32_t* evals, double* seconds) {
     if (seconds) *seconds = 0.0;
+    std::shared_lock<std::shared_mutex> l(mu_);
     if (nodes_.empty() || nq == 0 || size_ == 0) return "graph is empty";
     if (k <= 0) return "k must be positive";
     if ((int)len != dim_) return "vector dimensions do not match";
@@ -466,16 +625,20 @@ Error HNSW::SearchBatchRaw(const float* qs, uint32_t len, uint32_t nq, int k, ui
 Error HNSW::SearchBatch(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<HNSWResult>>* out, std::vector<uint32_t>* evals_out) {
     out->assign(nq, {});
     if (evals_out) evals_out->assign(nq, 0);
+    std::shared_lock<std::shared_mutex> l(mu_);                        // :603-604, once for the batch
     if (nodes_.empty() || nq == 0) return "";                          // hnsw.go:606-608
     if (k <= 0) return "k must be positive";                           // :610-612
     if ((int)len != dim_) return "vector dimensions do not match";
     if (k > (int)nodes_.size()) k = (int)nodes_.size();                // :615-617
     if (size_ == 0) return "";                                         // :632-634
-    Error e = syncDeviceGraph();
+    // configurations the device traversal does not take (k or efSearch above 512, degree bounds above 64) go through the
+    // host-driven Search query by query, like a device heap overflow
+    const bool on_device = k <= 512 && efS_ <= 512 && M_ <= 64 && maxM0_ <= 64;
+    Error e = on_device ? syncDeviceGraph() : Error("");
     if (!e.empty()) return e;
     std::vector<uint32_t> rows((size_t)nq * k), cnt(nq), ev(nq);
     std::vector<float> dist((size_t)nq * k);
-    if (k > 512 || efS_ > 512) { std::fill(cnt.begin(), cnt.end(), 0xFFFFFFFFu); }
+    if (!on_device) { std::fill(cnt.begin(), cnt.end(), 0xFFFFFFFFu); }
     else if (qv_graph_search(dg_, qs, nq, (uint32_t)k, (uint32_t)efS_, rows.data(), dist.data(), cnt.data(), ev.data()) != QV_OK) return qv_err();
     std::vector<uint32_t> underfilled;
     for (uint32_t q = 0; q < nq; q++) {
@@ -489,7 +652,7 @@ Error HNSW::SearchBatch(const float* qs, uint32_t len, uint32_t nq, int k, std::
             if (evals_out) (*evals_out)[q] = ev[q];
         } else {                                                       // device heap overflow: host traversal
             device_fallbacks_++;
-            e = Search(qs + (size_t)q * len, len, k, &(*out)[q]);
+            e = searchLocked(qs + (size_t)q * len, len, k, &(*out)[q]);
             if (!e.empty()) return e;
         }
     }
@@ -529,14 +692,41 @@ Error HNSW::SearchBatch(const float* qs, uint32_t len, uint32_t nq, int k, std::
 // =============================================================== HNSWAdapter ==========
 
 Error HNSWAdapter::Insert(const std::string& id, const float* v, uint32_t len) {   // hybrid/hnsw_adapter.go:47-54
-    if (dim_ == 0) dim_ = (int)len;
-    else if ((int)len != dim_) return fmt("vector dimension mismatch: expected %d, got %u", dim_, len);
+    int want = 0;
+    if (!dim_.compare_exchange_strong(want, (int)len) && (int)len != want) return fmt("vector dimension mismatch: expected %d, got %u", want, len);
     return hnsw_.Insert(id, v, len);
+}
+Error HNSWAdapter::InsertBatch(const std::vector<std::string>& ids, const float* packed, uint32_t len) {
+    if (ids.empty()) return "";
+    int want = 0;
+    if (!dim_.compare_exchange_strong(want, (int)len) && (int)len != want) return fmt("vector dimension mismatch: expected %d, got %u", want, len);
+    return hnsw_.InsertBatch(ids, packed, len);
 }
 Error HNSWAdapter::Delete(const std::string& id) {                     // hnsw_adapter.go:57-63
     Error e = hnsw_.Delete(id);
     if (e.empty() && Size() == 0) dim_ = 0;
     return e;
+}
+
+// adapter.go:57-92: convert the graph results; if they are fewer than k, add every other live node and sort by distance
+Error HNSWAdapter::fillPass(const float* q, int k, const std::vector<HNSWResult>& hr, std::vector<BasicSearchResult>* out) {
+    out->clear();
+    for (auto& r : hr) out->push_back({r.id, r.distance});             // :57-63
+    if ((int)out->size() < k) {                                        // :66 second fill pass
+        std::shared_lock<std::shared_mutex> l(hnsw_.mu_);
+        const uint32_t n = (uint32_t)hnsw_.nodes_.size();
+        std::vector<char> have(n, 0);
+        for (auto& r : hr) if (r.index < n) have[r.index] = 1;
+        std::vector<uint32_t> rest;
+        for (uint32_t i = 0; i < n; i++) if (hnsw_.Alive(i) && !have[i]) rest.push_back(i);   // :72-79
+        std::vector<float> d;
+        Error e = hnsw_.distancesLocked(q, rest, &d);
+        if (!e.empty()) return e;
+        for (size_t i = 0; i < rest.size(); i++) out->push_back({hnsw_.IdOf(rest[i]), d[i]});
+        std::stable_sort(out->begin(), out->end(), [](const BasicSearchResult& a, const BasicSearchResult& b) { return a.distance < b.distance; });   // :88
+        if ((int)out->size() > k) out->resize(k);
+    }
+    return "";
 }
 
 Error HNSWAdapter::adapterSearch(const float* q, uint32_t len, int k, std::vector<BasicSearchResult>* out) {   // hnsw/adapter.go:41-95
@@ -546,32 +736,39 @@ Error HNSWAdapter::adapterSearch(const float* q, uint32_t len, int k, std::vecto
     std::vector<HNSWResult> hr;
     Error e = hnsw_.Search(q, len, searchK, &hr);                      // :52 (searchK == 0 on an empty graph returns empty first, hnsw.go:606)
     if (!e.empty()) return e;
-    for (auto& r : hr) out->push_back({r.id, r.distance});             // :57-63
-    if ((int)out->size() < k) {                                        // :66 second fill pass
-        std::vector<char> have(hnsw_.Nodes(), 0);
-        for (auto& r : hr) have[r.index] = 1;
-        std::vector<uint32_t> rest;
-        for (uint32_t i = 0; i < hnsw_.Nodes(); i++) if (hnsw_.Alive(i) && !have[i]) rest.push_back(i);   // :72-79
-        std::vector<float> d;
-        e = hnsw_.Distances(q, rest, &d);
+    return fillPass(q, k, hr, out);
+}
+
+Error HNSWAdapter::SearchMany(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<BasicSearchResult>>* out) {
+    out->assign(nq, {});
+    const int dim = dim_.load();
+    if (dim > 0 && (int)len != dim) return fmt("query dimension mismatch: expected %d, got %u", dim, len);   // hnsw_adapter.go:67-69
+    if (k <= 0) return "k must be positive";                           // adapter.go:42-44
+    int searchK = std::min(k, Size());                                 // :47-50
+    std::vector<std::vector<HNSWResult>> hr;
+    if (searchK > 0) {
+        Error e = hnsw_.SearchBatch(qs, len, nq, searchK, &hr);        // the graph walks of all nq queries in one device call
         if (!e.empty()) return e;
-        for (size_t i = 0; i < rest.size(); i++) out->push_back({hnsw_.IdOf(rest[i]), d[i]});
-        std::stable_sort(out->begin(), out->end(), [](const BasicSearchResult& a, const BasicSearchResult& b) { return a.distance < b.distance; });   // :88
-        if ((int)out->size() > k) out->resize(k);
+    } else hr.assign(nq, {});
+    for (uint32_t i = 0; i < nq; i++) {
+        Error e = fillPass(qs + (size_t)i * len, k, hr[i], &(*out)[i]);
+        if (!e.empty()) return e;
     }
     return "";
 }
 
 Error HNSWAdapter::Search(const float* q, uint32_t len, int k, std::vector<BasicSearchResult>* out) {   // hnsw_adapter.go:66-71
-    if (dim_ > 0 && (int)len != dim_) return fmt("query dimension mismatch: expected %d, got %u", dim_, len);
+    const int dim = dim_.load();
+    if (dim > 0 && (int)len != dim) return fmt("query dimension mismatch: expected %d, got %u", dim, len);
     return adapterSearch(q, len, k, out);
 }
 
 Error HNSWAdapter::SearchWithNegative(const float* q, uint32_t len, const float* neg, uint32_t neg_len, float w, int k,
                                       std::vector<BasicSearchResult>* out) {
-    if (dim_ > 0) {                                                    // hnsw_adapter.go:76-83
-        if ((int)len != dim_) return fmt("query dimension mismatch: expected %d, got %u", dim_, len);
-        if ((int)neg_len != dim_) return fmt("negative example dimension mismatch: expected %d, got %u", dim_, neg_len);
+    const int dim = dim_.load();
+    if (dim > 0) {                                                     // hnsw_adapter.go:76-83
+        if ((int)len != dim) return fmt("query dimension mismatch: expected %d, got %u", dim, len);
+        if ((int)neg_len != dim) return fmt("negative example dimension mismatch: expected %d, got %u", dim, neg_len);
     }
     out->clear();
     if (k <= 0) return "k must be positive";                           // adapter.go:347-349
@@ -588,14 +785,17 @@ Error HNSWAdapter::SearchWithNegative(const float* q, uint32_t len, const float*
     }
     if (w > 1.0f) w = 1.0f;                                            // :375-377
     std::vector<uint32_t> rows; std::vector<size_t> pos;
-    for (size_t i = 0; i < initial.size(); i++) {                      // :387-405
-        uint32_t n;
-        if (!hnsw_.IndexOf(initial[i].id, &n) || !hnsw_.Alive(n)) continue;
-        rows.push_back(n); pos.push_back(i);
-    }
     std::vector<float> nd;
-    Error e = hnsw_.Distances(neg, rows, &nd);                         // :407 DistanceFunc(node.Vector, negativeExample), batched
-    if (!e.empty()) return e;
+    {
+        std::shared_lock<std::shared_mutex> l(hnsw_.mu_);              // adapter.go:380 RLock over the re-rank loop
+        for (size_t i = 0; i < initial.size(); i++) {                  // :387-405
+            uint32_t n;
+            if (!hnsw_.IndexOf(initial[i].id, &n) || !hnsw_.Alive(n)) continue;
+            rows.push_back(n); pos.push_back(i);
+        }
+        Error e = hnsw_.distancesLocked(neg, rows, &nd);               // :407 DistanceFunc(node.Vector, negativeExample), batched
+        if (!e.empty()) return e;
+    }
     std::vector<BasicSearchResult> ext;
     for (size_t i = 0; i < rows.size(); i++) {
         float prod = w * nd[i];                                        // :419 float32 arithmetic
@@ -622,9 +822,12 @@ HybridIndex::HybridIndex(const HybridConfig& c)
     : cfg_(c), exact_(c.metric, c.device), hnsw_(c.metric, c.device, c.hnsw), exact_threshold_(c.exact_threshold), rng_(c.seed) {}
 
 std::string HybridIndex::SelectStrategy(int vectorCount, int dimension, int k) {   // adaptive.go:41-72
-    if (rng_float64(&rng_) < cfg_.exploration_factor) {                // :46-51 exploration
-        if (rng_float64(&rng_) < 0.5) return "exact";
-        return "hnsw";
+    {
+        std::lock_guard<std::mutex> g(rng_mu_);                        // searches draw concurrently under the read lock
+        if (rng_float64(&rng_) < cfg_.exploration_factor) {            // :46-51 exploration
+            if (rng_float64(&rng_) < 0.5) return "exact";
+            return "hnsw";
+        }
     }
     if (vectorCount < exact_threshold_) return "exact";                // :56-58
     if (dimension > dim_threshold_) {                                  // :61-68
@@ -635,6 +838,7 @@ std::string HybridIndex::SelectStrategy(int vectorCount, int dimension, int k) {
 }
 
 Error HybridIndex::Insert(const std::string& id, const float* v, uint32_t len) {   // hybrid_index.go:86-129
+    std::unique_lock<std::shared_mutex> l(mu_);                        // :87
     if (vector_dim_ != 0 && (int)len != vector_dim_) return fmt("vector dimension mismatch: expected %d, got %u", vector_dim_, len);   // :88-91
     if (vectors_.count(id)) return fmt("vector with ID %s already exists", id.c_str());   // :92-95
     Error e = exact_.Insert(id, v, len);                               // :103-105
@@ -655,6 +859,7 @@ Error HybridIndex::Insert(const std::string& id, const float* v, uint32_t len) {
 }
 
 Error HybridIndex::InsertBatch(const std::vector<std::string>& ids, const std::vector<const float*>& vecs, const std::vector<uint32_t>& lens) {
+    std::unique_lock<std::shared_mutex> l(mu_);                        // :137
     if (ids.empty()) return "";                                        // :133-135
     int verifyDim = vector_dim_;                                       // :138-144
     if (verifyDim == 0) verifyDim = (int)lens[0];
@@ -662,22 +867,19 @@ Error HybridIndex::InsertBatch(const std::vector<std::string>& ids, const std::v
         if ((int)lens[i] != verifyDim) return fmt("vector dimension mismatch: expected %d, got %u", verifyDim, lens[i]);
     for (size_t i = 0; i < ids.size(); i++)                            // :151-156
         if (vectors_.count(ids[i])) return fmt("vector with ID %s already exists", ids[i].c_str());
-    // exact inserts, rollback on failure (:175-192)
-    for (size_t i = 0; i < ids.size(); i++) {
-        Error e = exact_.Insert(ids[i], vecs[i], lens[i]);
-        if (!e.empty()) {
-            for (size_t j = 0; j < i; j++) (void)exact_.Delete(ids[j]);
-            return "batch insert failed at ID " + ids[i] + ": " + e;
-        }
-    }
-    // HNSW inserts, rollback everything on failure (:195-216)
-    for (size_t i = 0; i < ids.size(); i++) {
-        Error e = hnsw_.Insert(ids[i], vecs[i], lens[i]);
-        if (!e.empty()) {
-            for (size_t j = 0; j < ids.size(); j++) (void)exact_.Delete(ids[j]);
-            for (size_t j = 0; j < i; j++) (void)hnsw_.Delete(ids[j]);
-            return "batch insert failed at ID " + ids[i] + ": " + e;
-        }
+    // one packed copy of the batch: both indexes take it in ONE device call each
+    const uint32_t len = (uint32_t)verifyDim;
+    std::vector<float> packed(ids.size() * (size_t)len);
+    for (size_t i = 0; i < ids.size(); i++) memcpy(&packed[i * (size_t)len], vecs[i], (size_t)len * sizeof(float));   // :161-172 (the copies)
+    // exact inserts, all-or-nothing (:175-192: insert one by one, delete the inserted ones on failure)
+    std::string failed;
+    Error e = exact_.InsertMany(ids, packed.data(), len, &failed);
+    if (!e.empty()) return "batch insert failed at ID " + failed + ": " + e;
+    // HNSW inserts, connected on the device; rollback everything on failure (:195-216)
+    e = hnsw_.InsertBatch(ids, packed.data(), len);
+    if (!e.empty()) {
+        for (size_t j = 0; j < ids.size(); j++) { (void)exact_.Delete(ids[j]); (void)hnsw_.Delete(ids[j]); }
+        return "batch insert failed: " + e;
     }
     if (vector_dim_ == 0) vector_dim_ = (int)lens[0];                  // :220-225
     for (size_t i = 0; i < ids.size(); i++) { vectors_[ids[i]].assign(vecs[i], vecs[i] + lens[i]); dimensions_.push_back((int)lens[i]); }
@@ -688,6 +890,7 @@ Error HybridIndex::InsertBatch(const std::vector<std::string>& ids, const std::v
 }
 
 Error HybridIndex::Delete(const std::string& id) {                     // hybrid_index.go:245-289
+    std::unique_lock<std::shared_mutex> l(mu_);                        // :246
     if (!vectors_.count(id)) return fmt("vector with ID %s not found", id.c_str());   // :247-250
     Error e = exact_.Delete(id); if (!e.empty()) return e;             // :254-256
     e = hnsw_.Delete(id); if (!e.empty()) return e;                    // :258-260
@@ -701,6 +904,7 @@ Error HybridIndex::Delete(const std::string& id) {                     // hybrid
 
 Error HybridIndex::DeleteBatch(const std::vector<std::string>& ids) {  // hybrid_index.go:292-372
     if (ids.empty()) return "";
+    std::unique_lock<std::shared_mutex> l(mu_);                        // :297
     std::string missing;
     for (auto& id : ids) if (!vectors_.count(id)) { if (!missing.empty()) missing += " "; missing += id; }   // :299-305
     if (!missing.empty()) return "some vectors not found: [" + missing + "]";   // :308-310
@@ -719,6 +923,12 @@ Error HybridIndex::DeleteBatch(const std::vector<std::string>& ids) {  // hybrid
 
 Error HybridIndex::searchWithStrategy(const float* q, uint32_t len, int k, const std::string& strategy_in, const float* neg, uint32_t neg_len,
                                       float neg_weight, bool has_weight, std::vector<BasicSearchResult>* out, std::string* used_out) {
+    std::shared_lock<std::shared_mutex> l(mu_);                        // :477-478
+    return searchImpl(q, len, k, strategy_in, neg, neg_len, neg_weight, has_weight, out, used_out);
+}
+
+Error HybridIndex::searchImpl(const float* q, uint32_t len, int k, const std::string& strategy_in, const float* neg, uint32_t neg_len,
+                              float neg_weight, bool has_weight, std::vector<BasicSearchResult>* out, std::string* used_out) {
     out->clear();
     if (vector_dim_ > 0 && (int)len != vector_dim_) return fmt("query dimension mismatch: expected %d, got %u", vector_dim_, len);   // :480-482
     std::string strategy = strategy_in;
@@ -766,43 +976,48 @@ Error HybridIndex::searchWithStrategy(const float* q, uint32_t len, int k, const
 Error HybridIndex::SearchWithRequest(const float* q, uint32_t len, int k, const std::string& force, const float* neg, uint32_t neg_len,
                                      float neg_weight, std::vector<BasicSearchResult>* out, std::string* used_out) {   // :383-470
     out->clear();
+    std::shared_lock<std::shared_mutex> l(mu_);                        // :388-389
     if (vector_dim_ > 0 && (int)len != vector_dim_) return fmt("query dimension mismatch: expected %d, got %u", vector_dim_, len);   // :392-394
     if (neg_len > 0 && vector_dim_ > 0 && (int)neg_len != vector_dim_)  // :395-397
         return fmt("negative example dimension mismatch: expected %d, got %u", vector_dim_, neg_len);
     if (k <= 0) return "k must be positive";                           // :400-402
     std::string strategy = force.empty() ? SelectStrategy(vector_count_, avg_dim_, k) : force;   // :405-411
-    if (neg_len > 0 && neg_weight > 0) return searchWithStrategy(q, len, k, strategy, neg, neg_len, neg_weight, true, out, used_out);   // :417-420
-    return searchWithStrategy(q, len, k, strategy, nullptr, 0, 0.5f, false, out, used_out);   // :422
+    if (neg_len > 0 && neg_weight > 0) return searchImpl(q, len, k, strategy, neg, neg_len, neg_weight, true, out, used_out);   // :417-420
+    return searchImpl(q, len, k, strategy, nullptr, 0, 0.5f, false, out, used_out);   // :422
 }
 
 Error HybridIndex::BatchSearch(const float* qs, uint32_t len, uint32_t nq, int k, const std::string& force,
                                std::vector<std::vector<BasicSearchResult>>* out, std::vector<std::string>* used_out) {   // :677-811
     out->clear();
     if (nq == 0) return "no queries provided";                         // :678-680
+    std::shared_lock<std::shared_mutex> l(mu_);                        // every goroutine's searchWithStrategy takes it shared (:477)
     if (vector_dim_ > 0 && (int)len != vector_dim_) return fmt("query 0 dimension mismatch: expected %d, got %u", vector_dim_, len);   // :707-713
     out->assign(nq, {});
     if (used_out) used_out->assign(nq, "");
-    // the reference fans out one goroutine per query (:703-705), each an independent
-    // searchWithStrategy; queries routed to the exact scan go down together in ONE device call
-    std::vector<uint32_t> exact_q;
+    // the reference fans out one goroutine per query (:703-705), each an independent searchWithStrategy; here the
+    // queries routed to one strategy go down together: ONE exact-scan call, ONE graph-traversal call
+    std::vector<uint32_t> exact_q, hnsw_q;
     for (uint32_t i = 0; i < nq; i++) {
         std::string s = force.empty() ? SelectStrategy(vector_count_, avg_dim_, k) : force;   // :730-738
         if (used_out) (*used_out)[i] = s;
         if (s == "exact") exact_q.push_back(i);
-        else if (s == "hnsw") {
-            Error e = hnsw_.Search(qs + (size_t)i * len, len, k, &(*out)[i]);
-            if (!e.empty()) return fmt("search %u failed: ", i) + e;   // :752-759
-        } else return fmt("search %u failed: invalid search strategy: ", i) + s;
+        else if (s == "hnsw") hnsw_q.push_back(i);
+        else return fmt("search %u failed: invalid search strategy: ", i) + s;
     }
-    if (!exact_q.empty()) {
-        std::vector<float> packed((size_t)exact_q.size() * len);
-        for (size_t j = 0; j < exact_q.size(); j++) memcpy(&packed[j * len], qs + (size_t)exact_q[j] * len, len * sizeof(float));
+    auto run = [&](const std::vector<uint32_t>& which, bool exact) -> Error {
+        if (which.empty()) return "";
+        std::vector<float> packed((size_t)which.size() * len);
+        for (size_t j = 0; j < which.size(); j++) memcpy(&packed[j * len], qs + (size_t)which[j] * len, len * sizeof(float));
         std::vector<std::vector<BasicSearchResult>> res;
-        Error e = exact_.SearchMany(packed.data(), len, (uint32_t)exact_q.size(), k, &res);
-        if (!e.empty()) return fmt("search %u failed: ", exact_q[0]) + e;
-        for (size_t j = 0; j < exact_q.size(); j++) (*out)[exact_q[j]] = std::move(res[j]);
-    }
-    return "";
+        Error e = exact ? exact_.SearchMany(packed.data(), len, (uint32_t)which.size(), k, &res)
+                        : hnsw_.SearchMany(packed.data(), len, (uint32_t)which.size(), k, &res);
+        if (!e.empty()) return fmt("search %u failed: ", which[0]) + e;   // :752-759
+        for (size_t j = 0; j < which.size(); j++) (*out)[which[j]] = std::move(res[j]);
+        return "";
+    };
+    Error e = run(hnsw_q, false);
+    if (!e.empty()) return e;
+    return run(exact_q, true);
 }
 
 }  // namespace quiver
@@ -840,6 +1055,7 @@ int qvh_exact_insert(void* p, const char* id, const float* v, uint32_t len) { re
 int qvh_exact_delete(void* p, const char* id) { return ret(static_cast<ExactIndex*>(p)->Delete(id)); }
 int qvh_exact_search(void* p, const float* q, uint32_t len, int k, void* res) { return ret(static_cast<ExactIndex*>(p)->Search(q, len, k, &static_cast<Results*>(res)->r)); }
 int qvh_exact_size(void* p) { return static_cast<ExactIndex*>(p)->Size(); }
+uint32_t qvh_exact_device_rows(void* p) { return static_cast<ExactIndex*>(p)->DeviceRows(); }
 
 // ---- HNSW
 void* qvh_hnsw_new(int metric, int device, int M, int maxM0, int efC, int efS, int maxLevel, uint64_t seed) {
@@ -848,6 +1064,11 @@ void* qvh_hnsw_new(int metric, int device, int M, int maxM0, int efC, int efS, i
 }
 void qvh_hnsw_free(void* p) { delete static_cast<HNSW*>(p); }
 int qvh_hnsw_insert(void* p, const char* id, const float* v, uint32_t len) { return ret(static_cast<HNSW*>(p)->Insert(id, v, len)); }
+int qvh_hnsw_insert_batch(void* p, const char** ids, const float* packed, uint32_t len, uint32_t n, uint32_t batch_max, uint32_t ramp_div) {
+    std::vector<std::string> i; for (uint32_t j = 0; j < n; j++) i.push_back(ids[j]);
+    return ret(static_cast<HNSW*>(p)->InsertBatch(i, packed, len, batch_max, ramp_div));
+}
+int qvh_hnsw_built_on_device(void* p) { return static_cast<HNSW*>(p)->BuiltOnDevice() ? 1 : 0; }
 int qvh_hnsw_delete(void* p, const char* id) { return ret(static_cast<HNSW*>(p)->Delete(id)); }
 int qvh_hnsw_search(void* p, const float* q, uint32_t len, int k, void* res, uint32_t* idx_out) {
     std::vector<HNSWResult> hr;
@@ -872,6 +1093,8 @@ int qvh_hnsw_search_batch(void* p, const float* qs, uint32_t len, uint32_t nq, i
 int qvh_hnsw_search_batch_raw(void* p, const float* qs, uint32_t len, uint32_t nq, int k, uint32_t* rows, float* dist, uint32_t* count, uint32_t* evals, double* seconds) {
     return ret(static_cast<HNSW*>(p)->SearchBatchRaw(qs, len, nq, k, rows, dist, count, evals, seconds));
 }
+uint32_t qvh_hybrid_exact_device_rows(void* p) { return static_cast<HybridIndex*>(p)->exact().DeviceRows(); }
+int qvh_hybrid_hnsw_built_on_device(void* p) { return static_cast<HybridIndex*>(p)->hnsw().graph().BuiltOnDevice() ? 1 : 0; }
 uint32_t qvh_hnsw_device_fallbacks(void* p) { return static_cast<HNSW*>(p)->DeviceFallbacks(); }
 uint32_t qvh_hnsw_topups(void* p) { return static_cast<HNSW*>(p)->TopUps(); }
 uint32_t qvh_hnsw_size(void* p) { return static_cast<HNSW*>(p)->Size(); }

@@ -53,6 +53,18 @@ class HNSW:
         v = f32(vector)
         check(hlib().qvh_hnsw_insert(self._h, id.encode(), v.ctypes.data, v.size))
 
+    def InsertBatch(self, ids, vectors, batch_max: int = 4096, ramp_div: int = 16) -> None:
+        """n Inserts connected on the device (qv_graph_insert): searches against the graph before each batch, links applied
+        in id order; batch_max = 1 is the sequential graph of n Insert calls"""
+        vs = np.ascontiguousarray(vectors, dtype=np.float32)
+        if vs.ndim != 2 or vs.shape[0] != len(ids):
+            raise ValueError("vectors must be [len(ids), dim]")
+        cids = (C.c_char_p * len(ids))(*[i.encode() for i in ids])
+        check(hlib().qvh_hnsw_insert_batch(self._h, cids, vs.ctypes.data, vs.shape[1], vs.shape[0], batch_max, ramp_div))
+
+    def built_on_device(self) -> bool:
+        return bool(hlib().qvh_hnsw_built_on_device(self._h))
+
     def Delete(self, id: str) -> None:
         check(hlib().qvh_hnsw_delete(self._h, id.encode()))
 

@@ -485,3 +485,150 @@ def test_hnsw_device_traversal_with_equal_distances_uses_the_exact_heap_kernel()
         assert [r.VectorIndex for r in res[i]] == er.tolist(), i
         assert np.array_equal(_bits([r.Distance for r in res[i]]), _bits(ed))
     assert h.device_fallbacks() == 0
+
+
+# ------------------------------------------------------------------ round 2: batched build, row reuse, locking ---
+
+def _host_graph(h):
+    return [(h.node_level(i), [h.links(i, l).tolist() for l in range(h.node_level(i) + 1)]) for i in range(h.nodes())], h.entry_point()
+
+
+def _oracle_graph(o):
+    return [(o.node_level(i), [o.links(i, l).tolist() for l in range(o.node_level(i) + 1)]) for i in range(o.nodes())], o.entry_point()
+
+
+@pytest.mark.parametrize("batch_max,ramp_div", [(1, 0), (64, 8)])
+def test_hnsw_insert_batch_builds_on_device_and_equals_oracle(batch_max, ramp_div):
+    """HNSW.InsertBatch: n Inserts connected by qv_graph_insert; the adjacency pulled back to the host equals the oracle's
+    (sequential Insert for batch_max = 1, qvo_hnsw_insert_batch otherwise), and both search paths agree with it"""
+    from quiver_amd import hnsw
+    from quiver_amd.device_index import graph_batch_size
+    n, dim = 1500, 32
+    rows = O.gen_rows(515, 0, n, dim)
+    h = hnsw.HNSW(hnsw.Config(M=8, EfConstruction=40, EfSearch=48, MaxLevel=6, DistanceFunc="hnsw_cosine", Seed=17))
+    ids = ["n%d" % i for i in range(n)]
+    h.InsertBatch(ids[:900], rows[:900], batch_max, ramp_div)
+    h.InsertBatch(ids[900:], rows[900:], batch_max, ramp_div)         # a second call continues the same device graph
+    assert h.built_on_device() and h.Size() == n
+    o = O.HNSW(5, dim, M=8, efConstruction=40, efSearch=48, maxLevel=6, seed=17)
+    done = 0
+    for seg in (900, n):
+        while done < seg:
+            b = min(graph_batch_size(done, batch_max, ramp_div), seg - done)
+            o.insert_batch(rows[done:done + b]); done += b
+    assert _host_graph(h) == _oracle_graph(o)
+    qs = O.gen_rows(516, 0, 24, dim)
+    batch = h.SearchBatch(qs, 5)
+    for i, q in enumerate(qs):
+        ro, do = o.search(q, 5)
+        single = h.Search(q, 5)                                       # host-driven walk over the pulled-back adjacency
+        assert [r.VectorIndex for r in single] == ro.tolist() and np.array_equal(_bits([r.Distance for r in single]), _bits(do))
+        assert [r.VectorIndex for r in batch[i]] == ro.tolist() and np.array_equal(_bits([r.Distance for r in batch[i]]), _bits(do))
+    # a host-driven Insert afterwards still works (and ends the device-built state)
+    extra = O.gen_rows(517, 0, 1, dim)[0]
+    h.Insert("extra", extra); o.insert(extra)
+    assert not h.built_on_device() and _host_graph(h) == _oracle_graph(o)
+    h.InsertBatch(["e2", "e3"], O.gen_rows(518, 0, 2, dim))           # falls back to a loop of Insert
+    assert h.Size() == n + 3
+
+
+def test_hnsw_insert_batch_duplicate_id_is_rejected_before_anything_changes():
+    from quiver_amd import hnsw
+    from quiver_amd._host import GoError
+    rows = O.gen_rows(9, 0, 10, 8)
+    h = hnsw.HNSW(hnsw.Config(M=4, DistanceFunc="hnsw_euclidean"))
+    h.InsertBatch(["a%d" % i for i in range(6)], rows[:6])
+    with pytest.raises(GoError, match="vector with ID a3 already exists"):
+        h.InsertBatch(["b0", "a3"], rows[6:8])
+    assert h.Size() == 6 and h.nodes() == 6
+
+
+def test_hybrid_insert_batch_is_two_device_calls_and_searches_agree():
+    from quiver_amd import hybrid, hnsw
+    n, dim = 1200, 24
+    rows = O.gen_rows(77, 0, n, dim)
+    idx = hybrid.HybridIndex(hybrid.IndexConfig(DistanceFunc="euclidean", HNSWConfig=hnsw.Config(M=8, EfConstruction=60, EfSearch=64), ExplorationFactor=0.0))
+    idx.InsertBatch({"v%d" % i: rows[i] for i in range(n)})
+    from quiver_amd._host import hlib
+    assert hlib().qvh_hybrid_hnsw_built_on_device(idx._h) == 1
+    qs = O.gen_rows(78, 0, 16, dim)
+    resp = idx.BatchSearch(hybrid.BatchSearchRequest(Queries=list(qs), K=5, ForceStrategy="hnsw"))     # one graph-traversal call
+    for i, q in enumerate(qs):
+        one = idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=q, K=5, ForceStrategy="hnsw"))
+        assert [(r.ID, r.Distance) for r in resp.Results[i]] == [(r.ID, r.Distance) for r in one.Results]
+    ex = idx.BatchSearch(hybrid.BatchSearchRequest(Queries=list(qs), K=5, ForceStrategy="exact"))
+    for i, q in enumerate(qs):
+        er, ed = O.exact_search(1, rows, q, 5)
+        assert [r.ID for r in ex.Results[i]] == ["v%d" % j for j in er]
+
+
+def test_exact_index_reuses_tombstoned_rows_under_churn():
+    """Collection.Update = Delete + Insert (collection.go): the device index must not grow with every update"""
+    from quiver_amd import hybrid
+    from quiver_amd._host import hlib
+    rows = O.gen_rows(3, 0, 600, 16)
+    e = hybrid.ExactIndex("cosine")
+    for i in range(200):
+        e.Insert("v%d" % i, rows[i])
+    for rnd in range(5):
+        for i in range(0, 200, 2):
+            e.Delete("v%d" % i)
+        for i in range(0, 200, 2):
+            e.Insert("v%d" % i, rows[200 + (rnd * 100 + i // 2) % 400])
+    assert e.Size() == 200 and hlib().qvh_exact_device_rows(e._h) == 200
+    live = {("v%d" % i): (rows[i] if i % 2 else rows[200 + (4 * 100 + i // 2) % 400]) for i in range(200)}
+    q = O.gen_rows(4, 0, 1, 16)[0]
+    got = e.Search(q, 7)
+    names = list(live.keys()); mat = np.stack([live[n_] for n_ in names])
+    er, ed = O.exact_search(0, mat, q, 7)
+    assert np.array_equal(_bits([r.Distance for r in got]), _bits(ed))
+    assert len(set(ed.tolist())) < 7 or [r.ID for r in got] == [names[j] for j in er]
+
+
+def test_concurrent_searches_on_one_hybrid_index_are_consistent():
+    """Collection.Search holds only a read lock (collection.go:647): many Index.Search calls run at once.  ctypes drops the GIL,
+    so Python threads really do enter the C++ mirror concurrently."""
+    import threading
+    from quiver_amd import hybrid, hnsw
+    n, dim = 800, 20
+    rows = O.gen_rows(21, 0, n, dim)
+    idx = hybrid.HybridIndex(hybrid.IndexConfig(DistanceFunc="cosine", HNSWConfig=hnsw.Config(M=8, EfConstruction=40, EfSearch=40), ExplorationFactor=0.0))
+    for i in range(n):
+        idx.Insert("v%d" % i, rows[i])                                # host-driven graph: Search walks it with per-thread visited stamps
+    qs = O.gen_rows(22, 0, 40, dim)
+
+    def serial(force):
+        return [[(r.ID, r.Distance) for r in idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=q, K=6, ForceStrategy=force)).Results] for q in qs]
+    want = {"hnsw": serial("hnsw"), "exact": serial("exact")}
+    errors = []
+
+    def worker(force, rounds):
+        try:
+            for _ in range(rounds):
+                if serial(force) != want[force]:
+                    errors.append("mismatch in " + force)
+        except Exception as ex:                                       # noqa: BLE001
+            errors.append(repr(ex))
+    ts = [threading.Thread(target=worker, args=(f, 3)) for f in ("hnsw", "exact", "hnsw", "exact", "hnsw", "hnsw")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+
+
+def test_hnsw_degree_bound_above_64_searches_through_the_host_walk():
+    """M = 48 -> MaxM0 = 96: the device traversal does not take it; SearchBatch must answer through the host-driven Search
+    (like k > 512), not fail"""
+    from quiver_amd import hnsw
+    rows = O.gen_rows(61, 0, 300, 12)
+    h = hnsw.HNSW(hnsw.Config(M=48, EfConstruction=60, EfSearch=40, MaxLevel=1, DistanceFunc="hnsw_euclidean", Seed=2))
+    o = O.HNSW(6, 12, M=48, efConstruction=60, efSearch=40, maxLevel=1, seed=2)
+    for i in range(300):
+        h.Insert("p%d" % i, rows[i]); o.insert(rows[i])
+    qs = O.gen_rows(62, 0, 5, 12)
+    out = h.SearchBatch(qs, 4)
+    for i, q in enumerate(qs):
+        ro, do = o.search(q, 4)
+        assert [r.VectorIndex for r in out[i]] == ro.tolist()
+    assert h.device_fallbacks() == 5
