@@ -261,6 +261,47 @@ int qv_graph_export(qv_graph* g, int8_t* levels, uint32_t* l0_deg, uint32_t* l0_
  * kernel (equal distances), qv_graph_search queries redone for the same reason. */
 int qv_graph_stats(const qv_graph* g, double* build_seconds, uint64_t* build_batches, uint64_t* build_redo, uint64_t* search_redo);
 
+/* ---- one corpus over the GPUs of a node --------------------------------
+ * No reference counterpart (the reference is one process on CPU cores): this is what lets the Go host reach all the
+ * GPUs of a node through ONE handle — what core.Index is for one GPU (qv_index), qv_sharded is for n.  One host
+ * process; devices[g] holds shard g (an exact index of its own) and runs its flat scan on its own stream; ONE RCCL
+ * all-gather per search carries every shard's top-k (nq*k*8 bytes per shard, over xGMI between the GPUs of a node:
+ * a latency collective); the merge on the first device orders by (distance, global row) like a single index.
+ *   global row ids   shard g owns [g * span, (g+1) * span), span = qv_sharded_span(n): "global row = shard base +
+ *                    local row" without knowing the corpus size up front; ids are stable as shards grow
+ *   qv_sharded_add   cuts a batch into one contiguous piece per shard so that the shards' fill evens out
+ *                    (qv_sharded_plan_add is the rule); global_rows_out[i] = id of rows[i] (the host maps string ids)
+ *   k <= 64          (the fused top-k width); larger k is QV_ERR_UNSUPPORTED — a filtered search ranks per shard
+ *   flags            QV_FLAG_ROWMAJOR passes through to the shards; QV_SHARDED_PEER_COPY replaces the collective with
+ *                    point-to-point copies into the first device (and lets several shards share one device, which
+ *                    RCCL does not allow: how the tests exercise 3 shards on a 1-GPU box)
+ * Threading: one call at a time per handle (internal mutex); different handles are independent. */
+typedef struct qv_sharded qv_sharded;
+#define QV_SHARDED_PEER_COPY (1ull << 32)
+uint32_t qv_sharded_span(int n_shards);
+int qv_sharded_plan_add(const uint64_t* rows_per_shard, int n_shards, uint64_t n, uint64_t* give_out);
+int qv_sharded_create(qv_sharded** out, uint32_t dim, qv_metric metric, const int* devices, int n_devices, uint64_t flags);
+void qv_sharded_destroy(qv_sharded* s);
+int qv_sharded_shards(const qv_sharded* s);
+uint64_t qv_sharded_size(const qv_sharded* s);                 /* live rows over all shards */
+uint32_t qv_sharded_dim(const qv_sharded* s);
+int qv_sharded_shard_info(const qv_sharded* s, int shard, int* device, uint32_t* base_row, uint32_t* rows, uint32_t* live);
+int qv_sharded_reserve(qv_sharded* s, uint64_t rows_total);
+int qv_sharded_add(qv_sharded* s, const float* rows, uint32_t n, uint32_t* global_rows_out);
+/* n synthetic rows (the generator of qv_index_add_synthetic), shard g taking the contiguous block [g*n/G, (g+1)*n/G) */
+int qv_sharded_add_synthetic(qv_sharded* s, uint64_t seed, uint64_t gen_row0, uint64_t n);
+int qv_sharded_remove(qv_sharded* s, const uint32_t* global_rows, uint32_t n);
+/* Same contract as qv_index_search (check order, clamping, padding, ordering); rows_out holds global row ids. */
+int qv_sharded_search(qv_sharded* s, const float* queries, uint32_t nq, uint32_t k, uint32_t* rows_out, float* dist_out, uint32_t* count_out);
+/* Queries and results resident on the FIRST device; everything is enqueued (no host synchronisation); `stream` (a
+ * stream of the first device, may be null) is ordered before and after the search. */
+int qv_sharded_search_device(qv_sharded* s, const float* d_queries, uint32_t nq, uint32_t k, uint32_t* d_rows_out, float* d_dist_out, void* stream);
+int qv_sharded_sync(qv_sharded* s);                            /* wait for every shard's stream */
+/* Measurement aid: with profiling on, every search is synchronous and its phases are timed with HIP events on the first
+ * device's stream: its own scan, the exchange (incl. waiting for the slowest shard), merge + download. */
+int qv_sharded_profile(qv_sharded* s, int enable);
+int qv_sharded_profile_read(qv_sharded* s, double* scan_ms_sum, double* exchange_ms_sum, double* merge_ms_sum, uint64_t* searches);
+
 /* Copy row `row` back to the host (ExactIndex keeps vectors readable,
  * hybrid_index.go:537 reads idx.vectors[id] for the re-rank). */
 int qv_index_get_row(qv_index* idx, uint32_t row, float* vec_out);

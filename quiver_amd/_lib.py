@@ -12,6 +12,7 @@ QV_OK = 0
 QV_ERR_INVALID_ARG, QV_ERR_DIM_MISMATCH, QV_ERR_K_NOT_POSITIVE, QV_ERR_OUT_OF_RANGE = -1, -2, -3, -4
 QV_ERR_NO_DEVICE, QV_ERR_DEVICE, QV_ERR_OOM, QV_ERR_UNSUPPORTED = -5, -6, -7, -8
 QV_FLAG_ROWMAJOR = 1
+QV_SHARDED_PEER_COPY = 1 << 32
 
 # include/qv.h qv_metric
 METRICS = {
@@ -76,6 +77,23 @@ PROTOTYPES = {
     "qv_graph_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p, _u32p, _u32p, C.POINTER(C.c_int)]),
     "qv_graph_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "qv_sharded_span": (C.c_uint32, [C.c_int]),
+    "qv_sharded_plan_add": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]),
+    "qv_sharded_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.c_uint64]),
+    "qv_sharded_destroy": (None, [C.c_void_p]),
+    "qv_sharded_shards": (C.c_int, [C.c_void_p]),
+    "qv_sharded_size": (C.c_uint64, [C.c_void_p]),
+    "qv_sharded_dim": (C.c_uint32, [C.c_void_p]),
+    "qv_sharded_shard_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), _u32p, _u32p, _u32p]),
+    "qv_sharded_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "qv_sharded_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "qv_sharded_add_synthetic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "qv_sharded_remove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "qv_sharded_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qv_sharded_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qv_sharded_sync": (C.c_int, [C.c_void_p]),
+    "qv_sharded_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "qv_sharded_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "qv_index_get_row": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "qv_last_error": (C.c_char_p, []),
     "qv_abi_version": (C.c_int, []),

@@ -109,7 +109,7 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
                             hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // merge n_lists lists of k (dist, row) pairs -> k best by (dist, row)
 hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t k,
-                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
+                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, bool planar = false);
 hipError_t launch_merge_pairs(const float* d_dist, const uint32_t* d_rows, uint32_t n_lists, uint32_t k,
                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 

@@ -252,6 +252,96 @@ class DeviceGraph:
             pass
 
 
+class ShardedIndex:
+    """One corpus over several GPUs behind ONE C-ABI handle (qv_sharded_* of include/qv.h): a shard (exact index) per device,
+    one RCCL all-gather of the per-shard top-k per search, merge on the first device.  `devices` may repeat a device only
+    with peer_copy=True (point-to-point exchange instead of the collective)."""
+
+    def __init__(self, dim: int, metric="cosine", devices=(0,), rowmajor: bool = False, peer_copy: bool = False):
+        self._h = C.c_void_p()
+        self.dim = int(dim)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        flags = (_lib.QV_FLAG_ROWMAJOR if rowmajor else 0) | (_lib.QV_SHARDED_PEER_COPY if peer_copy else 0)
+        check(lib().qv_sharded_create(C.byref(self._h), self.dim, metric_id(metric), devs, len(devices), flags))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().qv_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shards(self) -> int:
+        return int(lib().qv_sharded_shards(self._h))
+
+    def size(self) -> int:
+        return int(lib().qv_sharded_size(self._h))
+
+    def shard_info(self, g: int) -> dict:
+        dev = C.c_int(0); b, r, l = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        check(lib().qv_sharded_shard_info(self._h, g, C.byref(dev), C.byref(b), C.byref(r), C.byref(l)))
+        return {"device": dev.value, "base": b.value, "rows": r.value, "live": l.value}
+
+    def reserve(self, rows_total: int):
+        check(lib().qv_sharded_reserve(self._h, rows_total))
+
+    def add(self, rows) -> np.ndarray:
+        """-> global row id of every added row"""
+        rows = _f32c(rows)
+        if rows.ndim == 1:
+            rows = rows[None, :]
+        if rows.shape[1] != self.dim:
+            raise ValueError(f"vector dimension mismatch: expected {self.dim}, got {rows.shape[1]}")
+        ids = np.empty(rows.shape[0], dtype=np.uint32)
+        check(lib().qv_sharded_add(self._h, rows.ctypes.data, rows.shape[0], ids.ctypes.data))
+        return ids
+
+    def add_synthetic(self, seed: int, gen_row0: int, n: int):
+        check(lib().qv_sharded_add_synthetic(self._h, seed, gen_row0, n))
+
+    def remove(self, global_rows):
+        r = np.ascontiguousarray(global_rows, dtype=np.uint32).ravel()
+        check(lib().qv_sharded_remove(self._h, r.ctypes.data, r.size))
+
+    def search(self, queries, k: int):
+        q = _f32c(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.dim:
+            raise ValueError(f"query dimension mismatch: expected {self.dim}, got {q.shape[1]}")
+        nq, kk = q.shape[0], max(int(k), 0)
+        rows = np.full((nq, max(kk, 1)), 0xFFFFFFFF, dtype=np.uint32); dist = np.full((nq, max(kk, 1)), np.inf, dtype=np.float32)
+        count = np.zeros(nq, dtype=np.uint32)
+        check(lib().qv_sharded_search(self._h, q.ctypes.data, nq, kk, rows.ctypes.data, dist.ctypes.data, count.ctypes.data))
+        return rows[:, :kk], dist[:, :kk], count
+
+    def search_device(self, d_queries: int, nq: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
+        check(lib().qv_sharded_search_device(self._h, d_queries, nq, k, d_rows_out, d_dist_out, stream or None))
+
+    def sync(self):
+        check(lib().qv_sharded_sync(self._h))
+
+    def profile(self, enable: bool):
+        check(lib().qv_sharded_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self) -> dict:
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0); n = C.c_uint64(0)
+        check(lib().qv_sharded_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        m = max(int(n.value), 1)
+        return {"searches": int(n.value), "scan_ms": a.value / m, "exchange_ms": b.value / m, "merge_ms": c.value / m}
+
+
+def sharded_plan_add(rows_per_shard, n: int) -> np.ndarray:
+    have = np.ascontiguousarray(rows_per_shard, dtype=np.uint64)
+    give = np.zeros(have.size, dtype=np.uint64)
+    check(lib().qv_sharded_plan_add(have.ctypes.data, have.size, n, give.ctypes.data))
+    return give
+
+
 def graph_batch_size(nodes_linked: int, batch_max: int, ramp_div: int) -> int:
     return int(lib().qv_graph_batch_size(nodes_linked, batch_max, ramp_div))
 

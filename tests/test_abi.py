@@ -102,3 +102,21 @@ def test_header_is_plain_c_and_the_library_fails_loudly_without_a_gpu(tmp_path):
         assert "no device" in p.stdout and "no CPU path" in p.stdout
     else:
         assert p.stdout.startswith("ok:")
+
+
+def test_sharded_placement_rule_and_span():
+    """pure host arithmetic of qv_sharded_* (no device needed): the id space per shard and how a batch is cut over the shards"""
+    import numpy as np
+    from quiver_amd import _lib
+    from quiver_amd.device_index import sharded_plan_add
+    L = _lib.lib()
+    assert L.qv_sharded_span(8) == (1 << 29) - 64 and L.qv_sharded_span(3) % 64 == 0 and 3 * L.qv_sharded_span(3) <= 1 << 32
+    assert L.qv_sharded_span(1) % 64 == 0 and L.qv_sharded_span(1) > (1 << 31)
+    assert sharded_plan_add([0, 0, 0, 0], 10).tolist() == [3, 3, 2, 2]
+    assert sharded_plan_add([10, 0, 5], 9).tolist() == [0, 8, 1]
+    assert sharded_plan_add([100, 0, 0], 1).tolist() == [0, 1, 0]           # a single Insert goes to an emptiest shard
+    for have, n in (([7, 7, 7], 30), ([1000, 10, 10, 10], 5), ([0], 12345)):
+        give = sharded_plan_add(have, n)
+        assert int(give.sum()) == n
+        after = np.array(have) + give
+        assert after.max() - after.min() <= max(1, max(have) - min(have))
