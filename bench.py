@@ -1,32 +1,43 @@
 #!/usr/bin/env python3
 """bench.py — flat cosine scan QPS on MI355X (BASELINE.json metric), one JSON line.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            # N > 1 launches its own ranks (see below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): exact flat cosine top-10 over a synthetic unit-vector corpus of
---rows x 768 fp32 (default 10M x 768 = BASELINE.json configs[4]'s corpus, the shape the north
-star's roofline target is quoted on; it fits one GPU, so the same corpus is used at every N and
-the curve is strong scaling).  One STEP = one query against the whole corpus: every rank scans
-its contiguous row shard (qv_index_search_device: HIP flat scan + fused top-k), the per-shard
-top-k are all-gathered over RCCL and merged deterministically (qv_merge_topk_shards_device) — the
-orchestration is quiver_amd.sharded.ShardedFlatSearch, the same code the gloo tests cover; the
-exchange of step i overlaps the scan of step i+1.  Corpus and queries are resident in HBM
-before the timed region.
+Workload (config.workload): exact flat cosine top-10 over a synthetic unit-vector corpus of --rows x 768 fp32 (default
+10M x 768 = BASELINE.json configs[4]'s corpus, the shape the north star's roofline target is quoted on; it fits one GPU,
+so the same corpus is used at every N and the curve is strong scaling).  One STEP = one query against the whole corpus:
+every rank scans its contiguous row shard (qv_index_search_device: HIP flat scan + fused top-k), the per-shard top-k are
+all-gathered over RCCL and merged deterministically (qv_merge_topk_shards_device) — the orchestration is
+quiver_amd.sharded.ShardedFlatSearch, the same code the gloo tests cover; the exchange of step i overlaps the scan of
+step i+1.  Corpus and queries are resident in HBM before the timed region.
+
+Launching.  Under torch.distributed.run (RANK / WORLD_SIZE set) this file is one rank.  Run plainly with --gpus N > 1 it
+starts N fresh rank processes itself (python -m torch.distributed.run ... bench.py, before this process has touched the
+GPU) and passes their output and exit code through.  With fewer GPUs than ranks (a dry run of the N > 1 control path on a
+1-GPU box) ranks share devices and the exchange runs over gloo, because RCCL needs one device per rank; the line then says
+"exchange": "gloo (ranks share a device)".  --abi-sharded measures the same workload through ONE process and the C ABI's
+qv_sharded_* handle (a shard per device, ncclAllGather inside libqv) instead of one process per GPU.
 
 Extra objects on the line:
-  "roofline"     HBM roofline of the dominant kernel k_flat_scan (HIP events around that kernel,
-                 separate pass; traffic from the committed rocprofv3 PMC summary)
-  "cpu_baseline" the CPU oracle in reference-faithful mode on a bounded sample (checker/baseline
-                 only — never the product path)
-  "also"         (N=1) the other BASELINE configs measured in the same process: configs[1]
-                 flat cosine 1M x 768 single query; configs[2] 256 queries x 1M x 768 through the
-                 exact multi-query scan and through the fp32-MFMA filter (+ its MFMA roofline);
-                 the PCIe-inclusive single-query rate of the host-pointer entry point.
+  "roofline"     HBM roofline of the dominant kernel k_flat_scan (HIP events around that kernel, separate pass; traffic
+                 from the committed rocprofv3 PMC summary); at N > 1 also every GPU's fraction and the measured
+                 all-gather + merge latency
+  "cpu_baseline" the CPU oracle in reference-faithful mode on a bounded sample, 1 thread (what ExactIndex.Search uses) —
+                 plus, under "others": the same with one query per core (what BatchSearch does), and an optimised
+                 AVX-512 scan labelled NOT the reference; host model and core count (checker/baseline only — never the
+                 product path)
+  "also"         (N=1) the other BASELINE configs measured in the same process: configs[0] 10k x 128; configs[1] flat
+                 cosine 1M x 768 single query; configs[2] 256 queries x 1M x 768 (exact f64-matrix scan, fp32-MFMA filter for
+                 cosine and for dot-product, with MFMA rooflines); configs[3] HNSW M=16 efC=200 at 1M x 768: the graph
+                 built on the device, efSearch sweep, recall@10, CPU traversal of the identical graph; the PCIe-inclusive
+                 single-query rate of the host-pointer entry point.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,69 +62,375 @@ def parse():
     ap.add_argument("--metric", default="cosine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs measured at N=1")
+    ap.add_argument("--no-hnsw", action="store_true", help="skip the configs[3] HNSW build + search entries of `also`")
+    ap.add_argument("--hnsw-rows", type=int, default=1_000_000)
     ap.add_argument("--force-exchange", action="store_true",
-                    help="with one rank, still run the RCCL all-gather + merge per step (exercises the N>1 code path on a 1-GPU box)")
+                    help="with one rank, still run the all-gather + merge per step (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--scan-streams", type=int, default=0, help="scan streams alternated between consecutive queries; 0 = auto")
     ap.add_argument("--cpu-sample-rows", type=int, default=500_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=30)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-core CPU baselines; 0 = all cores")
+    ap.add_argument("--abi-sharded", action="store_true",
+                    help="one process, qv_sharded_* over --gpus devices (RCCL all-gather inside libqv) instead of one process per GPU")
+    ap.add_argument("--peer-copy", action="store_true", help="with --abi-sharded: point-to-point exchange (allows shards to share a device)")
     return ap.parse_args()
 
 
-def cpu_baseline(dim, k, sample_rows, sample_queries, total_rows):
-    """Reference-faithful ExactIndex.Search on the host (oracle 'port'): rows behind a string-keyed
-    hash map, scalar float64 distance per row, full sort of all N.  1 thread (what
-    ExactIndex.Search uses per query, exact.go:92-133)."""
+# ---------------------------------------------------------------------------------------------- launching
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as fresh child processes and pass their output through.
+    Nothing in this process has initialised the GPU (torch.cuda.device_count() does not), and it only waits."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+# ---------------------------------------------------------------------------------------------- CPU baselines
+def host_info():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def cpu_baseline(dim, k, sample_rows, sample_queries, total_rows, threads):
+    """Reference-faithful ExactIndex.Search on the host (oracle 'port'): rows behind a string-keyed hash map, scalar float64
+    distance per row, full sort of all N.  `value`: 1 thread (what ExactIndex.Search uses per query, exact.go:92-133).
+    others: one query per core (BatchSearch, hybrid_index.go:703-705) and an optimised AVX-512 scan (NOT the reference)."""
     from tests import _oracle as O
+    host = host_info()
+    T = threads or host["nproc"] or 1
     rows = O.gen_rows(CORPUS_SEED, 0, sample_rows, dim)
     f = O.Faithful(0, dim)
     for i in range(sample_rows):
         f.insert("v%d" % i, rows[i])
-    qs = O.gen_rows(QUERY_SEED, 0, sample_queries, dim)
+    qs = O.gen_rows(QUERY_SEED, 0, max(sample_queries, 2 * T), dim)
     f.search(qs[0], k)
     t0 = time.perf_counter()
-    for q in qs:
+    for q in qs[:sample_queries]:
         f.search(q, k)
     dt = time.perf_counter() - t0
     rows_per_s = sample_rows * sample_queries / dt
+    # the same searches, one per core at a time
+    nq_t = max(sample_queries, 2 * T)
+    dt_t, _ = f.search_many(qs[:nq_t], k, T)
+    rps_t = sample_rows * nq_t / dt_t
+    # NOT the reference: contiguous rows, cached norms, AVX-512 float32 lanes, rows split over the cores, partial top-k
+    T_o = max(1, T // 2) if T >= 16 else T                # one thread per physical core on an SMT host
+    opt = O.OptScan(rows, T_o)
+    opt.search(qs[:2], k)
+    dt_o, ro, _ = opt.search(qs[:sample_queries], k)
+    rps_o = sample_rows * sample_queries / dt_o
+    er, _ = O.exact_search(0, rows, qs[0], k)
     return {
         "value": rows_per_s / total_rows, "unit": "queries/s", "cores": 1, "kind": "port",
         "sample": "%d queries x first %d rows of the same corpus, reference-faithful ExactIndex.Search restatement "
                   "(oracle/qv_oracle.c qvo_faithful_search), %.2f s; value = measured rows/s / %d rows" %
                   (sample_queries, sample_rows, dt, total_rows),
         "rows_per_s": rows_per_s,
+        "others": {
+            "faithful_one_query_per_core": {
+                "value": rps_t / total_rows, "unit": "queries/s", "cores": T, "kind": "port", "rows_per_s": rps_t,
+                "sample": "%d queries over %d threads, each thread a whole faithful search at a time (BatchSearch's goroutine per "
+                          "query, hybrid_index.go:703-705), same %d rows, %.2f s" % (nq_t, T, sample_rows, dt_t)},
+            "optimised_scan_not_the_reference": {
+                "value": rps_o / total_rows, "unit": "queries/s", "cores": T_o, "kind": "port", "rows_per_s": rps_o,
+                "host_GBps": rps_o * dim * 4 / 1e9, "simd_bits": int(O.lib().qvo_opt_simd_bits()),
+                "top%d_overlap_with_exact_first_query" % k: len(set(er.tolist()) & set(ro[0].tolist())) / k,
+                "sample": "%d queries, rows split over %d pinned threads (NUMA-local slices), contiguous rows + cached norms + float32 FMA "
+                          "lanes + partial top-k (oracle/qv_cpu_baselines.c qvo_opt_cosine_scan): what a tuned CPU scan does, not what the "
+                          "reference does; %.3f s" % (sample_queries, T_o, dt_o)}},
+        "host": host,
     }
 
 
 def pmc_traffic(rows_per_gpu, dim):
-    """HBM bytes per k_flat_scan launch from the committed rocprofv3 PMC summary, when it was
-    taken on this exact per-GPU workload; else None."""
-    p = os.path.join(ROOT, "profiles", "r01_10Mx768_pmc.json")
+    """HBM bytes per k_flat_scan launch from the committed rocprofv3 PMC summary, when it was taken on this exact per-GPU
+    workload; else None."""
+    for name in ("r02_10Mx768_pmc.json", "r01_10Mx768_pmc.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if rows_per_gpu == 10_000_000 and dim == 768:
+                return d["hbm_bytes_per_launch"], "profiles/" + name
+        except Exception:  # noqa: BLE001
+            pass
+    return None, None
+
+
+# ---------------------------------------------------------------------------------------------- `also` (N = 1)
+def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
+    dim, k, nq_pool = a.dim, a.k, qs_host.shape[0]
+    sp = torch.cuda.current_stream().cuda_stream
+    qsz = dim * 4
+    d_r = torch.empty((k,), dtype=torch.int32, device="cuda")
+    d_d = torch.empty((k,), dtype=torch.float32, device="cuda")
+    also = {}
+    # host-pointer entry point on the same corpus: query up over PCIe, results down, one stream sync per query
+    idx.search(qs_host[0], k)
+    t1 = time.perf_counter()
+    for j in range(20):
+        idx.search(qs_host[j], k)
+    also["pcie_inclusive_single_query"] = {"workload": "qv_index_search (host pointers) on the same %dx%d corpus" % (a.rows, dim),
+                                           "qps": 20 / (time.perf_counter() - t1)}
+    # configs[1]/[2] live on a 1M x 768 corpus
+    idx1 = idx if a.rows == 1_000_000 else quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
+    if idx1 is not idx:
+        idx1.reserve(1_000_000)
+        idx1.add_synthetic(CORPUS_SEED, 0, 1_000_000)
+    for j in range(20):
+        idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
+    torch.cuda.synchronize()
+    steps1 = 500
+    t1 = time.perf_counter()
+    for j in range(steps1):
+        idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
+    torch.cuda.synchronize()
+    dt1 = time.perf_counter() - t1
+    idx1.profile(True)
+    for j in range(100):
+        idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
+    torch.cuda.synchronize()
+    ms1, n1 = idx1.profile_read()
+    idx1.profile(False)
+    b1 = 1_000_000 * dim * 4 + 1_000_000 * 8
+    also["flat_1Mx768_single_query"] = {
+        "workload": "flat cosine 1Mx768 fp32, k=10, single query (BASELINE configs[1])",
+        "qps": steps1 / dt1, "ms_per_query": dt1 / steps1 * 1e3, "scan_kernel_ms": ms1 / max(n1, 1),
+        "hbm_gbs": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9, "hbm_frac": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # configs[2]: 256 queries x 1M x 768
+    nqb = 256
+    d_rb = torch.empty((nqb, k), dtype=torch.int32, device="cuda")
+    d_db = torch.empty((nqb, k), dtype=torch.float32, device="cuda")
+    idx1.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        idx1.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
+    torch.cuda.synchronize()
+    dtb = (time.perf_counter() - t1) / 5
+    exact_rows = d_rb.cpu().numpy().view(np.uint32).copy()
+    exact_dist = d_db.cpu().numpy().copy()
+    flop = 2.0 * nqb * 1_000_000 * dim
+    also["batched_256x1Mx768_exact_scan"] = {
+        "workload": "256 queries x 1Mx768 cosine, k=10: exact multi-query scan on the f64 matrix cores (32 queries per corpus pass; v_mfma_f64 chains are bit-identical to the scalar f64 loop)",
+        "batch_ms": dtb * 1e3, "qps": nqb / dtb, "f64_tflops_equiv": flop / dtb / 1e12}
+
+    def mfma_entry(index, label, want_rows, want_dist):
+        d_flags = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
+        index.search_batched_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), d_flags.data_ptr(), sp)
+        torch.cuda.synchronize()
+        index.profile(True)
+        t2 = time.perf_counter()
+        for _ in range(10):
+            index.search_batched_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), d_flags.data_ptr(), sp)
+        torch.cuda.synchronize()
+        dtm = (time.perf_counter() - t2) / 10
+        msm, nm = index.profile_read()
+        index.profile(False)
+        redo = int(d_flags.sum().item())
+        rb, db = d_rb.cpu().numpy().view(np.uint32), d_db.cpu().numpy()
+        same = bool(redo == 0 and np.array_equal(rb, want_rows) and np.array_equal(db.view(np.uint32), want_dist.view(np.uint32)))
+        mf_ms = msm / max(nm, 1)
+        return {
+            "workload": "256 queries x 1Mx768 %s, k=10 (BASELINE configs[2]): fp32-MFMA filter + exact re-score, device-resident queries and "
+                        "results (sample scan, prep, filter, re-score all inside the timed region)" % label,
+            "batch_ms": dtm * 1e3, "qps": nqb / dtm, "identical_to_exact_scan": same, "queries_sent_back_to_exact_scan": redo,
+            "roofline": {"bound": "mfma", "kernel": "k_mfma_filter", "kernel_ms": mf_ms, "achieved": flop / (mf_ms * 1e-3) / 1e12,
+                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flop / (mf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                         "end_to_end_frac": flop / dtm / 1e12 / MFMA_F32_PEAK_TF, "algorithmic_flop_per_launch": flop}}
+    also["batched_256x1Mx768_mfma"] = mfma_entry(idx1, "cosine", exact_rows, exact_dist)
+    try:                                                   # configs[2] as written: dot-product
+        idot = quiver_amd.DeviceIndex(dim, "dot_product", device=local_rank)
+        idot.reserve(1_000_000)
+        idot.add_synthetic(CORPUS_SEED, 0, 1_000_000)
+        idot.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
+        torch.cuda.synchronize()
+        dot_rows, dot_dist = d_rb.cpu().numpy().view(np.uint32).copy(), d_db.cpu().numpy().copy()
+        also["batched_256x1Mx768_mfma_dot"] = mfma_entry(idot, "dot-product (1 - dot, distances.go:77-90)", dot_rows, dot_dist)
+        idot.close()
+    except Exception as ex:                                # noqa: BLE001
+        also["batched_256x1Mx768_mfma_dot"] = {"error": str(ex)}
+    if idx1 is not idx:
+        idx1.close()
+    # configs[0]: the reference's own CPU-runnable case, 10k x 128 cosine k=10, one query at a time through the host-pointer
+    # C ABI (query up, results down, one sync per call) — latency, not bandwidth; the CPU port beside it on the same rows
     try:
-        d = json.load(open(p))
-        if rows_per_gpu == 10_000_000 and dim == 768:
-            return d["hbm_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        pass
-    return None
+        c0 = quiver_amd.DeviceIndex(128, a.metric, device=local_rank)
+        c0.add_synthetic(CORPUS_SEED, 0, 10_000)
+        q0g = quiver_amd.DeviceIndex(128, a.metric, device=local_rank)
+        q0g.add_synthetic(QUERY_SEED, 0, 64)
+        q0 = np.stack([q0g.get_row(i) for i in range(64)])
+        q0g.close()
+        for j in range(50):
+            c0.search(q0[j % 64], k)
+        t1 = time.perf_counter()
+        for j in range(1000):
+            r0, d0, _ = c0.search(q0[j % 64], k)
+        dt0 = (time.perf_counter() - t1) / 1000
+        entry = {"workload": "pkg/hybrid exact flat scan 10k x 128 fp32 cosine, k=10 (BASELINE configs[0]), one query per call, host pointers",
+                 "latency_us": dt0 * 1e6, "qps_one_caller": 1.0 / dt0}
+        if not a.no_cpu_baseline:
+            from tests import _oracle as O
+            rows0 = O.gen_rows(CORPUS_SEED, 0, 10_000, 128)
+            f0 = O.Faithful(0, 128)
+            for i in range(10_000):
+                f0.insert("v%d" % i, rows0[i])
+            f0.search(q0[0], k)
+            t1 = time.perf_counter()
+            for j in range(200):
+                f0.search(q0[j % 64], k)
+            dtc = (time.perf_counter() - t1) / 200
+            entry["cpu_port_latency_us_1core"] = dtc * 1e6
+            entry["identical_to_oracle"] = bool(np.array_equal(r0[0], O.exact_search(0, rows0, q0[999 % 64], k)[0]))
+        also["config0_10kx128_single_query"] = entry
+        c0.close()
+    except Exception as ex:                                # noqa: BLE001
+        also["config0_10kx128_single_query"] = {"error": str(ex)}
+    # configs[3]: HNSW M=16 (MaxM0=32) efConstruction=200 over 1M x 768, the graph INSERTION-BUILT on the device
+    if not a.no_hnsw:
+        from tests.bench.bench_hnsw_build import run as hnsw_run
+        cpuq = 0 if a.no_cpu_baseline else 20
+        for key, max_level, efs, note in (
+                ("hnsw_1Mx768_reference_defaults", 16, (128,),
+                 "MaxLevel=16, the reference's default.  Its connectNode re-enters the lower levels from the new node itself "
+                 "(hnsw.go:463-467), so every node of level >= 1 links only to itself on level 0 and the level-0 graph is a forest of "
+                 "small islands around those nodes: graph traversals return few results and HNSW.Search completes most queries with its "
+                 "brute-force top-up (hnsw.go:676-710).  Reproduced faithfully (the build equals the CPU restatement's); the numbers "
+                 "below are what that structure gives"),
+                ("hnsw_1Mx768_maxlevel1", 1, (64, 128, 256, 512),
+                 "MaxLevel=1: every node on level 0, so the level quirk above is out of play and the level-0 graph is one connected "
+                 "M=16/MaxM0=32 graph — the configuration in which 'QPS @ recall' describes a graph search")):
+            try:
+                e = hnsw_run(rows=a.hnsw_rows, dim=dim, metric=a.metric, m=16, efc=200, max_level=max_level, efs=efs, nq=8192, k=k,
+                             cpu_queries=cpuq, device=local_rank, corpus_seed=CORPUS_SEED, query_seed=QUERY_SEED)
+                e["note"] = note
+                also[key] = e
+            except Exception as ex:                        # noqa: BLE001  (a measurement beside the headline; never fail the bench line over it)
+                also[key] = {"error": str(ex)}
+    return also
 
 
+# ---------------------------------------------------------------------------------------------- one process, C-ABI sharding
+def run_abi_sharded(a):
+    import torch
+    import quiver_amd
+    from quiver_amd.device_index import device_info
+    ndev = torch.cuda.device_count()
+    G, dim, k = a.gpus, a.dim, a.k
+    if ndev < G and not a.peer_copy:
+        raise SystemExit("--abi-sharded --gpus %d needs %d devices (have %d); --peer-copy co-locates shards for a dry run" % (G, G, ndev))
+    devices = [g % max(ndev, 1) for g in range(G)]
+    torch.cuda.set_device(devices[0])
+    sh = quiver_amd.ShardedIndex(dim, a.metric, devices=devices, peer_copy=a.peer_copy)
+    sh.reserve(a.rows)
+    t_gen = time.perf_counter()
+    sh.add_synthetic(CORPUS_SEED, 0, a.rows)
+    sh.sync()
+    t_gen = time.perf_counter() - t_gen
+    nq_pool = 256
+    qgen = quiver_amd.DeviceIndex(dim, a.metric, device=devices[0])
+    qgen.add_synthetic(QUERY_SEED, 0, nq_pool)
+    qs_host = np.stack([qgen.get_row(i) for i in range(nq_pool)])
+    qgen.close()
+    d_q = torch.from_numpy(qs_host).cuda()
+    total = a.warmup + a.steps
+    d_r = torch.empty((total, k), dtype=torch.int32, device="cuda")
+    d_d = torch.empty((total, k), dtype=torch.float32, device="cuda")
+    qsz = dim * 4
+
+    def run(first, count):
+        for i in range(first, first + count):
+            sh.search_device(d_q.data_ptr() + (i % nq_pool) * qsz, 1, k, d_r.data_ptr() + i * k * 4, d_d.data_ptr() + i * k * 4)
+
+    run(0, a.warmup)
+    sh.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.warmup, a.steps)
+    sh.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # verification: returned distances are the oracle's for the returned rows
+    from tests import _oracle as O
+    span = quiver_amd.lib().qv_sharded_span(G)
+    bounds = [g * a.rows // G for g in range(G + 1)]
+    rr, dd = d_r.cpu().numpy().view(np.uint32), d_d.cpu().numpy()
+    verified = True
+    mid = quiver_amd.metric_id(a.metric)
+    for j in range(min(a.steps, 4)):
+        step = a.warmup + j
+        for t_ in range(k):
+            g = int(rr[step, t_]) // span
+            gen_row = bounds[g] + int(rr[step, t_]) % span
+            want = O.distance(mid, qs_host[step % nq_pool], O.gen_rows(CORPUS_SEED, gen_row, 1, dim)[0])
+            verified &= bool(np.float32(want).view(np.uint32) == dd[step, t_].view(np.uint32))
+        verified &= all(dd[step, t_] <= dd[step, t_ + 1] for t_ in range(k - 1))
+    sh.profile(True)
+    for j in range(min(a.steps, 50)):
+        sh.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr())
+    prof = sh.profile_read()
+    sh.profile(False)
+    n_local = sh.shard_info(0)["rows"]
+    alg_bytes = n_local * dim * 4 + n_local * 8
+    achieved = alg_bytes / (prof["scan_ms"] * 1e-3) / 1e9 if prof["scan_ms"] > 0 else 0.0
+    info = device_info(devices[0])
+    out = {
+        "metric": "flat_cosine_qps_recall_1.0", "value": a.steps / dt, "unit": "queries/s", "n_gpus": G, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "flat %s scan %dx%d fp32, k=%d, single query per step, recall 1.0 (exact)" % (a.metric, a.rows, dim, k),
+                   "rows_total": a.rows, "rows_per_gpu": [sh.shard_info(g)["rows"] for g in range(G)], "dim": dim, "k": k,
+                   "sharding": "C ABI qv_sharded_*: ONE process, a shard per device, %s of the per-shard top-k inside libqv, merge on the first device"
+                               % ("hipMemcpyPeerAsync (point-to-point)" if a.peer_copy else "ncclAllGather (RCCL)"),
+                   "devices": devices, "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_flat_scan (first device's shard)", "kernel_ms": prof["scan_ms"], "algorithmic_bytes_per_launch": alg_bytes,
+                     "exchange_ms": prof["exchange_ms"], "merge_and_download_ms": prof["merge_ms"], "launches_timed": prof["searches"]},
+        "cpu_baseline": None, "verified_against_oracle": bool(verified),
+    }
+    print(json.dumps(out), flush=True)
+    sh.close()
+
+
+# ---------------------------------------------------------------------------------------------- one rank
 def main():
     a = parse()
+    if a.abi_sharded:
+        return run_abi_sharded(a)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
-        a.gpus = world
+    a.gpus = world
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    shared_devices = world > ndev                        # dry run: more ranks than GPUs
+    device_id = local_rank % ndev
+    torch.cuda.set_device(device_id)
     use_pg = world > 1 or a.force_exchange
+    backend = "gloo" if shared_devices else "nccl"
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_id))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import quiver_amd
     from quiver_amd.device_index import device_info
@@ -121,7 +438,7 @@ def main():
 
     dim, k, G = a.dim, a.k, world
     base, n_local = shard_bounds(a.rows, G, rank)
-    idx = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
+    idx = quiver_amd.DeviceIndex(dim, a.metric, device=device_id)
     idx.reserve(n_local)
     t_gen = time.perf_counter()
     done = 0
@@ -134,7 +451,7 @@ def main():
 
     # queries: the product's own synthetic generator (seed QUERY_SEED), read back once
     nq_pool = 256
-    qgen = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
+    qgen = quiver_amd.DeviceIndex(dim, a.metric, device=device_id)
     qgen.add_synthetic(QUERY_SEED, 0, nq_pool)
     qs_host = np.stack([qgen.get_row(i) for i in range(nq_pool)])
     qgen.close()
@@ -142,7 +459,7 @@ def main():
     sp = torch.cuda.current_stream().cuda_stream
     qsz = dim * 4
     total_steps = a.warmup + a.steps
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", device_id)
     search = ShardedFlatSearch(DeviceShard(idx), base, k, dev, world=G, ring=total_steps + 2, force_exchange=a.force_exchange)
 
     # consecutive queries are independent: alternating between scan streams lets the ramp-up of scan i+1 fill the tail of scan i
@@ -215,176 +532,37 @@ def main():
     kern_ms = scan_ms / max(launches, 1)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if launches else 0.0
 
+    # ---- N > 1: every GPU's roofline fraction, and the exchange (all-gather + merge) latency on its own ----
+    per_gpu, exchange_us = None, None
+    if use_pg:
+        mine = torch.tensor([achieved / HBM_PEAK_GBS, float(n_local), kern_ms], dtype=torch.float64, device="cuda")
+        allv = torch.empty((G, 3), dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(allv.view(-1), mine)
+        per_gpu = [{"rank": g, "rows": int(allv[g, 1].item()), "scan_kernel_ms": float(allv[g, 2].item()), "hbm_frac": float(allv[g, 0].item())} for g in range(G)]
+        b = search._ring[0]
+        reps = 50
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):                            # the exchange step alone, queues empty: one all-gather of [2][k] words + one merge launch
+            w = dist.all_gather_into_tensor(b["g_pack"].view(-1), b["pack"].view(-1), async_op=True)
+            search.finish((b, (w,)))
+            torch.cuda.synchronize()
+        exchange_us = (time.perf_counter() - t1) / reps * 1e6
+        t = torch.tensor([exchange_us], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange_us = float(t.item())
+
     also = None
-    if G == 1 and not a.no_also and a.metric == "cosine":
-        also = {}
-        # host-pointer entry point on the same corpus: query up over PCIe, results down, one stream sync per query
-        idx.search(qs_host[0], k)
-        t1 = time.perf_counter()
-        for j in range(20):
-            idx.search(qs_host[j], k)
-        also["pcie_inclusive_single_query"] = {"workload": "qv_index_search (host pointers) on the same %dx%d corpus" % (a.rows, dim),
-                                               "qps": 20 / (time.perf_counter() - t1)}
-        # configs[1]/[2] live on a 1M x 768 corpus
-        idx1 = idx if a.rows == 1_000_000 else quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
-        if idx1 is not idx:
-            idx1.reserve(1_000_000)
-            idx1.add_synthetic(CORPUS_SEED, 0, 1_000_000)
-        for j in range(20):
-            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
-        torch.cuda.synchronize()
-        steps1 = 500
-        t1 = time.perf_counter()
-        for j in range(steps1):
-            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
-        idx1.profile(True)
-        for j in range(100):
-            idx1.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr(), sp)
-        torch.cuda.synchronize()
-        ms1, n1 = idx1.profile_read()
-        idx1.profile(False)
-        b1 = 1_000_000 * dim * 4 + 1_000_000 * 8
-        also["flat_1Mx768_single_query"] = {
-            "workload": "flat cosine 1Mx768 fp32, k=10, single query (BASELINE configs[1])",
-            "qps": steps1 / dt1, "ms_per_query": dt1 / steps1 * 1e3, "scan_kernel_ms": ms1 / max(n1, 1),
-            "hbm_gbs": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9, "hbm_frac": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        # configs[2]: 256 queries x 1M x 768
-        nqb = 256
-        d_rb = torch.empty((nqb, k), dtype=torch.int32, device="cuda")
-        d_db = torch.empty((nqb, k), dtype=torch.float32, device="cuda")
-        idx1.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            idx1.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
-        torch.cuda.synchronize()
-        dtb = (time.perf_counter() - t1) / 5
-        exact_rows = d_rb.cpu().numpy().view(np.uint32).copy()
-        exact_dist = d_db.cpu().numpy().copy()
-        flop = 2.0 * nqb * 1_000_000 * dim
-        also["batched_256x1Mx768_exact_scan"] = {
-            "workload": "256 queries x 1Mx768 cosine, k=10: exact multi-query scan on the f64 matrix cores (32 queries per corpus pass; v_mfma_f64 chains are bit-identical to the scalar f64 loop)",
-            "batch_ms": dtb * 1e3, "qps": nqb / dtb, "f64_tflops_equiv": flop / dtb / 1e12}
-        d_flags = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
-        idx1.search_batched_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), d_flags.data_ptr(), sp)
-        torch.cuda.synchronize()
-        idx1.profile(True)
-        t1 = time.perf_counter()
-        for _ in range(10):
-            idx1.search_batched_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), d_flags.data_ptr(), sp)
-        torch.cuda.synchronize()
-        dtm = (time.perf_counter() - t1) / 10
-        msm, nm = idx1.profile_read()
-        idx1.profile(False)
-        redo = int(d_flags.sum().item())
-        rb, db = d_rb.cpu().numpy().view(np.uint32), d_db.cpu().numpy()
-        same = bool(redo == 0 and np.array_equal(rb, exact_rows) and np.array_equal(db.view(np.uint32), exact_dist.view(np.uint32)))
-        mf_ms = msm / max(nm, 1)
-        also["batched_256x1Mx768_mfma"] = {
-            "workload": "256 queries x 1Mx768 cosine, k=10 (BASELINE configs[2]): fp32-MFMA filter + exact re-score, "
-                        "device-resident queries and results (sample scan, prep, filter, re-score all inside the timed region)",
-            "batch_ms": dtm * 1e3, "qps": nqb / dtm, "identical_to_exact_scan": same, "queries_sent_back_to_exact_scan": redo,
-            "roofline": {"bound": "mfma", "kernel": "k_mfma_filter", "kernel_ms": mf_ms, "achieved": flop / (mf_ms * 1e-3) / 1e12,
-                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flop / (mf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                         "algorithmic_flop_per_launch": flop,
-                         "pmc": "profiles/r01_sweep_mq.txt: SQ_VALU_MFMA_BUSY_CYCLES = 81.8 % of kernel cycles at an effective 1.99 GHz"}}
-        if idx1 is not idx:
-            idx1.close()
-        # configs[0]: the reference's own CPU-runnable case, 10k x 128 cosine k=10, one query at a time through the host-pointer
-        # C ABI (query up, results down, one sync per call) — latency, not bandwidth; the CPU port beside it on the same rows
-        try:
-            c0 = quiver_amd.DeviceIndex(128, a.metric, device=local_rank)
-            c0.add_synthetic(CORPUS_SEED, 0, 10_000)
-            q0g = quiver_amd.DeviceIndex(128, a.metric, device=local_rank); q0g.add_synthetic(QUERY_SEED, 0, 64)
-            q0 = np.stack([q0g.get_row(i) for i in range(64)]); q0g.close()
-            for j in range(50):
-                c0.search(q0[j % 64], k)
-            t1 = time.perf_counter()
-            for j in range(1000):
-                r0, d0, _ = c0.search(q0[j % 64], k)
-            dt0 = (time.perf_counter() - t1) / 1000
-            entry = {"workload": "pkg/hybrid exact flat scan 10k x 128 fp32 cosine, k=10 (BASELINE configs[0]), one query per call, host pointers",
-                     "latency_us": dt0 * 1e6, "qps_one_caller": 1.0 / dt0}
-            if not a.no_cpu_baseline:
-                from tests import _oracle as O
-                rows0 = O.gen_rows(CORPUS_SEED, 0, 10_000, 128)
-                f0 = O.Faithful(0, 128)
-                for i in range(10_000):
-                    f0.insert("v%d" % i, rows0[i])
-                f0.search(q0[0], k)
-                t1 = time.perf_counter()
-                for j in range(200):
-                    ids0, dd0 = f0.search(q0[j % 64], k)
-                dtc = (time.perf_counter() - t1) / 200
-                er0, ed0 = O.exact_search(0, rows0, q0[199 % 64], k)
-                entry["cpu_port_latency_us_1core"] = dtc * 1e6
-                entry["identical_to_oracle"] = bool(np.array_equal(r0[0], O.exact_search(0, rows0, q0[999 % 64], k)[0]))
-            also["config0_10kx128_single_query"] = entry
-            c0.close()
-        except Exception as ex:
-            also["config0_10kx128_single_query"] = {"error": str(ex)}
-        # configs[3] shape at reduced N: HNSW traversal (efSearch=128, MaxM0=32) on an exact 32-NN graph over 100k rows,
-        # built here by the product's own scan (the reference's sequential Insert build is not a data-parallel path)
-        try:
-            hn, hm, hef, hq = 100_000, 32, 128, 8192
-            hidx = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank, rowmajor=True)
-            hidx.add_synthetic(CORPUS_SEED, 0, hn)
-            hrows = np.stack([hidx.get_row(i) for i in range(hn)])
-            t1 = time.perf_counter()
-            links = np.empty((hn, hm), np.uint32); cols = np.arange(hm)[None, :]
-            for s0 in range(0, hn, 8192):
-                e0 = min(hn, s0 + 8192)
-                nbr, _, _ = hidx.search(hrows[s0:e0], hm + 1, batched=True)
-                me = np.arange(s0, e0, dtype=np.uint32)[:, None]
-                hit = nbr == me
-                pos = np.where(hit.any(axis=1), hit.argmax(axis=1), hm)[:, None]
-                links[s0:e0] = np.where(cols < pos, nbr[:, :hm], nbr[:, 1:hm + 1])
-            t_knn = time.perf_counter() - t1
-            graph = quiver_amd.DeviceGraph(hidx, np.zeros(hn, np.int8), np.full(hn, hm, np.uint32), links, entry=0)
-            qg2 = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
-            qg2.add_synthetic(QUERY_SEED, 0, hq)
-            hqs = np.stack([qg2.get_row(i) for i in range(hq)]); qg2.close()
-            graph.search(hqs[:512], k, hef)
-            t1 = time.perf_counter()
-            _, _, hcnt, hev = graph.search(hqs, k, hef, with_evals=True)
-            dth = time.perf_counter() - t1
-            # the same batch with queries and results resident on the device (qv_graph_search_device)
-            dq = torch.from_numpy(hqs).cuda()
-            dr = torch.empty((hq, k), dtype=torch.int32, device="cuda"); dd2 = torch.empty((hq, k), dtype=torch.float32, device="cuda")
-            dc = torch.empty(hq, dtype=torch.int32, device="cuda")
-            graph.search_device(dq.data_ptr(), hq, k, hef, dr.data_ptr(), dd2.data_ptr(), dc.data_ptr(), 0, sp)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                graph.search_device(dq.data_ptr(), hq, k, hef, dr.data_ptr(), dd2.data_ptr(), dc.data_ptr(), 0, sp)
-            torch.cuda.synchronize()
-            dthd = (time.perf_counter() - t1) / 3
-            also["hnsw_traversal_100kx768"] = {
-                "workload": "HNSW.Search on the device (BASELINE configs[3] shape, reduced N): efSearch=%d, MaxM0=%d, k=%d, %d queries on an exact "
-                            "%d-NN graph over %dx%d rows; qv_graph_search incl. query upload and result download" % (hef, hm, k, hq, hm, hn, dim),
-                "qps": hq / dth, "batch_ms": dth * 1e3, "distance_evals_per_query": float(hev.mean()), "distance_evals_per_s": float(hev.sum()) / dth,
-                "device_resident": {"qps": hq / dthd, "batch_ms": dthd * 1e3, "distance_evals_per_s": float(hev.sum()) / dthd,
-                                    "gathered_GBps": float(hev.sum()) * dim * 4 / dthd / 1e9},
-                "roofline": {"bound": "hbm", "kernel": "k_hnsw_search_wave", "achieved": float(hev.sum()) * dim * 4 / dthd / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": float(hev.sum()) * dim * 4 / dthd / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes": "distance evaluations x dim x 4 (each evaluated row fetched once)",
-                             "note": "a 100k x 768 table is cache-resident (Infinity Cache); the row stream alone in this kernel's shape reaches "
-                                     "6.63 TB/s from a 1M x 768 table (tools/ubench/gather_rows.hip), the traversal 4.55 TB/s there"},
-                "gathered_GBps": float(hev.sum()) * dim * 4 / dth / 1e9, "underfilled_queries": int((hcnt < k).sum()), "knn_graph_build_s": t_knn,
-                "parity": "tests/test_gpu_graph.py, tests/test_gpu_host.py: rows, float32 bits and evaluation counts equal the CPU traversal of the same graph",
-                "larger": "profiles/r01_hnsw_knn_1Mx768.json (1Mx768: 314k QPS device-resident), profiles/r01_hnsw_20kx768.jsonl (reference-built graph: 441k QPS)"}
-            graph.close(); hidx.close()
-        except Exception as ex:                                   # a measurement beside the headline; never fail the bench line over it
-            also["hnsw_traversal_100kx768"] = {"error": str(ex)}
+    if G == 1 and rank == 0 and not a.no_also and a.metric == "cosine":
+        also = also_entries(a, torch, quiver_amd, idx, d_q, qs_host, device_id)
 
     cpu = None
     if rank == 0 and G == 1 and not a.no_cpu_baseline:          # the CPU baseline is a single-GPU-run artefact (rank 0, N=1 only)
-        cpu = cpu_baseline(dim, k, a.cpu_sample_rows, a.cpu_sample_queries, a.rows)
+        cpu = cpu_baseline(dim, k, a.cpu_sample_rows, a.cpu_sample_queries, a.rows, a.cpu_threads)
 
     if rank == 0:
-        info = device_info(local_rank)
+        info = device_info(device_id)
+        traffic, traffic_src = pmc_traffic(n_local, dim)
         out = {
             "metric": "flat_cosine_qps_recall_1.0", "value": qps, "unit": "queries/s",
             "n_gpus": G, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -393,13 +571,16 @@ def main():
             "config": {"workload": "flat %s scan %dx%d fp32, k=%d, single query per step, recall 1.0 (exact, bit-identical to the CPU oracle)" % (a.metric, a.rows, dim, k),
                        "rows_total": a.rows, "rows_per_gpu": n_local, "dim": dim, "k": k,
                        "arithmetic": "float64 accumulation over float32 rows, one rounding to float32 (the reference's arithmetic)",
-                       "scan_streams": n_scan_streams, "sharding": "contiguous row shards, per-shard top-k + RCCL all-gather (k*8 B/rank) + deterministic merge; exchange of step i overlaps scan of step i+1" if G > 1 else "single shard",
+                       "scan_streams": n_scan_streams,
+                       "sharding": ("contiguous row shards, one process per GPU, per-shard top-k + all-gather (k*8 B/rank) + deterministic merge; "
+                                    "exchange of step i overlaps scan of step i+1") if use_pg else "single shard",
+                       "exchange": None if not use_pg else ("RCCL (torch.distributed nccl backend)" if backend == "nccl" else "gloo (ranks share a device: RCCL needs one device per rank)"),
                        "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n_local, dim),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_flat_scan", "kernel_ms": kern_ms, "launches_timed": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "traffic_source": "profiles/r01_10Mx768_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per the gfx950 correction)"},
+                         "algorithmic_bytes_per_launch": alg_bytes, "traffic_source": traffic_src,
+                         "per_gpu": per_gpu, "allgather_plus_merge_us": exchange_us},
             "cpu_baseline": cpu,
             "verified_against_oracle": bool(verified),
         }

@@ -58,6 +58,19 @@ uint32_t      qvo_faithful_size(const qvo_faithful*);
 /* ids_out[k] receives pointers to the stored id strings (owned by the index) */
 int64_t       qvo_faithful_search(qvo_faithful*, const float* query, uint32_t k, const char** ids_out, float* dist_out);
 
+/* ---- CPU baselines beyond one thread (qv_cpu_baselines.c) ---------------------------------
+ * nq faithful searches over `threads` threads, one whole search per thread at a time: what HybridIndex.BatchSearch does
+ * with that many cores (hybrid_index.go:703-705).  dist_out [nq][k] optional.  Returns wall seconds. */
+double qvo_faithful_search_many(qvo_faithful*, uint32_t dim, const float* queries, uint32_t nq, uint32_t k, int threads, float* dist_out);
+/* NOT the reference: contiguous rows, cached norms, 16-wide float32 FMA lanes (AVX-512 where present), rows split over
+ * `threads` pinned threads (each slice allocated by its own thread: NUMA-local), per-thread partial top-k, spinning
+ * barriers.  Returns wall seconds for the nq queries, one after another (thread start-up excluded). */
+typedef struct qvo_opt qvo_opt;
+qvo_opt* qvo_opt_create(const float* rows, uint32_t n, uint32_t dim, int threads);   /* per-thread NUMA-local slices + cached norms */
+void   qvo_opt_destroy(qvo_opt*);
+double qvo_opt_cosine_scan(qvo_opt*, const float* queries, uint32_t nq, uint32_t k, uint32_t* rows_out, float* dist_out);
+int    qvo_opt_simd_bits(void);
+
 /* ---- HNSW restatement (pkg/hnsw/hnsw.go) ------------------------------------------ */
 typedef struct qvo_hnsw qvo_hnsw;
 /* NewHNSW hnsw.go:222-252; defaults M=16, MaxM0=2M, efC=200, efS=100, MaxLevel=16.

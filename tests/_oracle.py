@@ -45,6 +45,14 @@ def _load():
     lib.qvo_faithful_size.argtypes = [C.c_void_p]
     lib.qvo_faithful_search.restype = C.c_int64
     lib.qvo_faithful_search.argtypes = [C.c_void_p, _f32p, C.c_uint32, C.POINTER(C.c_char_p), _f32p]
+    lib.qvo_faithful_search_many.restype = C.c_double
+    lib.qvo_faithful_search_many.argtypes = [C.c_void_p, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    lib.qvo_opt_create.restype = C.c_void_p
+    lib.qvo_opt_create.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_int]
+    lib.qvo_opt_destroy.argtypes = [C.c_void_p]
+    lib.qvo_opt_cosine_scan.restype = C.c_double
+    lib.qvo_opt_cosine_scan.argtypes = [C.c_void_p, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]
+    lib.qvo_opt_simd_bits.restype = C.c_int
     lib.qvo_hnsw_create.restype = C.c_void_p
     lib.qvo_hnsw_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]
     lib.qvo_hnsw_destroy.argtypes = [C.c_void_p]
@@ -146,6 +154,30 @@ def exact_search_negative(metric: int, rows, query, negative, weight: float, k: 
     return ro[:got].copy(), do[:got].copy()
 
 
+class OptScan:
+    """the optimised (NOT reference-faithful) CPU cosine scan: per-thread NUMA-local slices, cached norms, SIMD lanes"""
+
+    def __init__(self, rows, threads: int):
+        rows = _f32(rows)
+        self.threads = threads
+        self._h = lib().qvo_opt_create(rows, rows.shape[0], rows.shape[1], threads)
+
+    def search(self, queries, k: int):
+        """-> (wall seconds of the scans, rows [nq, k], dist [nq, k])"""
+        qs = _f32(queries)
+        if qs.ndim == 1:
+            qs = qs[None, :]
+        ro = np.empty((qs.shape[0], k), dtype=np.uint32); do = np.empty((qs.shape[0], k), dtype=np.float32)
+        dt = lib().qvo_opt_cosine_scan(self._h, qs, qs.shape[0], k, ro, do)
+        return float(dt), ro, do
+
+    def __del__(self):
+        try:
+            lib().qvo_opt_destroy(self._h)
+        except Exception:
+            pass
+
+
 class Faithful:
     """reference-faithful ExactIndex (CPU baseline)"""
 
@@ -167,6 +199,13 @@ class Faithful:
         if got < 0:
             raise ValueError("k must be positive")
         return [ids[i].decode() for i in range(got)], do[:got].copy()
+
+    def search_many(self, queries, k: int, threads: int):
+        """nq faithful searches on `threads` threads (one whole search per thread at a time) -> (wall seconds, dist [nq, k])"""
+        qs = _f32(queries)
+        out = np.empty((qs.shape[0], k), dtype=np.float32)
+        dt = lib().qvo_faithful_search_many(self._h, self.dim, qs, qs.shape[0], k, threads, out.ctypes.data_as(C.c_void_p))
+        return float(dt), out
 
     def __del__(self):
         try:

@@ -41,7 +41,7 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session", autouse=True)
 def _build_oracle():
     so = os.path.join(ROOT, "oracle", "libqvoracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("qv_oracle.c", "qv_oracle_hnsw.c", "qv_oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("qv_oracle.c", "qv_oracle_hnsw.c", "qv_cpu_baselines.c", "qv_oracle.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     yield
