@@ -148,6 +148,14 @@ int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, u
 int qv_index_search_masked(qv_index* idx, const float* queries, uint32_t nq, uint32_t k, const uint64_t* mask,
                            uint32_t* rows_out, float* dist_out, uint32_t* count_out);
 
+/* Search with a negative example, the device part of HybridIndex.searchWithStrategy's exact branch
+ * (hybrid_index.go:517-570; the HNSW adapter's is adapter.go:345-437): the k_fetch = max(2k, 30) nearest rows of `query`
+ * (as qv_index_search), and for exactly those rows the distance to `negative` (as qv_distance_rows) — one call, one
+ * synchronisation, the row ids never leave the device in between.  The host forms score = d - w * d_neg in float32
+ * (:549) and sorts the <= k_fetch records by (score, id) (:552-557).  Outputs are [k_fetch]; *count_out = min(k_fetch, size). */
+int qv_index_search_negative(qv_index* idx, const float* query, const float* negative, uint32_t k_fetch,
+                             uint32_t* rows_out, float* dist_out, float* neg_dist_out, uint32_t* count_out);
+
 /* Batched-query path: approximate scores by fp32 MFMA GEMM with fused per-tile
  * candidate selection, then exact re-scoring of the candidates with the same
  * arithmetic as qv_index_search, so results are identical to it.  Same

@@ -121,3 +121,54 @@ class ArrowFlatIndex:
 
     def Load(self, path: str) -> None:                         # arrow_hnsw.go:201-241
         load_ipc(path, self.dim, self._add_block)
+
+
+class Graph:
+    """Mirror of arrowindex.Graph's query surface (pkg/arrowindex/graph.go:162-200, 459-534, 897-918): int ids, float64 vectors,
+    squared-L2 search.  Storage is the device index (metric QV_L2SQ_F64: float64 differences and accumulation, graph.go:749-794)
+    instead of chunked arrow Float64 arrays, so vectors must be float32-representable — which is what reaches this type in
+    the reference (ArrowHNSWIndex widens float32 rows, arrow_hnsw.go:66-80); anything else is refused rather than rounded.
+    Search follows graph.go:467-534: dimension check and wording, empty graph -> no results, k clamped to the node count,
+    and an EXHAUSTIVE ranking when len(nodes) <= m (:482-484).  Above m the reference walks its randomly-levelled graph
+    (math/rand, unseeded: graph.go:945-952) with ef = max(efSearch, 2k) (:522) and returns an approximation of the same
+    ranking; here every size gets the exact ranking (for len(nodes) > m a recall-1.0 stand-in, declared in DESIGN.md)."""
+
+    def __init__(self, dim: int, m: int = 16, efConstruction: int = 200, efSearch: int = 100, chunkSize: int = 1024, device: int = 0):
+        from .device_index import DeviceIndex
+        self.dim, self.m, self.efConstruction, self.efSearch, self.chunkSize = dim, m, efConstruction, efSearch, chunkSize
+        self._idx = DeviceIndex(dim, "arrow_squared_euclidean", device=device)
+        self._ids: List[int] = []                                  # node index -> ID (nodes[i].ID)
+
+    def AddBatch(self, items) -> None:                             # graph.go:203-274
+        vecs = []
+        for id_, vec in items:
+            v64 = np.asarray(vec, dtype=np.float64).ravel()
+            if v64.size != self.dim:
+                raise ValueError(f"vector dimension mismatch for id {id_}: got {v64.size}, want {self.dim}")
+            v32 = v64.astype(np.float32)
+            if not np.array_equal(v32.astype(np.float64), v64):
+                raise ValueError(f"vector of id {id_} is not float32-representable (device storage is float32)")
+            vecs.append(v32)
+        if vecs:
+            self._idx.add(np.stack(vecs))
+            self._ids.extend(int(id_) for id_, _ in items)
+
+    def Add(self, id: int, vec) -> None:                           # graph.go:459-464
+        self.AddBatch([(id, vec)])
+
+    def Len(self) -> int:                                          # graph.go:915-918
+        return len(self._ids)
+
+    def GetVector(self, idx: int):                                 # graph.go:897-901
+        return self._idx.get_row(idx).astype(np.float64) if 0 <= idx < len(self._ids) else None
+
+    def Search(self, query, k: int) -> List[int]:                  # graph.go:467-488
+        q = np.asarray(query, dtype=np.float64).ravel()
+        if q.size != self.dim:
+            raise ValueError(f"query dimension mismatch: got {q.size}, want {self.dim}")
+        n = len(self._ids)
+        if n == 0 or k <= 0:
+            return []
+        k = min(k, n)                                              # :478-480
+        rows, _, count = self._idx.search(q.astype(np.float32), k)  # exhaustiveSearch (:490-506): every node, nearest k
+        return [self._ids[int(rows[0, i])] for i in range(int(count[0]))]

@@ -140,6 +140,20 @@ Error ExactIndex::Search(const float* q, uint32_t len, int k, std::vector<BasicS
     return "";
 }
 
+Error ExactIndex::SearchWithNegativeDistances(const float* q, const float* neg, uint32_t len, int retrieveK,
+                                              std::vector<BasicSearchResult>* out, std::vector<float>* neg_out) {
+    out->clear(); neg_out->clear();
+    std::shared_lock<std::shared_mutex> l(mu_);
+    if (row_of_.empty()) return "";                                    // exact.go:96-98
+    if (dim_ > 0 && (int)len != dim_) return fmt("query dimension mismatch: expected %d, got %u", dim_, len);   // :100-102
+    if (retrieveK <= 0) return "k must be positive";                   // :104-106
+    const uint32_t kk = (uint32_t)std::min<size_t>((size_t)retrieveK, row_of_.size());
+    std::vector<uint32_t> rows(kk); std::vector<float> d(kk), nd(kk); uint32_t cnt = 0;
+    if (qv_index_search_negative(h_, q, neg, kk, rows.data(), d.data(), nd.data(), &cnt) != QV_OK) return qv_err();
+    for (uint32_t i = 0; i < cnt; i++) { out->push_back({id_of_[rows[i]], d[i]}); neg_out->push_back(nd[i]); }
+    return "";
+}
+
 Error ExactIndex::DistancesTo(const float* other, uint32_t len, const std::vector<std::string>& ids, std::vector<float>* out) {
     out->assign(ids.size(), 0.f);
     if (ids.empty()) return "";
@@ -942,18 +956,16 @@ Error HybridIndex::searchImpl(const float* q, uint32_t len, int k, const std::st
     if (strategy == "exact") {                                         // :515
         int retrieveK = k;
         if (hasNegative) { retrieveK = std::max(2 * k, 30); if (retrieveK > (int)vectors_.size()) retrieveK = (int)vectors_.size(); }   // :517-522
-        Error e = exact_.Search(q, len, retrieveK, out);               // :524
-        if (!e.empty()) return e;
-        if (hasNegative) {                                             // :529-570
-            std::vector<std::string> ids; std::vector<size_t> pos;
-            for (size_t i = 0; i < out->size(); i++) if (vectors_.count((*out)[i].id)) { ids.push_back((*out)[i].id); pos.push_back(i); }   // :537-540
-            std::vector<float> nd;
-            e = exact_.DistancesTo(neg, neg_len, ids, &nd);            // :543 distFunc(vector, negExample), batched
+        if (!hasNegative) return exact_.Search(q, len, retrieveK, out);   // :524
+        {                                                              // :524-570: the fetch and the negative distances in ONE device call
+            std::vector<float> nd_all;
+            Error e = exact_.SearchWithNegativeDistances(q, neg, len, retrieveK, out, &nd_all);   // :524 + :543 distFunc(vector, negExample)
             if (!e.empty()) return e;
             std::vector<BasicSearchResult> rr;
-            for (size_t i = 0; i < ids.size(); i++) {
-                float prod = negWeight * nd[i];                        // :549 float32
-                rr.push_back({ids[i], (*out)[pos[i]].distance - prod});
+            for (size_t i = 0; i < out->size(); i++) {
+                if (!vectors_.count((*out)[i].id)) continue;           // :537-540
+                float prod = negWeight * nd_all[i];                    // :549 float32
+                rr.push_back({(*out)[i].id, (*out)[i].distance - prod});
             }
             if (!rr.empty()) {
                 std::stable_sort(rr.begin(), rr.end(), [](const BasicSearchResult& a, const BasicSearchResult& b) {   // :552-557

@@ -53,6 +53,10 @@ public:
     // nq searches in one device call (what BatchSearch's goroutine fan-out becomes)
     Error SearchMany(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<BasicSearchResult>>* out);
     int Size() const { std::shared_lock<std::shared_mutex> l(mu_); return (int)row_of_.size(); }   // exact.go:136-141
+    // the retrieveK nearest results of q together with distFunc(vector, negative) for each of them (hybrid_index.go:524-546),
+    // in ONE device call (qv_index_search_negative)
+    Error SearchWithNegativeDistances(const float* q, const float* neg, uint32_t len, int retrieveK,
+                                      std::vector<BasicSearchResult>* out, std::vector<float>* neg_out);
     // distance(vector of `id`, other) for the re-rank loop (hybrid_index.go:543)
     Error DistancesTo(const float* other, uint32_t len, const std::vector<std::string>& ids, std::vector<float>* out);
     bool Has(const std::string& id) const { std::shared_lock<std::shared_mutex> l(mu_); return row_of_.count(id) != 0; }

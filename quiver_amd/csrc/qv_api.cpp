@@ -61,34 +61,37 @@ int stream_workspace(qv_index* idx, hipStream_t s, size_t bytes, void** out) {
 }
 
 // grow device storage to hold `rows` rows (whole tiles), preserving contents
+// one device array grown in place of the old one: the first keep_bytes are carried over, the rest is zero
+template <typename T> hipError_t regrow(T** p, size_t keep_bytes, size_t new_bytes) {
+    T* n = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&n), new_bytes);
+    if (e != hipSuccess) return e;
+    if (new_bytes > keep_bytes) e = hipMemset(reinterpret_cast<char*>(n) + keep_bytes, 0, new_bytes - keep_bytes);
+    if (e == hipSuccess && keep_bytes) e = hipMemcpy(n, *p, keep_bytes, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipFree(n); return e; }
+    (void)hipFree(*p);
+    *p = n;
+    return hipSuccess;
+}
+
+// grow device storage to hold `rows` rows (whole tiles), preserving contents.  The arrays are grown ONE AT A TIME (old + new
+// copy of one array live together, never of all four), and a failure half way leaves every array valid at its old or its
+// new size with the capacity unchanged: nothing leaks, nothing dangles.
 int ensure_rows(qv_index* idx, uint64_t rows, bool exact) {
     uint64_t need_tiles = (rows + 63) / 64;
     if (need_tiles <= idx->cap_tiles) return QV_OK;
     if (rows > 0xFFFFFFF0ull) return fail(QV_ERR_INVALID_ARG, "row count %llu exceeds the uint32 row space", (unsigned long long)rows);
     uint64_t new_tiles = exact ? need_tiles : std::max<uint64_t>(need_tiles, idx->cap_tiles + idx->cap_tiles / 2 + 16);
     const size_t tb = idx->tile_bytes();
-    float* nt = nullptr; double* nn = nullptr; uint64_t* na = nullptr; float* nr = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&nt), new_tiles * tb));
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nn), new_tiles * 64 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&na), new_tiles * sizeof(uint64_t));
-    if (e == hipSuccess && (idx->flags & QV_FLAG_ROWMAJOR)) e = hipMalloc(reinterpret_cast<void**>(&nr), new_tiles * 64 * (size_t)idx->dim * sizeof(float));
-    if (e != hipSuccess) {
-        (void)hipFree(nt); (void)hipFree(nn); (void)hipFree(na); (void)hipFree(nr);
-        return fail(QV_ERR_OOM, "device allocation for %llu rows failed: %s", (unsigned long long)(new_tiles * 64), hipGetErrorString(e));
-    }
     const uint64_t used_tiles = (idx->n_rows + 63) / 64;
-    // zero the new part (pad rows must be finite; alive bits must start clear), copy the used part
-    HIPCHK(hipMemset(reinterpret_cast<char*>(nt) + used_tiles * tb, 0, (new_tiles - used_tiles) * tb));
-    HIPCHK(hipMemset(nn + used_tiles * 64, 0, (new_tiles - used_tiles) * 64 * sizeof(double)));
-    HIPCHK(hipMemset(na + used_tiles, 0, (new_tiles - used_tiles) * sizeof(uint64_t)));
-    if (used_tiles) {
-        HIPCHK(hipMemcpy(nt, idx->d_tiles, used_tiles * tb, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy(nn, idx->d_rnorm, used_tiles * 64 * sizeof(double), hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy(na, idx->d_alive, used_tiles * sizeof(uint64_t), hipMemcpyDeviceToDevice));
-        if (nr) HIPCHK(hipMemcpy(nr, idx->d_rowmaj, (size_t)idx->n_rows * idx->dim * sizeof(float), hipMemcpyDeviceToDevice));
-    }
-    (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rowmaj);
-    idx->d_tiles = nt; idx->d_rnorm = nn; idx->d_alive = na; idx->d_rowmaj = nr;
+    // pad rows must be finite and alive bits must start clear: the new part of every array is zero
+    hipError_t e = regrow(&idx->d_tiles, used_tiles * tb, new_tiles * tb);
+    if (e == hipSuccess) e = regrow(&idx->d_rnorm, used_tiles * 64 * sizeof(double), new_tiles * 64 * sizeof(double));
+    if (e == hipSuccess) e = regrow(&idx->d_alive, used_tiles * sizeof(uint64_t), new_tiles * sizeof(uint64_t));
+    if (e == hipSuccess && (idx->flags & QV_FLAG_ROWMAJOR))
+        e = regrow(&idx->d_rowmaj, (size_t)idx->n_rows * idx->dim * sizeof(float), new_tiles * 64 * (size_t)idx->dim * sizeof(float));
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "device allocation for %llu rows failed: %s", (unsigned long long)(new_tiles * 64), hipGetErrorString(e));
     idx->cap_tiles = new_tiles;
     return QV_OK;
 }
@@ -289,12 +292,17 @@ int qv_index_get_row(qv_index* idx, uint32_t row, float* vec_out) {
     if (!vec_out) return fail(QV_ERR_INVALID_ARG, "vec_out is null");
     if (row >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", row, idx->n_rows);
     HIPCHK(hipSetDevice(idx->device));
-    float* d = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&d), (size_t)idx->dim * sizeof(float)));
-    hipError_t e = qv::launch_fetch_row(idx->view(), row, d, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(vec_out, d, (size_t)idx->dim * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipFree(d);
+    SearchCtx* c = nullptr;                                            // a pooled context: its stream and staging buffers, no allocation per call
+    int rc = acquire_ctx(idx, &c);
+    if (rc != QV_OK) return rc;
+    CtxGuard guard{idx, c};
+    const size_t bytes = (size_t)idx->dim * sizeof(float);
+    if ((rc = c->d_q.ensure(bytes)) || (rc = c->h_q.ensure(bytes))) return rc;
+    hipError_t e = qv::launch_fetch_row(idx->view(), row, static_cast<float*>(c->d_q.p), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_q.p, c->d_q.p, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "get_row failed: %s", hipGetErrorString(e));
+    memcpy(vec_out, c->h_q.p, bytes);
     return QV_OK;
 }
 
@@ -402,6 +410,48 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
     if (idx && nq >= 32 && k > 0 && idx->n_live >= 4 * (uint64_t)k && qv::batched_supported(idx->view(), nq, std::min(k, idx->n_live)))
         return qv_index_search_batched(idx, queries, nq, k, rows_out, dist_out, count_out);
     return exact_search_host(idx, queries, nq, k, rows_out, dist_out, count_out);
+}
+
+// Search with a negative example, device side of hybrid_index.go:517-570 / hnsw/adapter.go:345-437: the reference fetches
+// retrieveK = max(2k, 30) nearest results, then calls the distance function once more per result against the negative
+// example and re-ranks by d - w * d_neg.  Which rows are candidates depends on d alone, so the device part is: the flat scan
+// for k_fetch results, then — on the same stream, row ids never leaving the device — the neighbour-batch kernel for those
+// rows against the negative vector.  ONE call, one synchronisation; the host combines two floats per row and sorts <= 30
+// records by (score, string id).
+int qv_index_search_negative(qv_index* idx, const float* query, const float* negative, uint32_t k_fetch,
+                             uint32_t* rows_out, float* dist_out, float* neg_dist_out, uint32_t* count_out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (!query || !negative || !count_out) return fail(QV_ERR_INVALID_ARG, "query/negative/count_out is null");
+    if (idx->n_live == 0) { *count_out = 0; return QV_OK; }                     // exact.go:96-98
+    if (k_fetch == 0) return fail(QV_ERR_K_NOT_POSITIVE, "k must be positive"); // exact.go:104-106
+    if (!rows_out || !dist_out || !neg_dist_out) return fail(QV_ERR_INVALID_ARG, "rows_out/dist_out/neg_dist_out is null");
+    const uint32_t kk = std::min(k_fetch, idx->n_live);
+    HIPCHK(hipSetDevice(idx->device));
+    SearchCtx* c = nullptr;
+    int rc = acquire_ctx(idx, &c);
+    if (rc != QV_OK) return rc;
+    CtxGuard guard{idx, c};
+    const size_t vbytes = (size_t)idx->dim * sizeof(float), obytes = (size_t)kk * 4;
+    if ((rc = c->d_q.ensure(2 * vbytes)) || (rc = c->h_q.ensure(2 * vbytes)) || (rc = c->d_rows.ensure(obytes)) || (rc = c->d_dist.ensure(2 * obytes)) ||
+        (rc = c->h_rows.ensure(obytes)) || (rc = c->h_dist.ensure(2 * obytes)) || (rc = c->ws.ensure(search_ws_bytes(idx, 1, kk, kk))))
+        return rc;
+    memcpy(c->h_q.p, query, vbytes);
+    memcpy(static_cast<char*>(c->h_q.p) + vbytes, negative, vbytes);
+    HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, 2 * vbytes, hipMemcpyHostToDevice, c->stream));
+    float* d_dist = static_cast<float*>(c->d_dist.p);
+    rc = enqueue_search(idx, static_cast<const float*>(c->d_q.p), 1, kk, kk, c->ws.p, c->ws.cap, static_cast<uint32_t*>(c->d_rows.p), d_dist, c->stream);
+    if (rc != QV_OK) return rc;
+    hipError_t e = qv::launch_distance_rows(idx->view(), static_cast<const float*>(c->d_q.p) + idx->dim, static_cast<const uint32_t*>(c->d_rows.p), kk, d_dist + kk, c->stream);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_rows launch failed: %s", hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(c->h_rows.p, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_dist.p, d_dist, 2 * obytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(rows_out, c->h_rows.p, obytes);
+    memcpy(dist_out, c->h_dist.p, obytes);
+    memcpy(neg_dist_out, static_cast<const char*>(c->h_dist.p) + obytes, obytes);
+    for (uint32_t i = kk; i < k_fetch; i++) { rows_out[i] = 0xFFFFFFFFu; dist_out[i] = __builtin_inff(); neg_dist_out[i] = __builtin_inff(); }
+    *count_out = kk;
+    return QV_OK;
 }
 
 int qv_index_search_masked(qv_index* idx, const float* queries, uint32_t nq, uint32_t k, const uint64_t* mask,
@@ -677,16 +727,20 @@ int qv_distance_pairs(qv_metric metric, const float* a, const float* b, uint32_t
     if (e != hipSuccess || ndev <= 0) return fail(QV_ERR_NO_DEVICE, "no HIP device available; libqv has no CPU path");
     if (device < 0 || device >= ndev) return fail(QV_ERR_INVALID_ARG, "device %d out of range (have %d)", device, ndev);
     HIPCHK(hipSetDevice(device));
+    // grow-only device buffers per device, shared by all callers (one call at a time per device): no hipMalloc per call
+    struct PairBufs { std::mutex mu; Buf a, b, out; };
+    static std::mutex table_mu;
+    static std::map<int, PairBufs*> table;
+    PairBufs* pb;
+    { std::lock_guard<std::mutex> g(table_mu); PairBufs*& slot = table[device]; if (!slot) slot = new PairBufs(); pb = slot; }
+    std::lock_guard<std::mutex> g(pb->mu);
     const size_t bytes = (size_t)n * dim * sizeof(float);
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
-    e = hipMalloc(reinterpret_cast<void**>(&da), std::max<size_t>(bytes, 16));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&db), std::max<size_t>(bytes, 16));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), (size_t)n * sizeof(float));
-    if (e == hipSuccess && bytes) e = hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess && bytes) e = hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = qv::launch_distance_pairs((int)metric, da, db, n, dim, dout, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(dist_out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    int rc;
+    if ((rc = pb->a.ensure(std::max<size_t>(bytes, 16))) || (rc = pb->b.ensure(std::max<size_t>(bytes, 16))) || (rc = pb->out.ensure((size_t)n * sizeof(float)))) return rc;
+    if (bytes) e = hipMemcpy(pb->a.p, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && bytes) e = hipMemcpy(pb->b.p, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = qv::launch_distance_pairs((int)metric, static_cast<const float*>(pb->a.p), static_cast<const float*>(pb->b.p), n, dim, static_cast<float*>(pb->out.p), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(dist_out, pb->out.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_pairs failed: %s", hipGetErrorString(e));
     return QV_OK;
 }

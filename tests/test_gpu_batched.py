@@ -46,6 +46,25 @@ def test_mfma_batched_equals_exact_scan(metric):
         assert _eq(_exact(idx, qs[:m], k), idx.search(qs[:m], k, batched=True))
 
 
+def test_config2_dot_product_256x1Mx768_against_the_cpu_oracle():
+    """BASELINE.json configs[2] as written — 256 queries x 1M x 768, dot-product, fp32 MFMA + fused candidate selection — at
+    full size: three of the 256 queries against the CPU oracle over all 1M rows (rows and float32 bits), all 256 against the
+    exact scan"""
+    import os
+    import quiver_amd as q
+    from tests._par import exact_topk_synthetic
+    n, dim, nq = 1_000_000, 768, 256
+    idx = q.DeviceIndex(dim, "dot_product")
+    idx.reserve(n)
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    batched = idx.search(qs, 10, batched=True)
+    assert _eq(_exact(idx, qs, 10), batched)
+    for i in (0, 101, 255):
+        er, ed = exact_topk_synthetic(3, 20260424, n, dim, qs[i], 10, chunk=100_000, workers=min(16, os.cpu_count() or 8))
+        assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed)), i
+
+
 def test_mfma_batched_with_unrepresentative_sample_ties_and_tombstones():
     """the first 32K rows (the sample) are all far from the queries, so the sample bound is
     loose and candidate buffers overflow -> those queries are redone by the exact scan;

@@ -278,6 +278,22 @@ def test_config1_flat_cosine_1Mx768_k10_full_oracle_and_properties():
     assert np.array_equal(r2[0], r[0, 1:]) and np.array_equal(_bits(d2[0]), _bits(d[0, 1:]))
 
 
+def test_config4_flat_cosine_10Mx768_one_query_against_the_full_cpu_oracle():
+    """BASELINE.json configs[4] corpus on ONE GPU: the returned 10 rows are THE top-10 of all 10M — one query, the CPU
+    oracle's scalar arithmetic over every row (regenerated chunk by chunk on host threads), rows and float32 bits equal"""
+    import os
+    from tests._par import exact_topk_synthetic
+    n, dim, seed = 10_000_000, 768, 20260424
+    idx = _mk(dim, "cosine")
+    idx.reserve(n)
+    for s in range(0, n, 2_000_000):
+        idx.add_synthetic(seed, s, 2_000_000)
+    q = O.gen_rows(20260425, 7, 1, dim)[0]
+    r, d, c = idx.search(q, 10)
+    er, ed = exact_topk_synthetic(0, seed, n, dim, q, 10, chunk=100_000, workers=min(32, os.cpu_count() or 8))
+    assert c[0] == 10 and np.array_equal(r[0], er) and np.array_equal(_bits(d[0]), _bits(ed))
+
+
 def test_config4_flat_cosine_10Mx768_single_gpu_properties():
     """BASELINE.json configs[4] corpus on ONE GPU (30.8 GB): size-independent properties —
     planted neighbours come back first at distance ~0, results are sorted, every returned
