@@ -443,24 +443,36 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         const float dd = hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
         return lane < n ? make_key(dd, batch_l[lane]) : kDeadKey;
     };
-    // sorted insert of x (distance part xd), list capacity ef
+    // sorted insert of x (distance part xd) into the list; ef = size of the reference's result heap
+    // Equal distances.  The reference's two binary heaps order equal keys by their layout, so a list model is exact only
+    // while no decision falls on a tie.  Every decision compares VALUES except two, which pick an ELEMENT:
+    //   * the eviction results.pop() (hnsw.go:558-560) picks a maximum.  When the two largest of the ef + 1 entries are equal,
+    //     WHICH of them leaves the result heap is the heap's choice — but the one that leaves stays in the candidate heap
+    //     at a distance that is not above the new worst, so it is still expanded when its turn comes (:514 is a strict >).
+    //     The list therefore keeps the whole TIE GROUP at the worst value w = (ef-th smallest distance): ef or more entries,
+    //     everything above w dropped, admission tested against w.  Which members of the group the result heap holds matters
+    //     only if the output reaches into the group (checked at the end) — or if the group does not fit the registers;
+    //   * candidates.pop() (:511) picks a minimum: ambiguous iff another UNEXPANDED entry has the popped entry's distance
+    //     (checked at the pop).
+    // Only those situations (and a NaN, and for a plain Search equal distances among the returned entries, whose order is
+    // the heap's) flag the query for the exact-heap kernel.  Equal distances elsewhere in the list are harmless.
+    auto entry_at = [&](uint32_t e) -> uint64_t {
+        uint64_t r = kDeadKey;
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) if ((int)(e >> 6) == s2) r = readlane64(key[s2], e & 63);
+        return r;
+    };
     auto insert = [&](uint64_t x, uint32_t ef) {
         const uint32_t xd = (uint32_t)(x >> 32);
+        constexpr uint32_t kCap = (uint32_t)S * 64;
         if (xd == 0xFFFFFFFEu) tie = true;                              // NaN: heap order is not a function of distances
-        if (n_list >= ef) {
-            const uint32_t e = ef - 1;
-            uint64_t top = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) if ((int)(e >> 6) == s2) top = readlane64(key[s2], e & 63);
-            if (xd >= (uint32_t)(top >> 32)) return;    // hnsw.go:553 strict <: a key equal to the current worst is rejected whatever the heap layout
-        }
+        if (n_list >= ef && xd >= (uint32_t)(entry_at(ef - 1) >> 32)) return;   // hnsw.go:553 strict <: not below the worst of the result heap
+        const uint64_t lost = n_list == kCap ? entry_at(kCap - 1) : kDeadKey;  // falls off the end of the registers
         uint32_t p = 0;
 #pragma unroll
-        for (int s2 = 0; s2 < S; s2++) {
-            const uint32_t kd = (uint32_t)(key[s2] >> 32);
-            p += (uint32_t)__builtin_popcountll(__ballot(kd < xd));
-            if (__ballot(kd == xd && key[s2] != kDeadKey)) tie = true;
-        }
+        for (int s2 = 0; s2 < S; s2++)
+            p += (uint32_t)__builtin_popcountll(__ballot(key[s2] < x));      // full (distance, node) order: equal distances sit in node order,
+                                                                             // which is selectNeighbors' order (hnsw.go:589-594) when the build cuts the list
         const uint32_t s0 = p >> 6, l0 = p & 63;
         uint64_t carry = 0; uint64_t cbit = 0;
 #pragma unroll
@@ -479,12 +491,22 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             }
             carry = last; cbit = lastbit;
         }
-        if (n_list < ef) n_list++;
-        // drop whatever sits past the capacity
-        if (n_list == ef && ef < (uint32_t)(S * 64)) {
-            const uint32_t e = ef;
+        if (n_list < kCap) n_list++;
+        if (n_list > ef || lost != kDeadKey) {
+            // the result heap holds ef entries: everything above its worst value w goes, the entries AT w (the tie group) stay
+            const uint32_t w = (uint32_t)(entry_at(ef - 1) >> 32);
+            uint32_t dropped = 0;
 #pragma unroll
-            for (int s2 = 0; s2 < S; s2++) if ((int)(e >> 6) == s2) { if (lane == (e & 63)) key[s2] = kDeadKey; expd[s2] &= ~(1ull << (e & 63)); }
+            for (int s2 = 0; s2 < S; s2++) {
+                const uint32_t e = (uint32_t)s2 * 64 + lane;
+                const bool drop = e >= ef && key[s2] != kDeadKey && (uint32_t)(key[s2] >> 32) > w;
+                const uint64_t dm = __ballot(drop);
+                if (drop) key[s2] = kDeadKey;
+                expd[s2] &= ~dm;
+                dropped += (uint32_t)__builtin_popcountll(dm);
+            }
+            n_list -= dropped;
+            if (lost != kDeadKey && (uint32_t)(lost >> 32) == w) tie = true;   // a member of the tie group did not fit: which members the heap holds is unknown
         }
     };
 
@@ -520,14 +542,20 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     nb = 1;
                 } else {
                     // pop: first unexpanded entry
-                    uint32_t cur = 0xFFFFFFFFu;
+                    uint32_t cur = 0xFFFFFFFFu, cur_d = 0;
 #pragma unroll
                     for (int s2 = 0; s2 < S; s2++) {
                         if (cur != 0xFFFFFFFFu) continue;
                         const uint64_t m = __ballot(key[s2] != kDeadKey) & ~expd[s2];
-                        if (m) { const uint32_t l = (uint32_t)__builtin_ctzll(m); cur = (uint32_t)readlane64(key[s2], l); expd[s2] |= 1ull << l; }
+                        if (m) { const uint32_t l = (uint32_t)__builtin_ctzll(m); const uint64_t kc = readlane64(key[s2], l); cur = (uint32_t)kc; cur_d = (uint32_t)(kc >> 32); expd[s2] |= 1ull << l; }
                     }
                     if (cur == 0xFFFFFFFFu) break;
+                    {   // candidates.pop() among equal minima is the heap's choice: another unexpanded entry at the popped distance
+                        uint64_t same = 0;
+#pragma unroll
+                        for (int s2 = 0; s2 < S; s2++) same |= __ballot((uint32_t)(key[s2] >> 32) == cur_d && key[s2] != kDeadKey) & ~expd[s2];
+                        if (same) { tie = true; break; }
+                    }
                     HTICK(0);
                     uint32_t deg = 0; const uint32_t* links = nullptr;
                     if (alive(cur) && level <= (int)g.level[cur]) {
@@ -536,8 +564,13 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     }
                     uint32_t c = 0xFFFFFFFFu; bool fresh = false;
                     if (lane < deg) { c = links[lane]; fresh = alive(c); }
-                    // test-and-set in the hash: a node repeated inside one list is new for exactly one of its lanes (which one
-                    // does not matter here: without equal distances the admission order of a hop is immaterial)
+                    // a node repeated inside one list (the self-link quirk) is new at its FIRST occurrence: admissions of a hop go
+                    // in adjacency order (:537-560), and between two nodes of equal distance that order decides which one a full
+                    // result set keeps — so the hash's test-and-set must not pick the winner among a node's repeats
+                    for (uint32_t j = 0; j + 1 < deg; j++) {
+                        const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                        if (lane > j && c == cj) fresh = false;
+                    }
                     if (fresh) fresh = vis_hash_insert(tab, hmask, hshift, c);
                     const uint64_t fm = __ballot(fresh);
                     nb = (uint32_t)__builtin_popcountll(fm);
@@ -561,7 +594,29 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             if (level > stop && n_list > 0) entry = (uint32_t)readlane64(key[0], 0);   // :649-657
         }
         const uint32_t kq = build ? (stop == 0 ? g.max_m0 : g.max_m) : k;   // build: the level's degree bound (:395-398)
-        uint32_t cnt = n_list < kq ? n_list : kq;                       // :670-672
+        const uint32_t ef_last = build ? ef_search : (ef_search > k ? ef_search : k);
+        const uint32_t n_res = n_list < ef_last ? n_list : ef_last;     // size of the result heap (the list may also hold the rest of a tie group)
+        uint32_t cnt = n_res < kq ? n_res : kq;                         // :670-672
+        if (!tie && n_list > ef_last) {
+            // a tie group straddles the end of the result heap: which of its members the heap holds is the heap's choice.
+            // Harmless unless the output reaches into the group.
+            const uint32_t w = (uint32_t)(entry_at(ef_last - 1) >> 32);
+            uint32_t below = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) below += (uint32_t)__builtin_popcountll(__ballot((uint32_t)(key[s2] >> 32) < w));
+            if (cnt > below) tie = true;
+        }
+        if (!build && !tie) {
+            // results[:k] comes out of the max-heap in pop order (:566-577): among equal distances that order — and, at the cut,
+            // which of them is kept — is the heap's.  (The build re-sorts by (distance, node), selectNeighbors :589-594.)
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) {
+                const uint32_t e = (uint32_t)s2 * 64 + lane;
+                uint64_t nxt = __shfl_down(key[s2], 1);
+                if (lane == 63) nxt = s2 + 1 < S ? readlane64(key[s2 + 1 < S ? s2 + 1 : s2], 0) : kDeadKey;
+                if (__ballot(e < cnt && e + 1 < n_list && (uint32_t)(key[s2] >> 32) == (uint32_t)(nxt >> 32))) tie = true;
+            }
+        }
         if (tie) cnt = kHnswTieFlag;
         else {
 #pragma unroll
@@ -617,8 +672,9 @@ uint32_t hnsw_grid(int cus, uint32_t ef, uint32_t nq) {
 }
 // visited hash entries per wave slot: ~64 x ef (a search with ef = 128 evaluates ~4-5 k nodes of a 1M-node graph), 3/4 usable
 uint32_t hnsw_vis_hash_cap(uint32_t ef) {
+    static const int mult = env_int("QV_HNSW_VIS_MULT", 64);
     uint32_t cap = 4096;
-    while (cap < 64u * ef && cap < 65536u) cap <<= 1;
+    while (cap < (uint32_t)mult * ef && cap < 262144u) cap <<= 1;
     return cap;
 }
 hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
@@ -671,7 +727,9 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
                            static_cast<const double*>(d_qconst), nq, k, ef, o,                                       \
                            d_rows_out, d_dist_out, d_count_out, d_evals_out);                                         \
     })
-    if (efx <= 64) { QV_HW(1); } else if (efx <= 128) { QV_HW(2); } else if (efx <= 256) { QV_HW(4); } else { QV_HW(8); }
+    // list registers: S x 64 entries.  One notch more than efx needs where that is free (<= 128 VGPRs either way), so that a tie
+    // group at the end of the result heap has room (ef = 64 -> S = 2, ef = 128 -> S = 4; S = 8 would cost a wave per SIMD)
+    if (efx < 64) { QV_HW(1); } else if (efx < 128) { QV_HW(2); } else if (efx <= 256) { QV_HW(4); } else { QV_HW(8); }
 #undef QV_HW
     return hipGetLastError();
 }
