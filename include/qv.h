@@ -250,7 +250,7 @@ void qv_graph_destroy(qv_graph* g);
  *   levels[i]   level of row first_row + i: the caller draws them in node order (randomLevel, hnsw.go:716-738),
  *               which keeps the RNG — seeded from the wall clock in the reference, hnsw.go:248 — on the host side
  *   m, max_m0, ef_construction   0 = the reference's defaults 16 / 2m / 200 (hnsw.go:223-231); <= 64 / 64 / 512
- *   batch_max   largest batch (0 = 4096);  ramp_div: a batch never exceeds (nodes already linked) / ramp_div, so
+ *   batch_max   largest batch (0 = 16384, the maximum);  ramp_div: a batch never exceeds (nodes already linked) / ramp_div, so
  *               early nodes are inserted nearly one by one (0 = no ramp).  qv_graph_batch_size is the rule.
  * qv_graph_insert appends rows [first_row, first_row + n) (first_row must equal the graph's node count) and returns
  * when they are linked; the graph can be searched (qv_graph_search*) between and after calls. */

@@ -208,7 +208,7 @@ class DeviceGraph:
         return self
 
     @classmethod
-    def build(cls, index: DeviceIndex, levels, m: int = 16, max_m0: int = 0, ef_construction: int = 200, batch_max: int = 4096,
+    def build(cls, index: DeviceIndex, levels, m: int = 16, max_m0: int = 0, ef_construction: int = 200, batch_max: int = 16384,
               ramp_div: int = 16) -> "DeviceGraph":
         """hnsw.HNSW.Insert (hnsw.go:266-468) for rows 0..len(levels)-1 of `index`, in batches on the device"""
         levels = np.ascontiguousarray(levels, dtype=np.int8)
@@ -216,7 +216,7 @@ class DeviceGraph:
         self.insert(0, levels, batch_max, ramp_div)
         return self
 
-    def insert(self, first_row: int, levels, batch_max: int = 4096, ramp_div: int = 16):
+    def insert(self, first_row: int, levels, batch_max: int = 16384, ramp_div: int = 16):
         levels = np.ascontiguousarray(levels, dtype=np.int8)
         check(lib().qv_graph_insert(self._g, first_row, levels.size, levels.ctypes.data, batch_max, ramp_div))
 

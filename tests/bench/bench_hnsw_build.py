@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 
 
-def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, batch_max=4096, ramp_div=16, efs=(64, 128, 256, 512),
+def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, batch_max=16384, ramp_div=16, efs=(64, 128, 256, 512),
         nq=8192, k=10, cpu_queries=100, device=0, level_seed=1, corpus_seed=20260424, query_seed=20260425, cpu_build_rows=0):
     import torch                      # before libqv: both must share one HIP runtime (torch bundles its own)
     import quiver_amd
@@ -136,7 +136,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000); ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--metric", default="cosine"); ap.add_argument("--m", type=int, default=16); ap.add_argument("--efc", type=int, default=200)
-    ap.add_argument("--max-level", type=int, default=16); ap.add_argument("--batch-max", type=int, default=4096); ap.add_argument("--ramp-div", type=int, default=16)
+    ap.add_argument("--max-level", type=int, default=16); ap.add_argument("--batch-max", type=int, default=16384); ap.add_argument("--ramp-div", type=int, default=16)
     ap.add_argument("--efs", default="64,128,256,512"); ap.add_argument("--nq", type=int, default=8192); ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-queries", type=int, default=100); ap.add_argument("--cpu-build-rows", type=int, default=0)
     a = ap.parse_args()
