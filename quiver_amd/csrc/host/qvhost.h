@@ -91,7 +91,7 @@ public:
     // batch is the deterministic form of that — searches against the graph before the batch, links applied in id order.
     // packed = [n][len] row-major.  batch_max = 1 gives the sequential graph.  Available while every node so far came
     // in through InsertBatch (the device graph carries the link distances); otherwise it is a loop of Insert.
-    Error InsertBatch(const std::vector<std::string>& ids, const float* packed, uint32_t len, uint32_t batch_max = 4096, uint32_t ramp_div = 16);
+    Error InsertBatch(const std::vector<std::string>& ids, const float* packed, uint32_t len, uint32_t batch_max = 16384, uint32_t ramp_div = 16);
     Error Delete(const std::string& id);                                               // hnsw.go:741-842
     Error Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>* out);   // hnsw.go:602-713
     // nq searches walked on the device, one wavefront per query (qv_graph_search); a query whose

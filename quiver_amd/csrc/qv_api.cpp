@@ -45,11 +45,19 @@ struct CtxGuard {
     ~CtxGuard() { if (c) release_ctx(idx, c); }
 };
 
-int stream_workspace(qv_index* idx, hipStream_t s, size_t bytes, void** out) {
-    std::lock_guard<std::mutex> g(idx->ws_mu);
-    Workspace*& w = idx->stream_ws[s];
-    if (!w) w = new (std::nothrow) Workspace();
-    if (!w) return fail(QV_ERR_OOM, "out of host memory");
+// The workspace of a caller stream.  Returns with `hold` locked on that workspace: the caller keeps it until its launches
+// are enqueued, so that another thread using the same stream cannot grow (free) the buffer between "fetch the pointer" and
+// "launch" — once enqueued, stream order protects the kernels (a grow drains the stream first).
+int stream_workspace(qv_index* idx, hipStream_t s, size_t bytes, void** out, std::unique_lock<std::mutex>* hold) {
+    Workspace* w;
+    {
+        std::lock_guard<std::mutex> g(idx->ws_mu);
+        Workspace*& slot = idx->stream_ws[s];
+        if (!slot) slot = new (std::nothrow) Workspace();
+        if (!slot) return fail(QV_ERR_OOM, "out of host memory");
+        w = slot;
+    }
+    *hold = std::unique_lock<std::mutex>(w->mu);
     if (bytes > w->ws.cap) {
         // a larger workspace replaces one the stream may still be using: drain first
         HIPCHK(hipStreamSynchronize(s));
@@ -529,7 +537,8 @@ int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, u
     }
     const uint32_t kk = std::min(k, idx->n_live);
     void* ws = nullptr;
-    int rc = stream_workspace(idx, s, search_ws_bytes(idx, nq, kk, k), &ws);
+    std::unique_lock<std::mutex> ws_hold;
+    int rc = stream_workspace(idx, s, search_ws_bytes(idx, nq, kk, k), &ws, &ws_hold);
     if (rc != QV_OK) return rc;
     return enqueue_search(idx, d_queries, nq, kk, k, ws, 0, d_rows_out, d_dist_out, s);
 }
@@ -547,7 +556,8 @@ int qv_index_search_batched_device(qv_index* idx, const float* d_queries, uint32
     hipStream_t s = static_cast<hipStream_t>(stream);
     const qv::ScanPlan plan = qv::plan_scan(v.n_tiles, idx->cus);
     void* ws = nullptr;
-    int rc = stream_workspace(idx, s, qv::batched_workspace_bytes(v, plan, nq, k), &ws);
+    std::unique_lock<std::mutex> ws_hold;
+    int rc = stream_workspace(idx, s, qv::batched_workspace_bytes(v, plan, nq, k), &ws, &ws_hold);
     if (rc != QV_OK) return rc;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (idx->profiling && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {

@@ -47,7 +47,7 @@ struct PinBuf {         // growable pinned host buffer
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-struct Workspace { Buf ws; };
+struct Workspace { Buf ws; std::mutex mu; };
 
 struct SearchCtx {
     hipStream_t stream = nullptr;

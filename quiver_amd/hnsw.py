@@ -53,7 +53,7 @@ class HNSW:
         v = f32(vector)
         check(hlib().qvh_hnsw_insert(self._h, id.encode(), v.ctypes.data, v.size))
 
-    def InsertBatch(self, ids, vectors, batch_max: int = 4096, ramp_div: int = 16) -> None:
+    def InsertBatch(self, ids, vectors, batch_max: int = 16384, ramp_div: int = 16) -> None:
         """n Inserts connected on the device (qv_graph_insert): searches against the graph before each batch, links applied
         in id order; batch_max = 1 is the sequential graph of n Insert calls"""
         vs = np.ascontiguousarray(vectors, dtype=np.float32)
