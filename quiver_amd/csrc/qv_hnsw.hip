@@ -182,9 +182,38 @@ __device__ __forceinline__ void dma_issue_slab(const DmaRole& r, uint32_t sl, ui
         if (r.ng > 3) dma_issue_group<false>(r.src3, r.sw1, chunk0, dim4, buf + 3 * G);
     }
 }
+// The query values of one slab, one per lane: lane L (0..31; the upper half mirrors it) holds element 32*sl + L of the query
+// in the metric's Q type, fetched with ONE coalesced vector load per slab beside the slab's row DMA.  Element i is broadcast
+// to the arithmetic by v_readlane (wave-uniform -> an SGPR operand of the fma), so the query costs neither LDS bandwidth nor
+// scalar-cache traffic.  (Round 1 read it with s_load_dwordx16 at wave-uniform addresses: 16 waves x 6 KiB of queries cycle
+// through a 16 KiB scalar cache, four 64-byte loads per 32 elements, each drained with lgkmcnt(0) together with the row
+// reads.  Measured 1M x 768: efSearch 64 / 128 / 256 +6 % each; what bounds the traversal is the gather of 3 KiB rows itself,
+// 4.5-5.2 TB/s against 6.6 TB/s for the bare LDS-DMA row stream — profiles/r02_hnsw_query_operand.txt.)
+template <typename Q> struct QSlab;
+template <> struct QSlab<double> {
+    uint32_t lo, hi;
+    __device__ __forceinline__ void load(const double* __restrict__ q, uint32_t sl, uint32_t n_el, uint32_t lane) {
+        const uint32_t e = sl * (uint32_t)(kHnswSlab * 4) + (lane & (uint32_t)(kHnswSlab * 4 - 1));
+        const double v = e < n_el ? q[e] : 0.0;
+        lo = (uint32_t)__double2loint(v); hi = (uint32_t)__double2hiint(v);
+    }
+    __device__ __forceinline__ double at(uint32_t i) const {
+        return __hiloint2double((int)__builtin_amdgcn_readlane(hi, i), (int)__builtin_amdgcn_readlane(lo, i));
+    }
+};
+template <> struct QSlab<float> {
+    uint32_t w;
+    __device__ __forceinline__ void load(const float* __restrict__ q, uint32_t sl, uint32_t n_el, uint32_t lane) {
+        const uint32_t e = sl * (uint32_t)(kHnswSlab * 4) + (lane & (uint32_t)(kHnswSlab * 4 - 1));
+        w = __float_as_uint(e < n_el ? q[e] : 0.0f);
+    }
+    __device__ __forceinline__ float at(uint32_t i) const { return __uint_as_float(__builtin_amdgcn_readlane(w, i)); }
+};
+static_assert(kHnswSlab * 4 <= 64 && ((kHnswSlab * 4) & (kHnswSlab * 4 - 1)) == 0, "a slab's query elements must fit the lanes of a wave");
+
 // lane walks slab `sl` of row r (0..31) of the round, sequentially over the dims
 template <int M>
-__device__ __forceinline__ void slab_accumulate(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, const typename MT<M>::Q* __restrict__ q,
+__device__ __forceinline__ void slab_accumulate(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, const QSlab<typename MT<M>::Q>& qs,
                                                 uint32_t sl, uint32_t dim4) {
     typedef const __attribute__((address_space(3))) f4* lds_f4p;
     const uint32_t mg = r >> 3, mr = r & 7, msw = mr ^ (mg & 1);
@@ -193,15 +222,15 @@ __device__ __forceinline__ void slab_accumulate(typename MT<M>::A& acc, const ld
     uint32_t c = c0;
     for (; c + 8 <= c1; c += 8) {
         const lds_u8* pc = mine + ((c - c0) >> 3) * 1024;
+        const uint32_t e0 = (c - c0) * 4;                              // first query element of this piece within the slab
         f4 x0 = *(lds_f4p)(pc + ((0u ^ msw) << 4)), x1 = *(lds_f4p)(pc + ((1u ^ msw) << 4)), x2 = *(lds_f4p)(pc + ((2u ^ msw) << 4)), x3 = *(lds_f4p)(pc + ((3u ^ msw) << 4));
         f4 x4 = *(lds_f4p)(pc + ((4u ^ msw) << 4)), x5 = *(lds_f4p)(pc + ((5u ^ msw) << 4)), x6 = *(lds_f4p)(pc + ((6u ^ msw) << 4)), x7 = *(lds_f4p)(pc + ((7u ^ msw) << 4));
-        const typename MT<M>::Q* qq = q + (size_t)c * 4;          // wave-uniform global address: scalar loads, SGPR operands
-#define QV_ACC4(X, O) acc1<M>(acc, qq[O], X.x); acc1<M>(acc, qq[O + 1], X.y); acc1<M>(acc, qq[O + 2], X.z); acc1<M>(acc, qq[O + 3], X.w);
+#define QV_ACC4(X, O) acc1<M>(acc, qs.at(e0 + O), X.x); acc1<M>(acc, qs.at(e0 + O + 1), X.y); acc1<M>(acc, qs.at(e0 + O + 2), X.z); acc1<M>(acc, qs.at(e0 + O + 3), X.w);
         QV_ACC4(x0, 0) QV_ACC4(x1, 4) QV_ACC4(x2, 8) QV_ACC4(x3, 12) QV_ACC4(x4, 16) QV_ACC4(x5, 20) QV_ACC4(x6, 24) QV_ACC4(x7, 28)
     }
     for (; c < c1; c++) {
         const f4 x = *(lds_f4p)(mine + ((c - c0) >> 3) * 1024 + ((((c - c0) & 7) ^ msw) << 4));
-        const typename MT<M>::Q* qq = q + (size_t)c * 4;
+        const uint32_t e0 = (c - c0) * 4;
         QV_ACC4(x, 0)
     }
 #undef QV_ACC4
@@ -225,15 +254,22 @@ __device__ __forceinline__ float hnsw_eval_rows(const IndexView& v, const lds_u3
             DmaRole role;
             dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
             typename MT<M>::A acc = 0;
+            QSlab<typename MT<M>::Q> q_cur, q_nxt;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             dma_issue_slab(role, 0, v.dim4, slabs_l);
+            q_cur.load(q_g, 0, v.dim4 * 4, lane);
             for (uint32_t sl = 0; sl < nslab; sl++) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl has landed
-                if (sl + 1 < nslab) dma_issue_slab(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);   // lands while slab sl is consumed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl and its query values have landed
+                q_nxt = q_cur;
+                if (sl + 1 < nslab) {
+                    dma_issue_slab(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);   // lands while slab sl is consumed
+                    q_nxt.load(q_g, sl + 1, v.dim4 * 4, lane);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (me) slab_accumulate<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, (lane - base) & 31u, q_g, sl, v.dim4);
+                if (me) slab_accumulate<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, (lane - base) & 31u, q_cur, sl, v.dim4);
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this buffer's reads are done before it is refilled
+                q_cur = q_nxt;
             }
             if (me) out = finalize<M>(acc, qc, rn);
         }
@@ -721,15 +757,15 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
         hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
     });
 #define QV_HW(SS) QV_DISPATCH_METRIC(v.metric, {                                                                     \
-        e = set_lds(k_hnsw_search_wave<MM, 8, SS>, lds);                                                              \
+        e = set_lds(k_hnsw_search_wave<MM, 4, SS>, lds);                                                              \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL((k_hnsw_search_wave<MM, 8, SS>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
+        hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
                            static_cast<const double*>(d_qconst), nq, k, ef, o,                                       \
                            d_rows_out, d_dist_out, d_count_out, d_evals_out);                                         \
     })
     // list registers: S x 64 entries.  One notch more than efx needs where that is free (<= 128 VGPRs either way), so that a tie
-    // group at the end of the result heap has room (ef = 64 -> S = 2, ef = 128 -> S = 4; S = 8 would cost a wave per SIMD)
-    if (efx < 64) { QV_HW(1); } else if (efx < 128) { QV_HW(2); } else if (efx <= 256) { QV_HW(4); } else { QV_HW(8); }
+    // group at the end of the result heap has room (ef <= 127 -> S = 2, ef = 128..256 -> S = 4; S = 8 would cost a wave per SIMD)
+    if (efx < 128) { QV_HW(2); } else if (efx <= 256) { QV_HW(4); } else { QV_HW(8); }
 #undef QV_HW
     return hipGetLastError();
 }
