@@ -257,6 +257,11 @@ void qv_graph_destroy(qv_graph* g);
 uint32_t qv_graph_batch_size(uint32_t nodes_linked, uint32_t batch_max, uint32_t ramp_div);
 int qv_graph_create_empty(qv_graph** out, qv_index* idx, uint32_t capacity_nodes, uint32_t m, uint32_t max_m0, uint32_t ef_construction);
 int qv_graph_insert(qv_graph* g, uint32_t first_row, uint32_t n, const int8_t* levels, uint32_t batch_max, uint32_t ramp_div);
+/* A graph uploaded with qv_graph_create (built on the host) carries no per-link distances, which the device-side
+ * construction works on: this scores every existing link once (one wavefront per adjacency list, the traversal's
+ * arithmetic: computeDistance(node.Vector, conn.Vector), hnsw.go:438), after which qv_graph_insert can extend the graph.
+ * ef_construction as above.  No-op on a graph made by qv_graph_create_empty / qv_graph_build (apart from setting ef). */
+int qv_graph_make_buildable(qv_graph* g, uint32_t ef_construction);
 /* create_empty + insert of rows [0, n_nodes) */
 int qv_graph_build(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_t* levels, uint32_t m, uint32_t max_m0,
                    uint32_t ef_construction, uint32_t batch_max, uint32_t ramp_div);

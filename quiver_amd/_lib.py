@@ -74,6 +74,7 @@ PROTOTYPES = {
     "qv_graph_batch_size": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "qv_graph_create_empty": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "qv_graph_insert": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "qv_graph_make_buildable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "qv_graph_build": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "qv_graph_info": (C.c_int, [C.c_void_p, _u32p, _u32p, _u32p, _u32p, _u32p, C.POINTER(C.c_int)]),
     "qv_graph_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

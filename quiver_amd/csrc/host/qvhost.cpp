@@ -425,8 +425,17 @@ Error HNSW::insertLocked(const std::string& id, const float* v, uint32_t len) {
 Error HNSW::InsertBatch(const std::vector<std::string>& ids, const float* packed, uint32_t len, uint32_t batch_max, uint32_t ramp_div) {
     std::unique_lock<std::shared_mutex> l(mu_);
     if (ids.empty()) return "";
-    const bool device_ok = bg_synced_ && (bg_ != nullptr || nodes_.empty()) && M_ <= 64 && maxM0_ <= 64 && efC_ <= 512 && maxLevel_ <= 64;
-    if (!device_ok) {                                                  // the host graph has moved on without link distances: plain Inserts
+    bool device_ok = M_ <= 64 && maxM0_ <= 64 && efC_ <= 512 && maxLevel_ <= 64 && (h_ == nullptr || (int)len == dim_);
+    if (device_ok && !(bg_synced_ && (bg_ != nullptr || nodes_.empty()))) {
+        // the host graph has moved on (Insert / Delete) without the device graph's link distances: upload it as it stands and
+        // have the device score its links once (qv_graph_make_buildable); from then on it is extended on the device again
+        device_ok = false;
+        if (size_ > 0 && syncDeviceGraph().empty() && qv_graph_make_buildable(dg_, (uint32_t)efC_) == QV_OK) {
+            if (bg_ && bg_ != dg_) qv_graph_destroy(bg_);
+            bg_ = dg_; bg_synced_ = true; device_ok = true;
+        }
+    }
+    if (!device_ok) {                                                  // configurations the device build does not take: plain Inserts
         for (size_t i = 0; i < ids.size(); i++) {
             Error e = insertLocked(ids[i], packed + i * (size_t)len, len);
             if (!e.empty()) return e;

@@ -144,6 +144,10 @@ size_t  full_sort_workspace_bytes(uint32_t n_tiles);
 hipError_t launch_flat_fullsort(const IndexView& v, const ScanPlan& p, const float* d_query, uint32_t k,
                                 void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 
+// per-link distances of nodes [n0, n0 + nq) of an uploaded graph (what the device-side construction needs to extend it)
+hipError_t launch_graph_link_dists(const IndexView& v, const GraphView& g, void* d_qblk, uint32_t n0, uint32_t nq, float* d_l0_dist, float* d_up_dist,
+                                   uint32_t grid, hipStream_t s);
+
 // stable sort of n 64-bit keys by their upper 32 bits; hist: radix_hist_words(n) words; *sorted_out = a or b
 size_t radix_hist_words(uint32_t n);
 hipError_t launch_radix_sort_hi32(uint64_t* a, uint64_t* b, uint32_t n, uint32_t* hist, uint64_t** sorted_out, hipStream_t s);

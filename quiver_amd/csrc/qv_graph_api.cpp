@@ -302,11 +302,43 @@ int qv_graph_create_empty(qv_graph** out, qv_index* idx, uint32_t capacity_nodes
     return QV_OK;
 }
 
+int qv_graph_make_buildable(qv_graph* g, uint32_t ef_construction) {
+    if (!g) return fail(QV_ERR_INVALID_ARG, "graph is null");
+    if (ef_construction == 0) ef_construction = 200;
+    if (ef_construction > 512) return fail(QV_ERR_UNSUPPORTED, "efConstruction above 512 is not supported on the device path");
+    qv_index* idx = g->idx;
+    if (!idx->d_rowmaj) return fail(QV_ERR_UNSUPPORTED, "device-side construction needs the row-major copy (create the index with QV_FLAG_ROWMAJOR)");
+    HIPCHK(hipSetDevice(idx->device));
+    std::lock_guard<std::mutex> lock(g->mu);
+    g->efc = ef_construction;
+    if (g->buildable) return QV_OK;
+    HIPCHK(hipEventSynchronize(g->ev_last));
+    const uint32_t m0 = g->g.max_m0, m = g->g.max_m, n = g->g.n_nodes;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->d_l0dist), std::max<size_t>((size_t)g->cap_nodes * m0 * 4, 16));
+    if (e == hipSuccess) e = hipMemset(g->d_l0dist, 0, std::max<size_t>((size_t)g->cap_nodes * m0 * 4, 16));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_updist), std::max<size_t>((size_t)g->cap_blocks * m * 4, 16));
+    if (e == hipSuccess) e = hipMemset(g->d_updist, 0, std::max<size_t>((size_t)g->cap_blocks * m * 4, 16));
+    if (e != hipSuccess) { (void)hipFree(g->d_l0dist); (void)hipFree(g->d_updist); g->d_l0dist = g->d_updist = nullptr;
+                           return fail(e == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "link-distance storage failed: %s", hipGetErrorString(e)); }
+    // score every existing link once, a chunk of nodes at a time (their vectors are the queries)
+    const uint32_t chunk = 16384;
+    int rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(std::min(chunk, std::max(n, 1u)), idx->dim4));
+    if (rc != QV_OK) return rc;
+    const uint32_t grid = qv::hnsw_wave_grid(idx->cus, idx->metric, idx->dim4);
+    for (uint32_t n0 = 0; n0 < n; n0 += chunk) {
+        e = qv::launch_graph_link_dists(idx->view(), g->g, g->d_qblk.p, n0, std::min(chunk, n - n0), g->d_l0dist, g->d_updist, grid, g->stream);
+        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "link-distance launch failed: %s", hipGetErrorString(e));
+    }
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->buildable = true;
+    return QV_OK;
+}
+
 int qv_graph_insert(qv_graph* g, uint32_t first_row, uint32_t n, const int8_t* levels, uint32_t batch_max, uint32_t ramp_div) {
     if (!g) return fail(QV_ERR_INVALID_ARG, "graph is null");
     if (n == 0) return QV_OK;
     if (!levels) return fail(QV_ERR_INVALID_ARG, "levels is null");
-    if (!g->buildable) return fail(QV_ERR_UNSUPPORTED, "this graph was uploaded without link distances (qv_graph_create); device-side insertion needs a graph made by qv_graph_create_empty");
+    if (!g->buildable) return fail(QV_ERR_UNSUPPORTED, "this graph was uploaded without link distances (qv_graph_create): call qv_graph_make_buildable first");
     qv_index* idx = g->idx;
     if (first_row != g->g.n_nodes) return fail(QV_ERR_INVALID_ARG, "nodes are appended: expected first row %u, got %u", g->g.n_nodes, first_row);
     if ((uint64_t)first_row + n > idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "rows %u..%llu are not in the index (rows: %u)", first_row, (unsigned long long)first_row + n, idx->n_rows);

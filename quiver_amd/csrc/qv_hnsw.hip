@@ -681,6 +681,44 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     }
 }
 
+// ---- link distances of an uploaded graph ---------------------------------------------------
+// A graph that was built on the host arrives without the per-link distances the device-side construction works on
+// (qv_build.hip).  One wavefront per adjacency list of nodes [n0, n0 + nq): the node's own vector is the query (converted by
+// k_hnsw_prep_queries like any other), lane i scores link i with the same arithmetic as a traversal hop —
+// computeDistance(node.Vector, conn.Vector), what the reference's prune would compute (hnsw.go:438).
+template <int M, int U>
+__global__ void __launch_bounds__(64)
+k_graph_link_dists(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t n0, uint32_t nq,
+                   float* __restrict__ l0_dist, float* __restrict__ up_dist) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* batch = reinterpret_cast<uint32_t*>(smem);
+    lds_u32* batch_l = (lds_u32*)smem;
+    lds_u8* slabs_l = (lds_u8*)(batch_l + 64);
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        const uint32_t node = n0 + qi;
+        const int lv = (int)g.level[node];
+        if (lv < 0) continue;                                               // tombstone: its lists are never read
+        const typename MT<M>::Q* q_g = qblk + (size_t)qi * v.dim4 * 4;
+        QConst qc; qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
+        for (int level = 0; level <= lv; level++) {
+            uint32_t deg; const uint32_t* links; float* out;
+            if (level == 0) { deg = g.l0_deg[node]; links = g.l0_links + (size_t)node * g.max_m0; out = l0_dist + (size_t)node * g.max_m0; if (deg > g.max_m0) deg = g.max_m0; }
+            else {
+                const uint32_t blk = g.up_off[node] + (uint32_t)(level - 1);
+                const uint32_t* b = g.up_links + (size_t)blk * (1 + g.max_m);
+                deg = b[0] < g.max_m ? b[0] : g.max_m; links = b + 1; out = up_dist + (size_t)blk * g.max_m;
+            }
+            if (deg == 0) continue;
+            __syncthreads();
+            if (lane < deg) { const uint32_t c = links[lane]; batch[lane] = c < g.n_nodes ? c : node; }
+            __syncthreads();
+            const float d = hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, deg, lane);
+            if (lane < deg) out[lane] = d;
+        }
+    }
+}
+
 // ---- HNSW traversal ------------------------------------------------------------------
 // the wave kernel keeps no query in LDS: queries are pre-converted to the metric's Q type (zero-padded to dim4*4)
 // in global memory and read at wave-uniform addresses, i.e. by scalar loads into SGPR operands of v_fma_f64
@@ -770,5 +808,20 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     return hipGetLastError();
 }
 
+
+// distances of every link of nodes [n0, n0 + nq) (see k_graph_link_dists); d_qblk: hnsw_qblk_bytes(nq, dim4)
+hipError_t launch_graph_link_dists(const IndexView& v, const GraphView& g, void* d_qblk, uint32_t n0, uint32_t nq, float* d_l0_dist, float* d_up_dist,
+                                   uint32_t grid, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    if (!v.rowmaj || g.max_m0 > (uint32_t)kHnswMaxDeg || g.max_m > (uint32_t)kHnswMaxDeg) return hipErrorInvalidValue;
+    const size_t lds = hnsw_wave_lds_bytes(v.metric, v.dim4);
+    double* d_qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qblk) + (size_t)nq * v.dim4 * 4 * sizeof(double));
+    QV_DISPATCH_METRIC(v.metric, {
+        hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, v.rowmaj + (size_t)n0 * v.dim, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
+        hipLaunchKernelGGL((k_graph_link_dists<MM, 4>), dim3(std::min(grid, nq)), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk),
+                           static_cast<const double*>(d_qconst), n0, nq, d_l0_dist, d_up_dist);
+    });
+    return hipGetLastError();
+}
 
 }  // namespace qv

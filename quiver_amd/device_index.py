@@ -216,6 +216,10 @@ class DeviceGraph:
         self.insert(0, levels, batch_max, ramp_div)
         return self
 
+    def make_buildable(self, ef_construction: int = 200):
+        """score the links of an uploaded (host-built) graph once so that insert() can extend it on the device"""
+        check(lib().qv_graph_make_buildable(self._g, ef_construction))
+
     def insert(self, first_row: int, levels, batch_max: int = 16384, ramp_div: int = 16):
         levels = np.ascontiguousarray(levels, dtype=np.int8)
         check(lib().qv_graph_insert(self._g, first_row, levels.size, levels.ctypes.data, batch_max, ramp_div))

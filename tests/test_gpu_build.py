@@ -169,3 +169,28 @@ def test_recall_of_the_built_graph():
     er, ed, _ = idx.search(qs, 10)
     hit = sum(len(set(r[i, :c[i]].tolist()) & set(er[i].tolist())) for i in range(qs.shape[0]))
     assert hit / (10 * qs.shape[0]) > 0.97
+
+
+def test_uploaded_graph_can_be_extended_after_scoring_its_links():
+    """qv_graph_create (a host-built graph, no link distances) + qv_graph_make_buildable + qv_graph_insert == building it all by
+    batches: the first 2000 nodes come from the oracle's build, the next 1500 are inserted on the device"""
+    n0, n1, dim, m, efc = 2000, 1500, 40, 8, 50
+    rows = O.gen_rows(606, 0, n0 + n1, dim)
+    levels = random_levels(n0 + n1, 16, 9)
+    h = O.HNSW(1, dim, M=m, maxM0=2 * m, efConstruction=efc, maxLevel=16, seed=9)
+    done = 0
+    for b in batch_schedule(n0, 128, 8):
+        h.insert_batch(rows[done:done + b]); done += b
+    flat = h.export_flat(2 * m, m)
+    ep, lvl = h.entry_point()
+    idx = quiver_amd.DeviceIndex(dim, "l2", rowmajor=True)
+    idx.add(rows)
+    g = DeviceGraph(idx, flat[0], flat[1], flat[2], entry=ep, cur_level=lvl, up_off=flat[3], up_links=flat[4] if flat[4].shape[0] else None, max_m=m)
+    with pytest.raises(quiver_amd.QvError, match="qv_graph_make_buildable"):
+        g.insert(n0, levels[n0:], 128, 8)
+    g.make_buildable(efc)
+    g.insert(n0, levels[n0:], 128, 8)
+    while done < n0 + n1:
+        b = min(graph_batch_size(done, 128, 8), n0 + n1 - done)
+        h.insert_batch(rows[done:done + b]); done += b
+    _assert_same_graph(g, h, m, 2 * m)

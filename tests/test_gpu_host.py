@@ -524,12 +524,20 @@ def test_hnsw_insert_batch_builds_on_device_and_equals_oracle(batch_max, ramp_di
         single = h.Search(q, 5)                                       # host-driven walk over the pulled-back adjacency
         assert [r.VectorIndex for r in single] == ro.tolist() and np.array_equal(_bits([r.Distance for r in single]), _bits(do))
         assert [r.VectorIndex for r in batch[i]] == ro.tolist() and np.array_equal(_bits([r.Distance for r in batch[i]]), _bits(do))
-    # a host-driven Insert afterwards still works (and ends the device-built state)
+    # a host-driven Insert and a Delete afterwards still work (and end the device-built state) ...
     extra = O.gen_rows(517, 0, 1, dim)[0]
     h.Insert("extra", extra); o.insert(extra)
+    h.Delete("n17"); o.delete(17)
     assert not h.built_on_device() and _host_graph(h) == _oracle_graph(o)
-    h.InsertBatch(["e2", "e3"], O.gen_rows(518, 0, 2, dim))           # falls back to a loop of Insert
-    assert h.Size() == n + 3
+    # ... and the next InsertBatch uploads the host graph, has the device score its links (qv_graph_make_buildable) and goes on
+    # building on the device: still the oracle's graph
+    more = O.gen_rows(518, 0, 300, dim)
+    h.InsertBatch(["m%d" % i for i in range(300)], more, batch_max, ramp_div)
+    done = 0
+    while done < 300:
+        b = min(graph_batch_size(n + 1 + done, batch_max, ramp_div), 300 - done)
+        o.insert_batch(more[done:done + b]); done += b
+    assert h.built_on_device() and h.Size() == n + 300 and _host_graph(h) == _oracle_graph(o)
 
 
 def test_hnsw_insert_batch_duplicate_id_is_rejected_before_anything_changes():
