@@ -173,6 +173,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     qv_index* idx = g->idx;
     HIPCHK(hipSetDevice(idx->device));
     std::lock_guard<std::mutex> lock(g->mu);
+    HIPCHK(hipEventSynchronize(g->ev_last));                            // a device-form traversal still in flight uses the buffers (re)sized below
     const size_t qbytes = (size_t)nq * idx->dim * sizeof(float), obytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
     const uint32_t efx = std::max(ef_search, k);
     int rc;
@@ -352,6 +353,7 @@ int qv_graph_insert(qv_graph* g, uint32_t first_row, uint32_t n, const int8_t* l
     batch_max = std::min(batch_max, 16384u);
     HIPCHK(hipSetDevice(idx->device));
     std::lock_guard<std::mutex> lock(g->mu);
+    HIPCHK(hipEventSynchronize(g->ev_last));                            // no traversal in flight while the graph and the shared buffers change
     const auto t0 = std::chrono::steady_clock::now();
     int rc = graph_reserve(g, (uint64_t)first_row + n, (uint64_t)g->n_blocks + new_blocks);
     if (rc != QV_OK) return rc;

@@ -803,7 +803,7 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     })
     // list registers: S x 64 entries.  One notch more than efx needs where that is free (<= 128 VGPRs either way), so that a tie
     // group at the end of the result heap has room (ef <= 127 -> S = 2, ef = 128..256 -> S = 4; S = 8 would cost a wave per SIMD)
-    if (efx < 128) { QV_HW(2); } else if (efx <= 256) { QV_HW(4); } else { QV_HW(8); }
+    if (efx < 128) { QV_HW(2); } else if (efx < 256) { QV_HW(4); } else if (efx < 320) { QV_HW(5); } else if (efx < 512) { QV_HW(8); } else { QV_HW(9); }
 #undef QV_HW
     return hipGetLastError();
 }
