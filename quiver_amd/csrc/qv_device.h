@@ -43,6 +43,7 @@ struct GraphView {
     const uint32_t* up_links;   // blocks of (1 + max_m): degree, links
     uint32_t n_nodes, max_m0, max_m;
     uint32_t entry; int cur_level;
+    bool has_dead;              // some level[] entry is -1 (a graph built on the device has none)
 };
 
 // Extras of the traversal kernels beyond a plain Search: the build's per-query stop level, the device-side redo list of

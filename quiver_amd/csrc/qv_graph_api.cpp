@@ -144,6 +144,8 @@ int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_
     g->h_level.assign(levels, levels + n_nodes);
     g->n_blocks = n_up_blocks;
     g->g.n_nodes = n_nodes; g->g.entry = entry; g->g.cur_level = cur_level;
+    g->g.has_dead = false;
+    for (uint32_t i = 0; i < n_nodes; i++) if (levels[i] < 0) { g->g.has_dead = true; break; }
     *out = g;
     return QV_OK;
 }
@@ -295,7 +297,7 @@ int qv_graph_create_empty(qv_graph** out, qv_index* idx, uint32_t capacity_nodes
     qv_graph* g = new (std::nothrow) qv_graph();
     if (!g) return fail(QV_ERR_OOM, "out of host memory");
     g->idx = idx; g->buildable = true; g->efc = ef_construction;
-    g->g.max_m0 = max_m0; g->g.max_m = m; g->g.n_nodes = 0; g->g.entry = 0; g->g.cur_level = -1;
+    g->g.max_m0 = max_m0; g->g.max_m = m; g->g.n_nodes = 0; g->g.entry = 0; g->g.cur_level = -1; g->g.has_dead = false;
     int rc = graph_common_init(g);
     if (rc == QV_OK) rc = graph_reserve(g, std::max(capacity_nodes, 64u), std::max(capacity_nodes / 3 + capacity_nodes / 64, 64u));
     if (rc != QV_OK) { qv_graph_destroy(g); return rc; }

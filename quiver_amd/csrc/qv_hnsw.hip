@@ -462,7 +462,8 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     const uint32_t lane = threadIdx.x;
     uint32_t* tab = o.vis + (size_t)blockIdx.x * o.vis_cap;               // this wave slot's visited hash table
     const bool build = o.qlevel != nullptr;
-    auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
+    // a graph without tombstones (every graph built on the device) needs no level[] lookup to know a node is there
+    auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && (!g.has_dead || g.level[n] >= 0); };
 #ifdef QV_HNSW_PROF
     uint64_t T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_last = __builtin_readcyclecounter(); const uint64_t wc0 = wall_clock64(); uint64_t hops = 0;
     auto tick = [&](int ph) { uint64_t t = __builtin_readcyclecounter(); T[ph] += t - t_last; t_last = t; };
@@ -594,7 +595,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     }
                     HTICK(0);
                     uint32_t deg = 0; const uint32_t* links = nullptr;
-                    if (alive(cur) && level <= (int)g.level[cur]) {
+                    if (alive(cur) && (level == 0 ? (!g.has_dead || g.level[cur] >= 0) : level <= (int)g.level[cur])) {
                         if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
                         else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
                     }
@@ -620,7 +621,19 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                 }
                 const uint64_t kx = eval_keys(nb); n_eval += nb;
                 HTICK(7);
-                for (uint32_t i = 0; i < nb; i++) insert(readlane64(kx, i), ef);
+                {   // admissions in adjacency order (:553-560).  The worst value only ever decreases, so a neighbour that is not below
+                    // it now never will be: one ballot drops those up front (most of a hop once the list is full)
+                    uint64_t pend = __ballot(lane < nb);
+                    if (n_list >= ef) {
+                        const uint32_t w = (uint32_t)(entry_at(ef - 1) >> 32);
+                        pend = __ballot(lane < nb && (uint32_t)(kx >> 32) < w);
+                    }
+                    while (pend) {
+                        const uint32_t i = (uint32_t)__builtin_ctzll(pend);
+                        pend &= pend - 1;
+                        insert(readlane64(kx, i), ef);
+                    }
+                }
                 HTICK(4);
                 if (tie) break;                                              // flagged: the exact-heap kernel redoes it from scratch
 #ifdef QV_HNSW_PROF

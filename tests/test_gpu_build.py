@@ -95,6 +95,10 @@ def test_sequential_build_equals_committed_fixture():
     ("l2_f32", 24, 2500, 4, 20, 2, 512, 2),
     ("l2sq", 16, 1200, 8, 300, 16, 32, 8),          # efConstruction > 256: 8 list registers per lane
     ("cosine", 768, 1200, 16, 200, 16, 96, 8),      # the headline shape, small n
+    ("l2", 30, 1500, 8, 40, 16, 64, 8),             # dim % 4 != 0: rows come from the tile layout, not by LDS-DMA
+    ("cosine", 36, 1500, 32, 80, 16, 64, 8),        # M = 32 / MaxM0 = 64: full-width adjacency lists (the prune fills all 64 lanes)
+    ("dot", 20, 1200, 16, 10, 16, 64, 8),           # efConstruction < MaxM0: the search returns fewer than a list holds
+    ("l1", 24, 1200, 8, 64, 16, 64, 8),             # efConstruction = 64: the list registers' first spare notch
 ])
 def test_batched_build_equals_oracle_batch_semantics(metric, dim, n, m, efc, max_level, batch_max, ramp_div):
     mid = quiver_amd.metric_id(metric)
