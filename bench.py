@@ -325,19 +325,23 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
     if not a.no_hnsw:
         from tests.bench.bench_hnsw_build import run as hnsw_run
         cpuq = 0 if a.no_cpu_baseline else 20
-        for key, max_level, efs, note in (
-                ("hnsw_1Mx768_reference_defaults", 16, (128,),
+        for key, max_level, efs, idim, note in (
+                ("hnsw_1Mx768_reference_defaults", 16, (128,), 0,
                  "MaxLevel=16, the reference's default.  Its connectNode re-enters the lower levels from the new node itself "
                  "(hnsw.go:463-467), so every node of level >= 1 links only to itself on level 0 and the level-0 graph is a forest of "
                  "small islands around those nodes: graph traversals return few results and HNSW.Search completes most queries with its "
                  "brute-force top-up (hnsw.go:676-710).  Reproduced faithfully (the build equals the CPU restatement's); the numbers "
                  "below are what that structure gives"),
-                ("hnsw_1Mx768_maxlevel1", 1, (64, 128, 256, 512),
+                ("hnsw_1Mx768_maxlevel1", 1, (64, 128, 256, 512), 0,
                  "MaxLevel=1: every node on level 0, so the level quirk above is out of play and the level-0 graph is one connected "
-                 "M=16/MaxM0=32 graph — the configuration in which 'QPS @ recall' describes a graph search")):
+                 "M=16/MaxM0=32 graph — the configuration in which 'QPS @ recall' describes a graph search.  BASELINE's corpus is "
+                 "uniformly random 768-d unit vectors, which have no neighbourhood structure: recall stays low at any efSearch"),
+                ("hnsw_1Mx768_maxlevel1_structured", 1, (16, 32, 64, 128, 256), 16,
+                 "the same index shape over data WITH neighbourhood structure (unit vectors on a 16-dimensional subspace of R^768, the "
+                 "regime embeddings live in): same bytes per row, same kernels — this is the 'QPS @ recall' curve of the graph search")):
             try:
                 e = hnsw_run(rows=a.hnsw_rows, dim=dim, metric=a.metric, m=16, efc=200, max_level=max_level, efs=efs, nq=8192, k=k,
-                             cpu_queries=cpuq, device=local_rank, corpus_seed=CORPUS_SEED, query_seed=QUERY_SEED)
+                             cpu_queries=cpuq, device=local_rank, corpus_seed=CORPUS_SEED, query_seed=QUERY_SEED, intrinsic_dim=idim)
                 e["note"] = note
                 also[key] = e
             except Exception as ex:                        # noqa: BLE001  (a measurement beside the headline; never fail the bench line over it)

@@ -21,7 +21,7 @@ import numpy as np
 
 
 def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, batch_max=16384, ramp_div=16, efs=(64, 128, 256, 512),
-        nq=8192, k=10, cpu_queries=100, device=0, level_seed=1, corpus_seed=20260424, query_seed=20260425, cpu_build_rows=0):
+        nq=8192, k=10, cpu_queries=100, device=0, level_seed=1, corpus_seed=20260424, query_seed=20260425, cpu_build_rows=0, intrinsic_dim=0):
     import torch                      # before libqv: both must share one HIP runtime (torch bundles its own)
     import quiver_amd
     from quiver_amd.device_index import DeviceGraph, random_levels
@@ -33,7 +33,26 @@ def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, b
                     "(hnsw.go:266-468; batch of one == Insert)" % (batch_max, ramp_div)}
     idx = quiver_amd.DeviceIndex(D, metric, device=device, rowmajor=True)
     idx.reserve(N)
-    idx.add_synthetic(corpus_seed, 0, N)
+    if intrinsic_dim:
+        # Structured data: unit vectors on an `intrinsic_dim`-dimensional subspace of R^D (Gaussian coordinates under a random
+        # orthonormal basis) — the regime embeddings live in and the one where a graph index finds neighbours; uniformly random
+        # 768-d unit vectors (BASELINE's synthetic corpus) have no neighbourhood structure for any graph to follow.
+        gen = torch.Generator(device="cuda"); gen.manual_seed(corpus_seed)
+        basis = torch.linalg.qr(torch.randn((D, intrinsic_dim), generator=gen, device="cuda", dtype=torch.float64))[0].T.contiguous()
+        def lowrank(n):
+            z = torch.randn((n, intrinsic_dim), generator=gen, device="cuda", dtype=torch.float64)
+            x = z @ basis
+            return (x / x.norm(dim=1, keepdim=True)).to(torch.float32).contiguous()
+        host_rows = np.empty((N, D), np.float32) if cpu_queries else None
+        for s0 in range(0, N, 250_000):
+            x = lowrank(min(250_000, N - s0))
+            idx.add_device(x.data_ptr(), x.shape[0], torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            if host_rows is not None:
+                host_rows[s0:s0 + x.shape[0]] = x.cpu().numpy()
+        out["corpus"] = "unit vectors on a random %d-dimensional subspace of R^%d (Gaussian coordinates)" % (intrinsic_dim, D)
+    else:
+        idx.add_synthetic(corpus_seed, 0, N)
     levels = random_levels(N, max_level, level_seed)
     t0 = time.perf_counter()
     g = DeviceGraph.build(idx, levels, m=m, max_m0=2 * m, ef_construction=efc, batch_max=batch_max, ramp_div=ramp_div)
@@ -42,13 +61,16 @@ def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, b
     out["build"] = {"seconds": t_build, "nodes_per_s": N / t_build, "batches": st["build_batches"], "searches_redone_exact_heap": st["build_redo"],
                     "entry": info["entry"], "top_level": info["cur_level"], "upper_level_lists": info["n_up_blocks"]}
 
-    qg = quiver_amd.DeviceIndex(D, metric, device=device)
-    qg.add_synthetic(query_seed, 0, nq)
     # exact top-k of every query: the recall denominator (the flat scan is the oracle-checked exact path)
     dq = torch.empty((nq, D), dtype=torch.float32, device="cuda")
-    hq = np.stack([qg.get_row(i) for i in range(nq)])
-    dq.copy_(torch.from_numpy(hq))
-    qg.close()
+    if intrinsic_dim:
+        dq.copy_(lowrank(nq)); hq = dq.cpu().numpy()
+    else:
+        qg = quiver_amd.DeviceIndex(D, metric, device=device)
+        qg.add_synthetic(query_seed, 0, nq)
+        hq = np.stack([qg.get_row(i) for i in range(nq)])
+        dq.copy_(torch.from_numpy(hq))
+        qg.close()
     er, ed, _ = idx.search(hq, k, batched=True)
 
     dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
@@ -94,9 +116,12 @@ def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, b
     if cpu_queries:
         from tests import _oracle as O                    # checker / CPU baseline only
         t0 = time.perf_counter()
-        hrows = np.empty((N, D), np.float32)
-        for s in range(0, N, 100_000):
-            e = min(N, s + 100_000); hrows[s:e] = O.gen_rows(corpus_seed, s, e - s, D)
+        if intrinsic_dim:
+            hrows = host_rows
+        else:
+            hrows = np.empty((N, D), np.float32)
+            for s in range(0, N, 100_000):
+                e = min(N, s + 100_000); hrows[s:e] = O.gen_rows(corpus_seed, s, e - s, D)
         t_gen = time.perf_counter() - t0
         lv, l0_deg, l0_links, up_off, up_links = g.export()
         mid = quiver_amd.metric_id(metric)
@@ -139,6 +164,7 @@ if __name__ == "__main__":
     ap.add_argument("--max-level", type=int, default=16); ap.add_argument("--batch-max", type=int, default=16384); ap.add_argument("--ramp-div", type=int, default=16)
     ap.add_argument("--efs", default="64,128,256,512"); ap.add_argument("--nq", type=int, default=8192); ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cpu-queries", type=int, default=100); ap.add_argument("--cpu-build-rows", type=int, default=0)
+    ap.add_argument("--intrinsic-dim", type=int, default=0, help="0 = BASELINE's random unit vectors; r = unit vectors on an r-dimensional subspace")
     a = ap.parse_args()
     print(json.dumps(run(a.rows, a.dim, a.metric, a.m, a.efc, a.max_level, a.batch_max, a.ramp_div, tuple(int(x) for x in a.efs.split(",")),
-                         a.nq, a.k, a.cpu_queries, cpu_build_rows=a.cpu_build_rows)), flush=True)
+                         a.nq, a.k, a.cpu_queries, cpu_build_rows=a.cpu_build_rows, intrinsic_dim=a.intrinsic_dim)), flush=True)
