@@ -75,6 +75,7 @@ struct ScanPlan {
     uint32_t grid;        // workgroups
     uint32_t block;       // threads (multiple of 64)
     uint32_t n_lists;     // partial lists the scan writes (= grid)
+    uint32_t cus;         // compute units of the device the plan was made for
 };
 
 // how many workgroups a scan over n_tiles uses on a device with `cus` CUs

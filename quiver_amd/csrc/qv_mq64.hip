@@ -60,10 +60,25 @@ __global__ void k_mq64_prep(const float* __restrict__ queries, uint32_t nq, uint
         const uint32_t d = c * 4 + (lane >> 4);
         qfrag[(size_t)grp * per + i] = d < dim ? queries[(size_t)qi * dim + d] : 0.0f;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 16 * NB) {
-        uint32_t qi = grp * 16 * NB + threadIdx.x; if (qi >= nq) qi = nq - 1;
-        const QConst c = query_const<M>(queries + (size_t)qi * dim, dim);     // the query's own norm, element order of distances.go:20
-        qconst[(size_t)grp * 16 * NB + threadIdx.x] = c.qn;
+    if (blockIdx.x == 0) {
+        // the queries' own norms in the element order of distances.go:20 — one thread per query walks the chain, the block
+        // stages 64 dimensions of all 16*NB queries at a time so that the reads are whole lines
+        __shared__ float stage[16 * NB][65];
+        double ma = 0.0;
+        if constexpr (M == QV_COSINE) {
+            for (uint32_t d0 = 0; d0 < dim; d0 += 64) {
+                for (uint32_t i = threadIdx.x; i < 16 * NB * 64; i += blockDim.x) {
+                    uint32_t qi = grp * 16 * NB + (i >> 6); if (qi >= nq) qi = nq - 1;
+                    const uint32_t d = d0 + (i & 63);
+                    stage[i >> 6][i & 63] = d < dim ? queries[(size_t)qi * dim + d] : 0.0f;
+                }
+                __syncthreads();
+                if (threadIdx.x < 16 * NB)
+                    for (uint32_t c = 0; c < 64 && d0 + c < dim; c++) { const double a = (double)stage[threadIdx.x][c]; ma = __builtin_fma(a, a, ma); }
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x < 16 * NB) qconst[(size_t)grp * 16 * NB + threadIdx.x] = __builtin_sqrt(ma);     // dot: unused (0)
     }
 }
 
@@ -76,23 +91,56 @@ __device__ __forceinline__ void transpose_blocks(const f4 x, float& y0, float& y
     y0 = __uint_as_float(a[0]); y1 = __uint_as_float(a[1]); y2 = __uint_as_float(b[0]); y3 = __uint_as_float(b[1]);
 }
 
-// list maintenance happens once per query on the first tile and rarely afterwards; kept out of line so that the
-// 16*NB lists (distinct registers) do not each inline a bitonic network and an insertion loop
+// list maintenance is rare (see the bound below); kept out of line so that the 16*NB lists (distinct registers) do not each
+// inline a bitonic network and an insertion loop
 __attribute__((noinline)) __device__ uint64_t sort_out_of_line(uint64_t key, uint32_t lane) { return wave_sort64(key, lane); }
-__attribute__((noinline)) __device__ uint64_t insert_out_of_line(uint64_t list, uint64_t cand, uint32_t kth, uint32_t lane) {
-    uint64_t thr = readlane64(list, kth);
-    list_insert(list, thr, cand, kth, lane);
+// inserts every lane's candidate below `thr`; thr <- min(thr, the list's k-th key)
+__attribute__((noinline)) __device__ uint64_t insert_out_of_line(uint64_t list, uint64_t cand, uint64_t& thr, uint32_t kth, uint32_t lane) {
+    uint64_t mask = __ballot(cand < thr);
+    while (mask) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint64_t c = readlane64(cand, src);
+        if (c >= thr) continue;                      // threshold tightened since the ballot
+        const uint32_t pos = (uint32_t)__builtin_popcountll(__ballot(list < c));
+        const uint64_t up = wave_shr1(list);
+        list = lane > pos ? up : (lane == pos ? c : list);
+        const uint64_t kk = readlane64(list, kth);
+        thr = kk < thr ? kk : thr;
+    }
     return list;
 }
 
-// A single wave per SIMD issues f64 MFMAs at half the pipe's rate (mfma_f64_rate.hip: 38.9 vs 77.5 TFLOP/s), and
-// v_cvt_f64_f32 shares the DP pipe with them (mfma_f64_mix.hip), so the shapes trade registers for waves per SIMD and
-// MFMAs per row convert: see Mq64Shape above.  With H > 1, set h computes its query blocks for the SAME tiles as the
-// other sets (the second read of a tile is an L2 hit, HBM sees it once).
+// The k-th key of a SAMPLE of the corpus bounds every query's final k-th key from above.  k_flat_scan_mq64 runs twice:
+// over a few hundred tiles spread across the corpus (bound == nullptr: lists start from a sorted first tile), then — after
+// k_mq64_bound has turned the sample's lists into bound[q] = its k-th key + 1 — over all tiles with every list empty and every
+// threshold at bound[q].  Why: a wave sees only n_tiles / 2048 tiles of a pass (7.6 at 1M rows), so a threshold learnt from
+// its own rows never gets tight: 2 of its 64 rows beat it per query and tile, and the kernel spent more VALU instructions
+// maintaining lists (4.0e8 per 256 x 1M x 768 batch, SQ_INSTS_VALU) and sorting first tiles than on the scan itself
+// (profiles/r02_mq64_breakdown.txt).  With the sample's bound, 0.04 rows per query and tile pass the one-sided test below.
+__global__ void k_mq64_bound(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k, uint64_t* __restrict__ bound) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x, kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    const uint64_t* p = partial + (size_t)q * n_lists * k;
+    for (uint32_t i = 0; i < n_lists * k; i += 64) {
+        const uint64_t key = i + lane < n_lists * k ? p[i + lane] : kDeadKey;
+        list = insert_out_of_line(list, key, thr, kth, lane);
+    }
+    // fewer than k live rows in the sample: no bound (kDeadKey admits everything)
+    if (lane == 0) bound[q] = thr == kDeadKey ? kDeadKey : thr + 1;
+}
+
+// A single wave per SIMD issues f64 MFMAs at half the pipe's rate (mfma_f64_rate.hip: 38.9 vs 77.5 TFLOP/s), and every
+// other VALU instruction of the SIMD waits while one runs (mfma_f64_mix.hip, mfma_f64_intcvt.hip), so the shapes trade
+// registers for waves per SIMD and MFMAs per row convert: see Mq64Shape above.  With H > 1, set h computes its query
+// blocks for the SAME tiles as the other sets (the second read of a tile is an L2 hit, HBM sees it once).
+// Tiles visited: tile_step * i for i < n_iter (the sample pass strides, the full pass has tile_step 1, n_iter = n_tiles).
+// wave_lists: every wave writes its own lists (partial[(q * grid * W + wg * W + wave) * k + i]) instead of the workgroup's merged
+// ones — the sample pass, whose waves hold full lists: merging them on one wave was most of that pass's time.
 template <int M, int H, int NB, int U, int W, int WGS>
 __global__ void __launch_bounds__(64 * W * H, WGS)
 k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* __restrict__ qconst_g, uint32_t nq, uint32_t k,
-                 uint64_t* __restrict__ partial) {
+                 const uint64_t* __restrict__ bound, uint32_t n_iter, uint32_t tile_step, uint32_t wave_lists, uint64_t* __restrict__ partial) {
     static_assert(M == QV_COSINE || M == QV_DOT, "the f64 matrix path covers the fma(q, x, acc) metrics");
     constexpr int Q = 16 * NB;       // queries per wave (NB 16-query blocks)
     extern __shared__ __align__(16) unsigned char smem[];
@@ -101,7 +149,7 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
     float* qf = reinterpret_cast<float*>(smem);                                   // [NB][dim4][64]
     const lds_f32* qf3 = (const lds_f32*)smem;                                    // same, as an LDS-address-space pointer (ds_read)
     const size_t qf_bytes = (size_t)H * NB * v.dim4 * 64 * sizeof(float);
-    lds_u64* scratch = (lds_u64*)((__attribute__((address_space(3))) unsigned char*)smem + qf_bytes);   // [waves][4][64] first-tile transpose
+    lds_u64* scratch = (lds_u64*)((__attribute__((address_space(3))) unsigned char*)smem + qf_bytes);   // [waves][4][64] regrouping
     const uint32_t lane = lane_id();
     const uint32_t wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t half = wave_all / W, wave = wave_all % W;      // query block of this wave, tile slot of this wave
@@ -116,29 +164,50 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
     qf3 += half * NB * v.dim4 * 64;                                                      // this wave's query block
     // per-lane query constants: register (nb, r) belongs to query 16nb + 4r + blk
     double qn[NB][4];
+    uint64_t thrv[NB][4];                  // per lane: current threshold key of "its" query for register (nb, r)
 #pragma unroll
     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) qn[nb][r] = qconst_g[q0 + nb * 16 + r * 4 + blk];   // qconst is laid out by query index
+        for (int r = 0; r < 4; r++) {
+            const uint32_t qi = q0 + nb * 16 + r * 4 + blk;
+            qn[nb][r] = qconst_g[qi];                                                    // qconst is laid out by query slot
+            thrv[nb][r] = bound ? bound[qi < nq ? qi : nq - 1] : kDeadKey;
+        }
     __syncthreads();
 
     const uint32_t kth = k - 1;
     uint64_t list[Q];                      // wave-resident ascending top-k list per query (one key per lane)
-    uint64_t thrv[NB][4];                  // per lane: current k-th key of "its" query for register (nb, r)
 #pragma unroll
     for (int i = 0; i < Q; i++) list[i] = kDeadKey;
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) thrv[nb][r] = kDeadKey;
 
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     const uint32_t tw = gridDim.x * W;
-    bool first = true;
+    bool first = bound == nullptr;         // sample pass: the first tile's 64 rows per query are sorted into the list outright
     lds_u64* my_scratch = scratch + wave_all * 4 * 64;
 
-    for (uint32_t t = blockIdx.x * W + wave; t < v.n_tiles; t += tw) {
-        const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
+    // this lane's B elements of tile t: row 16g + lane%16, dim 4c + lane/16
+    auto tile_ptr = [&](uint32_t t) { return reinterpret_cast<const float*>(tiles + (size_t)t * v.dim4 * 64) + j16 * 4 + blk; };
+    float xa[U][4], xb[U][4];              // two register blocks of row elements and query values, used alternately
+    float qa[U][NB], qb2[U][NB];
+    const uint32_t nblk = v.dim4 / U;
+    auto load_x_from = [&](const float* pb, float (&x)[U][4], uint32_t c0) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) x[u][g] = pb[(size_t)(c0 + u) * 256 + g * 64];
+    };
+    auto load_q = [&](float (&q)[U][NB], uint32_t c0) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) q[u][nb] = qf3[((uint32_t)nb * v.dim4 + c0 + u) * 64 + lane];
+    };
+    const uint32_t it0 = blockIdx.x * W + wave;
+    if (it0 < n_iter && nblk) { load_x_from(tile_ptr(it0 * tile_step), xa, 0); load_q(qa, 0); }
+
+    for (uint32_t it = it0; it < n_iter; it += tw) {
+        const uint32_t t = it * tile_step;
+        const float* pb = tile_ptr(t);
         d4 acc[NB][4];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
@@ -150,11 +219,11 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
 #pragma unroll
         for (int g = 0; g < 4; g++) { rn[g] = 0.0; if constexpr (MT<M>::needs_rnorm) rn[g] = v.rnorm[(size_t)t * 64 + g * 16 + j16]; }
 
-        // one chunk: B operands from the row chunk (transpose + widen), A operands = the queries' values for this chunk
-        auto step = [&](const f4 x, const float (&qa)[NB]) {
-            float y0, y1, y2, y3;
-            transpose_blocks(x, y0, y1, y2, y3);
-            const double b0 = (double)y0, b1 = (double)y1, b2 = (double)y2, b3 = (double)y3;
+        // one chunk: B operands = this lane's (row 16g + lane%16, dim 4c + lane/16) elements, read straight from the tile in
+        // that arrangement (each of the four loads of a chunk covers one 256-byte run of 16 rows x 4 dims, so the tile is
+        // still fetched in whole lines, once); A operands = the queries' values for this chunk
+        auto step = [&](const float (&y)[4], const float (&qa)[NB]) {
+            const double b0 = (double)y[0], b1 = (double)y[1], b2 = (double)y[2], b3 = (double)y[3];
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) {
                 const double a = (double)qa[nb];
@@ -164,56 +233,68 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
                 acc[nb][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[nb][3], 0, 0, 0);
             }
         };
-        auto load_q = [&](float (&qa)[U][NB], uint32_t c0) {
+        auto load_x = [&](float (&x)[U][4], uint32_t c0) { load_x_from(pb, x, c0); };
+        auto consume = [&](const float (&x)[U][4], const float (&qa)[U][NB]) {
 #pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) qa[u][nb] = qf3[((uint32_t)nb * v.dim4 + c0 + u) * 64 + lane];
-        };
-        // chunks in order, U at a time; the next block's row chunks (HBM) and query values (LDS) are requested
-        // before the current block is consumed, so the matrix pipe never waits on a load it has just issued
-        f4 xa[U], xb[U];
-        float qa[U][NB], qb2[U][NB];
-        const uint32_t nblk = v.dim4 / U;
-        if (nblk) {
-#pragma unroll
-            for (int u = 0; u < U; u++) xa[u] = p[(size_t)u * 64];
-            load_q(qa, 0);
-        }
-        for (uint32_t bi = 0; bi < nblk; bi++) {
-            const uint32_t c0 = bi * U;
-            if (bi + 1 < nblk) {
-#pragma unroll
-                for (int u = 0; u < U; u++) xb[u] = p[(size_t)(c0 + U + u) * 64];
-                load_q(qb2, c0 + U);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) step(xa[u], qa[u]);
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                xa[u] = xb[u];
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) qa[u][nb] = qb2[u][nb];
-            }
+            for (int u = 0; u < U; u++) step(x[u], qa[u]);
             // keep the accumulators in the accumulation registers across the back-edge
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) asm volatile("" : "+v"(acc[nb][g]));
+        };
+        // chunks in order, U at a time: the next block's row elements (HBM) and query values (LDS) are requested before the
+        // current block is consumed, so the matrix pipe never waits on a load it has just issued, and no block is copied.
+        // Block 0 of a tile is requested before the previous tile's epilogue (xa is free by then whether nblk is odd or even).
+        for (uint32_t bi = 0; bi < nblk; bi += 2) {
+            if (bi + 1 < nblk) { load_x(xb, (bi + 1) * U); load_q(qb2, (bi + 1) * U); }
+            consume(xa, qa);
+            if (bi + 1 < nblk) {
+                if (bi + 2 < nblk) { load_x(xa, (bi + 2) * U); load_q(qa, (bi + 2) * U); }
+                consume(xb, qb2);
+            }
         }
+        if (it + tw < n_iter && nblk) { load_x_from(tile_ptr((it + tw) * tile_step), xa, 0); load_q(qa, 0); }
         for (uint32_t c = nblk * U; c < v.dim4; c++) {
-            float q1[NB];
+            float q1[NB], x1[4];
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) q1[nb] = qf3[((uint32_t)nb * v.dim4 + c) * 64 + lane];
-            step(p[(size_t)c * 64], q1);
+#pragma unroll
+            for (int g = 0; g < 4; g++) x1[g] = pb[(size_t)c * 256 + g * 64];
+            step(x1, q1);
         }
 
-        // epilogue: distances -> keys; lane (blk, j16), register (nb, g, r) = (query 16nb+4r+blk, row 64t+16g+j16)
+        // epilogue: lane (blk, j16), register (nb, g, r) = (query 16nb+4r+blk, row 64t+16g+j16)
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 QConst qc; qc.qn = qn[nb][r]; qc.qn32 = 0.0f;
+                // Almost no row beats its query's threshold.  A one-sided test on the accumulator settles that without the
+                // division, the rounding to float32 and the key: with Tu the next float32 above the threshold's distance, a
+                // row whose float64 value is provably above Tu cannot enter the list whatever its row id.
+                //   dot:    d = 1 - acc is the reference's own float64 value (distances.go:89); d > Tu => float32(d) >= Tu.
+                //   cosine: sim = acc / (qn*rn) (distances.go:30).  acc < P - |P| 2^-48 with P = ((1 - Tu) - 2^-50) qn rn
+                //           puts the rounded quotient below 1 - Tu - 2^-51, so 1 - sim rounds to >= Tu.  (Tu > 2 — a
+                //           threshold at the clamp — zero norms and NaN all fall through to the exact path.)
+                if (!first) {
+                    const uint32_t tk = (uint32_t)(thrv[nb][r] >> 32);
+                    bool cand = tk >= 0xFFFFFFFDu;                       // no threshold yet, or a NaN distance as threshold
+                    const double tu = (double)unord_f32(cand ? 0x80000000u : tk + 1);
+                    if constexpr (M == QV_DOT) {
+#pragma unroll
+                        for (int g = 0; g < 4; g++) cand |= !((1.0 - acc[nb][g][r]) > tu);
+                    } else {
+                        cand |= tu > 2.0;
+                        const double s0q = ((1.0 - tu) - 0x1p-50) * qc.qn;
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const double pth = s0q * rn[g];
+                            cand |= !(acc[nb][g][r] < pth - __builtin_fabs(pth) * 0x1p-48);
+                        }
+                    }
+                    if (__ballot(cand) == 0) continue;
+                }
                 uint64_t key[4];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
@@ -221,36 +302,39 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
                     const bool live = (alive_word >> (g * 16 + j16)) & 1ull;
                     key[g] = live ? make_key(finalize<M>(acc[nb][g][r], qc, rn[g]), row) : kDeadKey;
                 }
-                // Common case (after the first tile): no candidate beats its query's current k-th key — one ballot.
-                // Otherwise regroup the 4 x 64 candidates of these four queries through LDS to one per lane and
-                // hand each query's 64 to its list: sorted outright on the first tile, inserted afterwards.
-                bool slow = first;
+                // the exact keys against the thresholds; then regroup the 4 x 64 candidates of these four queries through
+                // LDS to one per lane and hand each query's 64 to its list
                 uint64_t hits = ~0ull;
                 if (!first) {
                     hits = __ballot(key[0] < thrv[nb][r] || key[1] < thrv[nb][r] || key[2] < thrv[nb][r] || key[3] < thrv[nb][r]);
-                    slow = hits != 0;
+                    if (hits == 0) continue;
                 }
-                if (slow) {
 #pragma unroll
-                    for (int g = 0; g < 4; g++) my_scratch[blk * 64 + g * 16 + j16] = key[g];
-                    __builtin_amdgcn_wave_barrier();
+                for (int g = 0; g < 4; g++) my_scratch[blk * 64 + g * 16 + j16] = key[g];
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int qb = 0; qb < 4; qb++) {
-                        if (((hits >> (16 * qb)) & 0xFFFFull) == 0) continue;
-                        const uint64_t cand = my_scratch[qb * 64 + lane];
-                        uint64_t& l = list[nb * 16 + r * 4 + qb];
-                        l = first ? sort_out_of_line(cand, lane) : insert_out_of_line(l, cand, kth, lane);
-                        const uint64_t thr = readlane64(l, kth);
-                        if (blk == (uint32_t)qb) thrv[nb][r] = thr;
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                for (int qb = 0; qb < 4; qb++) {
+                    if (((hits >> (16 * qb)) & 0xFFFFull) == 0) continue;
+                    const uint64_t cand = my_scratch[qb * 64 + lane];
+                    uint64_t& l = list[nb * 16 + r * 4 + qb];
+                    uint64_t thr = readlane64(thrv[nb][r], qb * 16);          // this query's threshold (lanes of block qb hold it)
+                    if (first) { l = sort_out_of_line(cand, lane); thr = readlane64(l, kth); }
+                    else l = insert_out_of_line(l, cand, thr, kth, lane);
+                    if (blk == (uint32_t)qb) thrv[nb][r] = thr;
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         first = false;
     }
 
-    // merge each set's 4 per-wave lists per query (the query fragments are dead: reuse their LDS)
+    if (wave_lists) {
+#pragma unroll
+        for (int i = 0; i < Q; i++)
+            if (q0 + i < nq && lane < k) partial[((size_t)(q0 + i) * gridDim.x * W + blockIdx.x * W + wave) * k + lane] = list[i];
+        return;
+    }
+    // merge each set's per-wave lists per query (the query fragments are dead: reuse their LDS)
     __syncthreads();
     lds_u64* wl = (lds_u64*)smem + (size_t)half * (W - 1) * Q * 64;      // [waves-1][Q][64] per set
     if (wave > 0) {
@@ -261,9 +345,11 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
     if (wave == 0) {
 #pragma unroll
         for (int i = 0; i < Q; i++) {
+            uint64_t thr = readlane64(list[i], kth);
             for (uint32_t w = 0; w + 1 < (uint32_t)W; w++) {
                 const uint64_t key = lane < k ? wl[(w * Q + i) * 64 + lane] : kDeadKey;
-                list[i] = insert_out_of_line(list[i], key, kth, lane);
+                if (__ballot(key < thr) == 0) continue;
+                list[i] = insert_out_of_line(list[i], key, thr, kth, lane);
             }
             if (q0 + i < nq && lane < k) partial[((size_t)(q0 + i) * gridDim.x + blockIdx.x) * k + lane] = list[i];
         }
@@ -283,18 +369,30 @@ int mq64_blocks(int metric, uint32_t dim4, uint32_t nq) {
     if (mq64_lds_bytes(dim4, sh) * sh.wgs > 158 * 1024) return 0;
     return 16 * sh.h * sh.nb;
 }
-size_t mq64_workspace_bytes(uint32_t nq, uint32_t dim4) { return (size_t)(nq + 32) * dim4 * 4 * sizeof(float) + (size_t)(nq + 32) * sizeof(double) + 512; }
+// query fragments + query constants + the sample pass's bounds
+size_t mq64_workspace_bytes(uint32_t nq, uint32_t dim4) {
+    return (size_t)(nq + 32) * dim4 * 4 * sizeof(float) + 256 + (size_t)(nq + 32) * sizeof(double) + 256 + (size_t)(nq + 32) * sizeof(uint64_t) + 256;
+}
 
-// partial[(q * grid + wg) * k + i]; returns the grid used through *grid_out
+// partial[(q * grid + wg) * k + i]; returns the grid used through *grid_out.  ev0/ev1 bracket the full pass.
 hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_queries, uint32_t nq, uint32_t k, void* d_qws, uint64_t* partial,
                                  uint32_t* grid_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (mq64_blocks(v.metric, v.dim4, nq) == 0) return hipErrorInvalidValue;
     const Mq64Shape sh = mq64_shape(nq);
     const uint32_t B = (uint32_t)(sh.h * sh.nb), Q = 16u * B, groups = (nq + Q - 1) / Q;
-    float* qfrag = static_cast<float*>(d_qws);
-    double* qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qws) + (((size_t)groups * Q * v.dim4 * 4 * sizeof(float)) + 255) / 256 * 256);
+    auto up256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    unsigned char* ws = static_cast<unsigned char*>(d_qws);
+    float* qfrag = reinterpret_cast<float*>(ws);
+    double* qconst = reinterpret_cast<double*>(ws + up256((size_t)groups * Q * v.dim4 * 4 * sizeof(float)));
+    uint64_t* bound = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(qconst) + up256((size_t)groups * Q * sizeof(double)));
     const uint32_t want = (v.n_tiles + (uint32_t)sh.w - 1) / (uint32_t)sh.w;
     const uint32_t grid = std::max(1u, std::min(want, (uint32_t)cus * (uint32_t)sh.wgs));
+    // the sample: one tile per wave of `sgrid` workgroups, spread evenly over the corpus (QV_MQ64_SAMPLE tiles, 0 = no sample
+    // pass: every wave learns its thresholds from its own tiles, the round-1 behaviour)
+    static const int sample_env = env_int("QV_MQ64_SAMPLE", 256);
+    const uint32_t stiles = std::min<uint32_t>(std::min<uint32_t>((uint32_t)std::max(sample_env, 0), v.n_tiles / 8), 4u * (uint32_t)cus);   // the partial buffer holds 8 lists per CU and query
+    const uint32_t sgrid = stiles / (uint32_t)sh.w;
+    const uint32_t n_s = sgrid * (uint32_t)sh.w, step_s = n_s ? v.n_tiles / n_s : 1;
     const size_t lds = mq64_lds_bytes(v.dim4, sh);
     hipError_t e = hipSuccess;
 #define QV_MQ64(MMM, HH, NBB, UU, WW, GG)                                                                                         \
@@ -304,7 +402,13 @@ hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_que
         e = set_lds(k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>, lds);                                                             \
         if (e != hipSuccess) return e;                                                                                            \
         if (ev0) (void)hipEventRecord(ev0, s);                                                                                    \
-        hipLaunchKernelGGL((k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>), dim3(grid, groups), dim3(64 * WW * HH), lds, s, v, qfrag, qconst, nq, k, partial); \
+        if (sgrid) {                                                                                                              \
+            hipLaunchKernelGGL((k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>), dim3(sgrid, groups), dim3(64 * WW * HH), lds, s, v, qfrag, qconst, nq, k, \
+                               (const uint64_t*)nullptr, n_s, step_s, 1u, partial);                                                \
+            hipLaunchKernelGGL(k_mq64_bound, dim3(nq), dim3(64), 0, s, partial, sgrid * (uint32_t)(WW), k, bound);                 \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>), dim3(grid, groups), dim3(64 * WW * HH), lds, s, v, qfrag, qconst, nq, k, \
+                           sgrid ? (const uint64_t*)bound : (const uint64_t*)nullptr, v.n_tiles, 1u, 0u, partial);                 \
         if (ev1) (void)hipEventRecord(ev1, s);                                                                                    \
     }
 #define QV_MQ64_SHAPES(MMM)                                                                  \

@@ -433,6 +433,7 @@ k_merge_shards(const uint32_t* __restrict__ packed, const uint32_t* __restrict__
 ScanPlan plan_scan(uint32_t n_tiles, int cus) {
     ScanPlan p;
     p.block = kScanBlock;
+    p.cus = (uint32_t)(cus > 0 ? cus : 1);
     uint32_t want = (n_tiles + kScanWaves - 1) / kScanWaves;          // one tile per wave at most
     static const int wg_per_cu = env_int("QV_SCAN_WG_PER_CU", 2);     // 2 workgroups = 8 waves per CU: measured best (profiles/r01_sweep.txt)
     uint32_t cap = (uint32_t)cus * (uint32_t)wg_per_cu;
@@ -499,7 +500,7 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
         if ((int)nq >= mq64_min && mq_qb_env == 0 && v.n_tiles >= 16u * p.grid && mq64_blocks(v.metric, v.dim4, nq) != 0) {
             uint32_t g64 = 0;
             if (trace) fprintf(stderr, "qv: scan kernel = k_flat_scan_mq64 (nq=%u, tiles=%u)\n", nq, v.n_tiles);
-            e = launch_flat_scan_mq64(v, (int)(p.grid / 2 ? p.grid / 2 : 1), d_queries, nq, k, qblk, partial, &g64, s, ev0, ev1);
+            e = launch_flat_scan_mq64(v, (int)p.cus, d_queries, nq, k, qblk, partial, &g64, s, ev0, ev1);
             if (e != hipSuccess) return e;
             const uint32_t total64 = g64 * k;
             const uint32_t mb64 = total64 >= 16 * 64 * 4 ? kMergeBlock : (total64 >= 4 * 64 ? 256 : 64);
