@@ -31,6 +31,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //   W  waves that share out the tiles;  H  such wave sets per workgroup, set h computing query blocks h*NB.. for the SAME tiles;
 //   NB 16-query blocks per wave;  U chunks per register block (double-buffered);  WGS workgroups per CU
 struct Mq64Shape { int h, nb, u, w, wgs; };
+constexpr int kMq64Cap = 1024;      // candidates a workgroup of k_mq64_bounded can hold
 static Mq64Shape mq64_shape(uint32_t nq) {
     // Measured, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt).  0: 16 queries/pass, 2 x 4 waves per CU on distinct tiles
     // (0.63 ms per pass); 1: 32 queries/pass as two 4-wave sets sharing tiles; 2: 32 queries/pass, 8 waves per CU with two
@@ -63,7 +64,7 @@ __global__ void k_mq64_prep(const float* __restrict__ queries, uint32_t nq, uint
     if (blockIdx.x == 0) {
         // the queries' own norms in the element order of distances.go:20 — one thread per query walks the chain, the block
         // stages 64 dimensions of all 16*NB queries at a time so that the reads are whole lines
-        __shared__ float stage[16 * NB][65];
+        __shared__ __align__(16) float stage[16 * NB][68];      // 64 dims + 4 floats of padding: rows stay 16-byte aligned
         double ma = 0.0;
         if constexpr (M == QV_COSINE) {
             for (uint32_t d0 = 0; d0 < dim; d0 += 64) {
@@ -73,8 +74,18 @@ __global__ void k_mq64_prep(const float* __restrict__ queries, uint32_t nq, uint
                     stage[i >> 6][i & 63] = d < dim ? queries[(size_t)qi * dim + d] : 0.0f;
                 }
                 __syncthreads();
-                if (threadIdx.x < 16 * NB)
-                    for (uint32_t c = 0; c < 64 && d0 + c < dim; c++) { const double a = (double)stage[threadIdx.x][c]; ma = __builtin_fma(a, a, ma); }
+                if (threadIdx.x < 16 * NB) {
+                    f4 x[16];                                      // all 64 values first: the chain then runs from registers
+#pragma unroll
+                    for (int c = 0; c < 16; c++) x[c] = reinterpret_cast<const f4*>(stage[threadIdx.x])[c];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) {                 // values beyond dim are 0: fma(0, 0, ma) == ma
+                        double a = (double)x[c].x; ma = __builtin_fma(a, a, ma);
+                        a = (double)x[c].y; ma = __builtin_fma(a, a, ma);
+                        a = (double)x[c].z; ma = __builtin_fma(a, a, ma);
+                        a = (double)x[c].w; ma = __builtin_fma(a, a, ma);
+                    }
+                }
                 __syncthreads();
             }
         }
@@ -118,7 +129,7 @@ __attribute__((noinline)) __device__ uint64_t insert_out_of_line(uint64_t list, 
 // its own rows never gets tight: 2 of its 64 rows beat it per query and tile, and the kernel spent more VALU instructions
 // maintaining lists (4.0e8 per 256 x 1M x 768 batch, SQ_INSTS_VALU) and sorting first tiles than on the scan itself
 // (profiles/r02_mq64_breakdown.txt).  With the sample's bound, 0.04 rows per query and tile pass the one-sided test below.
-__global__ void k_mq64_bound(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k, uint64_t* __restrict__ bound) {
+__global__ void k_mq64_bound(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k, uint64_t* __restrict__ bound, uint32_t* __restrict__ overflow) {
     const uint32_t q = blockIdx.x, lane = threadIdx.x, kth = k - 1;
     uint64_t list = kDeadKey, thr = kDeadKey;
     const uint64_t* p = partial + (size_t)q * n_lists * k;
@@ -128,6 +139,7 @@ __global__ void k_mq64_bound(const uint64_t* __restrict__ partial, uint32_t n_li
     }
     // fewer than k live rows in the sample: no bound (kDeadKey admits everything)
     if (lane == 0) bound[q] = thr == kDeadKey ? kDeadKey : thr + 1;
+    if (q == 0 && lane == 0) *overflow = 0;
 }
 
 // A single wave per SIMD issues f64 MFMAs at half the pipe's rate (mfma_f64_rate.hip: 38.9 vs 77.5 TFLOP/s), and every
@@ -140,8 +152,10 @@ __global__ void k_mq64_bound(const uint64_t* __restrict__ partial, uint32_t n_li
 template <int M, int H, int NB, int U, int W, int WGS>
 __global__ void __launch_bounds__(64 * W * H, WGS)
 k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* __restrict__ qconst_g, uint32_t nq, uint32_t k,
-                 const uint64_t* __restrict__ bound, uint32_t n_iter, uint32_t tile_step, uint32_t wave_lists, uint64_t* __restrict__ partial) {
+                 const uint64_t* __restrict__ bound, uint32_t n_iter, uint32_t tile_step, uint32_t wave_lists, const uint32_t* __restrict__ run_if,
+                 uint64_t* __restrict__ partial) {
     static_assert(M == QV_COSINE || M == QV_DOT, "the f64 matrix path covers the fma(q, x, acc) metrics");
+    if (run_if && *run_if == 0) return;       // the fallback launch after k_mq64_bounded: nothing overflowed
     constexpr int Q = 16 * NB;       // queries per wave (NB 16-query blocks)
     extern __shared__ __align__(16) unsigned char smem[];
     typedef __attribute__((address_space(3))) float lds_f32;
@@ -189,7 +203,7 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
     auto tile_ptr = [&](uint32_t t) { return reinterpret_cast<const float*>(tiles + (size_t)t * v.dim4 * 64) + j16 * 4 + blk; };
     float xa[U][4], xb[U][4];              // two register blocks of row elements and query values, used alternately
     float qa[U][NB], qb2[U][NB];
-    const uint32_t nblk = v.dim4 / U;
+    const uint32_t npair = v.dim4 / (2 * U);          // pairs of U-chunk register blocks; the remaining chunks go one at a time
     auto load_x_from = [&](const float* pb, float (&x)[U][4], uint32_t c0) {
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -203,7 +217,7 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
             for (int nb = 0; nb < NB; nb++) q[u][nb] = qf3[((uint32_t)nb * v.dim4 + c0 + u) * 64 + lane];
     };
     const uint32_t it0 = blockIdx.x * W + wave;
-    if (it0 < n_iter && nblk) { load_x_from(tile_ptr(it0 * tile_step), xa, 0); load_q(qa, 0); }
+    if (it0 < n_iter && npair) { load_x_from(tile_ptr(it0 * tile_step), xa, 0); load_q(qa, 0); }
 
     for (uint32_t it = it0; it < n_iter; it += tw) {
         const uint32_t t = it * tile_step;
@@ -243,19 +257,29 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
 #pragma unroll
                 for (int g = 0; g < 4; g++) asm volatile("" : "+v"(acc[nb][g]));
         };
-        // chunks in order, U at a time: the next block's row elements (HBM) and query values (LDS) are requested before the
-        // current block is consumed, so the matrix pipe never waits on a load it has just issued, and no block is copied.
-        // Block 0 of a tile is requested before the previous tile's epilogue (xa is free by then whether nblk is odd or even).
-        for (uint32_t bi = 0; bi < nblk; bi += 2) {
-            if (bi + 1 < nblk) { load_x(xb, (bi + 1) * U); load_q(qb2, (bi + 1) * U); }
+        // chunks in order, U at a time, register blocks in pairs with every load of the steady state unconditional (see
+        // k_mq64_bounded); the last pair requests block 0 of the wave's next tile before the epilogue
+        for (uint32_t pr = 0; pr + 1 < npair; pr++) {
+            load_x(xb, (2 * pr + 1) * U); load_q(qb2, (2 * pr + 1) * U);
+            __builtin_amdgcn_sched_barrier(0);
             consume(xa, qa);
-            if (bi + 1 < nblk) {
-                if (bi + 2 < nblk) { load_x(xa, (bi + 2) * U); load_q(qa, (bi + 2) * U); }
-                consume(xb, qb2);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(xa, (2 * pr + 2) * U); load_q(qa, (2 * pr + 2) * U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(xb, qb2);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (it + tw < n_iter && nblk) { load_x_from(tile_ptr((it + tw) * tile_step), xa, 0); load_q(qa, 0); }
-        for (uint32_t c = nblk * U; c < v.dim4; c++) {
+        if (npair) {
+            load_x(xb, (2 * npair - 1) * U); load_q(qb2, (2 * npair - 1) * U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(xa, qa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x_from(tile_ptr((it + tw < n_iter ? it + tw : it) * tile_step), xa, 0); load_q(qa, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(xb, qb2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (uint32_t c = 2 * npair * U; c < v.dim4; c++) {
             float q1[NB], x1[4];
 #pragma unroll
             for (int nb = 0; nb < NB; nb++) q1[nb] = qf3[((uint32_t)nb * v.dim4 + c) * 64 + lane];
@@ -356,6 +380,191 @@ k_flat_scan_mq64(IndexView v, const float* __restrict__ qfrag_g, const double* _
     }
 }
 
+// The full pass once every query has a bound: no lists at all.  A row whose key is below its query's bound is appended to a
+// small candidate buffer in LDS ((key, query slot); 0.04 rows per query and tile with a 256-tile sample), and after the last tile
+// each wave selects the top-k of a few queries from that buffer.  Without 16*NB lists, thresholds and per-query constants in
+// registers the kernel fits 3 waves per SIMD (12 per CU) instead of 2 — and a SIMD with a single runnable wave issues f64
+// MFMAs at half rate (mfma_f64_rate.hip), which is what every stall of one of two waves cost.  If a workgroup's buffer
+// overflows (a bound that admits too much: a sample with fewer than k live rows, or near-duplicates of a query's neighbours
+// concentrated in one workgroup's tiles) it raises *overflow and the register-list kernel redoes the pass.
+template <int M, int NB, int U, int WV>
+__global__ void __launch_bounds__(64 * WV, 1)
+k_mq64_bounded(IndexView v, const float* __restrict__ qfrag_g, const double* __restrict__ qconst_g, uint32_t nq, uint32_t k,
+               const uint64_t* __restrict__ bound, uint32_t cap, uint32_t* __restrict__ overflow, uint64_t* __restrict__ partial) {
+    static_assert(M == QV_COSINE || M == QV_DOT, "the f64 matrix path covers the fma(q, x, acc) metrics");
+    constexpr int Q = 16 * NB;
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) uint64_t lds_u64;
+    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    float* qf = reinterpret_cast<float*>(smem);                                   // [NB][dim4][64]
+    const lds_f32* qf3 = (const lds_f32*)smem;
+    const size_t qf_bytes = (size_t)NB * v.dim4 * 64 * sizeof(float);
+    lds_u8* base3 = (lds_u8*)smem + qf_bytes;
+    lds_u64* bnd = (lds_u64*)base3;                                               // [Q] bound keys
+    lds_f64* qnl = (lds_f64*)(base3 + Q * 8);                                     // [Q] query norms
+    lds_u32* cnt = (lds_u32*)(base3 + Q * 16);                                    // candidates appended (may exceed cap)
+    lds_u64* ckey = (lds_u64*)(base3 + Q * 16 + 16);                              // [cap]
+    lds_u32* cq = (lds_u32*)(base3 + Q * 16 + 16 + (size_t)cap * 8);              // [cap] query slot of the candidate
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t grp = blockIdx.y, q0 = grp * Q;
+    const uint32_t blk = lane >> 4, j16 = lane & 15;
+    {
+        const f4* src = reinterpret_cast<const f4*>(qfrag_g + (size_t)grp * NB * v.dim4 * 64);
+        f4* dst = reinterpret_cast<f4*>(qf);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)NB * v.dim4 * 16; i += blockDim.x) dst[i] = src[i];
+        if (threadIdx.x < Q) {
+            const uint32_t qi = q0 + threadIdx.x;
+            bnd[threadIdx.x] = bound[qi < nq ? qi : nq - 1];
+            qnl[threadIdx.x] = qconst_g[qi];
+        }
+        if (threadIdx.x == 0) *cnt = 0;
+    }
+    __syncthreads();
+
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t tw = gridDim.x * WV;
+    auto tile_ptr = [&](uint32_t t) { return reinterpret_cast<const float*>(tiles + (size_t)t * v.dim4 * 64) + j16 * 4 + blk; };
+    float xa[U][4], xb[U][4];
+    float qa[U][NB], qb2[U][NB];
+    const uint32_t npair = v.dim4 / (2 * U);          // pairs of U-chunk register blocks; the remaining chunks go one at a time
+    auto load_x_from = [&](const float* pb, float (&x)[U][4], uint32_t c0) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) x[u][g] = pb[(size_t)(c0 + u) * 256 + g * 64];
+    };
+    auto load_q = [&](float (&q)[U][NB], uint32_t c0) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) q[u][nb] = qf3[((uint32_t)nb * v.dim4 + c0 + u) * 64 + lane];
+    };
+    const uint32_t t0 = blockIdx.x * WV + wave;
+    if (t0 < v.n_tiles && npair) { load_x_from(tile_ptr(t0), xa, 0); load_q(qa, 0); }
+
+    for (uint32_t t = t0; t < v.n_tiles; t += tw) {
+        const float* pb = tile_ptr(t);
+        d4 acc[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc[nb][g] = (d4){0.0, 0.0, 0.0, 0.0};
+        auto step = [&](const float (&y)[4], const float (&qv)[NB]) {
+            const double b0 = (double)y[0], b1 = (double)y[1], b2 = (double)y[2], b3 = (double)y[3];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                const double a = (double)qv[nb];
+                acc[nb][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[nb][0], 0, 0, 0);
+                acc[nb][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[nb][1], 0, 0, 0);
+                acc[nb][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[nb][2], 0, 0, 0);
+                acc[nb][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[nb][3], 0, 0, 0);
+            }
+        };
+        auto consume = [&](const float (&x)[U][4], const float (&qv)[U][NB]) {
+#pragma unroll
+            for (int u = 0; u < U; u++) step(x[u], qv[u]);
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) asm volatile("" : "+v"(acc[nb][g]));
+        };
+        // Register blocks in pairs, every load of the steady state unconditional: the compiler's wait counts are then exact
+        // (vmcnt(16) before a block is consumed = only the block just requested may be outstanding).  With a load under a
+        // condition in the loop it merged the two paths' counters and waited for the block it had just requested, every
+        // second block (profiles/r02_mq64_breakdown.txt).  The last pair requests block 0 of the wave's next tile (its own
+        // tile again when there is none: a harmless reload) before the epilogue.
+        for (uint32_t pr = 0; pr + 1 < npair; pr++) {
+            load_x_from(pb, xb, (2 * pr + 1) * U); load_q(qb2, (2 * pr + 1) * U);
+            __builtin_amdgcn_sched_barrier(0);        // the scheduler would sink the requests below the block they overlap
+            consume(xa, qa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x_from(pb, xa, (2 * pr + 2) * U); load_q(qa, (2 * pr + 2) * U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(xb, qb2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (npair) {
+            load_x_from(pb, xb, (2 * npair - 1) * U); load_q(qb2, (2 * npair - 1) * U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(xa, qa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_x_from(tile_ptr(t + tw < v.n_tiles ? t + tw : t), xa, 0); load_q(qa, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(xb, qb2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (uint32_t c = 2 * npair * U; c < v.dim4; c++) {
+            float q1[NB], x1[4];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) q1[nb] = qf3[((uint32_t)nb * v.dim4 + c) * 64 + lane];
+#pragma unroll
+            for (int g = 0; g < 4; g++) x1[g] = pb[(size_t)c * 256 + g * 64];
+            step(x1, q1);
+        }
+
+        // epilogue: lane (blk, j16), register (nb, g, r) = (query slot 16nb+4r+blk, row 64t+16g+j16); the one-sided test of
+        // k_flat_scan_mq64 against the query's bound, then the exact key for the few that may pass
+        double rn[4];
+        const uint64_t alive_word = v.alive[t];
+#pragma unroll
+        for (int g = 0; g < 4; g++) { rn[g] = 0.0; if constexpr (MT<M>::needs_rnorm) rn[g] = v.rnorm[(size_t)t * 64 + g * 16 + j16]; }
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t qs = (uint32_t)(nb * 16 + r * 4) + blk;
+                const uint64_t bk = bnd[qs];
+                QConst qc; qc.qn = qnl[qs]; qc.qn32 = 0.0f;
+                const uint32_t tk = (uint32_t)(bk >> 32);
+                bool cand = tk >= 0xFFFFFFFDu;
+                const double tu = (double)unord_f32(cand ? 0x80000000u : tk + 1);
+                if constexpr (M == QV_DOT) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) cand |= !((1.0 - acc[nb][g][r]) > tu);
+                } else {
+                    cand |= tu > 2.0;
+                    const double s0q = ((1.0 - tu) - 0x1p-50) * qc.qn;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const double pth = s0q * rn[g];
+                        cand |= !(acc[nb][g][r] < pth - __builtin_fabs(pth) * 0x1p-48);
+                    }
+                }
+                if (__ballot(cand) == 0) continue;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t row = t * 64 + g * 16 + j16;
+                    const bool live = (alive_word >> (g * 16 + j16)) & 1ull;
+                    const uint64_t key = live ? make_key(finalize<M>(acc[nb][g][r], qc, rn[g]), row) : kDeadKey;
+                    if (key < bk) {
+                        const uint32_t pos = __hip_atomic_fetch_add((uint32_t*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (pos < cap) { ckey[pos] = key; cq[pos] = qs; }
+                    }
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+    const uint32_t total = *cnt;
+    if (total > cap) { if (threadIdx.x == 0) *overflow = 1; return; }             // the fallback launch redoes the pass
+    const uint32_t kth = k - 1;
+    for (uint32_t i = wave; i < (uint32_t)Q; i += WV) {
+        uint64_t list = kDeadKey, thr = kDeadKey;
+        for (uint32_t b = 0; b < total; b += 64) {
+            const uint32_t j = b + lane;
+            const uint64_t key = (j < total && cq[j] == i) ? ckey[j] : kDeadKey;
+            if (__ballot(key < thr) == 0) continue;
+            list = insert_out_of_line(list, key, thr, kth, lane);
+        }
+        if (q0 + i < nq && lane < k) partial[((size_t)(q0 + i) * gridDim.x + blockIdx.x) * k + lane] = list;
+    }
+}
+
 static size_t mq64_lds_bytes(uint32_t dim4, const Mq64Shape& sh) {
     const size_t qf = (size_t)sh.h * sh.nb * dim4 * 64 * sizeof(float);
     const size_t merge = (size_t)sh.h * (sh.w - 1) * 16 * sh.nb * 64 * sizeof(uint64_t);
@@ -371,7 +580,7 @@ int mq64_blocks(int metric, uint32_t dim4, uint32_t nq) {
 }
 // query fragments + query constants + the sample pass's bounds
 size_t mq64_workspace_bytes(uint32_t nq, uint32_t dim4) {
-    return (size_t)(nq + 32) * dim4 * 4 * sizeof(float) + 256 + (size_t)(nq + 32) * sizeof(double) + 256 + (size_t)(nq + 32) * sizeof(uint64_t) + 256;
+    return (size_t)(nq + 32) * dim4 * 4 * sizeof(float) + 256 + (size_t)(nq + 32) * sizeof(double) + 256 + (size_t)(nq + 32) * sizeof(uint64_t) + 256 + 256;
 }
 
 // partial[(q * grid + wg) * k + i]; returns the grid used through *grid_out.  ev0/ev1 bracket the full pass.
@@ -385,8 +594,9 @@ hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_que
     float* qfrag = reinterpret_cast<float*>(ws);
     double* qconst = reinterpret_cast<double*>(ws + up256((size_t)groups * Q * v.dim4 * 4 * sizeof(float)));
     uint64_t* bound = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(qconst) + up256((size_t)groups * Q * sizeof(double)));
+    uint32_t* overflow = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(bound) + up256((size_t)groups * Q * sizeof(uint64_t)));
     const uint32_t want = (v.n_tiles + (uint32_t)sh.w - 1) / (uint32_t)sh.w;
-    const uint32_t grid = std::max(1u, std::min(want, (uint32_t)cus * (uint32_t)sh.wgs));
+    uint32_t grid = std::max(1u, std::min(want, (uint32_t)cus * (uint32_t)sh.wgs));
     // the sample: one tile per wave of `sgrid` workgroups, spread evenly over the corpus (QV_MQ64_SAMPLE tiles, 0 = no sample
     // pass: every wave learns its thresholds from its own tiles, the round-1 behaviour)
     static const int sample_env = env_int("QV_MQ64_SAMPLE", 256);
@@ -395,6 +605,11 @@ hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_que
     const uint32_t n_s = sgrid * (uint32_t)sh.w, step_s = n_s ? v.n_tiles / n_s : 1;
     const size_t lds = mq64_lds_bytes(v.dim4, sh);
     hipError_t e = hipSuccess;
+#define QV_MQ64B(MMM, BNB_, BU_, BWV_)                                                                                           \
+    e = set_lds(k_mq64_bounded<MMM, BNB_, BU_, BWV_>, lds_b);                                                                     \
+    if (e != hipSuccess) return e;                                                                                                \
+    hipLaunchKernelGGL((k_mq64_bounded<MMM, BNB_, BU_, BWV_>), dim3(grid, groups), dim3(64 * BWV_), lds_b, s, v, qfrag, qconst, nq, k, \
+                       (const uint64_t*)bound, (uint32_t)kMq64Cap, overflow, partial);
 #define QV_MQ64(MMM, HH, NBB, UU, WW, GG)                                                                                         \
     {                                                                                                                             \
         const uint32_t per = (uint32_t)(HH * NBB) * v.dim4 * 64;                                                                   \
@@ -403,12 +618,19 @@ hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_que
         if (e != hipSuccess) return e;                                                                                            \
         if (ev0) (void)hipEventRecord(ev0, s);                                                                                    \
         if (sgrid) {                                                                                                              \
+            constexpr int BNB = HH * NBB, BU = BNB == 2 ? 4 : 8, BWV = 12;                                                         \
             hipLaunchKernelGGL((k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>), dim3(sgrid, groups), dim3(64 * WW * HH), lds, s, v, qfrag, qconst, nq, k, \
-                               (const uint64_t*)nullptr, n_s, step_s, 1u, partial);                                                \
-            hipLaunchKernelGGL(k_mq64_bound, dim3(nq), dim3(64), 0, s, partial, sgrid * (uint32_t)(WW), k, bound);                 \
+                               (const uint64_t*)nullptr, n_s, step_s, 1u, (const uint32_t*)nullptr, partial);                       \
+            hipLaunchKernelGGL(k_mq64_bound, dim3(nq), dim3(64), 0, s, partial, sgrid * (uint32_t)(WW), k, bound, overflow);       \
+            const size_t lds_b = (size_t)BNB * v.dim4 * 64 * sizeof(float) + 16 * BNB * 16 + 16 + (size_t)kMq64Cap * 12;          \
+            grid = (uint32_t)cus;                                                                                                 \
+            QV_MQ64B(MMM, BNB, BU, BWV)                                                                                           \
+            hipLaunchKernelGGL((k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>), dim3(grid, groups), dim3(64 * WW * HH), lds, s, v, qfrag, qconst, nq, k, \
+                               (const uint64_t*)nullptr, v.n_tiles, 1u, 0u, (const uint32_t*)overflow, partial);                   \
+        } else {                                                                                                                  \
+            hipLaunchKernelGGL((k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>), dim3(grid, groups), dim3(64 * WW * HH), lds, s, v, qfrag, qconst, nq, k, \
+                               (const uint64_t*)nullptr, v.n_tiles, 1u, 0u, (const uint32_t*)nullptr, partial);                     \
         }                                                                                                                         \
-        hipLaunchKernelGGL((k_flat_scan_mq64<MMM, HH, NBB, UU, WW, GG>), dim3(grid, groups), dim3(64 * WW * HH), lds, s, v, qfrag, qconst, nq, k, \
-                           sgrid ? (const uint64_t*)bound : (const uint64_t*)nullptr, v.n_tiles, 1u, 0u, partial);                 \
         if (ev1) (void)hipEventRecord(ev1, s);                                                                                    \
     }
 #define QV_MQ64_SHAPES(MMM)                                                                  \
