@@ -17,10 +17,8 @@
 //   A[i][k] = query (16*nb + i), dim 4c+k      lane l supplies i = l%16, k = l/16   (from LDS, f32 -> f64)
 //   B[k][j] = row (64t + 16g + j), dim 4c+k    lane l supplies k = l/16, j = l%16
 //   D: lane l, register r  <->  query 16*nb + 4r + l/16,  row 64t + 16g + l%16
-// The corpus stays in its tile layout ([dim4][64 rows][4 dims], lane == row, one f4 per lane and chunk):
-// the 4 components of the 4 lane blocks are transposed in registers with two v_permlane32_swap and two
-// v_permlane16_swap (gfx950), which turns "lane 16g+j holds dims 4c..4c+3 of row 16g+j" into "register g,
-// lane 16k+j holds dim 4c+k of row 16g+j" — exactly the four B operands of the chunk.
+// The corpus stays in its tile layout ([dim4][64 rows][4 dims]): lane l loads the float at (row 16g + l%16, dim 4c + l/16) of
+// the chunk directly — the B operand's own arrangement; the four loads of a chunk each cover one 256-byte run of 16 rows.
 #include "qv_kernels.h"
 
 namespace qv {
@@ -91,15 +89,6 @@ __global__ void k_mq64_prep(const float* __restrict__ queries, uint32_t nq, uint
         }
         if (threadIdx.x < 16 * NB) qconst[(size_t)grp * 16 * NB + threadIdx.x] = __builtin_sqrt(ma);     // dot: unused (0)
     }
-}
-
-// 4x4 transpose between "component of the f4" and "16-lane block" (see the header comment)
-__device__ __forceinline__ void transpose_blocks(const f4 x, float& y0, float& y1, float& y2, float& y3) {
-    const auto u02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.x), __float_as_uint(x.z), false, false);
-    const auto u13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.y), __float_as_uint(x.w), false, false);
-    const auto a = __builtin_amdgcn_permlane16_swap(u02[0], u13[0], false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(u02[1], u13[1], false, false);
-    y0 = __uint_as_float(a[0]); y1 = __uint_as_float(a[1]); y2 = __uint_as_float(b[0]); y3 = __uint_as_float(b[1]);
 }
 
 // list maintenance is rare (see the bound below); kept out of line so that the 16*NB lists (distinct registers) do not each
