@@ -630,6 +630,12 @@ hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_que
 #undef QV_MQ64_SHAPES
 #undef QV_MQ64
     *grid_out = grid;
+    static const int trace = env_int("QV_TRACE", 0);
+    if (trace && sgrid) {                           // debugging aid only: a synchronous read of the overflow flag
+        uint32_t h = 0;
+        if (hipMemcpyAsync(&h, overflow, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
+            fprintf(stderr, "qv: k_mq64_bounded %s\n", h ? "overflowed: the register-list kernel redid the pass" : "held every candidate");
+    }
     return hipGetLastError();
 }
 

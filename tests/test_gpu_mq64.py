@@ -72,4 +72,65 @@ def test_long_cosine_scans_with_9_or_more_queries_run_on_the_f64_matrix_kernel()
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert p.returncode == 0, p.stderr
     assert "k_flat_scan_mq64 (nq=12" in p.stderr, p.stderr
+    assert "k_mq64_bounded held every candidate" in p.stderr, p.stderr
     assert "k_flat_scan_mq QB=4 (nq=4" in p.stderr, p.stderr
+
+
+def test_a_bound_that_admits_everything_takes_the_fallback():
+    """the companion of the two fallback parity tests below: with every sampled tile deleted the bounded pass must report
+    an overflow (QV_TRACE=1 reads the flag back)"""
+    import os, subprocess, sys
+    code = ("import numpy as np, quiver_amd\n"
+            "n = 530000\n"
+            "idx = quiver_amd.DeviceIndex(16, 'dot'); idx.add_synthetic(1, 0, n)\n"
+            "nt = (n + 63) // 64; ns = min(256, nt // 8) // 8 * 8; step = nt // ns\n"
+            "dead = np.concatenate([np.arange(t * step * 64, (t * step + 1) * 64, dtype=np.uint32) for t in range(ns)])\n"
+            "idx.remove(dead)\n"
+            "q = np.random.default_rng(0).standard_normal((12, 16)).astype(np.float32)\n"
+            "idx.search(q, 10)\n")
+    env = dict(os.environ, QV_TRACE="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0, p.stderr
+    assert "k_mq64_bounded overflowed" in p.stderr, p.stderr
+
+
+def _sample_tiles(n):
+    """the tiles the sample pass of launch_flat_scan_mq64 reads on a 256-CU device: 256 tiles, evenly spaced"""
+    n_tiles = (n + 63) // 64
+    n_s = min(256, n_tiles // 8) // 8 * 8
+    step = n_tiles // n_s
+    return np.arange(n_s) * step
+
+
+def test_mq64_bound_that_admits_everything_falls_back_to_the_list_kernel():
+    """The sample pass's k-th key bounds the full pass.  Here every sampled tile holds far rows and every other row is close
+    to the queries, so the bound admits ~all 530k rows, the candidate buffers overflow and the register-list kernel must redo
+    the pass: results still equal the oracle's."""
+    n, dim, nq, k = 530_000, 32, 20, 10
+    rng = np.random.default_rng(77)
+    centre = rng.standard_normal(dim).astype(np.float32)
+    rows = (centre[None, :] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+    far = np.zeros(n, bool)
+    for t in _sample_tiles(n):
+        far[t * 64:(t + 1) * 64] = True
+    rows[far] = -rows[far]                                       # antipodal: the worst cosine distances in the corpus
+    idx = quiver_amd.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    qs = (centre[None, :] + 0.05 * rng.standard_normal((nq, dim))).astype(np.float32)
+    _check(idx, rows, None, "cosine", qs, k)
+
+
+def test_mq64_sample_with_fewer_than_k_live_rows():
+    """all but 3 rows of the sampled tiles are deleted: no bound can be derived (fewer than k live keys), every row is a
+    candidate, the fallback answers"""
+    n, dim, nq, k = 530_000, 16, 12, 10
+    rows = O.gen_rows(9011, 0, n, dim)
+    idx = quiver_amd.DeviceIndex(dim, "dot")
+    idx.add(rows)
+    st = _sample_tiles(n)
+    dead = np.concatenate([np.arange(t * 64, min(n, (t + 1) * 64), dtype=np.uint32) for t in st])
+    dead = np.setdiff1d(dead, np.array([st[0] * 64 + 1, st[5] * 64 + 7, st[200] * 64 + 63], dtype=np.uint32))
+    idx.remove(dead)
+    alive = np.ones(n, np.uint8); alive[dead] = 0
+    _check(idx, rows, alive, "dot", O.gen_rows(9012, 0, nq, dim), k)
