@@ -471,7 +471,9 @@ int qvo_hnsw_delete(qvo_hnsw* h, uint32_t idx) {
     return 0;
 }
 
-/* top-up sort: (Distance, id) hnsw.go:699-704; id order == node index here */
+/* top-up sort: (Distance, VectorID) hnsw.go:699-704.  VectorID is a STRING in the reference; this restatement has no ids and
+ * breaks ties by node index, which is the reference's order exactly when the ids sort like the indices (zero-padded
+ * decimal ids in the tests); the host mirror (csrc/host/qvhost.cpp) compares the real id strings. */
 static int topup_cmp(const void* pa, const void* pb) { return sel_cmp(pa, pb); }
 
 /* Search, hnsw.go:602-713 */

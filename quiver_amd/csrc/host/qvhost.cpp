@@ -461,6 +461,14 @@ Error HNSW::InsertBatch(const std::vector<std::string>& ids, const float* packed
         bg_synced_ = false;
         return ge;
     }
+    // The device graph always starts from a live node.  When EntryPoint names a deleted node the reference keeps it (Delete finds
+    // no replacement, hnsw.go:803-827) and every connectNode / Search walks from the first live node instead (:355-363, :621-629)
+    // — which is the entry the uploaded graph carries.  Unless the build itself moves the entry point (a node above CurrentLevel,
+    // :325-332), EntryPoint therefore stays what it was, deleted or not.
+    uint32_t eff_entry = entry_;
+    if (!ok(eff_entry)) for (uint32_t i = 0; i < first; i++) if (nodes_[i].alive) { eff_entry = i; break; }
+    const uint32_t entry_before = entry_; const int level_before = cur_level_;
+    const bool had_nodes = first > 0;
     if (qv_graph_insert(bg_, first, n, levels.data(), batch_max, ramp_div) != QV_OK) {
         Error ge = qv_err();                                           // :316-322 rollback keeps the slots (tombstones)
         std::vector<uint32_t> rows(n); for (uint32_t i = 0; i < n; i++) rows[i] = first + i;
@@ -479,6 +487,7 @@ Error HNSW::InsertBatch(const std::vector<std::string>& ids, const float* packed
     size_ += n;
     e = pullGraphFromDevice();
     if (!e.empty()) return e;
+    if (had_nodes && entry_ == eff_entry && cur_level_ == level_before) entry_ = entry_before;   // the build did not move it
     if (dg_ && dg_ != bg_) qv_graph_destroy(dg_);
     dg_ = bg_; dg_dirty_ = false;                                      // the graph just built is the one SearchBatch walks
     return "";

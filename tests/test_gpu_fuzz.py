@@ -48,7 +48,7 @@ def _compare(model, got, qs, k, sel=None):
         assert d[i, :ro.size].tobytes() == do.tobytes(), i
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(27))
 def test_random_operation_sequences_match_the_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     metric = METRICS[seed % len(METRICS)]
@@ -100,3 +100,60 @@ def test_random_operation_sequences_match_the_oracle(seed):
             assert idx.get_row(row).tobytes() == m.rows[row].tobytes()
         assert idx.rows() == m.rows.shape[0] and idx.size() == int(m.alive.sum())
     idx.close()
+
+
+def _graphs(h, o):
+    hg = [(h.node_level(i), [h.links(i, l).tolist() for l in range(h.node_level(i) + 1)]) for i in range(h.nodes())]
+    og = [(o.node_level(i), [o.links(i, l).tolist() for l in range(o.node_level(i) + 1)]) for i in range(o.nodes())]
+    return hg, og
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_hnsw_histories_match_the_oracle(seed):
+    """Insert / InsertBatch (device build, several batch schedules) / Delete / Search interleaved at random: after every
+    mutation the host mirror's graph equals the CPU restatement's link for link, and every search returns its rows and
+    float32 bits (hnsw.go:266-468, 471-713, 745-842).  Tie-heavy vectors on the even seeds.  Ids are zero-padded so that their
+    string order (the top-up's tie-break, hnsw.go:699-704) is the node order the oracle uses."""
+    from quiver_amd import hnsw
+    from quiver_amd.device_index import graph_batch_size
+    rng = np.random.default_rng(5000 + seed)
+    metric = [6, 5, 7, 0, 1, 3, 4, 2][seed % 8]
+    dim = int(rng.choice([4, 8, 24, 32]))
+    style = 0 if seed % 2 == 0 else 2
+    cfg = dict(M=int(rng.choice([4, 8, 16])), EfConstruction=int(rng.choice([16, 40, 100])), EfSearch=int(rng.choice([8, 32, 64])),
+               MaxLevel=int(rng.choice([1, 4, 16])))
+    h = hnsw.HNSW(hnsw.Config(DistanceFunc=metric, Seed=seed + 1, **cfg))
+    o = O.HNSW(metric, dim, seed=seed + 1, M=cfg["M"], efConstruction=cfg["EfConstruction"], efSearch=cfg["EfSearch"], maxLevel=cfg["MaxLevel"])
+    live, nxt = [], 0
+    for step in range(24):
+        op = rng.choice(["insert", "batch", "batch", "delete", "search", "search"]) if nxt else "batch"
+        if op == "insert":
+            v = _vectors(rng, 1, dim, style)[0]
+            h.Insert("n%06d" % nxt, v); o.insert(v); live.append(nxt); nxt += 1
+        elif op == "batch":
+            m = int(rng.choice([3, 40, 150]))
+            x = _vectors(rng, m, dim, style)
+            bm, rd = int(rng.choice([1, 16, 64])), int(rng.choice([0, 8]))
+            h.InsertBatch(["n%06d" % (nxt + i) for i in range(m)], x, bm, rd)
+            done = 0
+            while done < m:
+                b = min(graph_batch_size(nxt + done, bm, rd), m - done)
+                o.insert_batch(x[done:done + b]); done += b
+            live.extend(range(nxt, nxt + m)); nxt += m
+        elif op == "delete" and live:
+            who = live.pop(int(rng.integers(len(live))))
+            h.Delete("n%06d" % who); assert o.delete(who) == 0
+        else:
+            qs = _vectors(rng, 4, dim, style)
+            k = int(rng.choice([1, 5, 20]))
+            res = h.SearchBatch(qs, k)
+            for i in range(4):
+                er, ed = o.search(qs[i], k)
+                assert len(res[i]) == len(er), (step, i)
+                assert np.asarray([r.Distance for r in res[i]], np.float32).tobytes() == ed.tobytes(), (step, i)
+                assert [r.VectorIndex for r in res[i]] == er.tolist(), (step, i)
+            continue
+        assert h.Size() == o.size() == len(live)
+        hg, og = _graphs(h, o)
+        assert hg == og, step
+        assert h.entry_point() == o.entry_point()
