@@ -157,3 +157,100 @@ def test_random_hnsw_histories_match_the_oracle(seed):
         hg, og = _graphs(h, o)
         assert hg == og, step
         assert h.entry_point() == o.entry_point()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sharded_histories_match_the_oracle(seed):
+    """qv_sharded_* with 1..5 co-located shards (point-to-point exchange): add / remove / search in random order; the answer is
+    the oracle's over the live rows keyed by global row id, (distance, global row) order, float32 bits"""
+    from quiver_amd import ShardedIndex
+    rng = np.random.default_rng(9000 + seed)
+    metric = METRICS[seed % len(METRICS)]
+    mid = quiver_amd.metric_id(metric)
+    dim = int(rng.choice([3, 8, 20, 64]))
+    shards = int(rng.integers(1, 6))
+    style = seed % 3
+    idx = ShardedIndex(dim, metric, devices=[0] * shards, peer_copy=True)
+    live = {}
+    for step in range(25):
+        op = rng.choice(["add", "add", "remove", "search", "search"]) if live else "add"
+        if op == "add":
+            x = _vectors(rng, int(rng.choice([1, 2, 7, 64, 300])), dim, style)
+            gids = idx.add(x)
+            assert len(set(gids.tolist()) & set(live)) == 0
+            live.update(zip(gids.tolist(), x))
+        elif op == "remove":
+            who = [g for g in live if rng.random() < 0.1][:50] or [next(iter(live))]
+            idx.remove(who)
+            for g in who:
+                del live[g]
+        elif live:
+            gids = np.array(sorted(live), dtype=np.uint32)
+            mat = np.stack([live[g] for g in gids])
+            qs = _vectors(rng, int(rng.choice([1, 3, 9])), dim, style)
+            k = int(rng.choice([1, 10, 64]))
+            r, d, c = idx.search(qs, k)
+            for i in range(qs.shape[0]):
+                er, ed = O.exact_search(mid, mat, qs[i], k)
+                assert int(c[i]) == er.size
+                assert r[i, :er.size].tolist() == gids[er].tolist(), (step, i)
+                assert d[i, :er.size].tobytes() == ed.tobytes(), (step, i)
+        assert idx.size() == len(live)
+    idx.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_hybrid_histories(seed):
+    """hybrid.HybridIndex (hybrid_index.go:224-811) under random Insert / InsertBatch / Delete / DeleteBatch: forced-exact
+    searches equal the oracle's exact search over the live vectors (ids, float32 bits), single and batched; forced-HNSW
+    batched searches (device traversal) equal the single-query form (host-driven traversal) result for result."""
+    from quiver_amd import hybrid
+    rng = np.random.default_rng(12000 + seed)
+    metric = ["cosine", "euclidean", "dot_product", "manhattan"][seed % 4]
+    mid = quiver_amd.metric_id(metric)
+    dim = int(rng.choice([4, 16, 40]))
+    cfg = hybrid.IndexConfig(DistanceFunc=metric, Seed=seed + 1, ExplorationFactor=0.0)
+    cfg.HNSWConfig = hybrid.HNSWConfig(M=int(rng.choice([4, 16])), MaxM0=0, EfConstruction=int(rng.choice([20, 100])), EfSearch=int(rng.choice([16, 64])))
+    cfg.HNSWConfig.MaxM0 = 2 * cfg.HNSWConfig.M
+    idx = hybrid.HybridIndex(cfg)
+    live, nxt = {}, 0
+    for step in range(22):
+        op = rng.choice(["insert", "batch", "batch", "delete", "delbatch", "exact", "exact", "hnsw"]) if live else "batch"
+        if op == "insert":
+            v = _vectors(rng, 1, dim, 2)[0]
+            idx.Insert("id%06d" % nxt, v); live["id%06d" % nxt] = v; nxt += 1
+        elif op == "batch":
+            x = _vectors(rng, int(rng.choice([2, 30, 200])), dim, 2)
+            new = {"id%06d" % (nxt + i): x[i] for i in range(len(x))}
+            idx.InsertBatch(new); live.update(new); nxt += len(x)
+        elif op == "delete":
+            who = list(live)[int(rng.integers(len(live)))]
+            idx.Delete(who); del live[who]
+        elif op == "delbatch":
+            who = [i for i in live if rng.random() < 0.15][:40]
+            if who:
+                idx.DeleteBatch(who)
+                for i in who:
+                    del live[i]
+        elif op == "exact" and live:
+            ids = sorted(live)
+            mat = np.stack([live[i] for i in ids])
+            qs = _vectors(rng, int(rng.choice([1, 5, 12])), dim, 2)
+            k = int(rng.choice([1, 7, 30]))
+            resp = idx.BatchSearch(hybrid.BatchSearchRequest(Queries=list(qs), K=k, ForceStrategy="exact"))
+            for i in range(qs.shape[0]):
+                er, ed = O.exact_search(mid, mat, qs[i], k)
+                one = idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=qs[i], K=k, ForceStrategy="exact")).Results
+                for got in (resp.Results[i], one):
+                    assert [r.ID for r in got] == [ids[j] for j in er], (step, i)
+                    assert np.asarray([r.Distance for r in got], np.float32).tobytes() == ed.tobytes(), (step, i)
+        elif live:
+            qs = _vectors(rng, 6, dim, 2)
+            k = int(rng.choice([1, 5, 15]))
+            resp = idx.BatchSearch(hybrid.BatchSearchRequest(Queries=list(qs), K=k, ForceStrategy="hnsw"))
+            assert resp.StrategiesUsed == ["hnsw"] * 6
+            for i in range(6):
+                one = idx.SearchWithRequest(hybrid.HybridSearchRequest(Query=qs[i], K=k, ForceStrategy="hnsw")).Results
+                assert [(r.ID, np.float32(r.Distance).tobytes()) for r in resp.Results[i]] == [(r.ID, np.float32(r.Distance).tobytes()) for r in one], (step, i)
+                assert len(one) == min(k, len(live))
+        assert idx.Size() == len(live)
