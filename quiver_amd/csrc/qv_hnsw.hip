@@ -133,6 +133,12 @@ constexpr int kHnswSlab = QV_HNSW_SLAB;   // chunks per slab (128 B of each row)
                                           // (measured 5k x 768, efSearch 128: slab 8 -> 554k QPS, 16 -> 430k, 32 -> 209k: occupancy wins)
 constexpr int kHnswRound = 32;            // rows per round (MaxM0 = 32 by default: one round per hop)
 constexpr int kHnswSlabBytes = kHnswRound * kHnswSlab * 16;
+// The exact-heap kernel runs a handful of flagged queries, one wave per CU: nothing else covers a slab's DMA latency (~1.7 us
+// against 0.3 us of arithmetic per 128-byte slab), so it takes 1 KiB of every row per slab: 3 slabs per 768-d hop, arithmetic-
+// bound.  Measured per hop at efSearch 512 (QV_HNSW_PROF): evaluation 16 -> 14 us, heap inserts 11.5 us, links + visited 2.7 us,
+// pop 1.7 us (profiles/r02_hnsw_build_sweeps.txt).
+constexpr int kHnswHeapSlab = 64;
+template <int SL> constexpr int slab_bytes() { return kHnswRound * SL * 16; }
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -158,28 +164,29 @@ __device__ __forceinline__ void dma_role(DmaRole& r, const float* rowmaj, uint32
     r.src2 = rowmaj + (size_t)batch[16 + drow < cnt ? 16 + drow : 0u] * dim + r.sw0 * 4;
     r.src3 = rowmaj + (size_t)batch[24 + drow < cnt ? 24 + drow : 0u] * dim + r.sw1 * 4;
 }
-template <bool FULL>
+template <bool FULL, int SL>
 __device__ __forceinline__ void dma_issue_group(const float* src, uint32_t sw, uint32_t chunk0, uint32_t dim4, lds_u8* dst) {
 #pragma unroll
-    for (int p = 0; p < kHnswSlab / 8; p++) {
+    for (int p = 0; p < SL / 8; p++) {
         const uint32_t cbase = chunk0 + (uint32_t)p * 8;
         if (FULL) glds16(src + (size_t)cbase * 4, dst + p * 1024);
         else if (cbase + sw < dim4) glds16(src + (size_t)cbase * 4, dst + p * 1024);
     }
 }
+template <int SL>
 __device__ __forceinline__ void dma_issue_slab(const DmaRole& r, uint32_t sl, uint32_t dim4, lds_u8* buf) {
-    const uint32_t chunk0 = sl * kHnswSlab;
-    constexpr int G = kHnswSlab / 8 * 1024;
-    if (chunk0 + kHnswSlab <= dim4) {
-        dma_issue_group<true>(r.src0, r.sw0, chunk0, dim4, buf);
-        if (r.ng > 1) dma_issue_group<true>(r.src1, r.sw1, chunk0, dim4, buf + G);
-        if (r.ng > 2) dma_issue_group<true>(r.src2, r.sw0, chunk0, dim4, buf + 2 * G);
-        if (r.ng > 3) dma_issue_group<true>(r.src3, r.sw1, chunk0, dim4, buf + 3 * G);
+    const uint32_t chunk0 = sl * SL;
+    constexpr int G = SL / 8 * 1024;
+    if (chunk0 + SL <= dim4) {
+        dma_issue_group<true, SL>(r.src0, r.sw0, chunk0, dim4, buf);
+        if (r.ng > 1) dma_issue_group<true, SL>(r.src1, r.sw1, chunk0, dim4, buf + G);
+        if (r.ng > 2) dma_issue_group<true, SL>(r.src2, r.sw0, chunk0, dim4, buf + 2 * G);
+        if (r.ng > 3) dma_issue_group<true, SL>(r.src3, r.sw1, chunk0, dim4, buf + 3 * G);
     } else {
-        dma_issue_group<false>(r.src0, r.sw0, chunk0, dim4, buf);
-        if (r.ng > 1) dma_issue_group<false>(r.src1, r.sw1, chunk0, dim4, buf + G);
-        if (r.ng > 2) dma_issue_group<false>(r.src2, r.sw0, chunk0, dim4, buf + 2 * G);
-        if (r.ng > 3) dma_issue_group<false>(r.src3, r.sw1, chunk0, dim4, buf + 3 * G);
+        dma_issue_group<false, SL>(r.src0, r.sw0, chunk0, dim4, buf);
+        if (r.ng > 1) dma_issue_group<false, SL>(r.src1, r.sw1, chunk0, dim4, buf + G);
+        if (r.ng > 2) dma_issue_group<false, SL>(r.src2, r.sw0, chunk0, dim4, buf + 2 * G);
+        if (r.ng > 3) dma_issue_group<false, SL>(r.src3, r.sw1, chunk0, dim4, buf + 3 * G);
     }
 }
 // The query values of one slab, one per lane: lane L (0..31; the upper half mirrors it) holds element 32*sl + L of the query
@@ -189,44 +196,67 @@ __device__ __forceinline__ void dma_issue_slab(const DmaRole& r, uint32_t sl, ui
 // through a 16 KiB scalar cache, four 64-byte loads per 32 elements, each drained with lgkmcnt(0) together with the row
 // reads.  Measured 1M x 768: efSearch 64 / 128 / 256 +6 % each; what bounds the traversal is the gather of 3 KiB rows itself,
 // 4.5-5.2 TB/s against 6.6 TB/s for the bare LDS-DMA row stream — profiles/r02_hnsw_query_operand.txt.)
-template <typename Q> struct QSlab;
-template <> struct QSlab<double> {
-    uint32_t lo, hi;
+template <typename Q, int SL> struct QSlab;
+template <int SL> struct QSlab<double, SL> {
+    static constexpr int R = (SL * 4 + 63) / 64;          // registers (pairs) per lane: a slab's SL*4 query elements over 64 lanes
+    uint32_t lo[R], hi[R];
     __device__ __forceinline__ void load(const double* __restrict__ q, uint32_t sl, uint32_t n_el, uint32_t lane) {
-        const uint32_t e = sl * (uint32_t)(kHnswSlab * 4) + (lane & (uint32_t)(kHnswSlab * 4 - 1));
-        const double v = e < n_el ? q[e] : 0.0;
-        lo = (uint32_t)__double2loint(v); hi = (uint32_t)__double2hiint(v);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t e = sl * (uint32_t)(SL * 4) + (uint32_t)r * 64 + (SL * 4 < 64 ? (lane & (uint32_t)(SL * 4 - 1)) : lane);
+            const double v = e < n_el ? q[e] : 0.0;
+            lo[r] = (uint32_t)__double2loint(v); hi[r] = (uint32_t)__double2hiint(v);
+        }
     }
     __device__ __forceinline__ double at(uint32_t i) const {
-        return __hiloint2double((int)__builtin_amdgcn_readlane(hi, i), (int)__builtin_amdgcn_readlane(lo, i));
+        // the register is chosen AFTER the cross-lane read (a scalar select): a vector select under a partial exec mask would
+        // leave the source lane undefined when that lane is not active.  With a constant i only one pair of reads remains.
+        uint32_t h = __builtin_amdgcn_readlane(hi[0], i & 63), l = __builtin_amdgcn_readlane(lo[0], i & 63);
+#pragma unroll
+        for (int r = 1; r < R; r++)
+            if ((i >> 6) == (uint32_t)r) { h = __builtin_amdgcn_readlane(hi[r], i & 63); l = __builtin_amdgcn_readlane(lo[r], i & 63); }
+        return __hiloint2double((int)h, (int)l);
     }
 };
-template <> struct QSlab<float> {
-    uint32_t w;
+template <int SL> struct QSlab<float, SL> {
+    static constexpr int R = (SL * 4 + 63) / 64;
+    uint32_t w[R];
     __device__ __forceinline__ void load(const float* __restrict__ q, uint32_t sl, uint32_t n_el, uint32_t lane) {
-        const uint32_t e = sl * (uint32_t)(kHnswSlab * 4) + (lane & (uint32_t)(kHnswSlab * 4 - 1));
-        w = __float_as_uint(e < n_el ? q[e] : 0.0f);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t e = sl * (uint32_t)(SL * 4) + (uint32_t)r * 64 + (SL * 4 < 64 ? (lane & (uint32_t)(SL * 4 - 1)) : lane);
+            w[r] = __float_as_uint(e < n_el ? q[e] : 0.0f);
+        }
     }
-    __device__ __forceinline__ float at(uint32_t i) const { return __uint_as_float(__builtin_amdgcn_readlane(w, i)); }
+    __device__ __forceinline__ float at(uint32_t i) const {
+        uint32_t x = __builtin_amdgcn_readlane(w[0], i & 63);
+#pragma unroll
+        for (int r = 1; r < R; r++)
+            if ((i >> 6) == (uint32_t)r) x = __builtin_amdgcn_readlane(w[r], i & 63);
+        return __uint_as_float(x);
+    }
 };
-static_assert(kHnswSlab * 4 <= 64 && ((kHnswSlab * 4) & (kHnswSlab * 4 - 1)) == 0, "a slab's query elements must fit the lanes of a wave");
+static_assert(((kHnswSlab * 4) & (kHnswSlab * 4 - 1)) == 0 && kHnswSlab % 8 == 0 && kHnswHeapSlab % 8 == 0, "slabs are whole 128-byte pieces");
 
 // lane walks slab `sl` of row r (0..31) of the round, sequentially over the dims
-template <int M>
-__device__ __forceinline__ void slab_accumulate(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, const QSlab<typename MT<M>::Q>& qs,
+template <int M, int SL>
+__device__ __forceinline__ void slab_accumulate(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, const QSlab<typename MT<M>::Q, SL>& qs,
                                                 uint32_t sl, uint32_t dim4) {
     typedef const __attribute__((address_space(3))) f4* lds_f4p;
     const uint32_t mg = r >> 3, mr = r & 7, msw = mr ^ (mg & 1);
-    const lds_u8* mine = buf + mg * (kHnswSlab / 8 * 1024) + mr * 128;
-    const uint32_t c0 = sl * kHnswSlab, c1 = c0 + kHnswSlab < dim4 ? c0 + kHnswSlab : dim4;
+    const lds_u8* mine = buf + mg * (SL / 8 * 1024) + mr * 128;
+    const uint32_t c0 = sl * SL, c1 = c0 + SL < dim4 ? c0 + SL : dim4;
     uint32_t c = c0;
-    for (; c + 8 <= c1; c += 8) {
-        const lds_u8* pc = mine + ((c - c0) >> 3) * 1024;
-        const uint32_t e0 = (c - c0) * 4;                              // first query element of this piece within the slab
+#pragma unroll
+    for (int pi = 0; pi < SL / 8; pi++) {
+        if (c + 8 > c1) break;
+        const lds_u8* pc = mine + pi * 1024;
+        const uint32_t e0 = (uint32_t)pi * 32;                         // first query element of this piece within the slab
         f4 x0 = *(lds_f4p)(pc + ((0u ^ msw) << 4)), x1 = *(lds_f4p)(pc + ((1u ^ msw) << 4)), x2 = *(lds_f4p)(pc + ((2u ^ msw) << 4)), x3 = *(lds_f4p)(pc + ((3u ^ msw) << 4));
         f4 x4 = *(lds_f4p)(pc + ((4u ^ msw) << 4)), x5 = *(lds_f4p)(pc + ((5u ^ msw) << 4)), x6 = *(lds_f4p)(pc + ((6u ^ msw) << 4)), x7 = *(lds_f4p)(pc + ((7u ^ msw) << 4));
 #define QV_ACC4(X, O) acc1<M>(acc, qs.at(e0 + O), X.x); acc1<M>(acc, qs.at(e0 + O + 1), X.y); acc1<M>(acc, qs.at(e0 + O + 2), X.z); acc1<M>(acc, qs.at(e0 + O + 3), X.w);
         QV_ACC4(x0, 0) QV_ACC4(x1, 4) QV_ACC4(x2, 8) QV_ACC4(x3, 12) QV_ACC4(x4, 16) QV_ACC4(x5, 20) QV_ACC4(x6, 24) QV_ACC4(x7, 28)
+        c += 8;
     }
     for (; c < c1; c++) {
         const f4 x = *(lds_f4p)(mine + ((c - c0) >> 3) * 1024 + ((((c - c0) & 7) ^ msw) << 4));
@@ -238,13 +268,13 @@ __device__ __forceinline__ void slab_accumulate(typename MT<M>::A& acc, const ld
 
 // distance of the wave's query to the rows batch[0..n) (n <= 64): lane i returns distance(query, batch[i]).
 // Row-major copy present: LDS-DMA slabs as described above; otherwise each lane pulls its row from the tile layout.
-template <int M, int U>
+template <int M, int U, int SL = kHnswSlab>
 __device__ __forceinline__ float hnsw_eval_rows(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l,
                                                 const typename MT<M>::Q* __restrict__ q_g, const QConst& qc, uint32_t n, uint32_t lane) {
     float out = 0.0f;
     const bool use_rm = v.rowmaj != nullptr && (v.dim & 3) == 0;
     if (use_rm) {
-        const uint32_t nslab = (v.dim4 + kHnswSlab - 1) / kHnswSlab;
+        const uint32_t nslab = (v.dim4 + SL - 1) / SL;
         for (uint32_t base = 0; base < n; base += kHnswRound) {
             const uint32_t cnt = n - base < (uint32_t)kHnswRound ? n - base : (uint32_t)kHnswRound;
             const bool me = lane >= base && lane < base + cnt;       // row r of this round sits on lane base + r
@@ -254,19 +284,19 @@ __device__ __forceinline__ float hnsw_eval_rows(const IndexView& v, const lds_u3
             DmaRole role;
             dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
             typename MT<M>::A acc = 0;
-            QSlab<typename MT<M>::Q> q_cur, q_nxt;
+            QSlab<typename MT<M>::Q, SL> q_cur, q_nxt;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            dma_issue_slab(role, 0, v.dim4, slabs_l);
+            dma_issue_slab<SL>(role, 0, v.dim4, slabs_l);
             q_cur.load(q_g, 0, v.dim4 * 4, lane);
             for (uint32_t sl = 0; sl < nslab; sl++) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl and its query values have landed
                 q_nxt = q_cur;
                 if (sl + 1 < nslab) {
-                    dma_issue_slab(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);   // lands while slab sl is consumed
+                    dma_issue_slab<SL>(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * slab_bytes<SL>());   // lands while slab sl is consumed
                     q_nxt.load(q_g, sl + 1, v.dim4 * 4, lane);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (me) slab_accumulate<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, (lane - base) & 31u, q_cur, sl, v.dim4);
+                if (me) slab_accumulate<M, SL>(acc, slabs_l + (sl & 1) * slab_bytes<SL>(), (lane - base) & 31u, q_cur, sl, v.dim4);
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this buffer's reads are done before it is refilled
                 q_cur = q_nxt;
@@ -304,12 +334,12 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
     extern __shared__ __align__(16) unsigned char smem[];
     // LDS: two row slabs (hnsw_eval_rows) | candidate heap | result heap | the hop's batch | its distances
     lds_u8* slabs_l = (lds_u8*)smem;
-    unsigned char* base = smem + 2 * kHnswSlabBytes;
+    unsigned char* base = smem + 2 * slab_bytes<kHnswHeapSlab>();
     HRes* cand = reinterpret_cast<HRes*>(base);                       // [cand_cap]
     HRes* res = cand + cand_cap;                                      // [kHnswEfMax + 1]
     uint32_t* batch = reinterpret_cast<uint32_t*>(res + kHnswEfMax + 1);   // [kHnswMaxDeg]
     float* bd = reinterpret_cast<float*>(batch + kHnswMaxDeg);        // [kHnswMaxDeg]
-    const lds_u32* batch_l = (const lds_u32*)((lds_u8*)smem + 2 * kHnswSlabBytes + (size_t)(cand_cap + kHnswEfMax + 1) * sizeof(HRes));
+    const lds_u32* batch_l = (const lds_u32*)((lds_u8*)smem + 2 * slab_bytes<kHnswHeapSlab>() + (size_t)(cand_cap + kHnswEfMax + 1) * sizeof(HRes));
     const Q* q_g = qblk;
     __shared__ int s_ncand, s_nres, s_state;                           // state: 0 run, 1 done, 2 overflow
     __shared__ uint32_t s_cur;
@@ -322,12 +352,19 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
     // distances of batch[0..n) -> bd[0..n); lane i scores batch[i]
     QConst qc;
     auto eval = [&](uint32_t n) {
-        const float dd = hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
+        const float dd = hnsw_eval_rows<M, U, kHnswHeapSlab>(v, batch_l, slabs_l, q_g, qc, n, lane);
         if (lane < n) bd[lane] = dd;
         __syncthreads();
     };
     // searchLayer (hnsw.go:471-580); result: res[0..s_nres) ascending; returns false on overflow
     uint32_t n_eval = 0;
+#ifdef QV_HNSW_PROF
+    uint64_t T[6] = {0, 0, 0, 0, 0, 0}; uint64_t t_last = wall_clock64(); uint64_t hops = 0;
+    auto tk = [&](int ph) { uint64_t t = wall_clock64(); T[ph] += t - t_last; t_last = t; };
+#define HTK(ph) tk(ph)
+#else
+#define HTK(ph)
+#endif
     auto search_layer = [&](uint32_t entry, int ef, int level) -> bool {
         vis_bits_clear(bm, bm_words, lane);                            // :483-488
         if (lane == 0) { (void)vis_bits_insert(bm, entry); batch[0] = entry; }
@@ -339,6 +376,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
         }
         __syncthreads();
         for (;;) {
+            HTK(5);
             if (lane == 0) {
                 int nc = s_ncand, nr = s_nres;
                 if (nc == 0) s_state = 1;                              // :509
@@ -350,16 +388,25 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                 }
             }
             __syncthreads();
+            HTK(0);
             if (s_state != 0) break;
             const uint32_t cur = s_cur;
-            // neighbours of cur at `level` (:523-534)
+            // neighbours of cur at `level` (:523-534).  On level 0 the degree and the (fixed-width) list are requested together,
+            // and a graph without tombstones needs no level[] lookups at all: two dependent round trips less per hop for a
+            // wave that has a CU to itself.
             uint32_t deg = 0; const uint32_t* links = nullptr;
-            if (alive(cur) && level <= (int)g.level[cur]) {
-                if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
-                else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
-            }
             uint32_t c = 0xFFFFFFFFu; bool fresh = false;
-            if (lane < deg) { c = links[lane]; fresh = alive(c); }     // :539-541
+            if (level == 0 && !g.has_dead && cur < g.n_nodes) {
+                deg = g.l0_deg[cur];
+                const uint32_t cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu;
+                if (lane < deg) { c = cl; fresh = c < g.n_nodes; }
+            } else {
+                if (alive(cur) && level <= (int)g.level[cur]) {
+                    if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
+                    else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
+                }
+                if (lane < deg) { c = links[lane]; fresh = alive(c); }     // :539-541
+            }
             // a list may hold the same node twice (the self-link quirk): only its first occurrence is new
             for (uint32_t j = 0; j + 1 < deg; j++) {
                 uint32_t cj = __builtin_amdgcn_readlane(c, j);
@@ -370,8 +417,13 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
             const uint32_t n = (uint32_t)__builtin_popcountll(fm);
             if (fresh) batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c;   // adjacency order kept
             __syncthreads();
+            HTK(1);
             if (n == 0) continue;
             eval(n); n_eval += n;                                      // :548 (batched)
+            HTK(2);
+#ifdef QV_HNSW_PROF
+            hops++;
+#endif
             if (lane == 0) {
                 int nc = s_ncand, nr = s_nres;
                 for (uint32_t i = 0; i < n; i++) {
@@ -386,6 +438,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                 s_ncand = nc; s_nres = nr;
             }
             __syncthreads();
+            HTK(3);
             if (s_state == 2) return false;
         }
         if (lane == 0) {                                               // :566-577 heap -> ascending slice, in place
@@ -443,6 +496,9 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
         }
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
         __syncthreads();
+#ifdef QV_HNSW_PROF
+        if (lane == 0 && blockIdx.x == 1) printf("heap kernel q%u: pop %llu links+vis %llu eval %llu insert %llu other %llu (x10 ns) hops %llu evals %u\n", qi, T[0], T[1], T[2], T[3], T[5], hops, n_eval);
+#endif
     }
 }
 
@@ -750,7 +806,7 @@ size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4) { return (size_t)nq * dim4 * 
 // candidate min-heap slots of the exact-heap kernel: admissions of one searchLayer grow like ef * (1 + ln(visited / ef))
 static uint32_t hnsw_cand_cap(uint32_t ef) { return ef > 256 ? 2 * (uint32_t)kHnswCandCap : (uint32_t)kHnswCandCap; }
 size_t hnsw_lds_bytes(uint32_t ef) {
-    return 2 * (size_t)kHnswSlabBytes + (size_t)(hnsw_cand_cap(ef) + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 8 + 64;
+    return 2 * (size_t)slab_bytes<kHnswHeapSlab>() + (size_t)(hnsw_cand_cap(ef) + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 8 + 64;
 }
 uint32_t hnsw_grid(int cus, uint32_t ef, uint32_t nq) {
     const size_t lds = hnsw_lds_bytes(ef);
