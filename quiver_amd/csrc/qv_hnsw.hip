@@ -315,6 +315,84 @@ __device__ __forceinline__ float hnsw_eval_rows(const IndexView& v, const lds_u3
     return out;
 }
 
+// ---- the query through LDS ---------------------------------------------------------------------------------------------
+// The traversal kernels' form of hnsw_eval_rows (row-major copy, dim a multiple of 32).  Measured with QV_HNSW_PROF at 1M x 768,
+// efSearch 128: a hop spends 79 k of its 110 k cycles evaluating rows, 3.5 x the 22 k cycles its 768-step chain takes alone —
+// the four waves of a SIMD queue for the vector ALU, which is ~80 % busy.  (Keeping a second slab in flight per wave, by
+// reading a slab into registers at once and re-requesting its buffer early, changed nothing: 589 k vs 581 k QPS.)  So the
+// instructions per dimension are what counts: convert + fma, and — in the plain form — two v_readlane to broadcast the query
+// value from its one-per-lane register.  Here the query's 32 values of a slab arrive by LDS-DMA beside the rows (two 256-byte
+// buffers) and are read with uniform-address ds_reads one 16-byte chunk ahead of the arithmetic: the broadcast costs LDS
+// bandwidth instead of VALU issue slots, and no load with a register destination is left in the loop.
+constexpr int kHnswQBufBytes = kHnswSlab * 4 * 8;          // one slab of query values (32 x float64; float32 metrics use half)
+static inline bool hnsw_qlds_ok(const IndexView& v) { return v.rowmaj != nullptr && (v.dim & 31u) == 0 && v.dim >= 32; }
+
+template <typename Q>
+__device__ __forceinline__ void dma_issue_query(const Q* __restrict__ q_g, uint32_t sl, lds_u8* qbuf, uint32_t lane) {
+    constexpr uint32_t lanes = kHnswSlab * 4 * sizeof(Q) / 16;                    // 16 (float64) or 8 (float32) lanes x 16 bytes
+    if (lane < lanes) glds16(reinterpret_cast<const float*>(q_g + (size_t)sl * (kHnswSlab * 4)) + lane * 4, qbuf);
+}
+// lane walks its row's 8 chunks of the slab; chunk c+1 and the query's values for it are requested before chunk c is consumed
+template <int M>
+__device__ __forceinline__ void slab_accumulate_qlds(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, const lds_u8* qbuf) {
+    typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    typedef typename MT<M>::Q Q;
+    typedef const __attribute__((address_space(3))) Q* lds_qp;
+    const uint32_t mg = r >> 3, mr = r & 7, msw = mr ^ (mg & 1);
+    const lds_u8* mine = buf + mg * 1024 + mr * 128;
+    lds_qp q = (lds_qp)qbuf;
+    f4 x[2]; Q qq[2][4];
+    x[0] = *(lds_f4p)(mine + ((0u ^ msw) << 4));
+#pragma unroll
+    for (int e = 0; e < 4; e++) qq[0][e] = q[e];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        if (c + 1 < 8) {
+            x[nxt] = *(lds_f4p)(mine + (((uint32_t)(c + 1) ^ msw) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; e++) qq[nxt][e] = q[4 * (c + 1) + e];
+        }
+        acc1<M>(acc, qq[cur][0], x[cur].x); acc1<M>(acc, qq[cur][1], x[cur].y); acc1<M>(acc, qq[cur][2], x[cur].z); acc1<M>(acc, qq[cur][3], x[cur].w);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// slabs_l: 2 x kHnswSlabBytes of row buffers followed by 2 x kHnswQBufBytes of query buffers.  Requires hnsw_qlds_ok(v).
+template <int M, int U>
+__device__ __forceinline__ float hnsw_eval_rows_qlds(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l,
+                                                     const typename MT<M>::Q* __restrict__ q_g, const QConst& qc, uint32_t n, uint32_t lane) {
+    static_assert(kHnswSlab == 8, "one 128-byte piece per row and slab");
+    lds_u8* qbufs = slabs_l + 2 * kHnswSlabBytes;
+    float out = 0.0f;
+    const uint32_t nslab = v.dim4 >> 3;
+    for (uint32_t base = 0; base < n; base += kHnswRound) {
+        const uint32_t cnt = n - base < (uint32_t)kHnswRound ? n - base : (uint32_t)kHnswRound;
+        const bool me = lane >= base && lane < base + cnt;       // row r of this round sits on lane base + r
+        const uint32_t myrow = me ? batch_l[lane] : 0u;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[myrow]; }
+        DmaRole role;
+        dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
+        const uint32_t r = (lane - base) & 31u;
+        typename MT<M>::A acc = 0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        dma_issue_slab<kHnswSlab>(role, 0, v.dim4, slabs_l); dma_issue_query(q_g, 0, qbufs, lane);
+        for (uint32_t sl = 0; sl < nslab; sl++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl and its query values have landed
+            if (sl + 1 < nslab) {                                  // the next slab lands while this one is consumed
+                dma_issue_slab<kHnswSlab>(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);
+                dma_issue_query(q_g, sl + 1, qbufs + ((sl + 1) & 1) * kHnswQBufBytes, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (me) slab_accumulate_qlds<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, r, qbufs + (sl & 1) * kHnswQBufBytes);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this slab's buffers are read before they are refilled
+        }
+        if (me) out = finalize<M>(acc, qc, rn);
+    }
+    return out;
+}
+
 #ifdef QV_HNSW_PROF
 #define HTICK(ph) tick(ph)
 #else
@@ -503,7 +581,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
 }
 
 
-template <int M, int U, int S>
+template <int M, int U, int S, bool QLDS>
 __global__ void __launch_bounds__(64)
 k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t nq, uint32_t k, uint32_t ef_search,
                    HnswOpts o,
@@ -533,7 +611,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
 
     // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n)
     auto eval_keys = [&](uint32_t n) -> uint64_t {
-        const float dd = hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
+        const float dd = QLDS ? hnsw_eval_rows_qlds<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane) : hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
         return lane < n ? make_key(dd, batch_l[lane]) : kDeadKey;
     };
     // sorted insert of x (distance part xd) into the list; ef = size of the reference's result heap
@@ -842,7 +920,7 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
 }
 
 // wave-resident form: the list in registers, the LDS for the row slabs; tie-flagged queries report kHnswTieFlag
-size_t hnsw_wave_lds_bytes(int /*metric*/, uint32_t /*dim4*/) { return 64 * sizeof(uint32_t) + 2 * (size_t)kHnswSlabBytes + 64; }
+size_t hnsw_wave_lds_bytes(int /*metric*/, uint32_t /*dim4*/) { return 64 * sizeof(uint32_t) + 2 * (size_t)kHnswSlabBytes + 2 * (size_t)kHnswQBufBytes + 64; }
 uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4) {
     const size_t lds = hnsw_wave_lds_bytes(metric, dim4);
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
@@ -863,17 +941,22 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     QV_DISPATCH_METRIC(v.metric, {
         hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
     });
-#define QV_HW(SS) QV_DISPATCH_METRIC(v.metric, {                                                                     \
-        e = set_lds(k_hnsw_search_wave<MM, 4, SS>, lds);                                                              \
+#define QV_HWD(SS, DD) QV_DISPATCH_METRIC(v.metric, {                                                                \
+        e = set_lds(k_hnsw_search_wave<MM, 4, SS, DD>, lds);                                                          \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
+        hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS, DD>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
                            static_cast<const double*>(d_qconst), nq, k, ef, o,                                       \
                            d_rows_out, d_dist_out, d_count_out, d_evals_out);                                         \
     })
+    // the query through LDS for row-major indexes whose dimension is a multiple of 32 (QV_HNSW_QLDS=2: never)
+    static const int qlds_env = env_int("QV_HNSW_QLDS", 1);
+    const bool deep = qlds_env == 1 && hnsw_qlds_ok(v);
+#define QV_HW(SS) if (deep) { QV_HWD(SS, true); } else { QV_HWD(SS, false); }
     // list registers: S x 64 entries.  One notch more than efx needs where that is free (<= 128 VGPRs either way), so that a tie
     // group at the end of the result heap has room (ef <= 127 -> S = 2, ef = 128..256 -> S = 4; S = 8 would cost a wave per SIMD)
     if (efx < 128) { QV_HW(2); } else if (efx < 256) { QV_HW(4); } else if (efx < 320) { QV_HW(5); } else if (efx < 512) { QV_HW(8); } else { QV_HW(9); }
 #undef QV_HW
+#undef QV_HWD
     return hipGetLastError();
 }
 
