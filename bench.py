@@ -85,6 +85,27 @@ def _free_port():
     return p
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """The one JSON line is all this program may write to stdout, but libraries write there too (RCCL prints a version banner
+    when a communicator is created): point fd 1 at stderr for the run and keep the real stdout for emit()."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(out):
+    line = (json.dumps(out) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def self_launch(a):
     """--gpus N > 1 outside torch.distributed.run: start the N ranks as fresh child processes and pass their output through.
     Nothing in this process has initialised the GPU (torch.cuda.device_count() does not), and it only waits."""
@@ -424,17 +445,18 @@ def run_abi_sharded(a):
                      "exchange_ms": prof["exchange_ms"], "merge_and_download_ms": prof["merge_ms"], "launches_timed": prof["searches"]},
         "cpu_baseline": None, "verified_against_oracle": bool(verified),
     }
-    print(json.dumps(out), flush=True)
+    emit(out)
     sh.close()
 
 
 # ---------------------------------------------------------------------------------------------- one rank
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not a.abi_sharded:
+        return self_launch(a)
+    quiet_stdout()
     if a.abi_sharded:
         return run_abi_sharded(a)
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        return self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -609,7 +631,7 @@ def main():
         }
         if also:
             out["also"] = also
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
