@@ -30,6 +30,13 @@ def _knn_graph(rows, metric, m):
     ("dot", 36, 1500, 24, 40, 40),           # dim4 = 9: one full piece + a tail
     ("cosine_f32", 128, 2000, 32, 128, 10),
     ("l2sq", 20, 1000, 8, 16, 5),
+    # dimensions that are a multiple of 32 take the query through LDS (hnsw_eval_rows_qlds): every query type and metric once
+    ("dot", 96, 1500, 16, 64, 10),
+    ("l1", 32, 1500, 16, 64, 10),
+    ("dot_f32", 64, 1500, 16, 300, 10),      # ef >= 256: 5 list registers per lane
+    ("l2_f32", 160, 1500, 16, 512, 10),      # ef = 512: 9 list registers per lane
+    ("l2sq_f64", 224, 1200, 16, 64, 10),
+    ("l2sq", 256, 1200, 16, 64, 10),
 ])
 def test_knn_graph_traversal_identical_to_oracle(metric, dim, n, m, ef, k):
     mid = quiver_amd.metric_id(metric)
