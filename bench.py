@@ -48,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32 dense peak (same guide)
+MFMA_F64_PEAK_TF = 77.5     # v_mfma_f64_16x16x4_f64 as measured with register-resident operands (tools/ubench/mfma_f64_rate.hip; the guide quotes 78.6)
 CORPUS_SEED, QUERY_SEED = 20260424, 20260425
 
 
@@ -269,9 +270,10 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
     flop = 2.0 * nqb * 1_000_000 * dim
     also["batched_256x1Mx768_exact_scan"] = {
         "workload": "256 queries x 1Mx768 cosine, k=10: exact multi-query scan on the f64 matrix cores (32 queries per corpus pass; v_mfma_f64 chains are bit-identical to the scalar f64 loop)",
-        "batch_ms": dtb * 1e3, "qps": nqb / dtb, "f64_tflops_equiv": flop / dtb / 1e12}
+        "batch_ms": dtb * 1e3, "qps": nqb / dtb, "f64_tflops_equiv": flop / dtb / 1e12,
+        "frac_of_f64_matrix_peak": flop / dtb / 1e12 / MFMA_F64_PEAK_TF, "peak_tflops_measured": MFMA_F64_PEAK_TF}
 
-    def mfma_entry(index, label, want_rows, want_dist):
+    def mfma_entry(index, label, want_rows, want_dist, rows_n=1_000_000):
         d_flags = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
         index.search_batched_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), d_flags.data_ptr(), sp)
         torch.cuda.synchronize()
@@ -287,9 +289,10 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         rb, db = d_rb.cpu().numpy().view(np.uint32), d_db.cpu().numpy()
         same = bool(redo == 0 and np.array_equal(rb, want_rows) and np.array_equal(db.view(np.uint32), want_dist.view(np.uint32)))
         mf_ms = msm / max(nm, 1)
+        flop = 2.0 * nqb * rows_n * dim
         return {
-            "workload": "256 queries x 1Mx768 %s, k=10 (BASELINE configs[2]): fp32-MFMA filter + exact re-score, device-resident queries and "
-                        "results (sample scan, prep, filter, re-score all inside the timed region)" % label,
+            "workload": "256 queries x %dx768 %s, k=10 (BASELINE configs[2]): fp32-MFMA filter + exact re-score, device-resident queries and "
+                        "results (sample scan, prep, filter, re-score all inside the timed region)" % (rows_n, label),
             "batch_ms": dtm * 1e3, "qps": nqb / dtm, "identical_to_exact_scan": same, "queries_sent_back_to_exact_scan": redo,
             "roofline": {"bound": "mfma", "kernel": "k_mfma_filter", "kernel_ms": mf_ms, "achieved": flop / (mf_ms * 1e-3) / 1e12,
                          "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flop / (mf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
@@ -308,6 +311,25 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         also["batched_256x1Mx768_mfma_dot"] = {"error": str(ex)}
     if idx1 is not idx:
         idx1.close()
+    # the same two batched paths on the headline corpus (10M rows): the fixed costs of a batch amortise
+    if a.rows > 1_000_000:
+        try:
+            idx.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                idx.search_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), sp)
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - t1) / 3
+            big_rows, big_dist = d_rb.cpu().numpy().view(np.uint32).copy(), d_db.cpu().numpy().copy()
+            flop_big = 2.0 * nqb * a.rows * dim
+            also["batched_256x%dMx768_exact_scan" % (a.rows // 1_000_000)] = {
+                "workload": "256 queries x %dx768 cosine, k=10: exact multi-query scan on the f64 matrix cores" % a.rows,
+                "batch_ms": dtb * 1e3, "qps": nqb / dtb, "f64_tflops_equiv": flop_big / dtb / 1e12,
+                "frac_of_f64_matrix_peak": flop_big / dtb / 1e12 / MFMA_F64_PEAK_TF}
+            also["batched_256x%dMx768_mfma" % (a.rows // 1_000_000)] = mfma_entry(idx, "cosine", big_rows, big_dist, a.rows)
+        except Exception as ex:                            # noqa: BLE001
+            also["batched_256x%dMx768" % (a.rows // 1_000_000)] = {"error": str(ex)}
     # configs[0]: the reference's own CPU-runnable case, 10k x 128 cosine k=10, one query at a time through the host-pointer
     # C ABI (query up, results down, one sync per call) — latency, not bandwidth; the CPU port beside it on the same rows
     try:
