@@ -1,11 +1,13 @@
 /* Pure C11 consumer of include/qv.h, the way a cgo preamble sees it: proves the header is C (not C++), links against
- * libqv.so alone, and — when a GPU is present — runs create / add / search / remove / destroy through the C ABI.
+ * libqv.so alone, and — when a GPU is present — runs create / add / search / remove / destroy, a device HNSW build + search and
+ * a one-shard qv_sharded_* round trip through the C ABI.
  * Without a GPU every entry point must fail LOUDLY with QV_ERR_NO_DEVICE (no CPU path).
- *   gcc -std=c11 -Wall -Werror -I include tests/c/abi_smoke.c -L quiver_amd/lib -lqv -Wl,-rpath,$PWD/quiver_amd/lib -o abi_smoke */
+ *   gcc -std=c11 -Wall -Werror -I include tests/c/abi_smoke.c -L quiver_amd/lib -lqv -lm -Wl,-rpath,$PWD/quiver_amd/lib -o abi_smoke */
 #include "qv.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 int main(void) {
     if (qv_abi_version() != QV_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
@@ -30,6 +32,30 @@ int main(void) {
     if (qv_index_remove(idx, &dead, 1) != QV_OK || qv_index_size(idx) != 2) { fprintf(stderr, "remove: %s\n", qv_last_error()); return 9; }
     if (qv_index_search(idx, q, 1, 2, out_rows, out_dist, &count) != QV_OK || out_rows[0] != 1) { fprintf(stderr, "search after remove\n"); return 10; }
     qv_index_destroy(idx);
-    printf("ok: [%u %u] d0=%g\n", 1u, out_rows[1], out_dist[0]);
+
+    /* HNSW.Insert x n on the device (hnsw.go:266-468), then HNSW.Search (:602-713): 200 points on a circle, the query's
+     * nearest neighbours are its angular neighbours */
+    enum { N = 200, D = 4 };
+    static float pts[N][D]; static int8_t levels[N];
+    for (int i = 0; i < N; i++) { double a = 6.283185307179586 * i / N; pts[i][0] = (float)cos(a); pts[i][1] = (float)sin(a); pts[i][2] = 0; pts[i][3] = 0; levels[i] = 0; }
+    qv_index* gi = NULL; qv_graph* g = NULL;
+    if (qv_index_create(&gi, D, QV_L2, 0, QV_FLAG_ROWMAJOR) != QV_OK || qv_index_add(gi, &pts[0][0], N, &first) != QV_OK) { fprintf(stderr, "graph index: %s\n", qv_last_error()); return 11; }
+    if (qv_graph_build(&g, gi, N, levels, 8, 16, 50, 16, 4) != QV_OK) { fprintf(stderr, "graph build: %s\n", qv_last_error()); return 12; }
+    uint32_t nn = 0, ep = 0; int lvl = -2;
+    if (qv_graph_info(g, &nn, NULL, NULL, NULL, &ep, &lvl) != QV_OK || nn != N || lvl != 0) { fprintf(stderr, "graph info\n"); return 13; }
+    const float gq[D] = {pts[50][0], pts[50][1], 0, 0};
+    uint32_t gr[3], gc = 0; float gd[3];
+    if (qv_graph_search(g, gq, 1, 3, 32, gr, gd, &gc, NULL) != QV_OK || gc != 3) { fprintf(stderr, "graph search: %s\n", qv_last_error()); return 14; }
+    if (gr[0] != 50 || gd[0] != 0.0f || !((gr[1] == 49 && gr[2] == 51) || (gr[1] == 51 && gr[2] == 49))) { fprintf(stderr, "graph result [%u %u %u]\n", gr[0], gr[1], gr[2]); return 15; }
+    qv_graph_destroy(g); qv_index_destroy(gi);
+
+    /* one corpus behind one handle: a single shard here, a real RCCL communicator all the same */
+    qv_sharded* sh = NULL; const int devs[1] = {0};
+    if (qv_sharded_create(&sh, 4, QV_L2, devs, 1, 0) != QV_OK) { fprintf(stderr, "sharded create: %s\n", qv_last_error()); return 16; }
+    uint32_t gids[3];
+    if (qv_sharded_add(sh, &rows[0][0], 3, gids) != QV_OK || qv_sharded_size(sh) != 3) { fprintf(stderr, "sharded add: %s\n", qv_last_error()); return 17; }
+    if (qv_sharded_search(sh, q, 1, 2, out_rows, out_dist, &count) != QV_OK || count != 2 || out_rows[0] != gids[0] || out_rows[1] != gids[1]) { fprintf(stderr, "sharded search: %s\n", qv_last_error()); return 18; }
+    qv_sharded_destroy(sh);
+    printf("ok: [%u %u] d0=%g graph [%u %u %u]\n", 1u, out_rows[1], out_dist[0], gr[0], gr[1], gr[2]);
     return 0;
 }

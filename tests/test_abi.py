@@ -86,7 +86,7 @@ def _build_c_smoke(tmp_path):
     exe = str(tmp_path / "abi_smoke")
     libdir = os.path.join(root, "quiver_amd", "lib")
     subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"),
-                    "-L", libdir, "-lqv", "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True, text=True)
+                    "-L", libdir, "-lqv", "-lm", "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True, text=True)
     return exe
 
 
