@@ -33,13 +33,52 @@ __device__ __forceinline__ float f32_up(float x) {
 __device__ __forceinline__ float f32_down(float x) { return -f32_up(-x); }
 constexpr int kMfmaCandCap = 4096;        // candidate slots per query
 
+// |S~ - S| <= filter_gamma * |q||r| for the two filter kernels.
+//   fp32 MFMA (k_mfma_filter): a chain of K rounded fp32 multiply-adds: gamma_K = (K+2)u / (1 - (K+2)u), u = 2^-24.
+//   bf16 x 3 (k_bf16x3_filter): every operand is split q = qh + ql + rq, x = xh + xl + rx with qh = bf16(q), ql = bf16(q - qh)
+//     (round to nearest: |q - qh| <= 2^-8 |q|, q - qh exact in float32, |rq| <= 2^-16 |q|, likewise x) and the kernel sums the
+//     three products qh*xh + qh*xl + ql*xh, each EXACT in float32 (8 x 8 significand bits), in float32 accumulators.
+//     Dropped: ql*xl + rq*x + q*rx, at most 3.03 * 2^-16 |q_i||x_i| per element, hence (Cauchy-Schwarz) 4.63e-5 |q||r|.
+//     Accumulation: 3K + 2 float32 additions in whatever order the matrix core takes; allowing a full ulp per addition
+//     (u' = 2^-23, i.e. even a truncating adder) over terms of total magnitude <= 1.012 |q||r|.
+__host__ __device__ static inline double filter_gamma(uint32_t dim, int bf16x3) {
+    if (!bf16x3) { const double g = (double)(dim + 2) * 5.9604644775390625e-8; return g / (1.0 - g); }
+    const double g = (double)(3 * dim + 2) * 1.1920928955078125e-7;
+    return 1.012 * g / (1.0 - g) + 4.63e-5;
+}
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+// two floats -> (hi pair, lo pair) of bfloat16, packed: hi = bf16(x) (RNE), lo = bf16(x - hi) (x - hi is exact)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const bf2 h = {(__bf16)x0, (__bf16)x1};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xFFFF0000u);
+    const bf2 l = {(__bf16)(x0 - h0), (__bf16)(x1 - h1)};
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
 // Qt[qb32][chunk][32 queries][4 dims] (zero padded), per-query filter constants, counters reset
 __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t dim4,
                             const float* __restrict__ sample_dist /*[nq][k]*/, uint32_t k, int metric,
                             float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq,
-                            uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow) {
+                            uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3) {
     const uint32_t q = blockIdx.x;                     // one block per (padded) query
     const uint32_t dim4p = (dim4 + 1) & ~1u;           // chunk count padded to even: the MFMA step eats two chunks
+    if (bf16x3) {
+        // Qbf[(qb32 * steps + s) * 2 + {hi, lo}][64 lanes] x 16 bytes: lane 32h + j holds dims 16s + 8h .. +7 of query 32 qb32 + j
+        const uint32_t steps = (dim4 + 3) / 4;
+        uint4* Qbf = reinterpret_cast<uint4*>(Qt);
+        for (uint32_t i = threadIdx.x; i < steps * 2; i += blockDim.x) {
+            const uint32_t st = i >> 1, h = i & 1;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const uint32_t d = 16 * st + 8 * h + e; x[e] = (q < nq && d < dim) ? queries[(size_t)q * dim + d] : 0.f; }
+            uint4 hi, lo;
+            split2(x[0], x[1], hi.x, lo.x); split2(x[2], x[3], hi.y, lo.y); split2(x[4], x[5], hi.z, lo.z); split2(x[6], x[7], hi.w, lo.w);
+            const size_t base = ((size_t)(q >> 5) * steps + st) * 2 * 64 + 32 * h + (q & 31);
+            Qbf[base] = hi; Qbf[base + 64] = lo;
+        }
+    } else
     for (uint32_t c = threadIdx.x; c < dim4p; c += blockDim.x) {
         f4 x = {0.f, 0.f, 0.f, 0.f};
         if (q < nq && c < dim4) {
@@ -56,7 +95,7 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
             for (uint32_t i = 0; i < dim; i++) { double a = queries[(size_t)q * dim + i]; n2 = __builtin_fma(a, a, n2); }
             const double qn = __builtin_sqrt(n2);
             const double U = (double)sample_dist[(size_t)q * k + (k - 1)];     // +inf if the sample held < k live rows
-            const double gamma = (double)(dim + 2) * 5.9604644775390625e-8 / (1.0 - (double)(dim + 2) * 5.9604644775390625e-8);
+            const double gamma = filter_gamma(dim, bf16x3);
             double c, m;
             if (metric == QV_L2 || metric == QV_L2SQ) {
                 // squared domain: real d^2 = |q|^2 + |r|^2 - 2S.  The reference value D relates to the real d by
@@ -65,11 +104,11 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
                 const double T = metric == QV_L2 ? U * U * (1.0 + 4e-7) : U * (1.0 + gamma + 2e-6);
                 c = n2 * (1.0 - 2e-6) - T;                           // A_q; test: 2S~ >= A_q + (1-2e-6)|r|^2 - B_q|r|
                 m = 2.0 * (gamma + 1e-6) * qn;                       // B_q
-                if (!(U == U) || U > 1.0e18) { c = -3.0e38; m = 0.0; }
+                if (!(U == U) || U > 1.0e18 || (bf16x3 && qn < 1e-18)) { c = -3.0e38; m = 0.0; }
             } else {
                 c = metric == QV_COSINE ? (1.0 - U - 4e-7) * qn : (1.0 - U - 4e-7 * (1.0 + __builtin_fabs(U)));
                 m = (gamma + 1e-6) * qn;
-                if (!(U == U) || U > 3.0e38) { c = -3.0e38; m = 0.0; }            // no bound: everything is a candidate (overflow -> exact path)
+                if (!(U == U) || U > 3.0e38 || (bf16x3 && qn < 1e-18)) { c = -3.0e38; m = 0.0; }   // no bound: everything is a candidate (overflow -> exact path); bf16 operands below 2^-126 flush
             }
             c_ = f32_down((float)c);                                         // round towards "keep more"
             m_ = f32_up((float)m);
@@ -77,6 +116,52 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
         cq[q] = c_; mq[q] = m_;
         if (q < nq) { cand_cnt[q] = 0; overflow[q] = 0; }
     }
+}
+
+// the filter test on a wave's 64 x 128 scores: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31];
+// a row that may be in some query's top-k goes to that query's candidate list with its score
+template <int METRIC>
+__device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (&acc)[2][4], uint32_t t0, uint32_t t1, const float (&s_c)[4][64], const float (&s_m)[4][64],
+                                                uint32_t wave, uint32_t half, uint32_t l31, uint32_t qb64, float tiny_rn,
+                                                uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+        // epilogue: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31]
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t t = j < 2 ? t0 : t1;
+            if (j >= 2 && t1 == t0) continue;
+            const uint32_t row = t * 64 + 32 * (j & 1) + l31;
+            const bool live = (v.alive[t] >> (32 * (j & 1) + l31)) & 1ull;
+            const float rn = f32_up((float)v.rnorm[row]);
+            const float rlo = f32_down((float)v.rnorm[row]);
+            const float rn2c = f32_down(f32_down(rlo * rlo) * 0.999998f);   // (1-2e-6)|r|^2, rounded down (L2 family)
+            (void)rn2c;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                bool hit = false;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
+                    hit |= acc[i][j][r] >= thr;
+                }
+                hit |= rn < tiny_rn;                                   // bf16 operands of a vanishing row would flush: let the exact pass see it
+                if (hit && live) {                                  // rare: a row that may be in some query's top-k
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
+                        if (acc[i][j][r] >= thr || (rn < tiny_rn && s_c[wave][ql] < 3.0e38f)) {      // (padded query slots carry +inf)
+                            const uint32_t q = 64 * qb64 + ql;
+                            uint32_t slot = atomicAdd(&cand_cnt[q], 1u);
+                            if (slot < (uint32_t)kMfmaCandCap) {
+                                cand_rows[(size_t)q * kMfmaCandCap + slot] = row;
+                                cand_score[(size_t)q * kMfmaCandCap + slot] = acc[i][j][r];
+                            }
+                        }
+                    }
+                }
+            }
+        }
 }
 
 // grid: persistent waves; wave g -> query 64-block (g % nqb64), row groups (g / nqb64) + i*stride; a row group = 2 tiles = 128 rows
@@ -158,43 +243,239 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
 
-        // epilogue: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31]
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 0.0f, cand_rows, cand_score, cand_cnt);
+    }
+}
+
+// The same filter on the bfloat16 matrix instruction, three products per pair of operands (see filter_gamma): the scores keep
+// float32-class accuracy (margin 3.3e-4 |q||r| at 768 dims against 4.7e-5 for the fp32 chain), the matrix work drops from four
+// 64-cycle v_mfma_f32_32x32x2_f32 per dimension to 1.5 32-cycle v_mfma_f32_32x32x16_bf16, and the kernel becomes a reader of
+// the corpus: 128 rows x 3 KiB per 37 k matrix cycles per workgroup.  Rows are split on the fly (v_cvt_pk_bf16_f32, a shift,
+// a subtract, a second convert per pair of floats); queries are split once by k_mfma_prep.
+// Operand mapping: lane 32h + j supplies dims 16s + 8h .. +7 of query / row j of its 32-block for BOTH operands, so whatever
+// order the instruction walks k in, A and B agree on it.
+template <int METRIC>
+__global__ void __launch_bounds__(256, 1)
+k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
+                uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+    __shared__ float s_c[4][64], s_m[4][64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = blockIdx.x * 4 + wave, tw = gridDim.x * 4;
+    const uint32_t nqb64 = nq_pad >> 6;
+    const uint32_t qb64 = gw % nqb64;
+    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    const uint32_t stride = tw / nqb64;
+    {
+        const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
+        s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
+        s_m[wave][lane] = m;
+    }
+    __syncthreads();
+    if (stride == 0) return;
+    const uint32_t half = lane >> 5, l31 = lane & 31;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step
+    const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
+    const uint4* a1 = Qbf + ((size_t)(2 * qb64 + 1) * steps) * 2 * 64 + lane;
+
+    for (uint32_t g = gw / nqb64; g < n_groups; g += stride) {
+        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
+        const f4* b0 = tiles + (size_t)t0 * v.dim4 * 64 + l31;
+        const f4* b1 = tiles + (size_t)t1 * v.dim4 * 64 + l31;
+        f16v acc[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t t = j < 2 ? t0 : t1;
-            if (j >= 2 && t1 == t0) continue;
-            const uint32_t row = t * 64 + 32 * (j & 1) + l31;
-            const bool live = (v.alive[t] >> (32 * (j & 1) + l31)) & 1ull;
-            const float rn = f32_up((float)v.rnorm[row]);
-            const float rlo = f32_down((float)v.rnorm[row]);
-            const float rn2c = f32_down(f32_down(rlo * rlo) * 0.999998f);   // (1-2e-6)|r|^2, rounded down (L2 family)
-            (void)rn2c;
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                bool hit = false;
+            for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
-                    hit |= acc[i][j][r] >= thr;
-                }
-                if (hit && live) {                                  // rare: a row that may be in some query's top-k
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+        struct Ops { uint4 ah[2], al[2]; f4 b[4][2]; };           // a step's operands as loaded: A split by k_mfma_prep, B raw float32
+        struct Hl { uint4 ah[2], al[2], bh[4], bl[4]; };          // the same step ready for the matrix core
+        // branch-free fetch: a step past the end re-reads the last one (never used); chunks past dim4 re-read the last real chunk
+        // on the B side against zeros on the A side
+        auto load = [&](uint32_t st, Ops& o) {
+            const uint32_t sc = st < steps ? st : steps - 1;
+            o.ah[0] = a0[(size_t)sc * 128]; o.al[0] = a0[(size_t)sc * 128 + 64];
+            o.ah[1] = a1[(size_t)sc * 128]; o.al[1] = a1[(size_t)sc * 128 + 64];
+            const uint32_t c0 = 4 * sc + 2 * half;
+            const uint32_t ca = c0 < v.dim4 ? c0 : v.dim4 - 1, cb = c0 + 1 < v.dim4 ? c0 + 1 : v.dim4 - 1;
+            o.b[0][0] = __builtin_nontemporal_load(&b0[(size_t)ca * 64]);      o.b[0][1] = __builtin_nontemporal_load(&b0[(size_t)cb * 64]);
+            o.b[1][0] = __builtin_nontemporal_load(&b0[(size_t)ca * 64 + 32]); o.b[1][1] = __builtin_nontemporal_load(&b0[(size_t)cb * 64 + 32]);
+            o.b[2][0] = __builtin_nontemporal_load(&b1[(size_t)ca * 64]);      o.b[2][1] = __builtin_nontemporal_load(&b1[(size_t)cb * 64]);
+            o.b[3][0] = __builtin_nontemporal_load(&b1[(size_t)ca * 64 + 32]); o.b[3][1] = __builtin_nontemporal_load(&b1[(size_t)cb * 64 + 32]);
+        };
+        auto split = [&](const Ops& o, Hl& h) {                     // ~110 VALU instructions
+            h.ah[0] = o.ah[0]; h.al[0] = o.al[0]; h.ah[1] = o.ah[1]; h.al[1] = o.al[1];
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
-                        if (acc[i][j][r] >= thr) {
-                            const uint32_t q = 64 * qb64 + ql;
-                            uint32_t slot = atomicAdd(&cand_cnt[q], 1u);
-                            if (slot < (uint32_t)kMfmaCandCap) {
-                                cand_rows[(size_t)q * kMfmaCandCap + slot] = row;
-                                cand_score[(size_t)q * kMfmaCandCap + slot] = acc[i][j][r];
-                            }
-                        }
-                    }
-                }
+            for (int j = 0; j < 4; j++) {
+                split2(o.b[j][0].x, o.b[j][0].y, h.bh[j].x, h.bl[j].x); split2(o.b[j][0].z, o.b[j][0].w, h.bh[j].y, h.bl[j].y);
+                split2(o.b[j][1].x, o.b[j][1].y, h.bh[j].z, h.bl[j].z); split2(o.b[j][1].z, o.b[j][1].w, h.bh[j].w, h.bl[j].w);
+            }
+        };
+        auto mfma = [&](const Hl& h) {                              // 24 matrix instructions, 32 cycles each
+            const bf8 ah0 = __builtin_bit_cast(bf8, h.ah[0]), al0 = __builtin_bit_cast(bf8, h.al[0]);
+            const bf8 ah1 = __builtin_bit_cast(bf8, h.ah[1]), al1 = __builtin_bit_cast(bf8, h.al[1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bf8 bh = __builtin_bit_cast(bf8, h.bh[j]), bl = __builtin_bit_cast(bf8, h.bl[j]);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[0][j], 0, 0, 0);      // small terms first
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
+            }
+        };
+        // One step of the pipeline: the loads of step s+2 are requested, then the matrix instructions of step s are issued
+        // INTERLEAVED with the vector instructions that split step s+1 (one MFMA, five VALU, ...): a single wave per SIMD has
+        // nobody else to fill the 32 cycles a matrix instruction occupies the pipe.  (Split first, then 24 MFMAs back to back:
+        // matrix pipe 30 % busy, SQ_VALU_MFMA_COEXEC_CYCLES 6 % — profiles/r02_bf16x3_filter.txt.)
+        auto step = [&](uint32_t s_load, Ops& o_load, const Ops& o_split, Hl& h_split, const Hl& h_mfma) {
+            load(s_load, o_load);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(h_mfma);
+            split(o_split, h_split);
+#pragma unroll
+            for (int n = 0; n < 24; n++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        Ops o0, o1, o2;
+        Hl h0, h1;
+        uint32_t st = 0;
+        if (steps >= 6) {
+            load(0, o0); load(1, o1);
+            split(o0, h0);
+            __builtin_amdgcn_sched_barrier(0);
+            for (; st + 6 <= steps; st += 6) {      // loads run two steps ahead (three raw buffers), the split one step ahead (two)
+                step(st + 2, o2, o1, h1, h0);
+                step(st + 3, o0, o2, h0, h1);
+                step(st + 4, o1, o0, h1, h0);
+                step(st + 5, o2, o1, h0, h1);
+                step(st + 6, o0, o2, h1, h0);
+                step(st + 7, o1, o0, h0, h1);
             }
         }
+        for (; st < steps; st++) {                   // the steps that do not fill a round of six: one at a time
+            load(st, o0); split(o0, h0); mfma(h0);
+        }
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, cand_rows, cand_score, cand_cnt);
+    }
+}
+
+// The same with the row operand shared by the four waves of a workgroup (nq_pad a multiple of 256: the waves of a workgroup then
+// hold four different query blocks and walk the SAME row groups).  k_bf16x3_filter asks the CU's vector L1 for 2.4 MB per row
+// group — 64 B per clock at the matrix rate, all the L1 can deliver — because every wave fetches and splits all 128 rows itself.
+// Here wave w fetches and splits only rows 32w .. 32w+31 of the group and publishes the two bfloat16 planes in LDS (8 KiB per
+// step, three stages, one barrier per step); all four read their B operands from there: half the L1 traffic, a quarter of the
+// vector instructions and of the row loads per wave.
+template <int METRIC>
+__global__ void __launch_bounds__(256, 1)
+k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
+                       uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+    __shared__ float s_c[4][64], s_m[4][64];
+    __shared__ uint4 s_b[3][4][2][64];                              // [stage][32-row block][hi, lo][lane]
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nqb64 = nq_pad >> 6;                             // a multiple of 4
+    const uint32_t wgs_per_group = nqb64 >> 2;                      // workgroups that share one row group (different query blocks)
+    const uint32_t qb64 = (blockIdx.x % wgs_per_group) * 4 + wave;
+    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    const uint32_t stride = gridDim.x / wgs_per_group;
+    {
+        const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
+        s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
+        s_m[wave][lane] = m;
+    }
+    __syncthreads();
+    if (stride == 0) return;
+    const uint32_t half = lane >> 5, l31 = lane & 31;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step
+    const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
+    const uint4* a1 = Qbf + ((size_t)(2 * qb64 + 1) * steps) * 2 * 64 + lane;
+
+    for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
+        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
+        // this wave's quarter of the group: rows 32*(wave&1) .. +31 of tile (wave < 2 ? t0 : t1)
+        const f4* bw = tiles + (size_t)(wave < 2 ? t0 : t1) * v.dim4 * 64 + 32 * (wave & 1) + l31;
+        f16v acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+        struct Raw { f4 b[2]; };
+        struct Aop { uint4 ah[2], al[2]; };
+        auto load_b = [&](uint32_t st, Raw& o) {
+            const uint32_t sc = st < steps ? st : steps - 1;
+            const uint32_t c0 = 4 * sc + 2 * half;
+            const uint32_t ca = c0 < v.dim4 ? c0 : v.dim4 - 1, cb = c0 + 1 < v.dim4 ? c0 + 1 : v.dim4 - 1;
+            o.b[0] = __builtin_nontemporal_load(&bw[(size_t)ca * 64]); o.b[1] = __builtin_nontemporal_load(&bw[(size_t)cb * 64]);
+        };
+        auto load_a = [&](uint32_t st, Aop& o) {
+            const uint32_t sc = st < steps ? st : steps - 1;
+            o.ah[0] = a0[(size_t)sc * 128]; o.al[0] = a0[(size_t)sc * 128 + 64];
+            o.ah[1] = a1[(size_t)sc * 128]; o.al[1] = a1[(size_t)sc * 128 + 64];
+        };
+        auto publish = [&](const Raw& o, uint32_t stage) {          // split this wave's rows and put the two planes in LDS
+            uint4 h, l;
+            split2(o.b[0].x, o.b[0].y, h.x, l.x); split2(o.b[0].z, o.b[0].w, h.y, l.y);
+            split2(o.b[1].x, o.b[1].y, h.z, l.z); split2(o.b[1].z, o.b[1].w, h.w, l.w);
+            s_b[stage][wave][0][lane] = h; s_b[stage][wave][1][lane] = l;
+        };
+        auto mfma = [&](const Aop& a, uint32_t stage) {
+            const bf8 ah0 = __builtin_bit_cast(bf8, a.ah[0]), al0 = __builtin_bit_cast(bf8, a.al[0]);
+            const bf8 ah1 = __builtin_bit_cast(bf8, a.ah[1]), al1 = __builtin_bit_cast(bf8, a.al[1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bf8 bh = __builtin_bit_cast(bf8, s_b[stage][j][0][lane]), bl = __builtin_bit_cast(bf8, s_b[stage][j][1][lane]);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[0][j], 0, 0, 0);      // small terms first
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
+            }
+        };
+        // step s: request rows of step s+2 and queries of step s+1, publish step s+1, barrier, consume step s.  A stage is
+        // rewritten three steps after it was read, with a barrier in between.
+        Raw r0, r1, r2;
+        Aop q0, q1;
+        load_b(0, r0); load_b(1, r1); load_a(0, q0);
+        __syncthreads();                                            // the previous group's last stage has been read by everyone
+        publish(r0, 0);
+        uint32_t st = 0;
+        auto step = [&](uint32_t s_, Raw& r_load, const Raw& r_pub, Aop& a_load, const Aop& a_use) {
+            load_b(s_ + 2, r_load); load_a(s_ + 1, a_load);
+            __builtin_amdgcn_sched_barrier(0);
+            publish(r_pub, (s_ + 1) % 3);
+            __syncthreads();
+            mfma(a_use, s_ % 3);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (; st + 6 <= steps; st += 6) {
+            step(st,     r2, r1, q1, q0);
+            step(st + 1, r0, r2, q0, q1);
+            step(st + 2, r1, r0, q1, q0);
+            step(st + 3, r2, r1, q0, q1);
+            step(st + 4, r0, r2, q1, q0);
+            step(st + 5, r1, r0, q0, q1);
+        }
+        for (; st < steps; st++) {                                  // the steps that do not fill a round of six: unpipelined
+            __syncthreads();
+            load_b(st, r0); load_a(st, q0);
+            publish(r0, 0);
+            __syncthreads();
+            mfma(q0, 0);
+        }
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, cand_rows, cand_score, cand_cnt);
     }
 }
 
@@ -208,7 +489,7 @@ template <int M, int U>
 __global__ void __launch_bounds__(256)
 k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_score,
                  const uint32_t* __restrict__ cand_cnt, uint32_t k, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out,
-                 uint32_t* __restrict__ overflow) {
+                 uint32_t* __restrict__ overflow, double gamma) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
@@ -234,7 +515,7 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
     const uint32_t kth = k - 1;
     const uint32_t* cr = cand_rows + (size_t)qi * kMfmaCandCap;
     const float* cs = cand_score + (size_t)qi * kMfmaCandCap;
-    const double gamma = (double)(v.dim + 2) * 5.9604644775390625e-8 / (1.0 - (double)(v.dim + 2) * 5.9604644775390625e-8);
+    // gamma: |S~ - S| <= gamma |q||r| for the filter kernel that produced the scores (filter_gamma)
 
     // ---- stage 1: H = k-th smallest upper bound
     auto bounds = [&](uint32_t i, float& lo, float& hi) {
@@ -328,6 +609,11 @@ uint32_t batched_sample_rows(uint32_t n_rows, uint32_t k) {
     const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / 1536 + 8191) / 8192 * 8192;
     return (uint32_t)std::min<uint64_t>(n_rows, std::max<uint64_t>(8192, want));
 }
+int filter_mode() {
+    const char* e = getenv("QV_MFMA_FILTER");
+    const int m = e && *e ? atoi(e) : 2;
+    return m == 1 ? 1 : 2;
+}
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     // Measured crossover against the exact multi-query scans (256 queries x 768 dims, host pointers for the filter): 12k-16k
     // rows 0.49-0.50 vs 0.36-0.40 ms, 32k 0.51 vs 0.67, 64k 0.64 vs 1.34, 128k 0.85 vs 2.44, 200k 1.19 vs 3.16 — the filter's
@@ -347,7 +633,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     const uint32_t nq_pad = batched_nq_pad(nq);
     size_t b = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);   // sample scan (partials + query blocks)
     b = (b + 255) / 256 * 256;
-    b += (size_t)nq_pad * (v.dim4 + 1) * 16;                 // Qt (chunk count padded to even)
+    b += (size_t)nq_pad * (v.dim4 + 4) * 16;                 // Qt (chunk count padded to even) / the bf16 hi + lo planes (padded to 4 chunks)
     b += (size_t)nq_pad * 8;                                 // cq, mq
     b += (size_t)nq * kMfmaCandCap * 8;                      // candidates: rows + fp32 scores
     b += (size_t)nq * 8;                                     // counters, overflow flags
@@ -362,7 +648,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     char* w = static_cast<char*>(d_ws);
     size_t off = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);
     off = (off + 255) / 256 * 256;
-    float* Qt = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * (v.dim4 + 1) * 16;
+    float* Qt = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * (v.dim4 + 4) * 16;
     float* cq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 4;
     float* mq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 4;
     uint32_t* cand = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * kMfmaCandCap * 4;
@@ -379,20 +665,36 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     hipError_t e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
     if (e != hipSuccess) return e;
     // 2. query re-layout + filter constants
-    hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf);
+    // QV_MFMA_FILTER: 1 = fp32 MFMA (BASELINE configs[2] as written), 2 = bf16 x 3 (default: same candidates up to the margin,
+    // a quarter of the matrix cycles); read per call so that one process can compare the two
+    const int bf = filter_mode() == 2 ? 1 : 0;
+    hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf, bf);
     // 3. MFMA filter
     const uint32_t nqb64 = nq_pad / 64;
     uint32_t grid = (uint32_t)cus;                                     // one 4-wave workgroup per CU (512-register waves)
     while ((grid * 4) % nqb64) grid++;                                 // every query block gets the same number of waves
     if (ev0) (void)hipEventRecord(ev0, s);
-    if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_mfma_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+    static const int share_env = env_int("QV_MFMA_SHARE_ROWS", 1);
+    if (bf && nqb64 % 4 == 0 && share_env == 1) {
+        const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
+        uint32_t gs = (uint32_t)cus;
+        while (gs % (nqb64 / 4)) gs++;                                  // every row group is walked by nqb64/4 workgroups
+        if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter_shared<QV_COSINE>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
+        else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_bf16x3_filter_shared<QV_DOT>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
+        else hipLaunchKernelGGL(k_bf16x3_filter_shared<QV_L2>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
+    } else if (bf) {
+        const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
+        if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
+        else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_bf16x3_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
+        else hipLaunchKernelGGL(k_bf16x3_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
+    } else if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_mfma_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
     else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_mfma_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
     else hipLaunchKernelGGL(k_mfma_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter
     if (ev1) (void)hipEventRecord(ev1, s);
     // 4. exact re-scoring + selection
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * sizeof(uint32_t);
 #define QV_RS(MMM) { e = set_lds(k_rescore_select<MMM, 8>, lds); if (e != hipSuccess) return e;                                   \
-        hipLaunchKernelGGL((k_rescore_select<MMM, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf); }
+        hipLaunchKernelGGL((k_rescore_select<MMM, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, filter_gamma(v.dim, bf)); }
     if (v.metric == QV_COSINE) QV_RS(QV_COSINE) else if (v.metric == QV_DOT) QV_RS(QV_DOT) else if (v.metric == QV_L2) QV_RS(QV_L2) else QV_RS(QV_L2SQ)
 #undef QV_RS
     *d_overflow_out = ovf;

@@ -10,6 +10,14 @@ from tests import _oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["bf16x3", "fp32"], autouse=True)
+def filter_kernel(request, monkeypatch):
+    """every case runs with both filter kernels: the bfloat16 x 3 one (default) and the fp32 MFMA chain (QV_MFMA_FILTER=1,
+    BASELINE configs[2] as written); the library reads the variable per call"""
+    monkeypatch.setenv("QV_MFMA_FILTER", "2" if request.param == "bf16x3" else "1")
+    return request.param
+
+
 def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
@@ -25,10 +33,13 @@ def _eq(a, b):
     return np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1])) and np.array_equal(a[2], b[2])
 
 
-@pytest.mark.parametrize("metric", ["cosine", "dot_product", "euclidean", "squared_euclidean"])
-def test_mfma_batched_equals_exact_scan(metric):
+@pytest.mark.parametrize("metric,nq", [("cosine", 256), ("dot_product", 256), ("euclidean", 256), ("squared_euclidean", 256),
+                                       ("cosine", 100),      # pads to 128 queries: every wave fetches its own rows
+                                       ("dot_product", 600), # pads to 768: three workgroups share a row group's walk
+                                       ("euclidean", 40)])   # pads to 64: one query block
+def test_mfma_batched_equals_exact_scan(metric, nq):
     import quiver_amd as q
-    n, dim, nq = 300_000, 768, 256
+    n, dim = 300_000, 768
     idx = q.DeviceIndex(dim, metric)
     idx.add_synthetic(20260424, 0, n)
     qs = O.gen_rows(20260425, 0, nq, dim)
@@ -38,11 +49,13 @@ def test_mfma_batched_equals_exact_scan(metric):
     assert _eq(exact, idx.search(qs, 10))            # qv_index_search dispatches big batches to the same path
     # and against the CPU oracle for a few queries (bit-exact)
     corpus = O.gen_rows(20260424, 0, n, dim)
-    for i in (0, 17, 255):
+    for i in (0, 17 % nq, nq - 1):
         er, ed = O.exact_search(q.metric_id(metric), corpus, qs[i], 10)
         assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
     # other k, fewer queries (not a multiple of 64)
     for k, m in ((1, 100), (64, 40), (33, 64), (10, 160), (7, 200)):      # 160 and 200 queries: padded from 3-4 to 4 blocks of 64
+        if m > nq:
+            continue
         assert _eq(_exact(idx, qs[:m], k), idx.search(qs[:m], k, batched=True))
 
 
