@@ -123,6 +123,7 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
 template <int METRIC>
 __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (&acc)[2][4], uint32_t t0, uint32_t t1, const float (&s_c)[4][64], const float (&s_m)[4][64],
                                                 uint32_t wave, uint32_t half, uint32_t l31, uint32_t qb64, float tiny_rn,
+                                                const double (&rnd)[4], const uint64_t (&alv)[2],
                                                 uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
         // epilogue: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31]
 #pragma unroll
@@ -130,9 +131,9 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
             const uint32_t t = j < 2 ? t0 : t1;
             if (j >= 2 && t1 == t0) continue;
             const uint32_t row = t * 64 + 32 * (j & 1) + l31;
-            const bool live = (v.alive[t] >> (32 * (j & 1) + l31)) & 1ull;
-            const float rn = f32_up((float)v.rnorm[row]);
-            const float rlo = f32_down((float)v.rnorm[row]);
+            const bool live = (alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull;
+            const float rn = f32_up((float)rnd[j]);
+            const float rlo = f32_down((float)rnd[j]);
             const float rn2c = f32_down(f32_down(rlo * rlo) * 0.999998f);   // (1-2e-6)|r|^2, rounded down (L2 family)
             (void)rn2c;
 #pragma unroll
@@ -162,6 +163,13 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
                 }
             }
         }
+}
+
+// the group's row norms and alive words, requested before the K loop so that their latency is not the epilogue's
+__device__ __forceinline__ void filter_row_consts(const IndexView& v, uint32_t t0, uint32_t t1, uint32_t l31, double (&rnd)[4], uint64_t (&alv)[2]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) rnd[j] = v.rnorm[(size_t)(j < 2 ? t0 : t1) * 64 + 32 * (j & 1) + l31];
+    alv[0] = v.alive[t0]; alv[1] = v.alive[t1];
 }
 
 // grid: persistent waves; wave g -> query 64-block (g % nqb64), row groups (g / nqb64) + i*stride; a row group = 2 tiles = 128 rows
@@ -197,6 +205,8 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         const f4* b0 = tiles + (size_t)t0 * v.dim4 * 64 + l31;
         const f4* b1 = tiles + (size_t)t1 * v.dim4 * 64 + l31;
         f16v acc[2][4];
+        double rnd[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -243,7 +253,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
 
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 0.0f, cand_rows, cand_score, cand_cnt);
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 0.0f, rnd, alv, cand_rows, cand_score, cand_cnt);
     }
 }
 
@@ -284,6 +294,8 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
         const f4* b0 = tiles + (size_t)t0 * v.dim4 * 64 + l31;
         const f4* b1 = tiles + (size_t)t1 * v.dim4 * 64 + l31;
         f16v acc[2][4];
+        double rnd[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -363,7 +375,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
         for (; st < steps; st++) {                   // the steps that do not fill a round of six: one at a time
             load(st, o0); split(o0, h0); mfma(h0);
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, cand_rows, cand_score, cand_cnt);
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
     }
 }
 
@@ -404,6 +416,8 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
         // this wave's quarter of the group: rows 32*(wave&1) .. +31 of tile (wave < 2 ? t0 : t1)
         const f4* bw = tiles + (size_t)(wave < 2 ? t0 : t1) * v.dim4 * 64 + 32 * (wave & 1) + l31;
         f16v acc[2][4];
+        double rnd[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -475,7 +489,7 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
             __syncthreads();
             mfma(q0, 0);
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, cand_rows, cand_score, cand_cnt);
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
     }
 }
 
