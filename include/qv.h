@@ -156,10 +156,10 @@ int qv_index_search_masked(qv_index* idx, const float* queries, uint32_t nq, uin
 int qv_index_search_negative(qv_index* idx, const float* query, const float* negative, uint32_t k_fetch,
                              uint32_t* rows_out, float* dist_out, float* neg_dist_out, uint32_t* count_out);
 
-/* Batched-query path: approximate scores by fp32 MFMA GEMM with fused per-tile
- * candidate selection, then exact re-scoring of the candidates with the same
- * arithmetic as qv_index_search, so results are identical to it.  Same
- * arguments as qv_index_search. */
+/* Batched-query path: approximate scores by a GEMM on the matrix cores with a proven error margin (float32-class
+ * scores from three exact-product bfloat16 MFMA terms by default; the fp32 MFMA chain with QV_MFMA_FILTER=1) and
+ * fused per-tile candidate selection, then exact re-scoring of the candidates with the same arithmetic as
+ * qv_index_search, so results are identical to it.  Same arguments as qv_index_search. */
 int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                             uint32_t* rows_out, float* dist_out, uint32_t* count_out);
 

@@ -1,4 +1,4 @@
-// qv_batched.hip — fp32-MFMA batched filter + exact re-scoring
+// qv_batched.hip — batched filter on the matrix cores (fp32 MFMA chain, or three exact-product bfloat16 terms) + exact re-scoring
 // (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
 #include "qv_kernels.h"
 
