@@ -1,11 +1,11 @@
-// issue rate of v_mfma_f32_32x32x16_bf16 from one wave per SIMD: 8 independent accumulators, 2 accumulators used alternately
+// issue rate of v_mfma_f32_32x32x16_bf16 from one wave per SIMD: 8, 4 independent accumulators, 2 accumulators used alternately
 // (every instruction depends on the one two places back), and the same two-accumulator stream with 2 waves per SIMD
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 template <int NACC>
-__global__ void k(const uint4* A, float* D, unsigned long long* cyc, int n) {
+__global__ void __launch_bounds__(512) k(const uint4* A, float* D, unsigned long long* cyc, int n) {
     uint4 ua = A[threadIdx.x & 63], ub = A[64 + (threadIdx.x & 63)];
     bf8 a = __builtin_bit_cast(bf8, ua), b = __builtin_bit_cast(bf8, ub);
     f16v c[NACC];
