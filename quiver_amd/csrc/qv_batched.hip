@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256, 1)
 k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                        uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
     __shared__ float s_c[4][64], s_m[4][64];
-    __shared__ uint4 s_b[3][4][2][64];                              // [stage][32-row block][hi, lo][lane]
+    __shared__ uint4 s_b[4][4][2][64];                              // [stage][32-row block][hi, lo][lane]: 32 KiB
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nqb64 = nq_pad >> 6;                             // a multiple of 4
@@ -458,6 +458,63 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
                 acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
             }
         };
+        if ((steps & 7u) == 0) {
+            // Dimensions that are a multiple of 128: a round of eight steps with everything but the matrix instructions running
+            // underneath them.  Step s: barrier (step s+1 is published), read the B operands of step s+1 from LDS into the
+            // second register set, request the rows of step s+8 and the queries of step s+3, then the 24 matrix instructions
+            // of step s with the splitting and publishing of step s+2 scheduled between them.  A lone wave per SIMD has nobody
+            // to cover an exposed LDS read, barrier skew or split (the unpipelined loop below: matrix pipe 35 % busy).
+            struct Bset { uint4 h[4], l[4]; };
+            auto read_b = [&](uint32_t stage, Bset& b) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { b.h[j] = s_b[stage][j][0][lane]; b.l[j] = s_b[stage][j][1][lane]; }
+            };
+            auto mfma_r = [&](const Aop& a, const Bset& b) {
+                const bf8 ah0 = __builtin_bit_cast(bf8, a.ah[0]), al0 = __builtin_bit_cast(bf8, a.al[0]);
+                const bf8 ah1 = __builtin_bit_cast(bf8, a.ah[1]), al1 = __builtin_bit_cast(bf8, a.al[1]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bf8 bh = __builtin_bit_cast(bf8, b.h[j]), bl = __builtin_bit_cast(bf8, b.l[j]);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
+                }
+            };
+            Raw r[8];
+            Aop q[4];
+            Bset b0, b1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) load_b((uint32_t)i, r[i]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) load_a((uint32_t)i, q[i]);
+            __syncthreads();                                        // the previous group's stages have been read by everyone
+            publish(r[0], 0); publish(r[1], 1);
+            load_b(8, r[0]); load_b(9, r[1]);
+            __syncthreads();
+            read_b(0, b0);
+            auto pstep = [&](uint32_t s_, int k8, const Bset& b_use, Bset& b_next) {
+                __syncthreads();                                    // step s+1 is in LDS (published during step s-1)
+                read_b((uint32_t)(k8 + 1) & 3, b_next);
+                load_a(s_ + 3, q[(k8 + 3) & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_r(q[k8 & 3], b_use);
+                publish(r[(k8 + 2) & 7], (uint32_t)(k8 + 2) & 3);   // rows of step s+2, requested six steps ago
+                load_b(s_ + 10, r[(k8 + 2) & 7]);
+#pragma unroll
+                for (int n = 0; n < 24; n++) {                      // one matrix instruction, two others, ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200 | 0x020, 2, 0);   // VALU / DS read / DS write / VMEM read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (uint32_t st = 0; st < steps; st += 8) {
+                pstep(st, 0, b0, b1);     pstep(st + 1, 1, b1, b0); pstep(st + 2, 2, b0, b1); pstep(st + 3, 3, b1, b0);
+                pstep(st + 4, 4, b0, b1); pstep(st + 5, 5, b1, b0); pstep(st + 6, 6, b0, b1); pstep(st + 7, 7, b1, b0);
+            }
+        } else {
         // step s: request rows of step s+2 and queries of step s+1, publish step s+1, barrier, consume step s.  A stage is
         // rewritten three steps after it was read, with a barrier in between.
         Raw r0, r1, r2;
@@ -488,6 +545,7 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
             publish(r0, 0);
             __syncthreads();
             mfma(q0, 0);
+        }
         }
         filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
     }
