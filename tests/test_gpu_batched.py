@@ -183,3 +183,23 @@ def test_batched_device_pointer_entry_point():
     with pytest.raises(q.QvError) as e:
         small.search_batched_device(dq.data_ptr(), 96, 10, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), 0)
     assert e.value.code == -8
+
+
+@pytest.mark.parametrize("metric,dim", [("cosine", 128), ("dot_product", 96), ("euclidean", 200), ("squared_euclidean", 256), ("cosine", 52)])
+def test_mfma_batched_wide_dynamic_range(metric, dim):
+    """element magnitudes spread over 2^-12 .. 2^12: the bfloat16 split keeps float32's exponent range and its margin is relative to
+    |q||r|, so the filter must not lose a neighbour; dimensions exercise the eight-step rounds (128, 256), the plain loop (96) and
+    chunk counts that are not a multiple of 4 (200, 52)"""
+    import quiver_amd as q
+    rng = np.random.default_rng(dim)
+    n, nq = 150_000, 64                                    # 9.6 M query-rows: above the filter's 8 M crossover
+    rows = (rng.standard_normal((n, dim)) * np.exp2(rng.integers(-12, 13, size=(n, dim)))).astype(np.float32)
+    qs = (rng.standard_normal((nq, dim)) * np.exp2(rng.integers(-12, 13, size=(nq, dim)))).astype(np.float32)
+    qs[0] = rows[777]; rows[5] = 0.0
+    idx = q.DeviceIndex(dim, metric)
+    idx.add(rows)
+    exact = _exact(idx, qs, 10)
+    assert _eq(exact, idx.search(qs, 10, batched=True))
+    for i in (0, 31):
+        er, ed = O.exact_search(q.metric_id(metric), rows, qs[i], 10)
+        assert np.array_equal(exact[0][i], er) and np.array_equal(_bits(exact[1][i]), _bits(ed))
