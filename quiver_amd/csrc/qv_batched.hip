@@ -61,10 +61,12 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
 __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t dim4,
                             const float* __restrict__ sample_dist /*[nq][k]*/, uint32_t k, int metric,
                             float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq,
-                            uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3) {
+                            uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what) {
+    // what: 1 = operand layout only, 2 = filter constants only (needs sample_dist), 3 = both
     const uint32_t q = blockIdx.x;                     // one block per (padded) query
     const uint32_t dim4p = (dim4 + 1) & ~1u;           // chunk count padded to even: the MFMA step eats two chunks
-    if (bf16x3) {
+    if (!(what & 1)) {
+    } else if (bf16x3) {
         // Qbf[(qb32 * steps + s) * 2 + {hi, lo}][64 lanes] x 16 bytes: lane 32h + j holds dims 16s + 8h .. +7 of query 32 qb32 + j
         const uint32_t steps = (dim4 + 3) / 4;
         uint4* Qbf = reinterpret_cast<uint4*>(Qt);
@@ -88,7 +90,7 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
         }
         reinterpret_cast<f4*>(Qt)[((size_t)(q >> 5) * dim4p + c) * 32 + (q & 31)] = x;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && (what & 2)) {
         float c_ = __uint_as_float(0x7F800000u), m_ = 0.f;       // padded queries: +inf threshold, nothing passes
         if (q < nq) {
             double n2 = 0.0;
@@ -267,7 +269,9 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
 template <int METRIC>
 __global__ void __launch_bounds__(256, 1)
 k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
-                uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+                uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt,
+                float* __restrict__ score_out, uint32_t score_stride) {
+    // score_out != null: no filter — every score is written to score_out[query * score_stride + row] (the sample bound)
     __shared__ float s_c[4][64], s_m[4][64];
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -276,7 +280,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
     const uint32_t qb64 = gw % nqb64;
     const uint32_t n_groups = (v.n_tiles + 1) / 2;
     const uint32_t stride = tw / nqb64;
-    {
+    if (!score_out) {
         const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
         s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
         s_m[wave][lane] = m;
@@ -374,6 +378,20 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
         }
         for (; st < steps; st++) {                   // the steps that do not fill a round of six: one at a time
             load(st, o0); split(o0, h0); mfma(h0);
+        }
+        if (score_out) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j >= 2 && t1 == t0) continue;
+                const uint32_t row = (j < 2 ? t0 : t1) * 64 + 32 * (j & 1) + l31;
+                if (row >= score_stride) continue;
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        score_out[(size_t)(64 * qb64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half) * score_stride + row] = acc[i][j][r];
+            }
+            continue;
         }
         filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
     }
@@ -551,6 +569,78 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
     }
 }
 
+// [lo, hi] containing the reference distance d(q, r) given an approximate score S~ with |S~ - S| <= gamma |q||r| (filter_gamma):
+// qn_cos = the cosine metric's own query norm, qn_l2 = |q|, rn = the stored row norm
+template <int M>
+__device__ __forceinline__ void score_interval(double S, double qn_cos, double qn_l2, double rn, double gamma, float& lo, float& hi) {
+    double d, e;
+    if constexpr (M == QV_COSINE) {
+        if (qn_cos == 0.0 || rn == 0.0) { d = 1.0; e = 0.0; }
+        else { d = 1.0 - S / (qn_cos * rn); e = gamma + 2e-6; }      // |S~ - S| <= gamma |q||r|
+    } else if constexpr (M == QV_DOT) {
+        d = 1.0 - S; e = gamma * qn_l2 * rn + 2e-6 * (1.0 + __builtin_fabs(d));
+    } else {                                                        // QV_L2 / QV_L2SQ: interval on d^2, then into the metric's units
+        const double q2 = qn_l2 * qn_l2, r2 = rn * rn;
+        const double d2 = q2 + r2 - 2.0 * S, e2 = 2.0 * gamma * qn_l2 * rn + 2e-6 * (q2 + r2);
+        double l2 = d2 - e2 > 0.0 ? d2 - e2 : 0.0, h2 = d2 + e2 > 0.0 ? d2 + e2 : 0.0;
+        if constexpr (M == QV_L2) { l2 = __builtin_sqrt(l2) * (1.0 - 4e-7); h2 = __builtin_sqrt(h2) * (1.0 + 4e-7); }
+        else { l2 = l2 * (1.0 - gamma - 2e-6); h2 = h2 * (1.0 + gamma + 2e-6); }
+        lo = f32_down((float)l2); hi = f32_up((float)h2);
+        if (!(d2 == d2)) { lo = -__builtin_inff(); hi = __builtin_inff(); }
+        return;
+    }
+    lo = f32_down((float)(d - e)); hi = f32_up((float)(d + e));
+    if (!(d == d)) { lo = -__builtin_inff(); hi = __builtin_inff(); }   // NaN score: keep, the exact pass decides
+}
+
+// The sample bound without an exact scan: the filter kernel's scores of the first `srows` rows give every sampled row an UPPER
+// bound of its reference distance (score_interval), and the k-th smallest of those bounds is at least the k-th smallest true
+// distance over the sample, hence over the corpus.  One workgroup per query; writes U_q where k_mfma_prep reads it.
+template <int M>
+__global__ void __launch_bounds__(1024)
+k_sample_bound(IndexView v, const float* __restrict__ queries, const float* __restrict__ scores, uint32_t srows, uint32_t k, double gamma,
+               float* __restrict__ sample_dist) {
+    __shared__ uint64_t wl[16 * 64];
+    __shared__ double s_qn[2];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qi = blockIdx.x;
+    extern __shared__ float s_q[];                                  // the query, staged so that one thread can walk it quickly
+    for (uint32_t i = threadIdx.x; i < v.dim; i += blockDim.x) s_q[i] = queries[(size_t)qi * v.dim + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // |q| in the element order of distances.go:20 — for cosine this IS the metric's query constant (query_const<QV_COSINE>)
+        double n2 = 0.0;
+        for (uint32_t i = 0; i < v.dim; i++) { const double a = (double)s_q[i]; n2 = __builtin_fma(a, a, n2); }
+        s_qn[0] = __builtin_sqrt(n2); s_qn[1] = s_qn[0];
+    }
+    __syncthreads();
+    const double qn_cos = s_qn[0], qn_l2 = s_qn[1];
+    const uint32_t kth = k - 1;
+    const float* sc = scores + (size_t)qi * srows;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    for (uint32_t base = wave * 64; base < srows; base += 16 * 64) {
+        const uint32_t row = base + lane;
+        uint64_t key = kDeadKey;
+        if (row < srows && ((v.alive[row >> 6] >> (row & 63)) & 1ull)) {
+            float lo, hi;
+            score_interval<M>((double)sc[row], qn_cos, qn_l2, v.rnorm[row], gamma, lo, hi);
+            key = make_key(hi, row);
+        }
+        list_insert(list, thr, key, kth, lane);
+    }
+    wl[wave * 64 + lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        for (uint32_t w = 1; w < 16; w++) {
+            const uint64_t key = lane < k ? wl[w * 64 + lane] : kDeadKey;
+            list_insert(list, thr, key, kth, lane);
+        }
+        const uint64_t kk = readlane64(list, kth);
+        if (lane == 0) sample_dist[(size_t)qi * k + kth] = kk == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(kk >> 32));
+    }
+}
+
 // Exact re-scoring of one query's candidates + top-k; one workgroup per query.
 // Stage 1 narrows the candidates with their fp32 scores: with d~ the approximate distance and
 // e_r its error bound, d_r is in [d~ - e_r, d~ + e_r]; let H be the k-th smallest upper bound
@@ -591,26 +681,7 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 
     // ---- stage 1: H = k-th smallest upper bound
     auto bounds = [&](uint32_t i, float& lo, float& hi) {
-        const uint32_t row = cr[i];
-        const double rn = v.rnorm[row], S = (double)cs[i];
-        double d, e;
-        if constexpr (M == QV_COSINE) {
-            if (qc.qn == 0.0 || rn == 0.0) { d = 1.0; e = 0.0; }
-            else { d = 1.0 - S / (qc.qn * rn); e = gamma + 2e-6; }  // |S~ - S| <= gamma |q||r|
-        } else if constexpr (M == QV_DOT) {
-            d = 1.0 - S; e = gamma * qn_l2 * rn + 2e-6 * (1.0 + __builtin_fabs(d));
-        } else {                                                    // QV_L2 / QV_L2SQ: interval on d^2, then into the metric's units
-            const double q2 = qn_l2 * qn_l2, r2 = rn * rn;
-            const double d2 = q2 + r2 - 2.0 * S, e2 = 2.0 * gamma * qn_l2 * rn + 2e-6 * (q2 + r2);
-            double l2 = d2 - e2 > 0.0 ? d2 - e2 : 0.0, h2 = d2 + e2 > 0.0 ? d2 + e2 : 0.0;
-            if constexpr (M == QV_L2) { l2 = __builtin_sqrt(l2) * (1.0 - 4e-7); h2 = __builtin_sqrt(h2) * (1.0 + 4e-7); }
-            else { l2 = l2 * (1.0 - gamma - 2e-6); h2 = h2 * (1.0 + gamma + 2e-6); }
-            lo = f32_down((float)l2); hi = f32_up((float)h2);
-            if (!(d2 == d2)) { lo = -__builtin_inff(); hi = __builtin_inff(); }
-            return;
-        }
-        lo = f32_down((float)(d - e)); hi = f32_up((float)(d + e));
-        if (!(d == d)) { lo = -__builtin_inff(); hi = __builtin_inff(); }   // NaN score: keep, the exact pass decides
+        score_interval<M>((double)cs[i], qc.qn, qn_l2, v.rnorm[cr[i]], gamma, lo, hi);
     };
     uint64_t list = kDeadKey, thr = kDeadKey;
     for (uint32_t base = wave * 64; base < cnt; base += 4 * 64) {
@@ -710,6 +781,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     b += (size_t)nq * kMfmaCandCap * 8;                      // candidates: rows + fp32 scores
     b += (size_t)nq * 8;                                     // counters, overflow flags
     b += (size_t)nq * k * 8;                                 // sample rows/dist
+    b += (size_t)nq_pad * batched_sample_rows(v.n_rows, k) * 4 + 256;   // the sample's scores (bfloat16 filter: bound without an exact scan)
     return b + 1024;
 }
 
@@ -729,18 +801,37 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     uint32_t* ovf = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
     uint32_t* srows = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * k * 4;
     float* sdist = reinterpret_cast<float*>(w + off); off += (size_t)nq * k * 4;
-    // 1. exact top-k over a sample (first rows) -> per-query upper bound U_q of the k-th distance
+    // 1. per-query upper bound U_q of the k-th distance from a sample (the first rows)
     IndexView vs = v;
     vs.n_rows = batched_sample_rows(v.n_rows, k);
     vs.n_tiles = (vs.n_rows + 63) / 64;
-    ScanPlan ps = plan_scan(vs.n_tiles, cus);
-    hipError_t e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
-    if (e != hipSuccess) return e;
-    // 2. query re-layout + filter constants
     // QV_MFMA_FILTER: 1 = fp32 MFMA (BASELINE configs[2] as written), 2 = bf16 x 3 (default: same candidates up to the margin,
     // a quarter of the matrix cycles); read per call so that one process can compare the two
     const int bf = filter_mode() == 2 ? 1 : 0;
-    hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf, bf);
+    static const int sample_gemm = env_int("QV_MFMA_SAMPLE_GEMM", 1);
+    hipError_t e = hipSuccess;
+    if (bf && sample_gemm == 1) {
+        // the sample's scores by the filter kernel itself, their upper bounds' k-th smallest as U_q (k_sample_bound): 0.08 ms
+        // against 0.24 for an exact scan of the sample
+        off = (off + 255) / 256 * 256;
+        float* sscore = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * vs.n_rows * 4;
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf, 1, 1);
+        const uint32_t nqb64s = nq_pad / 64;
+        uint32_t gs = std::max(1u, std::min<uint32_t>((uint32_t)cus, ((vs.n_tiles + 1) / 2 * nqb64s + 3) / 4));
+        while ((gs * 4) % nqb64s) gs++;
+        const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
+#define QV_SB(MMM) { hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, vs, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows); \
+                     hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq), dim3(1024), (size_t)v.dim * sizeof(float), s, vs, d_queries, sscore, vs.n_rows, k, filter_gamma(v.dim, 1), sdist); }
+        if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
+#undef QV_SB
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf, 1, 2);
+    } else {
+        ScanPlan ps = plan_scan(vs.n_tiles, cus);
+        e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
+        if (e != hipSuccess) return e;
+        // 2. query re-layout + filter constants
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf, bf, 3);
+    }
     // 3. MFMA filter
     const uint32_t nqb64 = nq_pad / 64;
     uint32_t grid = (uint32_t)cus;                                     // one 4-wave workgroup per CU (512-register waves)
@@ -756,9 +847,9 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         else hipLaunchKernelGGL(k_bf16x3_filter_shared<QV_L2>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
     } else if (bf) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
-        if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
-        else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_bf16x3_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
-        else hipLaunchKernelGGL(k_bf16x3_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
+        if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u);
+        else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_bf16x3_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u);
+        else hipLaunchKernelGGL(k_bf16x3_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u);
     } else if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_mfma_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
     else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_mfma_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
     else hipLaunchKernelGGL(k_mfma_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter
