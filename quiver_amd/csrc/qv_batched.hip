@@ -429,10 +429,25 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
     const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
     const uint4* a1 = Qbf + ((size_t)(2 * qb64 + 1) * steps) * 2 * 64 + lane;
 
+    struct Raw { f4 b[2]; };
+    struct Aop { uint4 ah[2], al[2]; };
+    struct Bset { uint4 h[4], l[4]; };
+    // the rings of the eight-step form live across row groups: the requests that run past the end of a group are the first
+    // ones of the workgroup's next group, so a group starts with its operands on the way or already published
+    Raw r[8];
+    Aop q[4];
+    Bset b0, b1;
+    bool primed = false;
+    const bool deep = (steps & 7u) == 0 && steps >= 16;
+    auto rows_of = [&](uint32_t g_) {                                // this wave's quarter of group g_: rows 32*(wave&1) .. +31 of one of its tiles
+        const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
+        return tiles + (size_t)(wave < 2 ? ta : tb) * v.dim4 * 64 + 32 * (wave & 1) + l31;
+    };
+
     for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
         const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
-        // this wave's quarter of the group: rows 32*(wave&1) .. +31 of tile (wave < 2 ? t0 : t1)
-        const f4* bw = tiles + (size_t)(wave < 2 ? t0 : t1) * v.dim4 * 64 + 32 * (wave & 1) + l31;
+        const f4* bw = rows_of(g);
+        const f4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
         f16v acc[2][4];
         double rnd[4]; uint64_t alv[2];
         filter_row_consts(v, t0, t1, l31, rnd, alv);
@@ -443,16 +458,17 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-        struct Raw { f4 b[2]; };
-        struct Aop { uint4 ah[2], al[2]; };
         auto load_b = [&](uint32_t st, Raw& o) {
-            const uint32_t sc = st < steps ? st : steps - 1;
+            // deep form: a step past the end of this group is a step of the next one; plain form: re-reads the last step (never used)
+            const bool nx = deep && st >= steps;
+            const f4* base = nx ? bwn : bw;
+            const uint32_t sc = nx ? st - steps : (st < steps ? st : steps - 1);
             const uint32_t c0 = 4 * sc + 2 * half;
             const uint32_t ca = c0 < v.dim4 ? c0 : v.dim4 - 1, cb = c0 + 1 < v.dim4 ? c0 + 1 : v.dim4 - 1;
-            o.b[0] = __builtin_nontemporal_load(&bw[(size_t)ca * 64]); o.b[1] = __builtin_nontemporal_load(&bw[(size_t)cb * 64]);
+            o.b[0] = __builtin_nontemporal_load(&base[(size_t)ca * 64]); o.b[1] = __builtin_nontemporal_load(&base[(size_t)cb * 64]);
         };
         auto load_a = [&](uint32_t st, Aop& o) {
-            const uint32_t sc = st < steps ? st : steps - 1;
+            const uint32_t sc = deep && st >= steps ? st - steps : (st < steps ? st : steps - 1);
             o.ah[0] = a0[(size_t)sc * 128]; o.al[0] = a0[(size_t)sc * 128 + 64];
             o.ah[1] = a1[(size_t)sc * 128]; o.al[1] = a1[(size_t)sc * 128 + 64];
         };
@@ -476,13 +492,12 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
                 acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
             }
         };
-        if ((steps & 7u) == 0) {
+        if (deep) {
             // Dimensions that are a multiple of 128: a round of eight steps with everything but the matrix instructions running
             // underneath them.  Step s: barrier (step s+1 is published), read the B operands of step s+1 from LDS into the
             // second register set, request the rows of step s+8 and the queries of step s+3, then the 24 matrix instructions
             // of step s with the splitting and publishing of step s+2 scheduled between them.  A lone wave per SIMD has nobody
             // to cover an exposed LDS read, barrier skew or split (the unpipelined loop below: matrix pipe 35 % busy).
-            struct Bset { uint4 h[4], l[4]; };
             auto read_b = [&](uint32_t stage, Bset& b) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) { b.h[j] = s_b[stage][j][0][lane]; b.l[j] = s_b[stage][j][1][lane]; }
@@ -501,18 +516,17 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
                     acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
                 }
             };
-            Raw r[8];
-            Aop q[4];
-            Bset b0, b1;
+            if (!primed) {                                          // the workgroup's first group: fill the rings
+                primed = true;
 #pragma unroll
-            for (int i = 0; i < 8; i++) load_b((uint32_t)i, r[i]);
+                for (int i = 0; i < 8; i++) load_b((uint32_t)i, r[i]);
 #pragma unroll
-            for (int i = 0; i < 3; i++) load_a((uint32_t)i, q[i]);
-            __syncthreads();                                        // the previous group's stages have been read by everyone
-            publish(r[0], 0); publish(r[1], 1);
-            load_b(8, r[0]); load_b(9, r[1]);
-            __syncthreads();
-            read_b(0, b0);
+                for (int i = 0; i < 3; i++) load_a((uint32_t)i, q[i]);
+                publish(r[0], 0); publish(r[1], 1);
+                load_b(8, r[0]); load_b(9, r[1]);
+                __syncthreads();
+                read_b(0, b0);
+            }
             auto pstep = [&](uint32_t s_, int k8, const Bset& b_use, Bset& b_next) {
                 __syncthreads();                                    // step s+1 is in LDS (published during step s-1)
                 read_b((uint32_t)(k8 + 1) & 3, b_next);
