@@ -438,6 +438,8 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
     Aop q[4];
     Bset b0, b1;
     bool primed = false;
+    const f4* lp = nullptr;                                         // running pointers of the eight-step form: the next row chunk pair
+    const uint4* ap0 = a0; const uint4* ap1 = a1;                   // and the next query operands to request
     const bool deep = (steps & 7u) == 0 && steps >= 16;
     auto rows_of = [&](uint32_t g_) {                                // this wave's quarter of group g_: rows 32*(wave&1) .. +31 of one of its tiles
         const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
@@ -516,25 +518,38 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
                     acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
                 }
             };
+            // requests walk running pointers (no per-step clamps or selects: dimensions here are whole steps); the row pointer jumps
+            // to the workgroup's next group, the query pointers back to step 0, at fixed places of a group's last round
+            auto load_b_run = [&](Raw& o) {
+                o.b[0] = __builtin_nontemporal_load(lp); o.b[1] = __builtin_nontemporal_load(lp + 64);
+                lp += 256;
+            };
+            auto load_a_run = [&](Aop& o) {
+                o.ah[0] = ap0[0]; o.al[0] = ap0[64]; o.ah[1] = ap1[0]; o.al[1] = ap1[64];
+                ap0 += 128; ap1 += 128;
+            };
             if (!primed) {                                          // the workgroup's first group: fill the rings
                 primed = true;
+                lp = bw + 2 * half * 64;
 #pragma unroll
-                for (int i = 0; i < 8; i++) load_b((uint32_t)i, r[i]);
+                for (int i = 0; i < 8; i++) load_b_run(r[i]);
 #pragma unroll
-                for (int i = 0; i < 3; i++) load_a((uint32_t)i, q[i]);
+                for (int i = 0; i < 3; i++) load_a_run(q[i]);
                 publish(r[0], 0); publish(r[1], 1);
-                load_b(8, r[0]); load_b(9, r[1]);
+                load_b_run(r[0]); load_b_run(r[1]);
                 __syncthreads();
                 read_b(0, b0);
             }
             auto pstep = [&](uint32_t s_, int k8, const Bset& b_use, Bset& b_next) {
                 __syncthreads();                                    // step s+1 is in LDS (published during step s-1)
                 read_b((uint32_t)(k8 + 1) & 3, b_next);
-                load_a(s_ + 3, q[(k8 + 3) & 3]);
+                if (s_ + 3 == steps) { ap0 = a0; ap1 = a1; }
+                load_a_run(q[(k8 + 3) & 3]);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_r(q[k8 & 3], b_use);
                 publish(r[(k8 + 2) & 7], (uint32_t)(k8 + 2) & 3);   // rows of step s+2, requested six steps ago
-                load_b(s_ + 10, r[(k8 + 2) & 7]);
+                if (s_ + 10 == steps) lp = bwn + 2 * half * 64;
+                load_b_run(r[(k8 + 2) & 7]);
 #pragma unroll
                 for (int n = 0; n < 24; n++) {                      // one matrix instruction, two others, ...
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
