@@ -790,7 +790,11 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     // Measured crossover against the exact multi-query scans (256 queries x 768 dims, host pointers for the filter): 12k-16k
     // rows 0.49-0.50 vs 0.36-0.40 ms, 32k 0.51 vs 0.67, 64k 0.64 vs 1.34, 128k 0.85 vs 2.44, 200k 1.19 vs 3.16 — the filter's
     // fixed cost (sample scan, prep, re-score: ~0.4 ms) pays off from about 8M query-rows.
-    static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 32768), min_q = env_int("QV_MFMA_MIN_QUERIES", 32);
+    // with the bfloat16 filter a batch of 9..31 queries over 1M x 768 takes 0.70-0.76 ms against 0.96-1.2 ms for the exact f64-matrix scan
+    // (8 queries or fewer share one HBM-bound pass of k_flat_scan_mq: 0.45 ms); the fp32 filter pays off from 32 queries
+    static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 32768);
+    const int min_q_env = env_int("QV_MFMA_MIN_QUERIES", 0);          // read per call: tests of the exact scans switch the filter off with it
+    const int min_q = min_q_env > 0 ? min_q_env : (filter_mode() == 2 ? 9 : 32);
     static const int min_work_m = env_int("QV_MFMA_MIN_MROWS", 8);                       // millions of query-rows
     return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxFusedK && nq >= (uint32_t)min_q &&
            v.n_rows >= (uint32_t)min_rows && (uint64_t)nq * v.n_rows >= (uint64_t)min_work_m * 1000000ull;

@@ -23,9 +23,9 @@ def _bits(a):
 
 
 def _exact(idx, qs, k):
-    """the exact multi-query scan, forced: qv_index_search hands batches of >= 32 queries to the
-    MFMA path by itself, so the reference result is gathered 16 queries at a time"""
-    outs = [idx.search(qs[i: i + 16], k) for i in range(0, len(qs), 16)]
+    """the exact multi-query scan, forced: qv_index_search hands batches of >= 9 queries to the
+    filter + re-score path by itself, so the reference result is gathered 8 queries at a time"""
+    outs = [idx.search(qs[i: i + 8], k) for i in range(0, len(qs), 8)]
     return tuple(np.concatenate([o[j] for o in outs]) for j in range(3))
 
 

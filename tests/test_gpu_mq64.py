@@ -13,6 +13,13 @@ from tests import _oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def exact_scans_only(monkeypatch):
+    """qv_index_search hands batches of >= 9 queries over >= 8M query-rows to the filter + re-score path; these tests are about
+    the exact multi-query scan, so the filter is switched off (the library reads the variable per call)"""
+    monkeypatch.setenv("QV_MFMA_MIN_QUERIES", "1000000")
+
+
 def _check(idx, rows, alive, metric, qs, k):
     mid = quiver_amd.metric_id(metric)
     r, d, c = idx.search(qs, k, batched=False)              # qv_index_search: exact paths only
