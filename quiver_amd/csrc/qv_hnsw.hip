@@ -600,6 +600,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && (!g.has_dead || g.level[n] >= 0); };
 #ifdef QV_HNSW_PROF
     uint64_t T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_last = __builtin_readcyclecounter(); const uint64_t wc0 = wall_clock64(); uint64_t hops = 0;
+    uint64_t full_hops = 0, full_rows = 0, surv_hops = 0, surv_rows = 0;
     auto tick = [&](int ph) { uint64_t t = __builtin_readcyclecounter(); T[ph] += t - t_last; t_last = t; };
 #endif
 
@@ -761,6 +762,9 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     if (n_list >= ef) {
                         const uint32_t w = (uint32_t)(entry_at(ef - 1) >> 32);
                         pend = __ballot(lane < nb && (uint32_t)(kx >> 32) < w);
+#ifdef QV_HNSW_PROF
+                        full_hops++; full_rows += nb; surv_hops += pend != 0; surv_rows += (uint64_t)__builtin_popcountll(pend);
+#endif
                     }
                     while (pend) {
                         const uint32_t i = (uint32_t)__builtin_ctzll(pend);
@@ -822,8 +826,8 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
 #ifdef QV_HNSW_PROF
         if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 777) && qi >= nq - gridDim.x)
-            printf("blk %u: pop %llu links+vis %llu dma-wait %llu issue %llu compute %llu insert %llu other %llu/%llu hops %llu evals(last q) %u wall(10ns) %llu cyc %llu\n", blockIdx.x, T[0], T[1], T[2], T[6], T[3], T[4], T[5], T[7], hops, n_eval,
-                   (unsigned long long)(wall_clock64() - wc0), (unsigned long long)(T[0]+T[1]+T[2]+T[3]+T[4]+T[5]+T[6]+T[7]));
+            printf("blk %u: pop %llu links+vis %llu dma-wait %llu issue %llu compute %llu insert %llu other %llu/%llu hops %llu evals(last q) %u wall(10ns) %llu cyc %llu | list-full hops %llu rows %llu, with a row below the worst: hops %llu rows %llu\n", blockIdx.x, T[0], T[1], T[2], T[6], T[3], T[4], T[5], T[7], hops, n_eval,
+                   (unsigned long long)(wall_clock64() - wc0), (unsigned long long)(T[0]+T[1]+T[2]+T[3]+T[4]+T[5]+T[6]+T[7]), full_hops, full_rows, surv_hops, surv_rows);
 #endif
     }
 }
