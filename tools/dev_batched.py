@@ -37,3 +37,8 @@ torch.cuda.synchronize()
 same = bool(torch.equal(er, dr)) and er.cpu().numpy().tobytes() == dr.cpu().numpy().tobytes() and ed.cpu().numpy().tobytes() == dd.cpu().numpy().tobytes()
 print("batched %s nq=%d rows=%d: %.3f ms/batch, %.1f TFLOP/s fp32-equivalent, flagged %d, identical to the exact scan: %s"
       % (metric, nq, rows, dt * 1e3, 2.0 * nq * rows * dim / dt / 1e12, int(fl.sum().item()), same), flush=True)
+idx.search(hq, k, batched=True)
+t0 = time.perf_counter()
+for _ in range(3):
+    idx.search(hq, k, batched=True)
+print("  host pointers (qv_index_search_batched): %.3f ms/batch" % ((time.perf_counter() - t0) / 3 * 1e3), flush=True)
