@@ -31,16 +31,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct Mq64Shape { int h, nb, u, w, wgs; };
 constexpr int kMq64Cap = 1024;      // candidates a workgroup of k_mq64_bounded can hold
 static Mq64Shape mq64_shape(uint32_t nq) {
-    // Measured, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt).  0: 16 queries/pass, 2 x 4 waves per CU on distinct tiles
-    // (0.63 ms per pass); 1: 32 queries/pass as two 4-wave sets sharing tiles; 2: 32 queries/pass, 8 waves per CU with two
-    // blocks per wave (1.1 ms per pass).  Unforced, the shape with the cheaper total for this batch is taken: 9-16 queries
-    // and e.g. 33-48 go in 16-query passes, 17-32 and large batches in 32-query passes.
+    // 0: 16 queries/pass, 2 x 4 waves per CU on distinct tiles; 1: 32 queries/pass as two 4-wave sets sharing tiles; 2: 32
+    // queries/pass, 8 waves per CU with two blocks per wave.  Measured at 1M x 768 cosine with the bounded kernel
+    // (tools/sweep_shapes.py, profiles/r02_batch_shapes.txt): a lone 16-query pass 0.98 ms, further ones 0.75 ms each; 32-query
+    // passes 1.15 ms, then 0.85-0.99 ms each — so only a batch of 16 or fewer queries goes in the 16-query shape.
     static const int forced = env_int("QV_MQ64_MODE", 0) - 1;        // env value 1..3 -> mode 0..2 (0 = choose per batch)
     int mode = forced;
-    if (mode < 0) {
-        const uint32_t p16 = (nq + 15) / 16, p32 = (nq + 31) / 32;
-        mode = (p16 * 63 <= p32 * 110) ? 0 : 2;
-    }
+    if (mode < 0) mode = nq <= 16 ? 0 : 2;
     if (mode == 0) return {1, 1, 8, 4, 2};
     if (mode == 1) return {2, 1, 8, 4, 1};
     return {1, 2, 4, 8, 1};

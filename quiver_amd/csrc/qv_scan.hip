@@ -498,6 +498,15 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
         static const int trace = env_int("QV_TRACE", 0);                  // QV_TRACE=1: name the scan kernel chosen, on stderr
         // (not for short scans: its first tile per wave pays 16 out-of-line sorts; measured slower below ~4 tiles per wave)
         if ((int)nq >= mq64_min && mq_qb_env == 0 && v.n_tiles >= 16u * p.grid && mq64_blocks(v.metric, v.dim4, nq) != 0) {
+            // a last pass of 8 queries or fewer costs a whole 32-query pass of the matrix kernel (1.15 ms at 1M x 768) but only an
+            // HBM-bound pass of k_flat_scan_mq (0.45-0.65 ms): split it off.  Same stream, so the workspace is reused in order.
+            const uint32_t rem = nq & 31u;
+            if (nq > 32 && rem >= 1 && rem <= 8) {
+                e = launch_flat_topk(v, p, d_queries, nq - rem, k, d_ws, d_rows_out, d_dist_out, s, ev0, ev1);
+                if (e != hipSuccess) return e;
+                return launch_flat_topk(v, p, d_queries + (size_t)(nq - rem) * v.dim, rem, k, d_ws, d_rows_out + (size_t)(nq - rem) * k,
+                                        d_dist_out + (size_t)(nq - rem) * k, s, nullptr, nullptr);
+            }
             uint32_t g64 = 0;
             if (trace) fprintf(stderr, "qv: scan kernel = k_flat_scan_mq64 (nq=%u, tiles=%u)\n", nq, v.n_tiles);
             e = launch_flat_scan_mq64(v, (int)p.cus, d_queries, nq, k, qblk, partial, &g64, s, ev0, ev1);

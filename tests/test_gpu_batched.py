@@ -36,7 +36,9 @@ def _eq(a, b):
 @pytest.mark.parametrize("metric,nq", [("cosine", 256), ("dot_product", 256), ("euclidean", 256), ("squared_euclidean", 256),
                                        ("cosine", 100),      # pads to 128 queries: every wave fetches its own rows
                                        ("dot_product", 600), # pads to 768: three workgroups share a row group's walk
-                                       ("euclidean", 40)])   # pads to 64: one query block
+                                       ("euclidean", 40),    # pads to 64: one query block
+                                       ("cosine", 300),      # 256 + a tail of 44 in a filter call of its own
+                                       ("dot_product", 260)])  # 256 + a tail of 4 on the exact scan
 def test_mfma_batched_equals_exact_scan(metric, nq):
     import quiver_amd as q
     n, dim = 300_000, 768
@@ -57,6 +59,26 @@ def test_mfma_batched_equals_exact_scan(metric, nq):
         if m > nq:
             continue
         assert _eq(_exact(idx, qs[:m], k), idx.search(qs[:m], k, batched=True))
+
+
+@pytest.mark.parametrize("nq", [300, 260])
+def test_batched_device_entry_splits_a_small_tail(nq):
+    """qv_index_search_batched_device with 257-320 queries: the tail runs as a call of its own on the same stream"""
+    import torch
+    import quiver_amd as q
+    n, dim, k = 300_000, 768, 10
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    fl = torch.full((nq,), 7, dtype=torch.int32, device="cuda")
+    idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(fl.abs().sum().item()) == 0
+    exact = _exact(idx, qs, k)
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32), exact[0])
+    assert np.array_equal(_bits(dd.cpu().numpy()), _bits(exact[1]))
 
 
 def test_config2_dot_product_256x1Mx768_against_the_cpu_oracle():

@@ -31,10 +31,13 @@ def _check(idx, rows, alive, metric, qs, k):
 
 
 @pytest.mark.parametrize("metric,dim,nq,k", [
-    ("cosine", 32, 20, 10),        # two passes (16 + 4 queries)
-    ("dot", 32, 16, 64),           # k = 64: full-width lists
+    ("cosine", 32, 20, 10),        # one 32-query pass, 12 query slots replicated
+    ("dot", 32, 16, 64),           # k = 64: full-width lists; the 16-query shape
     ("cosine", 100, 9, 7),         # dim4 = 25: three register blocks + one tail chunk, 7 query slots replicated
-    ("cosine", 12, 31, 3),         # dim4 = 3: tail chunks only; two passes (16 + 15)
+    ("cosine", 12, 31, 3),         # dim4 = 3: tail chunks only
+    ("cosine", 32, 40, 10),        # 32 on the matrix kernel + a last pass of 8 on k_flat_scan_mq (split in launch_flat_topk)
+    ("dot", 64, 70, 5),            # two 32-query passes + 6 split off
+    ("cosine", 32, 45, 10),        # two 32-query passes, the second with 13 queries
 ])
 def test_mq64_equals_oracle(metric, dim, nq, k):
     n = 530_000                                              # 8282 tiles >= 16 per workgroup slot on 256 CUs
