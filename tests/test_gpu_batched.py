@@ -10,11 +10,11 @@ from tests import _oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["bf16x3", "fp32"], autouse=True)
+@pytest.fixture(params=["bf16x3", "fp32", "bf16x1"], autouse=True)
 def filter_kernel(request, monkeypatch):
-    """every case runs with both filter kernels: the bfloat16 x 3 one (default) and the fp32 MFMA chain (QV_MFMA_FILTER=1,
-    BASELINE configs[2] as written); the library reads the variable per call"""
-    monkeypatch.setenv("QV_MFMA_FILTER", "2" if request.param == "bf16x3" else "1")
+    """every case runs with the three filter kernels: bfloat16 x 3 (QV_MFMA_FILTER=2), the fp32 MFMA chain (=1, BASELINE
+    configs[2] as written) and the one-term bfloat16 filter (=3); the library reads the variable per call"""
+    monkeypatch.setenv("QV_MFMA_FILTER", {"bf16x3": "2", "fp32": "1", "bf16x1": "3"}[request.param])
     return request.param
 
 

@@ -1,5 +1,5 @@
 """Timing of the fp32-MFMA filter + exact re-score batch (qv_index_search_batched_device) on 256 x 1M x 768:
-python tools/dev_batched.py [metric] [nq] [rows]"""
+python tools/dev_batched.py [metric] [nq] [rows] [dim] [k]"""
 import os
 import sys
 import time
@@ -12,7 +12,8 @@ import quiver_amd
 metric = sys.argv[1] if len(sys.argv) > 1 else "cosine"
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
-dim, k = 768, 10
+dim = int(sys.argv[4]) if len(sys.argv) > 4 else 768
+k = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 idx = quiver_amd.DeviceIndex(dim, metric)
 idx.add_synthetic(20260424, 0, rows)
 qi = quiver_amd.DeviceIndex(dim, metric)
