@@ -156,8 +156,9 @@ int qv_index_search_masked(qv_index* idx, const float* queries, uint32_t nq, uin
 int qv_index_search_negative(qv_index* idx, const float* query, const float* negative, uint32_t k_fetch,
                              uint32_t* rows_out, float* dist_out, float* neg_dist_out, uint32_t* count_out);
 
-/* Batched-query path: approximate scores by a GEMM on the matrix cores with a proven error margin (float32-class
- * scores from three exact-product bfloat16 MFMA terms by default; the fp32 MFMA chain with QV_MFMA_FILTER=1) and
+/* Batched-query path: approximate scores by a GEMM on the matrix cores with a proven error margin (one bfloat16 MFMA
+ * term up to 1536 dimensions, three exact-product bfloat16 terms above or with QV_MFMA_FILTER=2; the fp32 MFMA chain
+ * with QV_MFMA_FILTER=1) and
  * fused per-tile candidate selection, then exact re-scoring of the candidates with the same arithmetic as
  * qv_index_search, so results are identical to it.  Same arguments as qv_index_search. */
 int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
