@@ -876,10 +876,12 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
 // workgroup then work on the same row group (its tiles are fetched once and hit L1/L2 for the other three) and the wave count
 // divides evenly over the blocks with one workgroup per CU.  Measured, 1M x 768: 160-192 queries as 3 blocks took 4.8 ms
 // (258 workgroups on 256 CUs: a second round), as 4 blocks 3.4 ms.
-static uint32_t batched_nq_pad(uint32_t nq) { return nq <= 64 ? 64u : (nq <= 128 ? 128u : (nq + 255) / 256 * 256); }
+// With the one-term filter 65-128 queries as two blocks took 1.24-1.33 ms on the per-wave kernel against 1.0 ms for 256 on the shared one:
+// there everything above one block is padded to whole workgroups of four.
+static uint32_t batched_nq_pad(uint32_t nq, uint32_t dim) { return nq <= 64 ? 64u : (nq <= 128 && filter_mode(dim) != 3 ? 128u : (nq + 255) / 256 * 256); }
 
 size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t nq, uint32_t k) {
-    const uint32_t nq_pad = batched_nq_pad(nq);
+    const uint32_t nq_pad = batched_nq_pad(nq, v.dim);
     size_t b = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);   // sample scan (partials + query blocks)
     b = (b + 255) / 256 * 256;
     b += (size_t)nq_pad * (v.dim4 + 4) * 16;                 // Qt (chunk count padded to even) / the bf16 hi + lo planes (padded to 4 chunks)
@@ -898,7 +900,7 @@ static uint32_t grid_multiple(uint32_t want, uint32_t unit) { const uint32_t g =
 hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k, void* d_ws,
                           uint32_t* d_rows_out, float* d_dist_out, uint32_t** d_overflow_out, int cus, hipStream_t s,
                           hipEvent_t ev0, hipEvent_t ev1) {
-    const uint32_t nq_pad = batched_nq_pad(nq);
+    const uint32_t nq_pad = batched_nq_pad(nq, v.dim);
     char* w = static_cast<char*>(d_ws);
     size_t off = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);
     off = (off + 255) / 256 * 256;
