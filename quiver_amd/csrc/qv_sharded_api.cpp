@@ -28,6 +28,7 @@ struct Shard {
     hipStream_t stream = nullptr;
     hipEvent_t ev_done = nullptr;       // this shard's part of the current search is on its way to the gather buffer
     Buf d_q, d_pack, d_gath;            // queries; [2][nq][k] local results; [G][2][nq][k] (RCCL: every shard; peer copy: first only)
+    Buf d_flags;                        // [nq] queries the batched filter hands back (candidate overflow): redone with the exact scan
     ncclComm_t comm = nullptr;
 };
 
@@ -97,14 +98,43 @@ int search_locked(qv_sharded* s, const float* queries_host, const float* d_queri
         if (g == 0 && !queries_host) HIPCHK(hipEventRecord(s0.ev_done, s0.stream));   // the query block is on the first device
     }
     if (s->profiling) { HIPCHK(hipSetDevice(s0.device)); HIPCHK(hipEventRecord(s->ev0, s0.stream)); }
+    std::vector<char> filtered(G, 0);
+    std::vector<uint32_t> flags_host;
     for (uint32_t g = 0; g < G; g++) {
         Shard& x = s->sh[g];
         uint32_t* pack = static_cast<uint32_t*>(x.d_pack.p);
         if (qv_index_size(x.idx) == 0) {                                   // empty shard: no results (0xFFFFFFFF rows are skipped by the merge)
             HIPCHK(hipSetDevice(x.device));
             HIPCHK(hipMemsetAsync(pack, 0xFF, words * 4, x.stream));
-        } else if ((rc = qv_index_search_device(x.idx, static_cast<const float*>(x.d_q.p), nq, k, pack, reinterpret_cast<float*>(pack + (size_t)nq * k), x.stream)))
+            continue;
+        }
+        // batches go through the matrix-core filter + exact re-score where it applies (same results, qv_index_search's own rule);
+        // everything else, and whatever the filter declines, through the exact scan
+        int rcb = QV_ERR_UNSUPPORTED;
+        if (nq >= 9) {
+            if ((rc = x.d_flags.ensure((size_t)nq * 4))) return rc;
+            rcb = qv_index_search_batched_device(x.idx, static_cast<const float*>(x.d_q.p), nq, k, pack, reinterpret_cast<float*>(pack + (size_t)nq * k),
+                                                 static_cast<uint32_t*>(x.d_flags.p), x.stream);
+        }
+        if (rcb == QV_OK) filtered[g] = 1;
+        else if (rcb != QV_ERR_UNSUPPORTED) return rcb;
+        else if ((rc = qv_index_search_device(x.idx, static_cast<const float*>(x.d_q.p), nq, k, pack, reinterpret_cast<float*>(pack + (size_t)nq * k), x.stream)))
             return rc;
+    }
+    for (uint32_t g = 0; g < G; g++) {                                      // queries whose candidate buffer overflowed: the exact scan, one by one (rare)
+        if (!filtered[g]) continue;
+        Shard& x = s->sh[g];
+        HIPCHK(hipSetDevice(x.device));
+        flags_host.resize(nq);
+        HIPCHK(hipMemcpyAsync(flags_host.data(), x.d_flags.p, (size_t)nq * 4, hipMemcpyDeviceToHost, x.stream));
+        HIPCHK(hipStreamSynchronize(x.stream));
+        uint32_t* pack = static_cast<uint32_t*>(x.d_pack.p);
+        for (uint32_t q = 0; q < nq; q++) {
+            if (!flags_host[q]) continue;
+            if ((rc = qv_index_search_device(x.idx, static_cast<const float*>(x.d_q.p) + (size_t)q * s->dim, 1, k, pack + (size_t)q * k,
+                                             reinterpret_cast<float*>(pack + (size_t)nq * k) + (size_t)q * k, x.stream)))
+                return rc;
+        }
     }
     // exchange
     if (s->profiling) { HIPCHK(hipSetDevice(s0.device)); HIPCHK(hipEventRecord(s->ev1, s0.stream)); }
@@ -231,7 +261,7 @@ void qv_sharded_destroy(qv_sharded* s) {
         (void)hipSetDevice(x.device);
         if (x.stream) (void)hipStreamSynchronize(x.stream);
         if (x.comm) (void)ncclCommDestroy(x.comm);
-        x.d_q.release(); x.d_pack.release(); x.d_gath.release();
+        x.d_q.release(); x.d_pack.release(); x.d_gath.release(); x.d_flags.release();
         if (x.ev_done) (void)hipEventDestroy(x.ev_done);
         if (x.stream) (void)hipStreamDestroy(x.stream);
         if (x.idx) qv_index_destroy(x.idx);

@@ -111,3 +111,23 @@ def test_device_pointer_form_and_synthetic_blocks_equal_single_index():
     sh.search(qs[:1], k)
     p = sh.profile_read()
     assert p["searches"] == 1 and p["scan_ms"] > 0
+
+
+@pytest.mark.parametrize("nq", [40, 300])
+def test_sharded_batches_take_the_filter_path_and_equal_the_exact_scan(nq, monkeypatch):
+    """a batch of 9+ queries goes through qv_index_search_batched_device on every shard that qualifies (the batched
+    MFMA path shards like the flat scan); the result equals the exact scan of one unsharded index"""
+    n, dim, k = 1_200_000, 64, 10
+    sh = ShardedIndex(dim, "cosine", devices=[0, 0, 0], peer_copy=True)
+    sh.add_synthetic(20260424, 0, n)
+    one = quiver_amd.DeviceIndex(dim, "cosine")
+    one.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    monkeypatch.setenv("QV_MFMA_MIN_QUERIES", "1000000")           # the reference: the exact multi-query scan
+    r1, d1, _ = one.search(qs, k)
+    monkeypatch.delenv("QV_MFMA_MIN_QUERIES")
+    r, d, c = sh.search(qs, k)
+    span = quiver_amd.lib().qv_sharded_span(3)
+    bounds = [g * n // 3 for g in range(4)]
+    back = np.array([[bounds[int(x) // span] + int(x) % span for x in row] for row in r], dtype=np.uint32)
+    assert (c == k).all() and np.array_equal(back, r1) and np.array_equal(d.view(np.uint32), d1.view(np.uint32))

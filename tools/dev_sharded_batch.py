@@ -1,0 +1,30 @@
+"""A batch of queries through qv_sharded_search_device with co-located shards: python tools/dev_sharded_batch.py [shards] [nq] [rows]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import quiver_amd
+from quiver_amd import ShardedIndex
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+dim, k = 768, 10
+sh = ShardedIndex(dim, "cosine", devices=[0] * G, peer_copy=G > 1)
+sh.add_synthetic(20260424, 0, n)
+qi = quiver_amd.DeviceIndex(dim, "cosine"); qi.add_synthetic(20260425, 0, nq)
+dq = torch.from_numpy(np.stack([qi.get_row(i) for i in range(nq)])).cuda()
+dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+sp = torch.cuda.current_stream().cuda_stream
+for env in ("1000000", None):
+    if env: os.environ["QV_MFMA_MIN_QUERIES"] = env
+    else: os.environ.pop("QV_MFMA_MIN_QUERIES", None)
+    sh.search_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), sp); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sh.search_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), sp)
+    torch.cuda.synchronize()
+    print("%d co-located shards, %d queries x %d x %d: %s %.3f ms/batch" % (G, nq, n, dim, "exact multi-query scan per shard" if env else "filter + re-score per shard     ", (time.perf_counter() - t0) / 5 * 1e3), flush=True)
