@@ -274,7 +274,7 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         "batch_ms": dtb * 1e3, "qps": nqb / dtb, "f64_tflops_equiv": flop / dtb / 1e12,
         "frac_of_f64_matrix_peak": flop / dtb / 1e12 / MFMA_F64_PEAK_TF, "peak_tflops_measured": MFMA_F64_PEAK_TF}
 
-    def mfma_entry(index, label, want_rows, want_dist, rows_n=1_000_000, kernel="bf16x3"):
+    def mfma_entry(index, label, want_rows, want_dist, rows_n=1_000_000, kernel="bf16x3", plane=False):
         os.environ["QV_MFMA_FILTER"] = {"bf16x3": "2", "fp32": "1", "bf16x1": "3"}[kernel]   # read by the library per call
         d_flags = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
         index.search_batched_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), d_flags.data_ptr(), sp)
@@ -300,16 +300,18 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
                         % (rows_n, label, "fp32-MFMA (v_mfma_f32_32x32x2_f32: the dense fp32 GEMM as written)" if kernel == "fp32" else
                            "bfloat16 x 3 MFMA (three exact-product v_mfma_f32_32x32x16_bf16 terms per operand pair: float32-class scores with a "
                            "proven margin, a quarter of the matrix cycles)" if kernel == "bf16x3" else
-                           "bfloat16 x 1 MFMA (one v_mfma_f32_32x32x16_bf16 term, |score error| <= 7.9e-3 |q||r| proven, a 4x larger sample to "
-                           "bound the candidates: the library's default up to 1536 dimensions)"),
+                           ("bfloat16 x 1 MFMA (one v_mfma_f32_32x32x16_bf16 term, |score error| <= 7.9e-3 |q||r| proven, a 4x larger sample to "
+                            "bound the candidates: the library's default up to 1536 dimensions)" +
+                            (" reading the index's bfloat16 copy of the rows (QV_FLAG_BF16_ROWS, +50 % memory)" if plane else ""))),
             "batch_ms": dtm * 1e3, "qps": nqb / dtm, "identical_to_exact_scan": same, "queries_sent_back_to_exact_scan": redo,
             "roofline": ({"bound": "mfma", "kernel": "k_mfma_filter", "kernel_ms": mf_ms, "achieved": flop / (mf_ms * 1e-3) / 1e12,
                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flop / (mf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                           "end_to_end_frac": flop / dtm / 1e12 / MFMA_F32_PEAK_TF, "algorithmic_flop_per_launch": flop} if kernel == "fp32" else
-                         {"bound": "hbm", "kernel": "k_bf16x3_filter_shared<1 term>", "kernel_ms": mf_ms,
-                          "achieved": rows_n * (dim * 4 + 8) / (mf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": rows_n * (dim * 4 + 8) / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": rows_n * (dim * 4 + 8),
-                          "why_hbm": "one term is 0.39 PFLOP of bfloat16 matrix work per launch = 0.16 ms at 2.5 PFLOP/s; reading the rows once is 0.38 ms at 8 TB/s",
+                         {"bound": "hbm", "kernel": "k_bf16rows_filter" if plane else "k_bf16x3_filter_shared<1 term>", "kernel_ms": mf_ms,
+                          "achieved": rows_n * (dim * (2 if plane else 4) + 8) / (mf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": rows_n * (dim * (2 if plane else 4) + 8) / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": rows_n * (dim * (2 if plane else 4) + 8),
+                          "why_hbm": "one term is 0.39 PFLOP of bfloat16 matrix work per launch = 0.16 ms at 2.5 PFLOP/s; reading the float32 rows once is 0.38 ms at 8 TB/s, the bfloat16 copy 0.19 ms",
                           "matrix_tflops": flop / (mf_ms * 1e-3) / 1e12, "fp32_equivalent_tflops_end_to_end": flop / dtm / 1e12,
                           "times_the_fp32_mfma_peak_end_to_end": flop / dtm / 1e12 / MFMA_F32_PEAK_TF} if kernel == "bf16x1" else
                          {"bound": "mfma", "kernel": "k_bf16x3_filter_shared", "kernel_ms": mf_ms, "achieved": 3.0 * flop / (mf_ms * 1e-3) / 1e12,
@@ -319,6 +321,14 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
     also["batched_256x1Mx768_mfma"] = mfma_entry(idx1, "cosine", exact_rows, exact_dist, kernel="fp32")
     also["batched_256x1Mx768_bf16x3"] = mfma_entry(idx1, "cosine", exact_rows, exact_dist)
     also["batched_256x1Mx768_bf16x1"] = mfma_entry(idx1, "cosine", exact_rows, exact_dist, kernel="bf16x1")
+    try:                                                   # the same with the optional bfloat16 copy of the rows
+        ibf = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank, bf16_rows=True)
+        ibf.reserve(1_000_000)
+        ibf.add_synthetic(CORPUS_SEED, 0, 1_000_000)
+        also["batched_256x1Mx768_bf16x1_bf16rows"] = mfma_entry(ibf, "cosine", exact_rows, exact_dist, kernel="bf16x1", plane=True)
+        ibf.close()
+    except Exception as ex:                                # noqa: BLE001
+        also["batched_256x1Mx768_bf16x1_bf16rows"] = {"error": str(ex)}
     try:                                                   # configs[2] as written: dot-product
         idot = quiver_amd.DeviceIndex(dim, "dot_product", device=local_rank)
         idot.reserve(1_000_000)
@@ -353,6 +363,11 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
             also["batched_256x%dMx768_mfma" % (a.rows // 1_000_000)] = mfma_entry(idx, "cosine", big_rows, big_dist, a.rows, kernel="fp32")
             also["batched_256x%dMx768_bf16x3" % (a.rows // 1_000_000)] = mfma_entry(idx, "cosine", big_rows, big_dist, a.rows)
             also["batched_256x%dMx768_bf16x1" % (a.rows // 1_000_000)] = mfma_entry(idx, "cosine", big_rows, big_dist, a.rows, kernel="bf16x1")
+            ibf = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank, bf16_rows=True)
+            ibf.reserve(a.rows)
+            ibf.add_synthetic(CORPUS_SEED, 0, a.rows)
+            also["batched_256x%dMx768_bf16x1_bf16rows" % (a.rows // 1_000_000)] = mfma_entry(ibf, "cosine", big_rows, big_dist, a.rows, kernel="bf16x1", plane=True)
+            ibf.close()
         except Exception as ex:                            # noqa: BLE001
             also["batched_256x%dMx768" % (a.rows // 1_000_000)] = {"error": str(ex)}
     # configs[0]: the reference's own CPU-runnable case, 10k x 128 cosine k=10, one query at a time through the host-pointer

@@ -75,6 +75,9 @@ typedef enum qv_status {
 #define QV_FLAG_NONE        0ull
 #define QV_FLAG_ROWMAJOR    1ull /* also keep a row-major copy: fast single-row gathers for
                                     qv_distance_rows / HNSW traversal (hnsw.go:536-563) */
+#define QV_FLAG_BF16_ROWS   2ull /* also keep a bfloat16 copy of the rows (+50 % memory): the batched path's filter reads it
+                                    instead of the float32 rows (half the bytes); results are unchanged — the filter only
+                                    selects candidates for the exact re-score */
 
 /* ---- lifecycle ------------------------------------------------------------------ */
 
@@ -286,7 +289,7 @@ int qv_graph_stats(const qv_graph* g, double* build_seconds, uint64_t* build_bat
  *   qv_sharded_add   cuts a batch into one contiguous piece per shard so that the shards' fill evens out
  *                    (qv_sharded_plan_add is the rule); global_rows_out[i] = id of rows[i] (the host maps string ids)
  *   k <= 64          (the fused top-k width); larger k is QV_ERR_UNSUPPORTED — a filtered search ranks per shard
- *   flags            QV_FLAG_ROWMAJOR passes through to the shards; QV_SHARDED_PEER_COPY replaces the collective with
+ *   flags            QV_FLAG_ROWMAJOR and QV_FLAG_BF16_ROWS pass through to the shards; QV_SHARDED_PEER_COPY replaces the collective with
  *                    point-to-point copies into the first device (and lets several shards share one device, which
  *                    RCCL does not allow: how the tests exercise 3 shards on a 1-GPU box)
  * Threading: one call at a time per handle (internal mutex); different handles are independent. */

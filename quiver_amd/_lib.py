@@ -12,6 +12,7 @@ QV_OK = 0
 QV_ERR_INVALID_ARG, QV_ERR_DIM_MISMATCH, QV_ERR_K_NOT_POSITIVE, QV_ERR_OUT_OF_RANGE = -1, -2, -3, -4
 QV_ERR_NO_DEVICE, QV_ERR_DEVICE, QV_ERR_OOM, QV_ERR_UNSUPPORTED = -5, -6, -7, -8
 QV_FLAG_ROWMAJOR = 1
+QV_FLAG_BF16_ROWS = 2
 QV_SHARDED_PEER_COPY = 1 << 32
 
 # include/qv.h qv_metric

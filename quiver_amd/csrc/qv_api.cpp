@@ -98,6 +98,8 @@ int ensure_rows(qv_index* idx, uint64_t rows, bool exact) {
     if (e == hipSuccess) e = regrow(&idx->d_alive, used_tiles * sizeof(uint64_t), new_tiles * sizeof(uint64_t));
     if (e == hipSuccess && (idx->flags & QV_FLAG_ROWMAJOR))
         e = regrow(&idx->d_rowmaj, (size_t)idx->n_rows * idx->dim * sizeof(float), new_tiles * 64 * (size_t)idx->dim * sizeof(float));
+    if (e == hipSuccess && (idx->flags & QV_FLAG_BF16_ROWS))
+        e = regrow(&idx->d_bf16, used_tiles * idx->bf16_tile_bytes(), new_tiles * idx->bf16_tile_bytes());
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "device allocation for %llu rows failed: %s", (unsigned long long)(new_tiles * 64), hipGetErrorString(e));
     idx->cap_tiles = new_tiles;
@@ -175,7 +177,7 @@ void qv_index_destroy(qv_index* idx) {
     (void)hipDeviceSynchronize();
     for (SearchCtx* c : idx->all_ctx) { c->release(); delete c; }
     for (auto& kv : idx->stream_ws) { kv.second->ws.release(); delete kv.second; }
-    (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rowmaj);
+    (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rowmaj); (void)hipFree(idx->d_bf16);
     idx->mut_stage.release();
     delete idx;
 }

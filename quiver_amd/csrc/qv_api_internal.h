@@ -74,6 +74,7 @@ struct qv_index {
     double* d_rnorm = nullptr;
     uint64_t* d_alive = nullptr;
     float* d_rowmaj = nullptr;
+    uint16_t* d_bf16 = nullptr;                // QV_FLAG_BF16_ROWS: refreshed by every call that writes rows
     std::vector<uint64_t> alive_host;          // mirror of d_alive, for size bookkeeping and validation
     Buf mut_stage;                             // grow-only staging buffer of the mutating calls (add / remove / update run under the
                                                // caller's exclusion, so one buffer serves them all: no hipMalloc per single-row Insert)
@@ -90,10 +91,11 @@ struct qv_index {
 
     qv::IndexView view() const {
         qv::IndexView v;
-        v.tiles = d_tiles; v.rnorm = d_rnorm; v.alive = d_alive; v.rowmaj = d_rowmaj;
+        v.tiles = d_tiles; v.rnorm = d_rnorm; v.alive = d_alive; v.rowmaj = d_rowmaj; v.bf16 = d_bf16;
         v.dim = dim; v.dim4 = dim4; v.n_rows = n_rows; v.n_tiles = (n_rows + 63) / 64; v.metric = metric;
         return v;
     }
     size_t tile_bytes() const { return (size_t)dim4 * 64 * 16; }
+    size_t bf16_tile_bytes() const { return (size_t)((dim4 + 1) / 2) * 64 * 16; }
 };
 

@@ -634,6 +634,110 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
     }
 }
 
+// The one-term filter reading the index's bfloat16 copy of the rows (QV_FLAG_BF16_ROWS) instead of converting float32 rows on the fly:
+// half the row bytes from HBM and through the vector L1s, no conversion work.  Same workgroup shape as k_bf16x3_filter_shared (four
+// query blocks share a 128-row group through LDS); wave w fetches rows 32w .. 32w+31, one 16-byte request per lane and step — which
+// IS the lane's B operand.  The pipelined form only: dimensions that are a multiple of 128 (16-dim steps in rounds of eight).
+template <int METRIC>
+__global__ void __launch_bounds__(256, 1)
+k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
+                  uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+    __shared__ float s_c[4][64], s_m[4][64];
+    __shared__ uint4 s_b[4][4][64];                                 // [stage][32-row block][lane]: 16 KiB
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nqb64 = nq_pad >> 6;                             // a multiple of 4
+    const uint32_t wgs_per_group = nqb64 >> 2;
+    const uint32_t qb64 = (blockIdx.x % wgs_per_group) * 4 + wave;
+    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    const uint32_t stride = gridDim.x / wgs_per_group;
+    {
+        const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
+        s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
+        s_m[wave][lane] = m;
+    }
+    __syncthreads();
+    if (stride == 0) return;
+    const uint32_t half = lane >> 5, l31 = lane & 31;
+    const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
+    const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step; a multiple of 8 here
+    const uint32_t dim8 = (v.dim4 + 1) / 2;
+    const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
+    const uint4* a1 = Qbf + ((size_t)(2 * qb64 + 1) * steps) * 2 * 64 + lane;
+    constexpr int RING = 8;
+    uint4 r[RING];
+    uint4 qa[4][2];
+    struct Bset { uint4 h[4]; };
+    Bset b0, b1;
+    bool primed = false;
+    const uint4* lp = nullptr;
+    const uint4* ap0 = a0; const uint4* ap1 = a1;
+    auto rows_of = [&](uint32_t g_) {                                // 8-dim group `half` of row 32*(wave&1) + l31 of this wave's tile of group g_
+        const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
+        return plane + (size_t)(wave < 2 ? ta : tb) * dim8 * 64 + 32 * (wave & 1) + l31 + half * 64;
+    };
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto load_b_run = [&](uint4& o) { o = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(lp))); lp += 128; };
+    auto load_a_run = [&](uint4 (&o)[2]) { o[0] = ap0[0]; o[1] = ap1[0]; ap0 += 128; ap1 += 128; };
+    auto read_b = [&](uint32_t stage, Bset& b) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) b.h[j] = s_b[stage][j][lane];
+    };
+    for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
+        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
+        const uint4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
+        f16v acc[2][4];
+        double rnd[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, alv);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+        if (!primed) {                                              // the workgroup's first group: fill the rings
+            primed = true;
+            lp = rows_of(g);
+#pragma unroll
+            for (int i = 0; i < RING; i++) load_b_run(r[i]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) load_a_run(qa[i]);
+            s_b[0][wave][lane] = r[0]; s_b[1][wave][lane] = r[1];
+            load_b_run(r[0]); load_b_run(r[1]);
+            __syncthreads();
+            read_b(0, b0);
+        }
+        auto pstep = [&](uint32_t s_, int k8, const Bset& b_use, Bset& b_next) {
+            __syncthreads();                                        // step s+1 is in LDS (published during step s-1)
+            read_b((uint32_t)(k8 + 1) & 3, b_next);
+            if (s_ + 3 == steps) { ap0 = a0; ap1 = a1; }
+            load_a_run(qa[(k8 + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf8 ah0 = __builtin_bit_cast(bf8, qa[k8 & 3][0]), ah1 = __builtin_bit_cast(bf8, qa[k8 & 3][1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bf8 bh = __builtin_bit_cast(bf8, b_use.h[j]);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
+            }
+            s_b[(uint32_t)(k8 + 2) & 3][wave][lane] = r[(k8 + 2) & (RING - 1)];   // rows of step s+2, requested RING steps ago
+            if (s_ + RING + 2 == steps) lp = bwn;
+            load_b_run(r[(k8 + 2) & (RING - 1)]);
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002 | 0x100 | 0x200 | 0x020, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (uint32_t st = 0; st < steps; st += RING) {
+#pragma unroll
+            for (int k8 = 0; k8 < RING; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
+        }
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
+    }
+}
+
 // [lo, hi] containing the reference distance d(q, r) given an approximate score S~ with |S~ - S| <= gamma |q||r| (filter_gamma):
 // qn_cos = the cosine metric's own query norm, qn_l2 = |q|, rn = the stored row norm
 template <int M>
@@ -955,7 +1059,11 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     if (shared) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
         const uint32_t gs = grid_multiple((uint32_t)cus, nqb64 / 4);      // every row group is walked by nqb64/4 workgroups
-#define QV_FS(MMM) { if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+        const uint32_t fsteps = (v.dim4 + 3) / 4;
+        static const int bfrows_env = env_int("QV_MFMA_BF16_ROWS", 1);                        // 2 = ignore the index's bfloat16 plane
+        const bool bfrows = gmode == 2 && v.bf16 != nullptr && bfrows_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;
+#define QV_FS(MMM) { if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 3, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         if (v.metric == QV_COSINE) QV_FS(QV_COSINE) else if (v.metric == QV_DOT) QV_FS(QV_DOT) else QV_FS(QV_L2)
 #undef QV_FS

@@ -1,5 +1,6 @@
 // qv_misc.hip — row gathers, pair distances, ingest, synthetic generator, tombstones
 // (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
+#include <algorithm>
 #include "qv_kernels.h"
 
 namespace qv {
@@ -249,26 +250,55 @@ hipError_t launch_distance_pairs(int metric, const float* d_a, const float* d_b,
     return hipGetLastError();
 }
 
+// The bfloat16 copy of tiles [t0, t1] (QV_FLAG_BF16_ROWS): [tile][dim8][64 rows][8 values], value = bf16(float32 row value), round to
+// nearest even — what the batched filter would compute on the fly.  One thread per (tile, 8-dim group, row); refreshed by every
+// launcher that writes rows, on the same stream, so the plane is never behind the tiles.
+__global__ void __launch_bounds__(256)
+k_bf16_plane(IndexView v, uint32_t t0, uint32_t n_tiles) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const uint32_t dim8 = (v.dim4 + 1) / 2;
+    const uint64_t total = (uint64_t)n_tiles * dim8 * 64;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i & 63), c8 = (uint32_t)((i >> 6) % dim8), t = t0 + (uint32_t)((i >> 6) / dim8);
+        const f4* src = reinterpret_cast<const f4*>(v.tiles) + (size_t)t * v.dim4 * 64 + r;
+        const f4 a = src[(size_t)(2 * c8) * 64];
+        f4 b = {0.f, 0.f, 0.f, 0.f};
+        if (2 * c8 + 1 < v.dim4) b = src[(size_t)(2 * c8 + 1) * 64];
+        const bf2 p0 = {(__bf16)a.x, (__bf16)a.y}, p1 = {(__bf16)a.z, (__bf16)a.w}, p2 = {(__bf16)b.x, (__bf16)b.y}, p3 = {(__bf16)b.z, (__bf16)b.w};
+        uint4 o;
+        o.x = __builtin_bit_cast(uint32_t, p0); o.y = __builtin_bit_cast(uint32_t, p1); o.z = __builtin_bit_cast(uint32_t, p2); o.w = __builtin_bit_cast(uint32_t, p3);
+        reinterpret_cast<uint4*>(v.bf16)[((size_t)t * dim8 + c8) * 64 + r] = o;
+    }
+}
+static hipError_t refresh_bf16(const IndexView& v, uint32_t t0, uint32_t t1, hipStream_t s) {
+    if (!v.bf16) return hipSuccess;
+    const uint64_t total = (uint64_t)(t1 - t0 + 1) * ((v.dim4 + 1) / 2) * 64;
+    hipLaunchKernelGGL(k_bf16_plane, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536)), dim3(256), 0, s, v, t0, t1 - t0 + 1);
+    return hipGetLastError();
+}
+
 hipError_t launch_ingest(const IndexView& v, const float* d_rows, uint32_t row0, uint32_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t t0 = row0 / 64, t1 = (row0 + n - 1) / 64;
     static const int tiled = env_int("QV_INGEST_TILED", 1);
     if ((v.dim & 3) == 0 && tiled == 1 && (reinterpret_cast<uintptr_t>(d_rows) & 15) == 0) {
         hipLaunchKernelGGL(k_ingest_tiled, dim3(t1 - t0 + 1), dim3(256), 0, s, v, d_rows, row0, n, t0);
-        return hipGetLastError();
+        hipError_t e0 = hipGetLastError();
+        return e0 != hipSuccess ? e0 : refresh_bf16(v, t0, t1, s);
     }
     hipLaunchKernelGGL(k_ingest, dim3(t1 - t0 + 1), dim3(64), 0, s, v, d_rows, row0, n, t0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (v.rowmaj) return hipMemcpyAsync(v.rowmaj + (size_t)row0 * v.dim, d_rows, (size_t)n * v.dim * sizeof(float), hipMemcpyDeviceToDevice, s);
-    return hipSuccess;
+    if (v.rowmaj) e = hipMemcpyAsync(v.rowmaj + (size_t)row0 * v.dim, d_rows, (size_t)n * v.dim * sizeof(float), hipMemcpyDeviceToDevice, s);
+    return e != hipSuccess ? e : refresh_bf16(v, t0, t1, s);
 }
 
 hipError_t launch_generate(const IndexView& v, uint64_t seed, uint64_t gen_row0, uint32_t row0, uint32_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t t0 = row0 / 64, t1 = (row0 + n - 1) / 64;
     hipLaunchKernelGGL(k_generate, dim3(t1 - t0 + 1), dim3(64), 0, s, v, seed, gen_row0, row0, n, t0);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    return e != hipSuccess ? e : refresh_bf16(v, t0, t1, s);
 }
 
 hipError_t launch_set_alive(const IndexView& v, const uint32_t* d_rows, uint32_t n, int alive, hipStream_t s) {

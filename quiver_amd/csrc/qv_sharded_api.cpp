@@ -212,7 +212,7 @@ int qv_sharded_create(qv_sharded** out, uint32_t dim, qv_metric metric, const in
     for (int g = 0; g < n_devices && rc == QV_OK; g++) {
         Shard& x = s->sh[(size_t)g];
         x.device = devices[g]; x.base = (uint32_t)g * s->span;
-        rc = qv_index_create(&x.idx, dim, metric, x.device, flags & QV_FLAG_ROWMAJOR);
+        rc = qv_index_create(&x.idx, dim, metric, x.device, flags & (QV_FLAG_ROWMAJOR | QV_FLAG_BF16_ROWS));
         if (rc != QV_OK) break;
         hipError_t e = hipSetDevice(x.device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking);

@@ -15,12 +15,12 @@ def _f32c(a) -> np.ndarray:
 
 
 class DeviceIndex:
-    def __init__(self, dim: int, metric="cosine", device: int = 0, rowmajor: bool = False):
+    def __init__(self, dim: int, metric="cosine", device: int = 0, rowmajor: bool = False, bf16_rows: bool = False):
         self._h = C.c_void_p()
         self.dim = int(dim)
         self.metric = metric_id(metric)
         self.device = device
-        check(lib().qv_index_create(C.byref(self._h), self.dim, self.metric, device, _lib.QV_FLAG_ROWMAJOR if rowmajor else 0))
+        check(lib().qv_index_create(C.byref(self._h), self.dim, self.metric, device, (_lib.QV_FLAG_ROWMAJOR if rowmajor else 0) | (_lib.QV_FLAG_BF16_ROWS if bf16_rows else 0)))
 
     # ---- lifecycle ----
     def close(self):
@@ -261,11 +261,11 @@ class ShardedIndex:
     one RCCL all-gather of the per-shard top-k per search, merge on the first device.  `devices` may repeat a device only
     with peer_copy=True (point-to-point exchange instead of the collective)."""
 
-    def __init__(self, dim: int, metric="cosine", devices=(0,), rowmajor: bool = False, peer_copy: bool = False):
+    def __init__(self, dim: int, metric="cosine", devices=(0,), rowmajor: bool = False, peer_copy: bool = False, bf16_rows: bool = False):
         self._h = C.c_void_p()
         self.dim = int(dim)
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
-        flags = (_lib.QV_FLAG_ROWMAJOR if rowmajor else 0) | (_lib.QV_SHARDED_PEER_COPY if peer_copy else 0)
+        flags = (_lib.QV_FLAG_ROWMAJOR if rowmajor else 0) | (_lib.QV_SHARDED_PEER_COPY if peer_copy else 0) | (_lib.QV_FLAG_BF16_ROWS if bf16_rows else 0)
         check(lib().qv_sharded_create(C.byref(self._h), self.dim, metric_id(metric), devs, len(devices), flags))
 
     def close(self):

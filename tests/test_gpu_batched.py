@@ -225,3 +225,31 @@ def test_mfma_batched_wide_dynamic_range(metric, dim):
     for i in (0, 31):
         er, ed = O.exact_search(q.metric_id(metric), rows, qs[i], 10)
         assert np.array_equal(exact[0][i], er) and np.array_equal(_bits(exact[1][i]), _bits(ed))
+
+
+@pytest.mark.parametrize("metric,dim", [("cosine", 768), ("dot_product", 256), ("euclidean", 128), ("squared_euclidean", 384), ("cosine", 96)])
+def test_bf16_row_plane_gives_the_same_results_and_follows_every_mutation(metric, dim):
+    """QV_FLAG_BF16_ROWS: the one-term filter reads the index's bfloat16 copy of the rows (dimensions that are a multiple of 128;
+    others keep converting the float32 rows).  The plane is refreshed by add (host / device / synthetic, across a regrow) and
+    update; results stay identical to the exact scan."""
+    import torch
+    import quiver_amd as q
+    rng = np.random.default_rng(dim)
+    idx = q.DeviceIndex(dim, metric, bf16_rows=True)
+    idx.add_synthetic(20260424, 0, 150_000)                                  # synthetic block
+    host = rng.standard_normal((50_000, dim)).astype(np.float32)
+    idx.add(host)                                                            # host rows: grows the arrays
+    dev = torch.from_numpy(rng.standard_normal((30_037, dim)).astype(np.float32)).cuda()
+    idx.add_device(dev.data_ptr(), dev.shape[0], torch.cuda.current_stream().cuda_stream)   # device rows, ragged last tile
+    torch.cuda.synchronize()
+    qs = rng.standard_normal((256, dim)).astype(np.float32)                # 256 queries: four query blocks share the rows (the kernel that reads the plane)
+    qs[:8] = host[100:108] + 0.01 * rng.standard_normal((8, dim)).astype(np.float32)       # near the rows that get replaced below
+    assert _eq(_exact(idx, qs, 10), idx.search(qs, 10, batched=True))
+    for j in range(100, 108):                                                # replace rows the first queries are close to
+        idx.update(150_000 + j, -host[j])
+    idx.remove(np.arange(150_000 + 200, 150_000 + 260, dtype=np.uint32))
+    idx.update(150_000 + 210, qs[9])                                         # revive a removed row as an exact match of query 9
+    e = _exact(idx, qs, 10)
+    assert _eq(e, idx.search(qs, 10, batched=True))
+    assert e[0][9][0] == 150_000 + 210
+    assert _eq(_exact(idx, qs[:44], 7), idx.search(qs[:44], 7, batched=True))     # one query block: the per-wave kernel on the float32 rows
