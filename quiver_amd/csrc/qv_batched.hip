@@ -638,8 +638,10 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
 // half the row bytes from HBM and through the vector L1s, no conversion work.  Same workgroup shape as k_bf16x3_filter_shared (four
 // query blocks share a 128-row group through LDS); wave w fetches rows 32w .. 32w+31, one 16-byte request per lane and step — which
 // IS the lane's B operand.  The pipelined form only: dimensions that are a multiple of 128 (16-dim steps in rounds of eight).
+// Two workgroups per CU (256 registers per lane: the lean rings leave room; the float32-row kernel at that occupancy spills into its
+// loop, 1.47 ms against 1.0): a second wave per SIMD covers the other's barriers — 0.86 -> 0.79 ms, 256 x 10M x 768 5.73 -> 5.09 ms.
 template <int METRIC>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, 2)
 k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                   uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
     __shared__ float s_c[4][64], s_m[4][64];
@@ -1062,7 +1064,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t fsteps = (v.dim4 + 3) / 4;
         static const int bfrows_env = env_int("QV_MFMA_BF16_ROWS", 1);                        // 2 = ignore the index's bfloat16 plane
         const bool bfrows = gmode == 2 && v.bf16 != nullptr && bfrows_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;
-#define QV_FS(MMM) { if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+#define QV_FS(MMM) { if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 3, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         if (v.metric == QV_COSINE) QV_FS(QV_COSINE) else if (v.metric == QV_DOT) QV_FS(QV_DOT) else QV_FS(QV_L2)
