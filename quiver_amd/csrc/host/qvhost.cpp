@@ -1,5 +1,6 @@
 // qvhost.cpp — see qvhost.h.  Host-side restatement of the reference's Go callers of the
 // hot path over libqv's C ABI.  Citations are file:line in the reference tree.
+#include <cstdlib>
 #include "qvhost.h"
 
 #include <algorithm>
@@ -37,7 +38,9 @@ ExactIndex::~ExactIndex() { if (h_) qv_index_destroy(h_); }
 Error ExactIndex::insertLocked(const std::string& id, const float* v, uint32_t len) {
     if (dim_ == 0) {                                                   // exact.go:43-44 dimension lock-in
         if (len == 0) return "vector dimension mismatch: expected >0, got 0";
-        if (qv_index_create(&h_, len, metric_, device_, 0) != QV_OK) return qv_err();
+        // QV_BF16_ROWS=1: the exact index also keeps the bfloat16 copy of its rows that BatchSearch's filter reads (+50 % device memory)
+        const char* bf = getenv("QV_BF16_ROWS");
+        if (qv_index_create(&h_, len, metric_, device_, bf && atoi(bf) == 1 ? QV_FLAG_BF16_ROWS : QV_FLAG_NONE) != QV_OK) return qv_err();
         dim_ = (int)len;
     } else if ((int)len != dim_) {
         return fmt("vector dimension mismatch: expected %d, got %u", dim_, len);      // exact.go:45-47
