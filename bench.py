@@ -326,6 +326,22 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         ibf.reserve(1_000_000)
         ibf.add_synthetic(CORPUS_SEED, 0, 1_000_000)
         also["batched_256x1Mx768_bf16x1_bf16rows"] = mfma_entry(ibf, "cosine", exact_rows, exact_dist, kernel="bf16x1", plane=True)
+        # the usual BatchSearch sizes: one query block (k_bf16rows_filter_q64 with the plane, the per-wave three-term kernel without)
+        small = {}
+        for nqs in (16, 64):
+            for label_s, index_s in (("float32_rows", idx1), ("bf16_rows", ibf)):
+                fl_s = torch.zeros((nqs,), dtype=torch.int32, device="cuda")
+                index_s.search_batched_device(d_q.data_ptr(), nqs, k, d_rb.data_ptr(), d_db.data_ptr(), fl_s.data_ptr(), sp)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(10):
+                    index_s.search_batched_device(d_q.data_ptr(), nqs, k, d_rb.data_ptr(), d_db.data_ptr(), fl_s.data_ptr(), sp)
+                torch.cuda.synchronize()
+                dts = (time.perf_counter() - t3) / 10
+                ok_s = bool(np.array_equal(d_rb[:nqs].cpu().numpy().view(np.uint32), exact_rows[:nqs]) and
+                            np.array_equal(d_db[:nqs].cpu().numpy().view(np.uint32), exact_dist[:nqs].view(np.uint32))) and int(fl_s.sum().item()) == 0
+                small["%d_queries_%s" % (nqs, label_s)] = {"batch_ms": dts * 1e3, "qps": nqs / dts, "identical_to_exact_scan": ok_s}
+        also["batched_small_1Mx768"] = small
         ibf.close()
     except Exception as ex:                                # noqa: BLE001
         also["batched_256x1Mx768_bf16x1_bf16rows"] = {"error": str(ex)}

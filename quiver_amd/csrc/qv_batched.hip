@@ -740,6 +740,90 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
     }
 }
 
+// One query block (9-64 queries, the usual BatchSearch sizes) over an index with the bfloat16 row copy: all eight waves of the
+// workgroup work for the SAME 64 queries, so their one-term operands (steps x 2 KiB: 96 KiB at 768 dimensions) sit in LDS for the
+// whole kernel, and every wave streams its own row groups from the bfloat16 plane straight into B operands — no barrier, no
+// conversion, no query traffic in the loop: one pass over half the bytes.  Dimensions that are a multiple of 64, up to 1024.
+template <int METRIC>
+__global__ void __launch_bounds__(512, 1)
+k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
+                      uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+    extern __shared__ __align__(16) unsigned char smem_q64[];
+    uint4* s_a = reinterpret_cast<uint4*>(smem_q64);                // [step][query half][lane]
+    __shared__ float s_c[4][64], s_m[4][64];                        // row 0 is used (filter_epilogue's shape)
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step; a multiple of 4 here
+    const uint32_t dim8 = (v.dim4 + 1) / 2;
+    for (uint32_t i = threadIdx.x; i < steps * 128; i += 512) {
+        const uint32_t st = i >> 7, hq = (i >> 6) & 1, l = i & 63;
+        s_a[i] = Qbf[(((size_t)hq * steps + st) * 2) * 64 + l];     // the hi plane of query half hq, step st
+    }
+    if (threadIdx.x < 64) {
+        const float c = cq[threadIdx.x], m = mq[threadIdx.x];
+        s_c[0][threadIdx.x] = METRIC == QV_COSINE ? c - m : c;
+        s_m[0][threadIdx.x] = m;
+    }
+    __syncthreads();
+    const uint32_t half = lane >> 5, l31 = lane & 31;
+    const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
+    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    const uint32_t gw = blockIdx.x * 8 + wave, tw = gridDim.x * 8;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int R = 4;                                            // steps of rows in flight
+    uint4 rb[R][4];
+    const uint4* p[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto bases = [&](uint32_t g_, const uint4* (&o)[4]) {            // block j of group g_: rows 32*(j&1) .. +31 of tile 2g + (j >> 1)
+        const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = plane + (size_t)(j < 2 ? ta : tb) * dim8 * 64 + 32 * (j & 1) + l31 + half * 64;
+    };
+    auto load_step = [&](uint4 (&o)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p[j]))); p[j] += 128; }
+    };
+    bool primed = false;
+    for (uint32_t g = gw; g < n_groups; g += tw) {
+        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
+        const uint4* nb[4];
+        bases(g + tw < n_groups ? g + tw : g, nb);
+        f16v acc[2][4];
+        double rnd[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, alv);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+        if (!primed) {
+            primed = true;
+            bases(g, p);
+#pragma unroll
+            for (int i = 0; i < R; i++) load_step(rb[i]);
+        }
+        for (uint32_t st = 0; st < steps; st += R) {
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const uint4 a0 = s_a[(st + k) * 128 + lane], a1 = s_a[(st + k) * 128 + 64 + lane];
+                const bf8 ah0 = __builtin_bit_cast(bf8, a0), ah1 = __builtin_bit_cast(bf8, a1);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bf8 bh = __builtin_bit_cast(bf8, rb[k][j]);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
+                }
+                if (st + k + R == steps) {                          // the requests from here on are the first steps of this wave's next group
+#pragma unroll
+                    for (int j = 0; j < 4; j++) p[j] = nb[j];
+                }
+                load_step(rb[k]);
+            }
+        }
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 0u, half, l31, 0u, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
+    }
+}
+
 // [lo, hi] containing the reference distance d(q, r) given an approximate score S~ with |S~ - S| <= gamma |q||r| (filter_gamma):
 // qn_cos = the cosine metric's own query norm, qn_l2 = |q|, rn = the stored row norm
 template <int M>
@@ -1030,7 +1114,10 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     static const int sample_gemm = env_int("QV_MFMA_SAMPLE_GEMM", 1);
     static const int share_env = env_int("QV_MFMA_SHARE_ROWS", 1);
     const bool shared = bf && (nq_pad / 64) % 4 == 0 && share_env == 1;
-    const int gmode = !bf ? 0 : (fmode == 3 && shared ? 2 : 1);        // which filter_gamma the main pass obeys (the one-term form exists for the shared kernel)
+    static const int q64_env = env_int("QV_MFMA_Q64", 1);                                     // 2 = off
+    const uint32_t fsteps0 = (v.dim4 + 3) / 4;
+    const bool q64 = bf && fmode == 3 && nq_pad == 64 && v.bf16 != nullptr && q64_env == 1 && (v.dim4 & 3u) == 0 && fsteps0 % 4 == 0 && fsteps0 >= 8 && fsteps0 <= 64;
+    const int gmode = !bf ? 0 : (fmode == 3 && (shared || q64) ? 2 : 1);   // which filter_gamma the main pass obeys (one term: the shared kernels and the one-block kernel)
     hipError_t e = hipSuccess;
     if (bf && sample_gemm == 1) {
         // the sample's scores by the filter kernel itself, their upper bounds' k-th smallest as U_q (k_sample_bound): 0.08 ms
@@ -1058,7 +1145,14 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     // one 4-wave workgroup per CU (512-register waves); every query block gets the same number of waves
     const uint32_t grid = grid_multiple((uint32_t)cus, nqb64 / std::gcd(nqb64, 4u));
     if (ev0) (void)hipEventRecord(ev0, s);
-    if (shared) {
+    if (q64) {
+        const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
+        const size_t lds_a = (size_t)fsteps0 * 128 * sizeof(uint4);
+#define QV_FQ(MMM) { e = set_lds(k_bf16rows_filter_q64<MMM>, lds_a); if (e != hipSuccess) return e; \
+                     hipLaunchKernelGGL((k_bf16rows_filter_q64<MMM>), dim3((uint32_t)cus), dim3(512), lds_a, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
+        if (v.metric == QV_COSINE) QV_FQ(QV_COSINE) else if (v.metric == QV_DOT) QV_FQ(QV_DOT) else QV_FQ(QV_L2)
+#undef QV_FQ
+    } else if (shared) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
         const uint32_t gs = grid_multiple((uint32_t)cus, nqb64 / 4);      // every row group is walked by nqb64/4 workgroups
         const uint32_t fsteps = (v.dim4 + 3) / 4;

@@ -252,4 +252,5 @@ def test_bf16_row_plane_gives_the_same_results_and_follows_every_mutation(metric
     e = _exact(idx, qs, 10)
     assert _eq(e, idx.search(qs, 10, batched=True))
     assert e[0][9][0] == 150_000 + 210
-    assert _eq(_exact(idx, qs[:44], 7), idx.search(qs[:44], 7, batched=True))     # one query block: the per-wave kernel on the float32 rows
+    for m, kk in ((44, 7), (9, 10), (64, 1)):          # one query block: k_bf16rows_filter_q64 (queries resident in LDS) where the dimension allows
+        assert _eq(_exact(idx, qs[:m], kk), idx.search(qs[:m], kk, batched=True))
