@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float x0, float x1) { const bf2 h 
 
 // Qt[qb32][chunk][32 queries][4 dims] (zero padded), per-query filter constants, counters reset
 __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t dim4,
-                            const float* __restrict__ sample_dist /*[nq][k]*/, uint32_t k, int metric,
+                            const float* __restrict__ sample_dist /*[nq][k], or [nq][parts][k] ascending partial lists*/, uint32_t parts, uint32_t k, int metric,
                             float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq,
                             uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what) {
     // what: 1 = operand layout only, 2 = filter constants only (needs sample_dist), 3 = both
@@ -118,7 +118,22 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
         float c_ = __uint_as_float(0x7F800000u), m_ = 0.f;       // padded queries: +inf threshold, nothing passes
         if (q < nq) {
             const double qn = __builtin_sqrt(n2);
-            const double U = (double)sample_dist[(size_t)q * k + (k - 1)];     // +inf if the sample held < k live rows
+            double U;                                                          // +inf if the sample held < k live rows
+            if (parts <= 1) U = (double)sample_dist[(size_t)q * k + (k - 1)];
+            else {                                                             // k-th smallest over the parts' ascending lists (k_sample_bound)
+                const float* sp = sample_dist + (size_t)q * parts * k;
+                uint32_t at[4] = {0, 0, 0, 0};
+                float best = 0.f;
+                for (uint32_t t = 0; t < k; t++) {
+                    best = __builtin_inff(); uint32_t bp = 0;
+                    for (uint32_t pp = 0; pp < parts; pp++) {
+                        const float val = at[pp] < k ? sp[pp * k + at[pp]] : __builtin_inff();
+                        if (val < best) { best = val; bp = pp; }
+                    }
+                    at[bp]++;
+                }
+                U = (double)best;
+            }
             const double gamma = filter_gamma(dim, bf16x3);
             double c, m;
             if (metric == QV_L2 || metric == QV_L2SQ) {
@@ -854,7 +869,7 @@ __device__ __forceinline__ void score_interval(double S, double qn_cos, double q
 template <int M>
 __global__ void __launch_bounds__(1024)
 k_sample_bound(IndexView v, const float* __restrict__ queries, const float* __restrict__ scores, uint32_t srows, uint32_t k, double gamma,
-               float* __restrict__ sample_dist) {
+               float* __restrict__ sample_dist, uint32_t parts) {
     __shared__ uint64_t wl[16 * 64];
     __shared__ double s_qn[2];
     const uint32_t lane = lane_id();
@@ -874,28 +889,33 @@ k_sample_bound(IndexView v, const float* __restrict__ queries, const float* __re
     const double qn_cos = s_qn[0], qn_l2 = s_qn[1];
     const uint32_t kth = k - 1;
     const float* sc = scores + (size_t)qi * srows;
+    // grid (nq, parts): this workgroup takes the rows [r_lo, r_hi) of the sample and writes the k smallest upper bounds it saw, ascending;
+    // k_mfma_prep takes the k-th smallest over the parts (a few queries alone would leave most CUs idle: 38 us for 64 queries)
+    const uint32_t part = blockIdx.y;
+    const uint32_t per_part = ((srows + parts - 1) / parts + 63) / 64 * 64;
+    const uint32_t r_lo = part * per_part, r_hi = r_lo + per_part < srows ? r_lo + per_part : srows;
     uint64_t list = kDeadKey, thr = kDeadKey;
     // eight batches of 64 rows per round: their scores, norms and alive words are requested together (one batch at a time the
     // loop was a chain of 32 exposed round trips: 60 us per launch at a 32k-row sample)
-    for (uint32_t base0 = wave * 64; base0 < srows; base0 += 8 * 16 * 64) {
+    for (uint32_t base0 = r_lo + wave * 64; base0 < r_hi; base0 += 8 * 16 * 64) {
         float scv[8]; double rnv[8]; uint64_t alw[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t row = base0 + (uint32_t)j * (16 * 64) + lane;
-            const bool in = row < srows;
+            const bool in = row < r_hi;
             scv[j] = in ? sc[row] : 0.f; rnv[j] = in ? v.rnorm[row] : 0.0; alw[j] = in ? v.alive[row >> 6] : 0ull;
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t row = base0 + (uint32_t)j * (16 * 64) + lane;
             uint64_t key = kDeadKey;
-            if (row < srows && ((alw[j] >> (row & 63)) & 1ull)) {
+            if (row < r_hi && ((alw[j] >> (row & 63)) & 1ull)) {
                 float lo, hi;
                 score_interval<M>((double)scv[j], qn_cos, qn_l2, rnv[j], gamma, lo, hi);
                 key = make_key(hi, row);
             }
-            if (base0 + (uint32_t)j * (16 * 64) >= srows) continue;
-            if (base0 == wave * 64 && j == 0) list_seed(list, thr, key, kth, lane); else list_insert(list, thr, key, kth, lane);
+            if (base0 + (uint32_t)j * (16 * 64) >= r_hi) continue;
+            if (base0 == r_lo + wave * 64 && j == 0) list_seed(list, thr, key, kth, lane); else list_insert(list, thr, key, kth, lane);
         }
     }
     wl[wave * 64 + lane] = list;
@@ -906,7 +926,8 @@ k_sample_bound(IndexView v, const float* __restrict__ queries, const float* __re
             list_insert(list, thr, key, kth, lane);
         }
         const uint64_t kk = readlane64(list, kth);
-        if (lane == 0) sample_dist[(size_t)qi * k + kth] = kk == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(kk >> 32));
+        if (parts <= 1) { if (lane == 0) sample_dist[(size_t)qi * k + kth] = kk == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(kk >> 32)); }
+        else if (lane < k) sample_dist[((size_t)qi * parts + part) * k + lane] = list == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(list >> 32));
     }
 }
 
@@ -1079,6 +1100,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     b += (size_t)nq * kMfmaCandCap * 8;                      // candidates: rows + fp32 scores
     b += (size_t)nq * 8;                                     // counters, overflow flags
     b += (size_t)nq * k * 8;                                 // sample rows/dist
+    b += (size_t)nq * k * 16 + 256;                          // k_sample_bound's partial lists (up to four parts per query)
     b += (size_t)nq_pad * batched_sample_rows(v.n_rows, k, v.dim) * 4 + 256;   // the sample's scores (bfloat16 filter: bound without an exact scan)
     return b + 1024;
 }
@@ -1103,6 +1125,9 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     uint32_t* ovf = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
     uint32_t* srows = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * k * 4;
     float* sdist = reinterpret_cast<float*>(w + off); off += (size_t)nq * k * 4;
+    off = (off + 255) / 256 * 256;
+    float* sparts = reinterpret_cast<float*>(w + off); off += (size_t)nq * k * 16;
+    const uint32_t bparts = nq <= 64 ? 4u : (nq <= 128 ? 2u : 1u);       // (four parts at 256 queries: 44 -> 74 us, every workgroup stages its query again)
     // 1. per-query upper bound U_q of the k-th distance from a sample (the first rows)
     IndexView vs = v;
     vs.n_rows = batched_sample_rows(v.n_rows, k, v.dim);
@@ -1124,21 +1149,21 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         // against 0.24 for an exact scan of the sample
         off = (off + 255) / 256 * 256;
         float* sscore = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * vs.n_rows * 4;
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf, 1, 1);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, cnt, ovf, 1, 1);
         const uint32_t nqb64s = nq_pad / 64;
         const uint32_t gs = grid_multiple(std::min<uint32_t>((uint32_t)cus, ((vs.n_tiles + 1) / 2 * nqb64s + 3) / 4), nqb64s / std::gcd(nqb64s, 4u));
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
 #define QV_SB(MMM) { hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, vs, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows); \
-                     hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq), dim3(1024), (size_t)v.dim * sizeof(float), s, vs, d_queries, sscore, vs.n_rows, k, filter_gamma(v.dim, 1), sdist); }
+                     hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), (size_t)v.dim * sizeof(float), s, vs, d_queries, sscore, vs.n_rows, k, filter_gamma(v.dim, 1), bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf, gmode, 2);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 ? sparts : sdist, bparts, k, v.metric, Qt, cq, mq, cnt, ovf, gmode, 2);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
         e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
         if (e != hipSuccess) return e;
         // 2. query re-layout + filter constants
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, k, v.metric, Qt, cq, mq, cnt, ovf, gmode, 3);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, cnt, ovf, gmode, 3);
     }
     // 3. MFMA filter
     const uint32_t nqb64 = nq_pad / 64;
