@@ -1079,7 +1079,9 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 32768);
     const int min_q_env = env_int("QV_MFMA_MIN_QUERIES", 0);          // read per call: tests of the exact scans switch the filter off with it
     const int min_q = min_q_env > 0 ? min_q_env : (filter_mode(v.dim) >= 2 ? 9 : 32);
-    static const int min_work_m = env_int("QV_MFMA_MIN_MROWS", 8);                       // millions of query-rows
+    // millions of query-rows.  Round 2's one-term filter moved the crossover down: 16 / 64 queries x 100k x 768 take 0.17 / 0.18 ms here against
+    // 0.30 / 0.57 ms on the exact multi-query scan, x 400k rows 0.36 / 0.37 against 0.59 / 1.65 (8 M query-rows was the three-term crossover)
+    static const int min_work_m = env_int("QV_MFMA_MIN_MROWS", 1);
     return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxFusedK && nq >= (uint32_t)min_q &&
            v.n_rows >= (uint32_t)min_rows && (uint64_t)nq * v.n_rows >= (uint64_t)min_work_m * 1000000ull;
 }
