@@ -182,7 +182,9 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
                 for (int r = 0; r < 16; r++) {
                     const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                     const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
-                    hit |= acc[i][j][r] >= thr;
+                    // a score that is NaN or infinite (rows or queries near FLT_MAX overflow the float32 sums, in either direction and
+                    // possibly only on the way) says nothing about the row: it counts as a hit and the exact pass decides
+                    hit |= !(acc[i][j][r] < thr) || acc[i][j][r] < -3.0e38f;
                 }
                 hit |= rn < tiny_rn;                                   // bf16 operands of a vanishing row would flush: let the exact pass see it
                 if (hit && live) {                                  // rare: a row that may be in some query's top-k
@@ -190,7 +192,7 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
                     for (int r = 0; r < 16; r++) {
                         const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                         const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
-                        if (acc[i][j][r] >= thr || (rn < tiny_rn && s_c[wave][ql] < 3.0e38f)) {      // (padded query slots carry +inf)
+                        if ((!(acc[i][j][r] < thr) || acc[i][j][r] < -3.0e38f || rn < tiny_rn) && s_c[wave][ql] < 3.0e38f) {      // (padded query slots carry +inf)
                             const uint32_t q = 64 * qb64 + ql;
                             uint32_t slot = atomicAdd(&cand_cnt[q], 1u);
                             if (slot < (uint32_t)kMfmaCandCap) {
@@ -843,6 +845,7 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
 // qn_cos = the cosine metric's own query norm, qn_l2 = |q|, rn = the stored row norm
 template <int M>
 __device__ __forceinline__ void score_interval(double S, double qn_cos, double qn_l2, double rn, double gamma, float& lo, float& hi) {
+    if (!(__builtin_fabs(S) < 3.0e38)) { lo = -__builtin_inff(); hi = __builtin_inff(); return; }   // overflowed float32 sum (or NaN): no information
     double d, e;
     if constexpr (M == QV_COSINE) {
         if (qn_cos == 0.0 || rn == 0.0) { d = 1.0; e = 0.0; }

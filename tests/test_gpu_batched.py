@@ -227,6 +227,26 @@ def test_mfma_batched_wide_dynamic_range(metric, dim):
         assert np.array_equal(exact[0][i], er) and np.array_equal(_bits(exact[1][i]), _bits(ed))
 
 
+def test_rows_near_flt_max_are_not_lost_by_the_filter():
+    """rows whose elements sit near FLT_MAX overflow the filter's float32 sums: +inf for same-sign rows, inf - inf = NaN for mixed signs.
+    Both must reach the exact re-score (which accumulates in float64): a query pointing along such a row finds it at distance ~0."""
+    import quiver_amd as q
+    rng = np.random.default_rng(7)
+    n, dim, nq = 150_000, 128, 64
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    huge_mixed = np.arange(1000, 1050); huge_pos = np.arange(2000, 2010)
+    rows[huge_mixed] = (3.0e38 * rng.choice([-1.0, 1.0], size=(50, dim)) * rng.uniform(0.5, 1.0, size=(50, dim))).astype(np.float32)
+    rows[huge_pos] = (3.0e38 * rng.uniform(0.5, 1.0, size=(10, dim))).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    qs[0] = 1.0                                                     # along the all-positive rows
+    qs[1] = (rows[1007].astype(np.float64) / 1.0e38).astype(np.float32)   # along a mixed-sign huge row
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    exact = _exact(idx, qs, 10)
+    assert exact[0][1][0] == 1007 and exact[0][0][0] in huge_pos
+    assert _eq(exact, idx.search(qs, 10, batched=True))
+
+
 @pytest.mark.parametrize("metric,dim", [("cosine", 768), ("dot_product", 256), ("euclidean", 128), ("squared_euclidean", 384), ("cosine", 96)])
 def test_bf16_row_plane_gives_the_same_results_and_follows_every_mutation(metric, dim):
     """QV_FLAG_BF16_ROWS: the one-term filter reads the index's bfloat16 copy of the rows (dimensions that are a multiple of 128;
