@@ -309,15 +309,17 @@ template <int METRIC>
 __global__ void __launch_bounds__(256, 1)
 k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                 uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt,
-                float* __restrict__ score_out, uint32_t score_stride) {
-    // score_out != null: no filter — every score is written to score_out[query * score_stride + row] (the sample bound)
+                float* __restrict__ score_out, uint32_t score_stride, uint32_t gstep) {
+    // score_out != null: no filter — the scores of the SAMPLE, row groups 0, gstep, 2 gstep, ... (score_stride / 128 of them, spread over the
+    // corpus so that a corpus stored cluster by cluster still yields a representative bound), are written to
+    // score_out[query * score_stride + 128 * (group's place in the sample) + row of the group]
     __shared__ float s_c[4][64], s_m[4][64];
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * 4 + wave, tw = gridDim.x * 4;
     const uint32_t nqb64 = nq_pad >> 6;
     const uint32_t qb64 = gw % nqb64;
-    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    const uint32_t n_groups = score_out ? (score_stride + 127) / 128 : (v.n_tiles + 1) / 2;
     const uint32_t stride = tw / nqb64;
     if (!score_out) {
         const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
@@ -333,7 +335,8 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
     const uint4* a1 = Qbf + ((size_t)(2 * qb64 + 1) * steps) * 2 * 64 + lane;
 
     for (uint32_t g = gw / nqb64; g < n_groups; g += stride) {
-        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
+        const uint32_t ga = score_out ? g * gstep : g;             // the group's place in the corpus
+        const uint32_t t0 = 2 * ga, t1 = (2 * ga + 1 < v.n_tiles) ? 2 * ga + 1 : t0;
         const f4* b0 = tiles + (size_t)t0 * v.dim4 * 64 + l31;
         const f4* b1 = tiles + (size_t)t1 * v.dim4 * 64 + l31;
         f16v acc[2][4];
@@ -422,7 +425,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (j >= 2 && t1 == t0) continue;
-                const uint32_t row = (j < 2 ? t0 : t1) * 64 + 32 * (j & 1) + l31;
+                const uint32_t row = g * 128 + (j < 2 ? 0u : 64u) + 32 * (j & 1) + l31;      // place in the sample
                 if (row >= score_stride) continue;
 #pragma unroll
                 for (int i = 0; i < 2; i++)
@@ -872,7 +875,7 @@ __device__ __forceinline__ void score_interval(double S, double qn_cos, double q
 template <int M>
 __global__ void __launch_bounds__(1024)
 k_sample_bound(IndexView v, const float* __restrict__ queries, const float* __restrict__ scores, uint32_t srows, uint32_t k, double gamma,
-               float* __restrict__ sample_dist, uint32_t parts) {
+               float* __restrict__ sample_dist, uint32_t parts, uint32_t gstep) {
     __shared__ uint64_t wl[16 * 64];
     __shared__ double s_qn[2];
     const uint32_t lane = lane_id();
@@ -904,15 +907,17 @@ k_sample_bound(IndexView v, const float* __restrict__ queries, const float* __re
         float scv[8]; double rnv[8]; uint64_t alw[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const uint32_t row = base0 + (uint32_t)j * (16 * 64) + lane;
-            const bool in = row < r_hi;
-            scv[j] = in ? sc[row] : 0.f; rnv[j] = in ? v.rnorm[row] : 0.0; alw[j] = in ? v.alive[row >> 6] : 0ull;
+            const uint32_t row = base0 + (uint32_t)j * (16 * 64) + lane;                        // place in the sample
+            const uint32_t arow = (row >> 7) * gstep * 128 + (row & 127);                          // row of the corpus
+            const bool in = row < r_hi && arow < v.n_rows;
+            scv[j] = in ? sc[row] : 0.f; rnv[j] = in ? v.rnorm[arow] : 0.0; alw[j] = in ? v.alive[arow >> 6] : 0ull;
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t row = base0 + (uint32_t)j * (16 * 64) + lane;
+            const uint32_t arow = (row >> 7) * gstep * 128 + (row & 127);
             uint64_t key = kDeadKey;
-            if (row < r_hi && ((alw[j] >> (row & 63)) & 1ull)) {
+            if (row < r_hi && arow < v.n_rows && ((alw[j] >> (arow & 63)) & 1ull)) {
                 float lo, hi;
                 score_interval<M>((double)scv[j], qn_cos, qn_l2, rnv[j], gamma, lo, hi);
                 key = make_key(hi, row);
@@ -1158,8 +1163,11 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t nqb64s = nq_pad / 64;
         const uint32_t gs = grid_multiple(std::min<uint32_t>((uint32_t)cus, ((vs.n_tiles + 1) / 2 * nqb64s + 3) / 4), nqb64s / std::gcd(nqb64s, 4u));
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
-#define QV_SB(MMM) { hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, vs, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows); \
-                     hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), (size_t)v.dim * sizeof(float), s, vs, d_queries, sscore, vs.n_rows, k, filter_gamma(v.dim, 1), bparts > 1 ? sparts : sdist, bparts); }
+        // the sample's row groups are spread evenly over the corpus (a corpus stored cluster by cluster: the first S rows would bound nothing)
+        const uint32_t sgroups = (vs.n_rows + 127) / 128, all_groups = v.n_tiles / 2;
+        const uint32_t gstep = sgroups && all_groups > sgroups ? all_groups / sgroups : 1u;
+#define QV_SB(MMM) { hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
+                     hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), (size_t)v.dim * sizeof(float), s, v, d_queries, sscore, vs.n_rows, k, filter_gamma(v.dim, 1), bparts > 1 ? sparts : sdist, bparts, gstep); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
         hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 ? sparts : sdist, bparts, k, v.metric, Qt, cq, mq, cnt, ovf, gmode, 2);
@@ -1195,9 +1203,9 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
 #undef QV_FS
     } else if (bf) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
-        if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u);
-        else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_bf16x3_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u);
-        else hipLaunchKernelGGL(k_bf16x3_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u);
+        if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u, 1u);
+        else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_bf16x3_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u, 1u);
+        else hipLaunchKernelGGL(k_bf16x3_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u, 1u);
     } else if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_mfma_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
     else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_mfma_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
     else hipLaunchKernelGGL(k_mfma_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter

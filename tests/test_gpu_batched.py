@@ -227,6 +227,32 @@ def test_mfma_batched_wide_dynamic_range(metric, dim):
         assert np.array_equal(exact[0][i], er) and np.array_equal(_bits(exact[1][i]), _bits(ed))
 
 
+def test_corpus_stored_cluster_by_cluster_keeps_the_filter_path(filter_kernel):
+    """the bound sample is spread over the corpus: with rows stored cluster after cluster (how data often arrives) the first rows alone
+    would bound nothing for queries of the later clusters, every candidate buffer would overflow and every query fall back to the
+    exact scan.  No query may be handed back, and the results equal the exact scan."""
+    import torch
+    import quiver_amd as q
+    rng = np.random.default_rng(11)
+    dim, n_clusters, per = 128, 30, 10_000
+    centres = rng.standard_normal((n_clusters, dim))
+    rows = np.concatenate([c + 0.3 * rng.standard_normal((per, dim)) for c in centres]).astype(np.float32)
+    nq, k = 64, 10
+    qs = (centres[rng.integers(0, n_clusters, nq)] + 0.3 * rng.standard_normal((nq, dim))).astype(np.float32)
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    fl = torch.full((nq,), 7, dtype=torch.int32, device="cuda")
+    idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    exact = _exact(idx, qs, k)
+    assert _eq(exact, idx.search(qs, k, batched=True))               # through the host entry point (which redoes what is handed back)
+    if filter_kernel != "fp32":                                      # (the fp32 chain keeps round 1's bound: an exact scan of the first rows)
+        assert int(fl.abs().sum().item()) == 0
+        assert np.array_equal(dr.cpu().numpy().view(np.uint32), exact[0]) and np.array_equal(_bits(dd.cpu().numpy()), _bits(exact[1]))
+
+
 def test_rows_near_flt_max_are_not_lost_by_the_filter():
     """rows whose elements sit near FLT_MAX overflow the filter's float32 sums: +inf for same-sign rows, inf - inf = NaN for mixed signs.
     Both must reach the exact re-score (which accumulates in float64): a query pointing along such a row finds it at distance ~0."""
