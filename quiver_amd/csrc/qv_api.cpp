@@ -563,6 +563,20 @@ int qv_index_search_batched_device(qv_index* idx, const float* d_queries, uint32
         return fail(QV_ERR_UNSUPPORTED, "the MFMA batched path does not apply to this index/query shape; use qv_index_search_device");
     HIPCHK(hipSetDevice(idx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nq > kHostBatch) {                                                        // bound the workspace (sample scores + candidate slots: ~160 KB per query)
+        for (uint32_t q0 = 0; q0 < nq; q0 += kHostBatch) {
+            const uint32_t m = std::min(kHostBatch, nq - q0);
+            int rc0;
+            if (qv::batched_supported(v, m, k))
+                rc0 = qv_index_search_batched_device(idx, d_queries + (size_t)q0 * idx->dim, m, k, d_rows_out + (size_t)q0 * k, d_dist_out + (size_t)q0 * k, d_redo_flags_out + q0, stream);
+            else {
+                HIPCHK(hipMemsetAsync(d_redo_flags_out + q0, 0, (size_t)m * sizeof(uint32_t), s));
+                rc0 = qv_index_search_device(idx, d_queries + (size_t)q0 * idx->dim, m, k, d_rows_out + (size_t)q0 * k, d_dist_out + (size_t)q0 * k, stream);
+            }
+            if (rc0 != QV_OK) return rc0;
+        }
+        return QV_OK;
+    }
     if (const uint32_t tail = batched_tail(v, nq, k)) {
         const uint32_t head = nq - tail;
         int rc0 = qv_index_search_batched_device(idx, d_queries, head, k, d_rows_out, d_dist_out, d_redo_flags_out, stream);

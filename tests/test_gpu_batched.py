@@ -227,6 +227,27 @@ def test_mfma_batched_wide_dynamic_range(metric, dim):
         assert np.array_equal(exact[0][i], er) and np.array_equal(_bits(exact[1][i]), _bits(ed))
 
 
+def test_device_entry_slices_very_large_batches():
+    """more than 8192 queries through qv_index_search_batched_device go in slices on the caller's stream (bounded workspace)"""
+    import torch
+    import quiver_amd as q
+    n, dim, nq, k = 120_000, 64, 9000, 5
+    idx = q.DeviceIndex(dim, "dot_product")
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    er = torch.empty((nq, k), dtype=torch.int32, device="cuda"); ed = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    fl = torch.full((nq,), 7, dtype=torch.int32, device="cuda")
+    sp = torch.cuda.current_stream().cuda_stream
+    idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), sp)
+    idx.search_device(dq.data_ptr(), nq, k, er.data_ptr(), ed.data_ptr(), sp)
+    torch.cuda.synchronize()
+    ok = (fl == 0)
+    assert int((~ok).sum().item()) <= 8
+    assert torch.equal(dr[ok], er[ok]) and dd[ok].cpu().numpy().tobytes() == ed[ok].cpu().numpy().tobytes()
+
+
 def test_corpus_stored_cluster_by_cluster_keeps_the_filter_path(filter_kernel):
     """the bound sample is spread over the corpus: with rows stored cluster after cluster (how data often arrives) the first rows alone
     would bound nothing for queries of the later clusters, every candidate buffer would overflow and every query fall back to the
