@@ -254,3 +254,44 @@ def test_random_hybrid_histories(seed):
                 assert [(r.ID, np.float32(r.Distance).tobytes()) for r in resp.Results[i]] == [(r.ID, np.float32(r.Distance).tobytes()) for r in one], (step, i)
                 assert len(one) == min(k, len(live))
         assert idx.Size() == len(live)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_filter_path_under_random_mutations_equals_the_exact_scan(seed, monkeypatch):
+    """the matrix-core filter + re-score (qv_index_search's route for 9+ queries over >= 32768 rows) on indexes that grow, lose and
+    replace rows between batches, with and without the bfloat16 row copy: every batch equals the exact multi-query scan of the same
+    index (forced with QV_MFMA_MIN_QUERIES), and a few queries per seed equal the CPU oracle"""
+    rng = np.random.default_rng(5000 + seed)
+    metric = ["cosine", "dot_product", "euclidean", "squared_euclidean"][seed % 4]
+    dim = int(rng.choice([32, 64, 128, 200, 256, 768]))
+    idx = quiver_amd.DeviceIndex(dim, metric, bf16_rows=bool(seed & 1))
+    m = Model(metric, dim)
+    style = seed % 3
+    x = _vectors(rng, 45_000, dim, style)
+    assert idx.add(x) == m.add(x)
+    for step in range(6):
+        n = m.rows.shape[0]
+        op = rng.choice(["add", "remove", "update"])
+        if op == "add":
+            x = _vectors(rng, int(rng.choice([1, 64, 1000, 9000])), dim, style)
+            assert idx.add(x) == m.add(x)
+        elif op == "remove":
+            lo = int(rng.integers(0, n - 3000))
+            who = np.arange(lo, lo + int(rng.integers(1, 3000)), dtype=np.uint32)
+            idx.remove(who); m.alive[who] = 0
+        else:
+            for row in rng.integers(0, n, size=20):
+                v = _vectors(rng, 1, dim, style)[0]
+                idx.update(int(row), v); m.rows[row] = v; m.alive[row] = 1
+        n = m.rows.shape[0]
+        nq = int(rng.choice([9, 40, 64, 100, 300, 600]))
+        k = int(rng.choice([1, 10, 64]))
+        qs = _vectors(rng, nq, dim, style)
+        qs[0] = m.rows[rng.integers(n)]
+        got = idx.search(qs, k)                                    # the filter path (>= 1 M query-rows) or the exact scan below it
+        monkeypatch.setenv("QV_MFMA_MIN_QUERIES", "1000000")
+        want = idx.search(qs, k)
+        monkeypatch.delenv("QV_MFMA_MIN_QUERIES")
+        assert np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes() and np.array_equal(got[2], want[2]), (seed, step)
+        _compare(m, (got[0][:2], got[1][:2], got[2][:2]), qs[:2], k)
+    idx.close()
