@@ -96,6 +96,6 @@ struct qv_index {
         return v;
     }
     size_t tile_bytes() const { return (size_t)dim4 * 64 * 16; }
-    size_t bf16_tile_bytes() const { return (size_t)((dim4 + 1) / 2) * 64 * 16; }
+    size_t bf16_tile_bytes() const { return (size_t)(((dim4 + 1) / 2 + 1) / 2) * 2 * 64 * 16; }   // whole 16-dim steps (k_bf16_plane's layout)
 };
 

@@ -159,14 +159,14 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
 
 // the filter test on a wave's 64 x 128 scores: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31];
 // a row that may be in some query's top-k goes to that query's candidate list with its score
-template <int METRIC>
-__device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (&acc)[2][4], uint32_t t0, uint32_t t1, const float (&s_c)[4][64], const float (&s_m)[4][64],
+template <int METRIC, int NJ>
+__device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (&acc)[2][NJ], uint32_t t0, uint32_t t1, const float (&s_c)[4][64], const float (&s_m)[4][64],
                                                 uint32_t wave, uint32_t half, uint32_t l31, uint32_t qb64, float tiny_rn,
-                                                const double (&rnd)[4], const uint64_t (&alv)[2],
+                                                const double (&rnd)[NJ], const uint64_t (&alv)[NJ / 2],
                                                 uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
         // epilogue: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31]
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NJ; j++) {
             const uint32_t t = j < 2 ? t0 : t1;
             if (j >= 2 && t1 == t0) continue;
             const uint32_t row = t * 64 + 32 * (j & 1) + l31;
@@ -207,10 +207,12 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
 }
 
 // the group's row norms and alive words, requested before the K loop so that their latency is not the epilogue's
-__device__ __forceinline__ void filter_row_consts(const IndexView& v, uint32_t t0, uint32_t t1, uint32_t l31, double (&rnd)[4], uint64_t (&alv)[2]) {
+template <int NJ>
+__device__ __forceinline__ void filter_row_consts(const IndexView& v, uint32_t t0, uint32_t t1, uint32_t l31, double (&rnd)[NJ], uint64_t (&alv)[NJ / 2]) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) rnd[j] = v.rnorm[(size_t)(j < 2 ? t0 : t1) * 64 + 32 * (j & 1) + l31];
-    alv[0] = v.alive[t0]; alv[1] = v.alive[t1];
+    for (int j = 0; j < NJ; j++) rnd[j] = v.rnorm[(size_t)(j < 2 ? t0 : t1) * 64 + 32 * (j & 1) + l31];
+    alv[0] = v.alive[t0];
+    if constexpr (NJ == 4) alv[1] = v.alive[t1];
 }
 
 // grid: persistent waves; wave g -> query 64-block (g % nqb64), row groups (g / nqb64) + i*stride; a row group = 2 tiles = 128 rows
@@ -696,7 +698,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
     const uint4* ap0 = a0; const uint4* ap1 = a1;
     auto rows_of = [&](uint32_t g_) {                                // 8-dim group `half` of row 32*(wave&1) + l31 of this wave's tile of group g_
         const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
-        return plane + (size_t)(wave < 2 ? ta : tb) * dim8 * 64 + 32 * (wave & 1) + l31 + half * 64;
+        return plane + (size_t)(wave < 2 ? ta : tb) * dim8 * 64 + 64 * (wave & 1) + 32 * half + l31;    // dim8 is even here: dim8 * 64 = steps * 128
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     auto load_b_run = [&](uint4& o) { o = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(lp))); lp += 128; };
@@ -764,7 +766,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
 // workgroup work for the SAME 64 queries, so their one-term operands (steps x 2 KiB: 96 KiB at 768 dimensions) sit in LDS for the
 // whole kernel, and every wave streams its own row groups from the bfloat16 plane straight into B operands — no barrier, no
 // conversion, no query traffic in the loop: one pass over half the bytes.  Dimensions that are a multiple of 64, up to 1024.
-template <int METRIC>
+template <int METRIC, int NB, int R>
 __global__ void __launch_bounds__(512, 1)
 k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                       uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
@@ -787,33 +789,34 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
     __syncthreads();
     const uint32_t half = lane >> 5, l31 = lane & 31;
     const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
-    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    // NB = 4: a row group is two tiles (128 rows), R steps of them in flight; NB = 2: one tile per group and 64 accumulators less, which
+    // buys twice the steps in flight (each wave's requests are what feeds the HBM stream: 4.9 TB/s with 16 KB per wave)
+    const uint32_t n_groups = NB == 4 ? (v.n_tiles + 1) / 2 : v.n_tiles;
     const uint32_t gw = blockIdx.x * 8 + wave, tw = gridDim.x * 8;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int R = 4;                                            // steps of rows in flight
-    uint4 rb[R][4];
-    const uint4* p[4] = {nullptr, nullptr, nullptr, nullptr};
-    auto bases = [&](uint32_t g_, const uint4* (&o)[4]) {            // block j of group g_: rows 32*(j&1) .. +31 of tile 2g + (j >> 1)
-        const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
+    uint4 rb[R][NB];
+    const uint4* p[NB];
+    auto bases = [&](uint32_t g_, const uint4* (&o)[NB]) {           // block j of group g_: rows 32*(j&1) .. +31 of the group's tile j >> 1
+        const uint32_t ta = NB == 4 ? 2 * g_ : g_, tb = (NB == 4 && 2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
 #pragma unroll
-        for (int j = 0; j < 4; j++) o[j] = plane + (size_t)(j < 2 ? ta : tb) * dim8 * 64 + 32 * (j & 1) + l31 + half * 64;
+        for (int j = 0; j < NB; j++) o[j] = plane + (size_t)(j < 2 ? ta : tb) * dim8 * 64 + 64 * (j & 1) + 32 * half + l31;
     };
-    auto load_step = [&](uint4 (&o)[4]) {
+    auto load_step = [&](uint4 (&o)[NB]) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) { o[j] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p[j]))); p[j] += 128; }
+        for (int j = 0; j < NB; j++) { o[j] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p[j]))); p[j] += 128; }
     };
     bool primed = false;
     for (uint32_t g = gw; g < n_groups; g += tw) {
-        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
-        const uint4* nb[4];
+        const uint32_t t0 = NB == 4 ? 2 * g : g, t1 = (NB == 4 && 2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
+        const uint4* nb[NB];
         bases(g + tw < n_groups ? g + tw : g, nb);
-        f16v acc[2][4];
-        double rnd[4]; uint64_t alv[2];
+        f16v acc[2][NB];
+        double rnd[NB]; uint64_t alv[NB / 2];
         filter_row_consts(v, t0, t1, l31, rnd, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < NB; j++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
         if (!primed) {
@@ -828,14 +831,14 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
                 const uint4 a0 = s_a[(st + k) * 128 + lane], a1 = s_a[(st + k) * 128 + 64 + lane];
                 const bf8 ah0 = __builtin_bit_cast(bf8, a0), ah1 = __builtin_bit_cast(bf8, a1);
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < NB; j++) {
                     const bf8 bh = __builtin_bit_cast(bf8, rb[k][j]);
                     acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0][j], 0, 0, 0);
                     acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
                 }
                 if (st + k + R == steps) {                          // the requests from here on are the first steps of this wave's next group
 #pragma unroll
-                    for (int j = 0; j < 4; j++) p[j] = nb[j];
+                    for (int j = 0; j < NB; j++) p[j] = nb[j];
                 }
                 load_step(rb[k]);
             }
@@ -1186,10 +1189,14 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     if (q64) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
         const size_t lds_a = (size_t)fsteps0 * 128 * sizeof(uint4);
-#define QV_FQ(MMM) { e = set_lds(k_bf16rows_filter_q64<MMM>, lds_a); if (e != hipSuccess) return e; \
-                     hipLaunchKernelGGL((k_bf16rows_filter_q64<MMM>), dim3((uint32_t)cus), dim3(512), lds_a, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
+#define QV_FQ1(MMM, NBB, RR) { e = set_lds(k_bf16rows_filter_q64<MMM, NBB, RR>, lds_a); if (e != hipSuccess) return e; \
+                     hipLaunchKernelGGL((k_bf16rows_filter_q64<MMM, NBB, RR>), dim3((uint32_t)cus), dim3(512), lds_a, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
+        // (one tile per group with sixteen steps in flight, <MMM, 2, 16>, and a plane layout with contiguous KiB per request measure the same
+        // 304-315 us at 64 x 1M x 768 as <MMM, 4, 4>: the kernel sits at 4.9-5.0 TB/s whatever each wave keeps in flight)
+#define QV_FQ(MMM) { QV_FQ1(MMM, 4, 4) }
         if (v.metric == QV_COSINE) QV_FQ(QV_COSINE) else if (v.metric == QV_DOT) QV_FQ(QV_DOT) else QV_FQ(QV_L2)
 #undef QV_FQ
+#undef QV_FQ1
     } else if (shared) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
         const uint32_t gs = grid_multiple((uint32_t)cus, nqb64 / 4);      // every row group is walked by nqb64/4 workgroups

@@ -28,7 +28,7 @@ struct IndexView {
     double*   rnorm;
     uint64_t* alive;
     float*    rowmaj;     // may be null
-    uint16_t* bf16;       // may be null: bfloat16 copy of the rows, [tile][ceil(dim/8)][64 rows][8 values] (QV_FLAG_BF16_ROWS)
+    uint16_t* bf16;       // may be null: bfloat16 copy of the rows, [tile][ceil(dim/16)][2 row blocks][2 halves][32 rows][8 values] (QV_FLAG_BF16_ROWS)
     uint32_t  dim;
     uint32_t  dim4;       // ceil(dim/4)
     uint32_t  n_rows;     // rows ever added

@@ -250,7 +250,8 @@ hipError_t launch_distance_pairs(int metric, const float* d_a, const float* d_b,
     return hipGetLastError();
 }
 
-// The bfloat16 copy of tiles [t0, t1] (QV_FLAG_BF16_ROWS): [tile][dim8][64 rows][8 values], value = bf16(float32 row value), round to
+// The bfloat16 copy of tiles [t0, t1] (QV_FLAG_BF16_ROWS): [tile][16-dim step][32-row block][8-dim half][row of the block][8 values] — the
+// 64 lanes of a wave that wants (step, block) as its MFMA B operand read ONE contiguous KiB; value = bf16(float32 row value), round to
 // nearest even — what the batched filter would compute on the fly.  One thread per (tile, 8-dim group, row); refreshed by every
 // launcher that writes rows, on the same stream, so the plane is never behind the tiles.
 __global__ void __launch_bounds__(256)
@@ -267,7 +268,8 @@ k_bf16_plane(IndexView v, uint32_t t0, uint32_t n_tiles) {
         const bf2 p0 = {(__bf16)a.x, (__bf16)a.y}, p1 = {(__bf16)a.z, (__bf16)a.w}, p2 = {(__bf16)b.x, (__bf16)b.y}, p3 = {(__bf16)b.z, (__bf16)b.w};
         uint4 o;
         o.x = __builtin_bit_cast(uint32_t, p0); o.y = __builtin_bit_cast(uint32_t, p1); o.z = __builtin_bit_cast(uint32_t, p2); o.w = __builtin_bit_cast(uint32_t, p3);
-        reinterpret_cast<uint4*>(v.bf16)[((size_t)t * dim8 + c8) * 64 + r] = o;
+        const uint32_t steps8 = (dim8 + 1) / 2;
+        reinterpret_cast<uint4*>(v.bf16)[((((size_t)t * steps8 + (c8 >> 1)) * 2 + (r >> 5)) * 2 + (c8 & 1)) * 32 + (r & 31)] = o;
     }
 }
 static hipError_t refresh_bf16(const IndexView& v, uint32_t t0, uint32_t t1, hipStream_t s) {
