@@ -100,8 +100,132 @@ def quiet_stdout():
         os.dup2(2, 1)
 
 
+MAX_LINE = 4000            # the driver keeps the last 8 KB of stdout: the contract line must fit with room to spare
+
+
+def _r(x, nd=4):
+    """floats rounded to `nd` significant digits (the sidecar keeps full precision)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (nd, x))
+
+
+def _pick(d, keys, nd=4):
+    return {k: _r(d[k], nd) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_also(also, budget):
+    """One or two numbers per extra config (ms or QPS + fraction of its roofline, `same` = identical to the exact scan / oracle);
+    everything else lives in the sidecar.  Entries are shed from the least important end until the text fits `budget` bytes."""
+    c = {}
+    for key, e in also.items():
+        if not isinstance(e, dict):
+            continue
+        short = key.replace("batched_256x", "b256x").replace("_single_query", "").replace("hnsw_1Mx768_", "hnsw_1M_")
+        if "error" in e:
+            c[short] = {"error": str(e["error"])[:60]}
+        elif key.startswith("hnsw_"):
+            o = {}
+            b = e.get("build") or {}
+            if "seconds" in b:
+                o["build_s"] = _r(b["seconds"], 3)
+            srch = e.get("search") or []
+            pick = next((x for x in srch if x.get("ef_search") == 128), srch[-1] if srch else None)
+            if pick:
+                g, sc = pick.get("graph_traversal", {}), pick.get("search_complete", {})
+                o.update({"ef": pick.get("ef_search"), "qps": _r(g.get("qps_device_resident"), 4), "recall10": _r(sc.get("recall_at_10_vs_exact"), 4),
+                          "gather_frac": _r(g.get("gathered_GBps", 0.0) / HBM_PEAK_GBS, 3)})
+            cpu = (e.get("cpu_traversal_same_graph") or {}).get("by_ef") or []
+            cpick = next((x for x in cpu if pick and x.get("ef_search") == pick.get("ef_search")), None)
+            if cpick:
+                o.update({"cpu_qps": _r(cpick.get("qps"), 4), "same": cpick.get("identical_to_device")})
+            c[short] = o
+        elif key == "batched_small_1Mx768":
+            c["b_small_1Mx768_ms"] = {k2.replace("_queries_", "q_").replace("float32", "f32"): _r(v2.get("batch_ms"), 3) for k2, v2 in e.items() if isinstance(v2, dict)}
+        elif key == "pcie_inclusive_single_query":
+            c["pcie_inclusive_qps"] = _r(e.get("qps"), 4)
+        else:
+            o = {}
+            for src, dst in (("batch_ms", "ms"), ("qps", "qps"), ("hbm_frac", "frac"), ("frac_of_f64_matrix_peak", "frac"), ("latency_us", "us"),
+                             ("cpu_port_latency_us_1core", "cpu_us"), ("identical_to_exact_scan", "same"), ("identical_to_oracle", "same")):
+                if e.get(src) is not None and not (src == "qps" and "batch_ms" in e):
+                    o[dst] = _r(e[src], 4)
+            rf = e.get("roofline")
+            if isinstance(rf, dict):
+                o.update({"bound": rf.get("bound"), "kernel_ms": _r(rf.get("kernel_ms"), 4), "frac": _r(rf.get("frac"), 3)})
+                if "end_to_end_frac" in rf:
+                    o["e2e"] = _r(rf["end_to_end_frac"], 3)
+            c[short] = o
+    shed = [k for k in c if "10M" in k] + [k for k in c if k.endswith("_dot")] + ["b_small_1Mx768_ms"] + [k for k in c if "bf16x3" in k] + list(c)
+    dropped = 0
+    while len(json.dumps(c, separators=(",", ":"))) > budget and shed:
+        if c.pop(shed.pop(0), None) is not None:
+            dropped += 1
+    if dropped:
+        c["in_sidecar_only"] = dropped
+    return c
+
+
+def compact_line(out, sidecar=None):
+    """The contract line: headline + roofline + cpu_baseline (two numbers per extra CPU leg) + a compact `also`.  <= MAX_LINE bytes."""
+    line = {k: (_r(v, 6) if isinstance(v, float) else v) for k, v in out.items() if k not in ("also", "cpu_baseline", "roofline", "config")}
+    cfg = dict(out.get("config") or {})
+    for k in list(cfg):
+        if isinstance(cfg[k], str) and len(cfg[k]) > 160:
+            cfg[k] = cfg[k][:157] + "..."
+    line["config"] = cfg
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = {k: (_r(v, 6) if isinstance(v, float) else v) for k, v in rf.items() if v is not None or k == "traffic"}
+        pg = rf.get("per_gpu")
+        if pg:
+            line["roofline"]["per_gpu"] = [{"rank": g["rank"], "ms": _r(g["scan_kernel_ms"], 4), "frac": _r(g["hbm_frac"], 3)} for g in pg]
+    else:
+        line["roofline"] = rf
+    cpu = out.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        cc = {"value": _r(cpu["value"], 5), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": cpu["sample"][:200]}
+        cc["others"] = {k: {"value": _r(v["value"], 5), "cores": v["cores"]} for k, v in (cpu.get("others") or {}).items()}
+        h = cpu.get("host") or {}
+        cc["host"] = _pick(h, ("cpu_model", "nproc", "usable_cores"))
+        line["cpu_baseline"] = cc
+    else:
+        line["cpu_baseline"] = cpu
+    if sidecar:
+        line["full_record"] = sidecar
+
+    def dumps():
+        return json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(dumps()) > MAX_LINE - 200:                      # shrink the descriptive strings before anything measured
+        for k in ("config", "cpu_baseline"):
+            if isinstance(line.get(k), dict):
+                line[k] = {kk: (vv[:80] if isinstance(vv, str) else vv) for kk, vv in line[k].items()}
+    if out.get("also"):                                    # the extras get what is left; the sidecar has all of them
+        line["also"] = compact_also(out["also"], MAX_LINE - len(dumps()) - 16)
+    text = dumps()
+    assert len(text) <= MAX_LINE, len(text)
+    return text
+
+
+def write_sidecar(out):
+    """The full record (every leg of `also`, samples, notes) next to the contract line: gpurun_out/bench_full.json (merged back
+    from the GPU box), or $QV_BENCH_SIDECAR; on failure the record goes to stderr only."""
+    path = os.environ.get("QV_BENCH_SIDECAR") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        sys.stderr.write(json.dumps(out) + "\n")
+        return None
+
+
 def emit(out):
-    line = (json.dumps(out) + "\n").encode()
+    sidecar = write_sidecar(out)
+    line = (compact_line(out, sidecar) + "\n").encode()
     if _REAL_STDOUT is None:
         sys.stdout.write(line.decode()); sys.stdout.flush()
     else:
