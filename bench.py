@@ -326,6 +326,15 @@ def cpu_baseline(dim, k, sample_rows, sample_queries, total_rows, threads):
     }
 
 
+def short_runtime(text):
+    """qv_runtime_info, shortened for the line: versions + the directory each library came from"""
+    import re
+    m = re.match(r"hip_runtime=(\S+) lib=(\S+); rccl=(\S+) lib=(\S+)", text)
+    if not m:
+        return text[:150]
+    return "hip %s (%s), rccl %s (%s)" % (m.group(1), os.path.dirname(m.group(2)), m.group(3), os.path.dirname(m.group(4)))
+
+
 def pmc_traffic(rows_per_gpu, dim):
     """HBM bytes per k_flat_scan launch from the committed rocprofv3 PMC summary, when it was taken on this exact per-GPU
     workload; else None."""
@@ -399,7 +408,7 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         "frac_of_f64_matrix_peak": flop / dtb / 1e12 / MFMA_F64_PEAK_TF, "peak_tflops_measured": MFMA_F64_PEAK_TF}
 
     def mfma_entry(index, label, want_rows, want_dist, rows_n=1_000_000, kernel="bf16x3", plane=False):
-        os.environ["QV_MFMA_FILTER"] = {"bf16x3": "2", "fp32": "1", "bf16x1": "3"}[kernel]   # read by the library per call
+        index.set_filter(kernel)                                # qv_index_set_filter: the index's own choice of filter kernel
         d_flags = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
         index.search_batched_device(d_q.data_ptr(), nqb, k, d_rb.data_ptr(), d_db.data_ptr(), d_flags.data_ptr(), sp)
         torch.cuda.synchronize()
@@ -417,7 +426,7 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         same = bool(np.array_equal(rb[done], want_rows[done]) and np.array_equal(db.view(np.uint32)[done], want_dist.view(np.uint32)[done]))
         mf_ms = msm / max(nm, 1)
         flop = 2.0 * nqb * rows_n * dim
-        os.environ.pop("QV_MFMA_FILTER", None)
+        index.set_filter("auto")
         return {
             "workload": "256 queries x %dx768 %s, k=10 (BASELINE configs[2]): %s filter + exact re-score, device-resident queries and "
                         "results (sample scan, prep, filter, re-score all inside the timed region)"
@@ -576,7 +585,7 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
 def run_abi_sharded(a):
     import torch
     import quiver_amd
-    from quiver_amd.device_index import device_info
+    from quiver_amd.device_index import device_info, runtime_info
     ndev = torch.cuda.device_count()
     G, dim, k = a.gpus, a.dim, a.k
     if ndev < G and not a.peer_copy:
@@ -629,10 +638,19 @@ def run_abi_sharded(a):
     for j in range(min(a.steps, 50)):
         sh.search_device(d_q.data_ptr() + (j % nq_pool) * qsz, 1, k, d_r.data_ptr(), d_d.data_ptr())
     prof = sh.profile_read()
+    # every shard's scan KERNEL (HIP events on the shard's own stream around k_flat_scan): the per-GPU roofline numerators
+    per_gpu = []
+    for g in range(G):
+        ms_g, n_g = sh.profile_read_shard(g)
+        rows_g = sh.shard_info(g)["rows"]
+        kms = ms_g / max(n_g, 1)
+        bytes_g = rows_g * dim * 4 + rows_g * 8
+        per_gpu.append({"rank": g, "rows": rows_g, "scan_kernel_ms": kms, "hbm_frac": (bytes_g / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms > 0 else 0.0})
     sh.profile(False)
     n_local = sh.shard_info(0)["rows"]
     alg_bytes = n_local * dim * 4 + n_local * 8
-    achieved = alg_bytes / (prof["scan_ms"] * 1e-3) / 1e9 if prof["scan_ms"] > 0 else 0.0
+    kern_ms0 = per_gpu[0]["scan_kernel_ms"]
+    achieved = alg_bytes / (kern_ms0 * 1e-3) / 1e9 if kern_ms0 > 0 else 0.0
     info = device_info(devices[0])
     out = {
         "metric": "flat_cosine_qps_recall_1.0", "value": a.steps / dt, "unit": "queries/s", "n_gpus": G, "steps": a.steps, "warmup": a.warmup,
@@ -641,10 +659,11 @@ def run_abi_sharded(a):
                    "rows_total": a.rows, "rows_per_gpu": [sh.shard_info(g)["rows"] for g in range(G)], "dim": dim, "k": k,
                    "sharding": "C ABI qv_sharded_*: ONE process, a shard per device, %s of the per-shard top-k inside libqv, merge on the first device"
                                % ("hipMemcpyPeerAsync (point-to-point)" if a.peer_copy else "ncclAllGather (RCCL)"),
-                   "devices": devices, "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3)},
+                   "devices": devices, "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3), "runtime": short_runtime(runtime_info())},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_flat_scan (first device's shard)", "kernel_ms": prof["scan_ms"], "algorithmic_bytes_per_launch": alg_bytes,
-                     "exchange_ms": prof["exchange_ms"], "merge_and_download_ms": prof["merge_ms"], "launches_timed": prof["searches"]},
+                     "kernel": "k_flat_scan", "kernel_ms": kern_ms0, "algorithmic_bytes_per_launch": alg_bytes, "per_gpu": per_gpu,
+                     "scan_phase_ms": prof["scan_ms"], "allgather_plus_merge_us": (prof["exchange_ms"] + prof["merge_ms"]) * 1e3,
+                     "exchange_us": prof["exchange_ms"] * 1e3, "merge_and_download_us": prof["merge_ms"] * 1e3, "launches_timed": prof["searches"]},
         "cpu_baseline": None, "verified_against_oracle": bool(verified),
     }
     emit(out)
@@ -680,7 +699,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import quiver_amd
-    from quiver_amd.device_index import device_info
+    from quiver_amd.device_index import device_info, runtime_info
     from quiver_amd.sharded import DeviceShard, ShardedFlatSearch, shard_bounds
 
     dim, k, G = a.dim, a.k, world
@@ -822,7 +841,8 @@ def main():
                        "sharding": ("contiguous row shards, one process per GPU, per-shard top-k + all-gather (k*8 B/rank) + deterministic merge; "
                                     "exchange of step i overlaps scan of step i+1") if use_pg else "single shard",
                        "exchange": None if not use_pg else ("RCCL (torch.distributed nccl backend)" if backend == "nccl" else "gloo (ranks share a device: RCCL needs one device per rank)"),
-                       "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3)},
+                       "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3),
+                       "runtime": short_runtime(runtime_info()) if use_pg else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_flat_scan", "kernel_ms": kern_ms, "launches_timed": launches,

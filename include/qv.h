@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define QV_ABI_VERSION 2
+#define QV_ABI_VERSION 3
 
 typedef struct qv_index qv_index; /* opaque; owns device memory */
 
@@ -160,12 +160,22 @@ int qv_index_search_negative(qv_index* idx, const float* query, const float* neg
                              uint32_t* rows_out, float* dist_out, float* neg_dist_out, uint32_t* count_out);
 
 /* Batched-query path: approximate scores by a GEMM on the matrix cores with a proven error margin (one bfloat16 MFMA
- * term up to 1536 dimensions, three exact-product bfloat16 terms above or with QV_MFMA_FILTER=2; the fp32 MFMA chain
- * with QV_MFMA_FILTER=1) and
+ * term up to 1536 dimensions, three exact-product bfloat16 terms above; qv_index_set_filter chooses otherwise) and
  * fused per-tile candidate selection, then exact re-scoring of the candidates with the same arithmetic as
  * qv_index_search, so results are identical to it.  Same arguments as qv_index_search. */
 int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                             uint32_t* rows_out, float* dist_out, uint32_t* count_out);
+
+/* Which filter kernel the batched path of this index uses: QV_FILTER_AUTO (the rule above), QV_FILTER_FP32_MFMA (the dense
+ * fp32 GEMM on v_mfma_f32_32x32x2_f32, BASELINE configs[2] as written), QV_FILTER_BF16X3, QV_FILTER_BF16X1.  Results are
+ * identical whichever runs (the filter only selects candidates for the exact re-score).  Needs external exclusion against
+ * running searches, like the mutations.  The environment variable QV_MFMA_FILTER (read once per process) sets the default of
+ * indexes that never call this. */
+#define QV_FILTER_AUTO      0
+#define QV_FILTER_FP32_MFMA 1
+#define QV_FILTER_BF16X3    2
+#define QV_FILTER_BF16X1    3
+int qv_index_set_filter(qv_index* idx, int filter);
 
 /* Device-pointer form of the batched path: enqueues on `stream`, no sync.  d_redo_flags_out[nq]
  * (uint32) is set to 1 for queries whose candidate buffer overflowed: the caller must redo those
@@ -186,6 +196,13 @@ int qv_distance_rows_device(qv_index* idx, const float* d_query, const uint32_t*
  * independent pairs a[i], b[i] (each [dim]); computed on the device `device`. */
 int qv_distance_pairs(qv_metric metric, const float* a, const float* b, uint32_t n, uint32_t dim,
                       float* dist_out, int device);
+
+/* The DistanceFunc contract for ONE pair, on the HOST: what a Go `vectortypes.DistanceFunc` wrapper calls
+ * (surface.go:8; 78 ns per call in the reference, final_bench.txt:47 — no device round trip can serve a per-pair call).  Same
+ * arithmetic, bit for bit, as qv_distance_pairs and the scans: it is the kernels' own per-pair routine compiled for the CPU.
+ * Not a fallback: no search, scan or batch entry point uses it, and those fail without a GPU.  The length check (the reference
+ * panics on len(a) != len(b), distances.go:13-15) stays in the host-language wrapper, which knows both lengths. */
+int qv_distance_pair(qv_metric metric, const float* a, const float* b, uint32_t dim, float* out);
 
 /* Deterministic merge of per-shard top-k lists (the exchange step of the sharded flat
  * scan: every rank all-gathers its k (distance, global row) pairs over RCCL, then
@@ -280,19 +297,27 @@ int qv_graph_stats(const qv_graph* g, double* build_seconds, uint64_t* build_bat
 
 /* ---- one corpus over the GPUs of a node --------------------------------
  * No reference counterpart (the reference is one process on CPU cores): this is what lets the Go host reach all the
- * GPUs of a node through ONE handle — what core.Index is for one GPU (qv_index), qv_sharded is for n.  One host
- * process; devices[g] holds shard g (an exact index of its own) and runs its flat scan on its own stream; ONE RCCL
- * all-gather per search carries every shard's top-k (nq*k*8 bytes per shard, over xGMI between the GPUs of a node:
- * a latency collective); the merge on the first device orders by (distance, global row) like a single index.
+ * GPUs of a node through ONE handle — what core.Index (pkg/core/collection.go:78-96) is for one GPU (qv_index),
+ * qv_sharded is for n, with the same surface: add / remove / update / get / search with any k / filtered search /
+ * search with a negative example / listed-row distances.  One host process; devices[g] holds shard g (an exact index
+ * of its own) and runs its flat scan on a stream of its own; ONE RCCL all-gather per search carries every shard's
+ * result list (nq*k*8 bytes per shard for a top-k, over xGMI between the GPUs of a node: a latency collective); the merge
+ * on the first device orders by (distance, global row) like a single index.
  *   global row ids   shard g owns [g * span, (g+1) * span), span = qv_sharded_span(n): "global row = shard base +
  *                    local row" without knowing the corpus size up front; ids are stable as shards grow
  *   qv_sharded_add   cuts a batch into one contiguous piece per shard so that the shards' fill evens out
- *                    (qv_sharded_plan_add is the rule); global_rows_out[i] = id of rows[i] (the host maps string ids)
- *   k <= 64          (the fused top-k width); larger k is QV_ERR_UNSUPPORTED — a filtered search ranks per shard
+ *                    (qv_sharded_plan_add is the rule); global_rows_out[i] = id of rows[i] (the host maps string ids);
+ *                    all-or-nothing like qv_index_add
+ *   any k            k <= 64: per-shard fused top-k + one wavefront-list merge.  k > 64 (a filtered Collection.Search asks
+ *                    for k = Index.Size(), collection.go:679-682): every shard ranks its rows (radix sort), the sorted runs
+ *                    are exchanged and one stable radix sort on the first device merges them
  *   flags            QV_FLAG_ROWMAJOR and QV_FLAG_BF16_ROWS pass through to the shards; QV_SHARDED_PEER_COPY replaces the collective with
  *                    point-to-point copies into the first device (and lets several shards share one device, which
- *                    RCCL does not allow: how the tests exercise 3 shards on a 1-GPU box)
- * Threading: one call at a time per handle (internal mutex); different handles are independent. */
+ *                    RCCL does not allow: how the tests exercise 3 and 8 shards on a 1-GPU box)
+ * Threading: as qv_index — searches, qv_sharded_distance_rows and qv_sharded_get_row(s) may run concurrently from many
+ * threads (the reference searches under a read lock, collection.go:647): every call works in a context of its own
+ * (streams, staging and exchange buffers from a pool); add / remove / update / reserve take the handle exclusively
+ * (they wait for running searches); destroy needs external exclusion. */
 typedef struct qv_sharded qv_sharded;
 #define QV_SHARDED_PEER_COPY (1ull << 32)
 uint32_t qv_sharded_span(int n_shards);
@@ -301,6 +326,7 @@ int qv_sharded_create(qv_sharded** out, uint32_t dim, qv_metric metric, const in
 void qv_sharded_destroy(qv_sharded* s);
 int qv_sharded_shards(const qv_sharded* s);
 uint64_t qv_sharded_size(const qv_sharded* s);                 /* live rows over all shards */
+uint64_t qv_sharded_rows(const qv_sharded* s);                 /* rows ever added over all shards (tombstones included) */
 uint32_t qv_sharded_dim(const qv_sharded* s);
 int qv_sharded_shard_info(const qv_sharded* s, int shard, int* device, uint32_t* base_row, uint32_t* rows, uint32_t* live);
 int qv_sharded_reserve(qv_sharded* s, uint64_t rows_total);
@@ -308,25 +334,54 @@ int qv_sharded_add(qv_sharded* s, const float* rows, uint32_t n, uint32_t* globa
 /* n synthetic rows (the generator of qv_index_add_synthetic), shard g taking the contiguous block [g*n/G, (g+1)*n/G) */
 int qv_sharded_add_synthetic(qv_sharded* s, uint64_t seed, uint64_t gen_row0, uint64_t n);
 int qv_sharded_remove(qv_sharded* s, const uint32_t* global_rows, uint32_t n);
-/* Same contract as qv_index_search (check order, clamping, padding, ordering); rows_out holds global row ids. */
+/* qv_index_update / qv_index_get_row / qv_index_get_rows on the shard that owns the row (Collection.Update,
+ * pkg/core/collection.go:417-465; hybrid_index.go:537 reads idx.vectors[id]) */
+int qv_sharded_update(qv_sharded* s, uint32_t global_row, const float* vec);
+int qv_sharded_get_row(qv_sharded* s, uint32_t global_row, float* vec_out);
+int qv_sharded_get_rows(qv_sharded* s, const uint32_t* global_rows, uint32_t n, float* out /* [n][dim] */);
+/* Same contract as qv_index_search (check order, clamping, padding, ordering, any k); rows_out holds global row ids. */
 int qv_sharded_search(qv_sharded* s, const float* queries, uint32_t nq, uint32_t k, uint32_t* rows_out, float* dist_out, uint32_t* count_out);
-/* Queries and results resident on the FIRST device; everything is enqueued (no host synchronisation); `stream` (a
- * stream of the first device, may be null) is ordered before and after the search. */
+/* qv_index_search_masked over the shards.  The candidates are LISTED (n_selected global row ids, any order, duplicates
+ * allowed) rather than given as a bitmap, because global row ids are sparse (one id range per shard); dead rows in the list
+ * are ignored; an id outside every shard is QV_ERR_OUT_OF_RANGE.  count_out[q] = min(k, live selected rows). */
+int qv_sharded_search_masked(qv_sharded* s, const float* queries, uint32_t nq, uint32_t k, const uint32_t* selected_global_rows, uint32_t n_selected,
+                             uint32_t* rows_out, float* dist_out, uint32_t* count_out);
+/* qv_index_search_negative over the shards (hybrid_index.go:517-570): every shard also evaluates distance(row, negative)
+ * for its own k_fetch candidates before the exchange, so the merged list carries both distances after ONE exchange. */
+int qv_sharded_search_negative(qv_sharded* s, const float* query, const float* negative, uint32_t k_fetch,
+                               uint32_t* rows_out, float* dist_out, float* neg_dist_out, uint32_t* count_out);
+/* qv_distance_rows with global row ids: every shard evaluates the rows it owns, all shards in flight together. */
+int qv_sharded_distance_rows(qv_sharded* s, const float* query, const uint32_t* global_rows, uint32_t n, float* dist_out);
+/* Queries and results resident on the FIRST device.  The work is enqueued on the handle's own streams and ordered after
+ * what `stream` (a stream of the first device; null = the null stream, as in qv_index_search_device) held at the call and
+ * before anything `stream` runs afterwards; there is no host synchronisation for nq <= 8.  Batches (nq >= 9) that go
+ * through the matrix-core filter are SYNCHRONOUS per shard: the filter's hand-back flags are read on the host to redo
+ * those queries with the exact scan, so such a call cannot be captured into a graph.  Any k. */
 int qv_sharded_search_device(qv_sharded* s, const float* d_queries, uint32_t nq, uint32_t k, uint32_t* d_rows_out, float* d_dist_out, void* stream);
-int qv_sharded_sync(qv_sharded* s);                            /* wait for every shard's stream */
+int qv_sharded_sync(qv_sharded* s);                            /* wait for every stream of the handle */
 /* Measurement aid: with profiling on, every search is synchronous and its phases are timed with HIP events on the first
- * device's stream: its own scan, the exchange (incl. waiting for the slowest shard), merge + download. */
+ * device's stream: its own scan, the exchange (incl. waiting for the slowest shard), merge + download; and every shard's
+ * scan KERNEL is bracketed by events on its own stream (qv_index_profile): qv_sharded_profile_read_shard returns the summed
+ * kernel time and launch count of one shard since the last read — the per-GPU roofline numerator. */
+int qv_sharded_set_filter(qv_sharded* s, int filter);          /* qv_index_set_filter on every shard */
 int qv_sharded_profile(qv_sharded* s, int enable);
 int qv_sharded_profile_read(qv_sharded* s, double* scan_ms_sum, double* exchange_ms_sum, double* merge_ms_sum, uint64_t* searches);
+int qv_sharded_profile_read_shard(qv_sharded* s, int shard, double* scan_kernel_ms_sum, uint64_t* launches);
 
 /* Copy row `row` back to the host (ExactIndex keeps vectors readable,
  * hybrid_index.go:537 reads idx.vectors[id] for the re-rank). */
 int qv_index_get_row(qv_index* idx, uint32_t row, float* vec_out);
+/* n rows in one device pass (ArrowHNSWIndex.Save writes every vector, index/arrow_hnsw.go:138-198): out = [n][dim] */
+int qv_index_get_rows(qv_index* idx, const uint32_t* rows, uint32_t n, float* out);
 
 /* ---- misc ----------------------------------------------------------------------- */
 const char* qv_last_error(void);          /* thread-local */
 int         qv_abi_version(void);
 int         qv_device_count(void);
+/* One line naming the HIP runtime and the RCCL this process bound (version + file): "hip_runtime=7.2.x lib=...; rccl=2.27.7
+ * lib=...".  Both resolve by soname to whatever the process loaded first (PyTorch bundles its own pair); qv_sharded_create
+ * refuses an RCCL exchange when the two come from different installations.  For reports of multi-GPU runs. */
+int         qv_runtime_info(char* out, size_t cap);
 /* Timing of the last qv_index_search_device-style launch is the caller's business
  * (HIP events on its stream); this returns static facts for reports. */
 int         qv_device_info(int device, char* name_out, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);

@@ -8,6 +8,6 @@ mirrors of the reference's host interfaces for this path (``hybrid``, ``hnsw``,
 the Go packages they stand in for.
 """
 from ._lib import QvError, lib, load_library, METRICS, metric_id  # noqa: F401
-from .device_index import DeviceIndex, DeviceGraph, ShardedIndex  # noqa: F401
+from .device_index import DeviceIndex, DeviceGraph, GraphReplicas, ShardedIndex  # noqa: F401
 
-__all__ = ["QvError", "lib", "load_library", "METRICS", "metric_id", "DeviceIndex", "DeviceGraph", "ShardedIndex"]
+__all__ = ["QvError", "lib", "load_library", "METRICS", "metric_id", "DeviceIndex", "DeviceGraph", "GraphReplicas", "ShardedIndex"]

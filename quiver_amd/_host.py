@@ -19,7 +19,7 @@ _SIGS = {
     "qvh_results_many_count": (_i, [_vp]), "qvh_results_many_len": (_i, [_vp, _i]),
     "qvh_results_many_id": (_cp, [_vp, _i, _i]), "qvh_results_many_distance": (_f, [_vp, _i, _i]),
     "qvh_results_many_strategy": (_cp, [_vp, _i]),
-    "qvh_exact_new": (_vp, [_i, _i]), "qvh_exact_free": (None, [_vp]),
+    "qvh_exact_new": (_vp, [_i, _i]), "qvh_exact_new_placed": (_vp, [_i, _vp, _i, _i, _i]), "qvh_exact_free": (None, [_vp]),
     "qvh_exact_insert": (_i, [_vp, _cp, _vp, _u32]), "qvh_exact_delete": (_i, [_vp, _cp]),
     "qvh_exact_search": (_i, [_vp, _vp, _u32, _i, _vp]), "qvh_exact_size": (_i, [_vp]), "qvh_exact_device_rows": (_u32, [_vp]),
     "qvh_hnsw_insert_batch": (_i, [_vp, C.POINTER(_cp), _vp, _u32, _u32, _u32, _u32]), "qvh_hnsw_built_on_device": (_i, [_vp]),
@@ -38,6 +38,7 @@ _SIGS = {
     "qvh_adapter_search": (_i, [_vp, _vp, _u32, _i, _vp]),
     "qvh_adapter_search_negative": (_i, [_vp, _vp, _u32, _vp, _u32, _f, _i, _vp]), "qvh_adapter_size": (_i, [_vp]),
     "qvh_hybrid_new": (_vp, [_i, _i, _i, _i, _i, _i, _i, C.c_double, C.c_uint64]), "qvh_hybrid_free": (None, [_vp]),
+    "qvh_hybrid_new_placed": (_vp, [_i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.c_double, C.c_uint64]),
     "qvh_hybrid_insert": (_i, [_vp, _cp, _vp, _u32]),
     "qvh_hybrid_insert_batch": (_i, [_vp, C.POINTER(_cp), _vp, _vp, _u32]),
     "qvh_hybrid_delete": (_i, [_vp, _cp]), "qvh_hybrid_delete_batch": (_i, [_vp, C.POINTER(_cp), _u32]),

@@ -62,9 +62,12 @@ PROTOTYPES = {
     "qv_index_search_batched_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_distance_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qv_distance_rows_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "qv_distance_pair": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, _f32p]),
     "qv_distance_pairs": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]),
     "qv_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_merge_topk_shards_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qv_index_set_filter": (C.c_int, [C.c_void_p, C.c_int]),
+    "qv_sharded_set_filter": (C.c_int, [C.c_void_p, C.c_int]),
     "qv_index_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "qv_index_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "qv_graph_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -92,15 +95,25 @@ PROTOTYPES = {
     "qv_sharded_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qv_sharded_add_synthetic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "qv_sharded_remove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "qv_sharded_rows": (C.c_uint64, [C.c_void_p]),
+    "qv_sharded_update": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "qv_sharded_get_row": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "qv_sharded_get_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "qv_sharded_search_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qv_sharded_search_negative": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, _u32p]),
+    "qv_sharded_distance_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "qv_sharded_profile_read_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "qv_sharded_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_sharded_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_sharded_sync": (C.c_int, [C.c_void_p]),
     "qv_sharded_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "qv_sharded_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "qv_index_get_row": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "qv_index_get_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "qv_last_error": (C.c_char_p, []),
     "qv_abi_version": (C.c_int, []),
     "qv_device_count": (C.c_int, []),
+    "qv_runtime_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "qv_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
 }
 

@@ -116,7 +116,7 @@ class ArrowFlatIndex:
 
     def Save(self, path: str) -> None:                         # arrow_hnsw.go:138-198
         n = self._idx.rows()
-        vecs = np.stack([self._idx.get_row(i) for i in range(n)]) if n else np.zeros((0, self.dim), np.float32)
+        vecs = self._idx.get_rows(np.arange(n, dtype=np.uint32)) if n else np.zeros((0, self.dim), np.float32)   # one device pass (qv_index_get_rows)
         save_ipc(path, self.idxToID, vecs)
 
     def Load(self, path: str) -> None:                         # arrow_hnsw.go:201-241
@@ -170,5 +170,8 @@ class Graph:
         if n == 0 or k <= 0:
             return []
         k = min(k, n)                                              # :478-480
-        rows, _, count = self._idx.search(q.astype(np.float32), k)  # exhaustiveSearch (:490-506): every node, nearest k
+        q32 = q.astype(np.float32)
+        if not np.array_equal(q32.astype(np.float64), q):          # the same rule AddBatch applies: refused, never rounded
+            raise ValueError("query vector is not float32-representable (device arithmetic starts from float32 values)")
+        rows, _, count = self._idx.search(q32, k)                  # exhaustiveSearch (:490-506): every node, nearest k
         return [self._ids[int(rows[0, i])] for i in range(int(count[0]))]

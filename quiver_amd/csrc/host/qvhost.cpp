@@ -30,17 +30,50 @@ inline double rng_float64(uint64_t* s) { return (double)(sm64_next(s) >> 11) * (
 
 }  // namespace
 
+// --------------------------------------------------------------- RowStore ------------
+
+int RowStore::create(uint32_t dim, qv_metric metric, const Placement& w) {
+    const uint64_t flags = w.bf16_rows ? QV_FLAG_BF16_ROWS : QV_FLAG_NONE;
+    if (!w.sharded()) return qv_index_create(&one_, dim, metric, w.first(), flags);
+    return qv_sharded_create(&many_, dim, metric, w.devices.data(), (int)w.devices.size(), flags | (w.peer_copy ? QV_SHARDED_PEER_COPY : 0));
+}
+void RowStore::destroy() {
+    if (one_) qv_index_destroy(one_);
+    if (many_) qv_sharded_destroy(many_);
+    one_ = nullptr; many_ = nullptr;
+}
+int RowStore::add(const float* rows, uint32_t n, uint32_t* rows_out) {
+    if (many_) return qv_sharded_add(many_, rows, n, rows_out);
+    uint32_t first = 0;
+    const int rc = qv_index_add(one_, rows, n, &first);
+    if (rc == QV_OK) for (uint32_t i = 0; i < n; i++) rows_out[i] = first + i;
+    return rc;
+}
+int RowStore::update(uint32_t row, const float* v) { return many_ ? qv_sharded_update(many_, row, v) : qv_index_update(one_, row, v); }
+int RowStore::remove(const uint32_t* rows, uint32_t n) { return many_ ? qv_sharded_remove(many_, rows, n) : qv_index_remove(one_, rows, n); }
+int RowStore::search(const float* qs, uint32_t nq, uint32_t k, uint32_t* rows, float* dist, uint32_t* count) {
+    if (many_) return qv_sharded_search(many_, qs, nq, k, rows, dist, count);     // batches take the matrix-core filter per shard by themselves
+    // nq > 1: the batched entry point (MFMA filter + exact re-score when it pays, exact multi-query scan otherwise)
+    return nq > 1 ? qv_index_search_batched(one_, qs, nq, k, rows, dist, count) : qv_index_search(one_, qs, nq, k, rows, dist, count);
+}
+int RowStore::search_negative(const float* q, const float* neg, uint32_t k_fetch, uint32_t* rows, float* dist, float* neg_dist, uint32_t* count) {
+    return many_ ? qv_sharded_search_negative(many_, q, neg, k_fetch, rows, dist, neg_dist, count)
+                 : qv_index_search_negative(one_, q, neg, k_fetch, rows, dist, neg_dist, count);
+}
+int RowStore::distance_rows(const float* q, const uint32_t* rows, uint32_t n, float* out) {
+    return many_ ? qv_sharded_distance_rows(many_, q, rows, n, out) : qv_distance_rows(one_, q, rows, n, out);
+}
+uint64_t RowStore::rows() const { return many_ ? qv_sharded_rows(many_) : (one_ ? qv_index_rows(one_) : 0); }
+
 // =============================================================== ExactIndex ==========
 
-ExactIndex::ExactIndex(qv_metric metric, int device) : metric_(metric), device_(device) {}
-ExactIndex::~ExactIndex() { if (h_) qv_index_destroy(h_); }
+ExactIndex::ExactIndex(qv_metric metric, const Placement& where) : metric_(metric), where_(where) {}
+ExactIndex::~ExactIndex() {}
 
 Error ExactIndex::insertLocked(const std::string& id, const float* v, uint32_t len) {
     if (dim_ == 0) {                                                   // exact.go:43-44 dimension lock-in
         if (len == 0) return "vector dimension mismatch: expected >0, got 0";
-        // QV_BF16_ROWS=1: the exact index also keeps the bfloat16 copy of its rows that BatchSearch's filter reads (+50 % device memory)
-        const char* bf = getenv("QV_BF16_ROWS");
-        if (qv_index_create(&h_, len, metric_, device_, bf && atoi(bf) == 1 ? QV_FLAG_BF16_ROWS : QV_FLAG_NONE) != QV_OK) return qv_err();
+        if (h_.create(len, metric_, where_) != QV_OK) return qv_err();
         dim_ = (int)len;
     } else if ((int)len != dim_) {
         return fmt("vector dimension mismatch: expected %d, got %u", dim_, len);      // exact.go:45-47
@@ -49,11 +82,10 @@ Error ExactIndex::insertLocked(const std::string& id, const float* v, uint32_t l
     uint32_t row = 0;
     if (!free_rows_.empty()) {                                         // a deleted entry's slot is reused (the reference's map frees it, exact.go:65):
         row = free_rows_.back();                                       // storage, HBM and scan time stay bounded under insert/delete churn
-        if (qv_index_update(h_, row, v) != QV_OK) return qv_err();     // overwrites the row in place and marks it live
+        if (h_.update(row, v) != QV_OK) return qv_err();               // overwrites the row in place and marks it live
         free_rows_.pop_back();
-    } else if (qv_index_add(h_, v, 1, &row) != QV_OK) return qv_err(); // copies (exact.go:53-56)
+    } else if (h_.add(v, 1, &row) != QV_OK) return qv_err();           // copies (exact.go:53-56)
     row_of_[id] = row;
-    if (id_of_.size() <= row) id_of_.resize(row + 1);
     id_of_[row] = id;
     return "";
 }
@@ -81,14 +113,13 @@ Error ExactIndex::InsertMany(const std::vector<std::string>& ids, const float* p
     }
     if (i < ids.size()) {                                              // the rest: one device copy
         const uint32_t n = (uint32_t)(ids.size() - i);
-        uint32_t first = 0;
-        if (qv_index_add(h_, packed + i * (size_t)len, n, &first) != QV_OK) {
+        std::vector<uint32_t> rows(n);
+        if (h_.add(packed + i * (size_t)len, n, rows.data()) != QV_OK) {
             Error e = qv_err();
             for (size_t j = 0; j < i; j++) (void)deleteLocked(ids[j]);
             return failed(ids[i], e);
         }
-        if (id_of_.size() < (size_t)first + n) id_of_.resize((size_t)first + n);
-        for (uint32_t j = 0; j < n; j++) { row_of_[ids[i + j]] = first + j; id_of_[first + j] = ids[i + j]; }
+        for (uint32_t j = 0; j < n; j++) { row_of_[ids[i + j]] = rows[j]; id_of_[rows[j]] = ids[i + j]; }
     }
     return "";
 }
@@ -97,13 +128,13 @@ Error ExactIndex::deleteLocked(const std::string& id) {
     auto it = row_of_.find(id);
     if (it != row_of_.end()) {                                         // exact.go:65 delete(map, id): absent id is not an error
         uint32_t row = it->second;
-        if (qv_index_remove(h_, &row, 1) != QV_OK) return qv_err();
-        id_of_[row].clear();
+        if (h_.remove(&row, 1) != QV_OK) return qv_err();
+        id_of_.erase(row);
         row_of_.erase(it);
         free_rows_.push_back(row);
     }
-    if (row_of_.empty() && h_) {                                       // exact.go:66-68 reset the dimension when empty
-        qv_index_destroy(h_); h_ = nullptr; dim_ = 0; id_of_.clear(); free_rows_.clear();
+    if (row_of_.empty() && h_.live()) {                                // exact.go:66-68 reset the dimension when empty
+        h_.destroy(); dim_ = 0; id_of_.clear(); free_rows_.clear();
     }
     return "";
 }
@@ -113,7 +144,7 @@ Error ExactIndex::Delete(const std::string& id) {
     return deleteLocked(id);
 }
 
-uint32_t ExactIndex::DeviceRows() const { std::shared_lock<std::shared_mutex> l(mu_); return h_ ? qv_index_rows(h_) : 0; }
+uint32_t ExactIndex::DeviceRows() const { std::shared_lock<std::shared_mutex> l(mu_); return (uint32_t)h_.rows(); }
 
 Error ExactIndex::SearchMany(const float* qs, uint32_t len, uint32_t nq, int k, std::vector<std::vector<BasicSearchResult>>* out) {
     out->assign(nq, {});
@@ -124,13 +155,11 @@ Error ExactIndex::SearchMany(const float* qs, uint32_t len, uint32_t nq, int k, 
     uint32_t kk = (uint32_t)std::min<size_t>((size_t)k, row_of_.size());   // :109-111
     std::vector<uint32_t> rows((size_t)nq * kk), count(nq);
     std::vector<float> dist((size_t)nq * kk);
-    // nq > 1: the batched entry point (MFMA filter + exact re-score when it pays, exact multi-query scan otherwise)
-    if ((nq > 1 ? qv_index_search_batched(h_, qs, nq, kk, rows.data(), dist.data(), count.data())
-                : qv_index_search(h_, qs, nq, kk, rows.data(), dist.data(), count.data())) != QV_OK) return qv_err();
+    if (h_.search(qs, nq, kk, rows.data(), dist.data(), count.data()) != QV_OK) return qv_err();
     for (uint32_t q = 0; q < nq; q++) {
         auto& o = (*out)[q];
         o.reserve(count[q]);
-        for (uint32_t i = 0; i < count[q]; i++) o.push_back({id_of_[rows[(size_t)q * kk + i]], dist[(size_t)q * kk + i]});
+        for (uint32_t i = 0; i < count[q]; i++) o.push_back({id_of_.at(rows[(size_t)q * kk + i]), dist[(size_t)q * kk + i]});
     }
     return "";
 }
@@ -152,8 +181,8 @@ Error ExactIndex::SearchWithNegativeDistances(const float* q, const float* neg, 
     if (retrieveK <= 0) return "k must be positive";                   // :104-106
     const uint32_t kk = (uint32_t)std::min<size_t>((size_t)retrieveK, row_of_.size());
     std::vector<uint32_t> rows(kk); std::vector<float> d(kk), nd(kk); uint32_t cnt = 0;
-    if (qv_index_search_negative(h_, q, neg, kk, rows.data(), d.data(), nd.data(), &cnt) != QV_OK) return qv_err();
-    for (uint32_t i = 0; i < cnt; i++) { out->push_back({id_of_[rows[i]], d[i]}); neg_out->push_back(nd[i]); }
+    if (h_.search_negative(q, neg, kk, rows.data(), d.data(), nd.data(), &cnt) != QV_OK) return qv_err();
+    for (uint32_t i = 0; i < cnt; i++) { out->push_back({id_of_.at(rows[i]), d[i]}); neg_out->push_back(nd[i]); }
     return "";
 }
 
@@ -170,7 +199,7 @@ Error ExactIndex::DistancesTo(const float* other, uint32_t len, const std::vecto
     }
     // distFunc(vector, negExample) (hybrid_index.go:543): every metric here is symmetric in its
     // value AND in its bits (products and |differences| commute; sqrt(ma)*sqrt(mb) commutes)
-    if (qv_distance_rows(h_, other, rows.data(), (uint32_t)rows.size(), out->data()) != QV_OK) return qv_err();
+    if (h_.distance_rows(other, rows.data(), (uint32_t)rows.size(), out->data()) != QV_OK) return qv_err();
     return "";
 }
 
@@ -452,18 +481,17 @@ Error HNSW::InsertBatch(const std::vector<std::string>& ids, const float* packed
     Error e = ensureIndex(len);
     if (!e.empty()) return e;
     const uint32_t n = (uint32_t)ids.size(), first = (uint32_t)nodes_.size();
+    // the graph under construction exists BEFORE any row is added: a failed allocation here leaves nothing to roll back
+    // (device rows and nodes_ stay in step, so later Inserts keep working)
+    if (!bg_ && qv_graph_create_empty(&bg_, h_, std::max<uint32_t>(first + n, 1024u), (uint32_t)M_, (uint32_t)maxM0_, (uint32_t)efC_) != QV_OK) {
+        bg_ = nullptr;
+        return qv_err();
+    }
     uint32_t row0 = 0;
     if (qv_index_add(h_, packed, n, &row0) != QV_OK) return qv_err();  // :281-282 copies; device row == node index
     if (row0 != first) return "internal: device row and node index diverged";
     std::vector<int8_t> levels(n);
     for (uint32_t i = 0; i < n; i++) levels[i] = (int8_t)RandomLevel();    // :275, in node order
-    if (!bg_ && qv_graph_create_empty(&bg_, h_, std::max<uint32_t>(first + n, 1024u), (uint32_t)M_, (uint32_t)maxM0_, (uint32_t)efC_) != QV_OK) {
-        Error ge = qv_err();
-        std::vector<uint32_t> rows(n); for (uint32_t i = 0; i < n; i++) rows[i] = first + i;
-        (void)qv_index_remove(h_, rows.data(), n);
-        bg_synced_ = false;
-        return ge;
-    }
     // The device graph always starts from a live node.  When EntryPoint names a deleted node the reference keeps it (Delete finds
     // no replacement, hnsw.go:803-827) and every connectNode / Search walks from the first live node instead (:355-363, :621-629)
     // — which is the entry the uploaded graph carries.  Unless the build itself moves the entry point (a node above CurrentLevel,
@@ -854,7 +882,7 @@ static int avg_dim(const std::vector<int>& d) {                        // hybrid
 }
 
 HybridIndex::HybridIndex(const HybridConfig& c)
-    : cfg_(c), exact_(c.metric, c.device), hnsw_(c.metric, c.device, c.hnsw), exact_threshold_(c.exact_threshold), rng_(c.seed) {}
+    : cfg_(c), exact_(c.metric, c.placement), hnsw_(c.metric, c.placement.first(), c.hnsw), exact_threshold_(c.exact_threshold), rng_(c.seed) {}
 
 std::string HybridIndex::SelectStrategy(int vectorCount, int dimension, int k) {   // adaptive.go:41-72
     {
@@ -1082,7 +1110,11 @@ float qvh_results_many_distance(void* r, int q, int i) { return static_cast<Resu
 const char* qvh_results_many_strategy(void* r, int q) { return static_cast<Results*>(r)->used[q].c_str(); }
 
 // ---- ExactIndex
-void* qvh_exact_new(int metric, int device) { return new ExactIndex((qv_metric)metric, device); }
+void* qvh_exact_new(int metric, int device) { return new ExactIndex((qv_metric)metric, Placement(device)); }
+// the same index over a device list (one row shard per entry); peer_copy: point-to-point exchange (shards may share a device)
+void* qvh_exact_new_placed(int metric, const int* devices, int n_devices, int peer_copy, int bf16_rows) {
+    return new ExactIndex((qv_metric)metric, Placement(std::vector<int>(devices, devices + n_devices), peer_copy != 0, bf16_rows != 0));
+}
 void qvh_exact_free(void* p) { delete static_cast<ExactIndex*>(p); }
 int qvh_exact_insert(void* p, const char* id, const float* v, uint32_t len) { return ret(static_cast<ExactIndex*>(p)->Insert(id, v, len)); }
 int qvh_exact_delete(void* p, const char* id) { return ret(static_cast<ExactIndex*>(p)->Delete(id)); }
@@ -1160,8 +1192,15 @@ int qvh_adapter_search_negative(void* p, const float* q, uint32_t len, const flo
 int qvh_adapter_size(void* p) { return static_cast<HNSWAdapter*>(p)->Size(); }
 
 // ---- HybridIndex
+void* qvh_hybrid_new_placed(int metric, const int* devices, int n_devices, int peer_copy, int bf16_rows, int M, int maxM0, int efC, int efS,
+                            int exact_threshold, double exploration, uint64_t seed) {
+    HybridConfig c; c.metric = (qv_metric)metric; c.placement = Placement(std::vector<int>(devices, devices + n_devices), peer_copy != 0, bf16_rows != 0);
+    c.hnsw.M = M; c.hnsw.MaxM0 = maxM0; c.hnsw.EfConstruction = efC; c.hnsw.EfSearch = efS;
+    c.hnsw.seed = seed; c.exact_threshold = exact_threshold; c.exploration_factor = exploration; c.seed = seed ^ 0xA5A5A5A5ull;
+    return new HybridIndex(c);
+}
 void* qvh_hybrid_new(int metric, int device, int M, int maxM0, int efC, int efS, int exact_threshold, double exploration, uint64_t seed) {
-    HybridConfig c; c.metric = (qv_metric)metric; c.device = device; c.hnsw.M = M; c.hnsw.MaxM0 = maxM0; c.hnsw.EfConstruction = efC; c.hnsw.EfSearch = efS;
+    HybridConfig c; c.metric = (qv_metric)metric; c.placement = Placement(device); c.hnsw.M = M; c.hnsw.MaxM0 = maxM0; c.hnsw.EfConstruction = efC; c.hnsw.EfSearch = efS;
     c.hnsw.seed = seed; c.exact_threshold = exact_threshold; c.exploration_factor = exploration; c.seed = seed ^ 0xA5A5A5A5ull;
     return new HybridIndex(c);
 }

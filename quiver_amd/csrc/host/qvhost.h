@@ -40,9 +40,43 @@ struct BasicSearchResult {   // pkg/types/search.go:9-14
 // error = empty string means nil
 using Error = std::string;
 
+// Where an exact index keeps its rows: one GPU (a qv_index) or the GPUs of a node (a qv_sharded handle: one row shard per
+// listed device).  The reference has no counterpart (it is one process on CPU cores); the host code above is
+// the same either way.  peer_copy: point-to-point exchange instead of the RCCL all-gather (lets shards share a device).
+// bf16_rows: also keep the bfloat16 copy of the rows that BatchSearch's filter reads (QV_FLAG_BF16_ROWS, +50 % device memory).
+struct Placement {
+    std::vector<int> devices{0};
+    bool peer_copy = false;
+    bool bf16_rows = false;
+    Placement() = default;
+    Placement(int device) : devices{device} {}                                   // NOLINT: one device is the common case
+    Placement(std::vector<int> devs, bool peer = false, bool bf16 = false) : devices(std::move(devs)), peer_copy(peer), bf16_rows(bf16) {}
+    bool sharded() const { return devices.size() > 1 || peer_copy; }
+    int first() const { return devices.empty() ? 0 : devices[0]; }
+};
+
+// The rows behind an ExactIndex: qv_index_* on one device, qv_sharded_* over a device list — the same calls, row ids opaque.
+class RowStore {
+public:
+    ~RowStore() { destroy(); }
+    bool live() const { return one_ || many_; }
+    int create(uint32_t dim, qv_metric metric, const Placement& where);
+    void destroy();
+    int add(const float* rows, uint32_t n, uint32_t* rows_out /* [n] */);
+    int update(uint32_t row, const float* v);
+    int remove(const uint32_t* rows, uint32_t n);
+    int search(const float* qs, uint32_t nq, uint32_t k, uint32_t* rows, float* dist, uint32_t* count);
+    int search_negative(const float* q, const float* neg, uint32_t k_fetch, uint32_t* rows, float* dist, float* neg_dist, uint32_t* count);
+    int distance_rows(const float* q, const uint32_t* rows, uint32_t n, float* out);
+    uint64_t rows() const;
+private:
+    qv_index* one_ = nullptr;
+    qv_sharded* many_ = nullptr;
+};
+
 class ExactIndex {
 public:
-    ExactIndex(qv_metric metric, int device);
+    ExactIndex(qv_metric metric, const Placement& where);
     ~ExactIndex();
     Error Insert(const std::string& id, const float* v, uint32_t len);                 // exact.go:38-58
     // n Inserts under one lock and (when no tombstoned row is waiting for reuse) one device copy; all-or-nothing on a
@@ -67,11 +101,11 @@ private:
     Error insertLocked(const std::string& id, const float* v, uint32_t len);
     Error deleteLocked(const std::string& id);
     mutable std::shared_mutex mu_;                 // exact.go:25
-    qv_metric metric_; int device_;
-    qv_index* h_ = nullptr;
+    qv_metric metric_; Placement where_;
+    RowStore h_;
     int dim_ = 0;                                  // 0 until the first insert (exact.go:43-47)
     std::unordered_map<std::string, uint32_t> row_of_;
-    std::vector<std::string> id_of_;               // row -> id ("" = tombstoned)
+    std::unordered_map<uint32_t, std::string> id_of_;   // row -> id (row ids are sparse over shards: one id range per shard)
     std::vector<uint32_t> free_rows_;              // tombstoned rows, reused by the next Insert (the reference's map frees the entry, exact.go:65)
 };
 
@@ -178,7 +212,8 @@ struct HybridConfig {        // pkg/hybrid/types.go:27-45
     int exact_threshold = 1000;
     double exploration_factor = 0.1;   // adaptive.go:46; tests set 0 (adaptive_test.go:44-104)
     uint64_t seed = 1;
-    int device = 0;
+    Placement placement;               // the exact index shards over placement.devices; the HNSW graph lives on the first of them
+                                       // (graph traversal is sequentially dependent: "replicas only")
 };
 
 class HybridIndex {

@@ -316,6 +316,32 @@ int qv_index_get_row(qv_index* idx, uint32_t row, float* vec_out) {
     return QV_OK;
 }
 
+int qv_index_get_rows(qv_index* idx, const uint32_t* rows, uint32_t n, float* out) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (n == 0) return QV_OK;
+    if (!rows || !out) return fail(QV_ERR_INVALID_ARG, "rows/out is null");
+    for (uint32_t i = 0; i < n; i++)
+        if (rows[i] >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", rows[i], idx->n_rows);
+    HIPCHK(hipSetDevice(idx->device));
+    SearchCtx* c = nullptr;
+    int rc = acquire_ctx(idx, &c);
+    if (rc != QV_OK) return rc;
+    CtxGuard guard{idx, c};
+    const size_t row_bytes = (size_t)idx->dim * sizeof(float);
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, ((size_t)64 << 20) / row_bytes));   // <= 64 MiB per pass
+    if ((rc = c->d_ids.ensure((size_t)chunk * 4)) || (rc = c->h_ids.ensure((size_t)chunk * 4)) || (rc = c->d_q.ensure((size_t)chunk * row_bytes))) return rc;
+    for (uint32_t done = 0; done < n; done += chunk) {
+        const uint32_t m = std::min(chunk, n - done);
+        memcpy(c->h_ids.p, rows + done, (size_t)m * 4);
+        HIPCHK(hipMemcpyAsync(c->d_ids.p, c->h_ids.p, (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+        hipError_t e = qv::launch_fetch_rows(idx->view(), static_cast<const uint32_t*>(c->d_ids.p), m, static_cast<float*>(c->d_q.p), c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)done * idx->dim, c->d_q.p, (size_t)m * row_bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "get_rows failed: %s", hipGetErrorString(e));
+    }
+    return QV_OK;
+}
+
 // shared by the host and device entry points: enqueue nq searches of list length kk
 // (kk = min(k, live)), results written with row stride k_stride
 static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
@@ -545,6 +571,27 @@ int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, u
     return enqueue_search(idx, d_queries, nq, kk, k, ws, 0, d_rows_out, d_dist_out, s);
 }
 
+}  // extern "C"
+
+// Internal (qv_api_internal.h), for the sharded handle: the exact scan over the rows selected by a DEVICE bitmap d_candidates
+// (already ANDed with the live rows by the caller; `matching` = its population count), enqueued on `stream`, no
+// synchronisation.  Writes [nq][k_stride] lists: min(k_stride, matching) results, the rest padded (0xFFFFFFFF, +inf).
+int qv_internal_search_candidates_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k_stride, const uint64_t* d_candidates,
+                                         uint64_t matching, uint32_t* d_rows_out, float* d_dist_out, void* stream) {
+    if (!idx || !d_queries || !d_candidates || !d_rows_out || !d_dist_out || k_stride == 0) return fail(QV_ERR_INVALID_ARG, "null argument");
+    if (nq == 0) return QV_OK;
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(k_stride, matching);
+    void* ws = nullptr;
+    std::unique_lock<std::mutex> ws_hold;
+    int rc = stream_workspace(idx, s, search_ws_bytes(idx, nq, kk, k_stride), &ws, &ws_hold);
+    if (rc != QV_OK) return rc;
+    return enqueue_search(idx, d_queries, nq, kk, k_stride, ws, 0, d_rows_out, d_dist_out, s, d_candidates);
+}
+
+extern "C" {
+
 // The filter walks the corpus once per 256 queries, so 257-320 queries cost two walks (2.6 ms against 1.4 ms at 1M x 768) while
 // a batch of 64 or fewer costs half a walk: a small tail goes in a call of its own (0 = no split).
 static uint32_t batched_tail(const qv::IndexView& v, uint32_t nq, uint32_t k) {
@@ -622,6 +669,13 @@ int qv_merge_topk_shards_device(const uint32_t* d_packed_lists, const uint32_t* 
     if (k > (uint32_t)qv::kMaxFusedK || n_lists == 0 || (uint64_t)n_lists * k > 65536) return fail(QV_ERR_UNSUPPORTED, "merge supports k <= %d and n_lists*k <= 65536", qv::kMaxFusedK);
     hipError_t e = qv::launch_merge_shards(d_packed_lists, d_bases, n_lists, nq, k, d_rows_out, d_dist_out, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "merge launch failed: %s", hipGetErrorString(e));
+    return QV_OK;
+}
+
+int qv_index_set_filter(qv_index* idx, int filter) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (filter < 0 || filter > 3) return fail(QV_ERR_INVALID_ARG, "filter must be 0 (automatic), 1 (fp32 MFMA), 2 (bfloat16 x 3) or 3 (bfloat16 x 1); got %d", filter);
+    idx->filter = filter;
     return QV_OK;
 }
 
@@ -764,6 +818,18 @@ int qv_distance_rows(qv_index* idx, const float* query, const uint32_t* rows, ui
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_rows launch failed: %s", hipGetErrorString(e));
     HIPCHK(hipStreamSynchronize(c->stream));
     memcpy(dist_out, c->h_dist.p, obytes);
+    return QV_OK;
+}
+
+// The DistanceFunc contract for ONE pair (surface.go:8; SURVEY.md 8b lists this entry point as host code): the reference calls
+// it per pair at ~78 ns (final_bench.txt:47) from code that is not part of the scan — Surface.Distance, tests, the Go HNSW that
+// reloaded collections use — and no GPU round trip (tens of microseconds) can serve that.  It is NOT a fallback of anything:
+// every search / scan / batch entry point of this library runs on the device or fails, and none of them calls this.  The body
+// is the kernels' own pair_distance<M> (qv_kernels.h) compiled for the host, so device and host state the arithmetic once.
+int qv_distance_pair(qv_metric metric, const float* a, const float* b, uint32_t dim, float* out) {
+    if ((int)metric < 0 || (int)metric >= QV_METRIC_COUNT) return fail(QV_ERR_INVALID_ARG, "unknown metric %d", (int)metric);
+    if (!out || (dim && (!a || !b))) return fail(QV_ERR_INVALID_ARG, "a/b/out is null");
+    *out = qv::host_pair_distance((int)metric, a, b, dim);
     return QV_OK;
 }
 

@@ -49,6 +49,10 @@ struct PinBuf {         // growable pinned host buffer
 
 struct Workspace { Buf ws; std::mutex mu; };
 
+// qv_api.cpp, for qv_sharded_api.cpp: exact scan over the rows of a device-resident candidate bitmap (see the definition)
+int qv_internal_search_candidates_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k_stride, const uint64_t* d_candidates,
+                                         uint64_t matching, uint32_t* d_rows_out, float* d_dist_out, void* stream);
+
 struct SearchCtx {
     hipStream_t stream = nullptr;
     Buf d_q, d_rows, d_dist, d_ids, d_mask, ws;
@@ -68,6 +72,7 @@ struct qv_index {
     uint32_t dim = 0, dim4 = 0;
     int metric = QV_COSINE;
     uint64_t flags = 0;
+    int filter = 0;                            // qv_index_set_filter
     uint32_t n_rows = 0, n_live = 0;
     uint64_t cap_tiles = 0;
     float* d_tiles = nullptr;
@@ -92,7 +97,7 @@ struct qv_index {
     qv::IndexView view() const {
         qv::IndexView v;
         v.tiles = d_tiles; v.rnorm = d_rnorm; v.alive = d_alive; v.rowmaj = d_rowmaj; v.bf16 = d_bf16;
-        v.dim = dim; v.dim4 = dim4; v.n_rows = n_rows; v.n_tiles = (n_rows + 63) / 64; v.metric = metric;
+        v.dim = dim; v.dim4 = dim4; v.n_rows = n_rows; v.n_tiles = (n_rows + 63) / 64; v.metric = metric; v.filter = filter;
         return v;
     }
     size_t tile_bytes() const { return (size_t)dim4 * 64 * 16; }

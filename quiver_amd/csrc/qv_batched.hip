@@ -1060,23 +1060,26 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 // filter up to 1536 dimensions, three terms above.  Its window (2 x 7.9e-3 |q||r|) is measured in units of the scores' spread,
 // which shrinks like 1/sqrt(dim) on unstructured data: 256 queries x 3 GB of rows take 1.93 / 1.14 / 1.08 / 1.39 / 1.34 / 2.55 ms at
 // 128 / 384 / 768 / 1024 / 1536 / 3072 dimensions against 2.65 / 1.69 / 1.63 / 2.00 / 1.56 / 1.73 ms with three terms.
-int filter_mode(uint32_t dim) {
-    const char* e = getenv("QV_MFMA_FILTER");                        // read per call
-    const int m = e && *e ? atoi(e) : 0;
-    return m == 1 ? 1 : (m == 2 ? 2 : (m == 3 ? 3 : (dim <= 1536 ? 3 : 2)));
+// The choice is the index's (qv_index_set_filter, carried in IndexView::filter); QV_MFMA_FILTER, read ONCE per process, only
+// sets the default of indexes that never chose.
+int filter_mode(const IndexView& v) {
+    static const int env_default = env_int("QV_MFMA_FILTER", 0);
+    const int m = v.filter >= 1 && v.filter <= 3 ? v.filter : env_default;
+    return m == 1 ? 1 : (m == 2 ? 2 : (m == 3 ? 3 : (v.dim <= 1536 ? 3 : 2)));
 }
 // ---- MFMA batched path --------------------------------------------------------------
 // Rows of the exact sample scan that bounds each query's k-th distance.  A sample of S of N rows lets about k*N/S rows through
 // the filter per query; the candidate buffer holds kMfmaCandCap (4096), so S grows with N and k to keep that near 1536
 // (10M rows or k = 64 with the former fixed 8192 overflowed nearly every query into the exact redo: 256 x 10M x 768 took 108 ms).
-uint32_t batched_sample_rows(uint32_t n_rows, uint32_t k, uint32_t dim) {
+uint32_t batched_sample_rows(const IndexView& v, uint32_t k) {
+    const uint32_t n_rows = v.n_rows;
     static const int forced = env_int("QV_MFMA_SAMPLE_ROWS", 0);
     if (forced > 0) return std::min<uint32_t>(n_rows, (uint32_t)forced);
     // ~1536 expected candidates (3 sigma of the k-th order statistic at k = 10 stays under the 4096 slots), in whole multiples
     // of 8192 rows = 128 tiles: with 16 query groups that is one full round of the 2048 scan waves per multiple
     // the one-term bfloat16 filter's window is 2 x 7.9e-3 |q||r| wide — 0.44 sigma of the scores of unstructured 768-d data, which
     // lets ~4.6 x as many rows through at the same bound: four times the sample keeps the candidate count where it was
-    const bool one = filter_mode(dim) == 3;
+    const bool one = filter_mode(v) == 3;
     const uint64_t per = one ? 384 : 1536;
     const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / per + 8191) / 8192 * 8192;
     return (uint32_t)std::min<uint64_t>(n_rows, std::max<uint64_t>(one ? 32768 : 8192, want));
@@ -1089,7 +1092,7 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     // (8 queries or fewer share one HBM-bound pass of k_flat_scan_mq: 0.45 ms); the fp32 filter pays off from 32 queries
     static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 32768);
     const int min_q_env = env_int("QV_MFMA_MIN_QUERIES", 0);          // read per call: tests of the exact scans switch the filter off with it
-    const int min_q = min_q_env > 0 ? min_q_env : (filter_mode(v.dim) >= 2 ? 9 : 32);
+    const int min_q = min_q_env > 0 ? min_q_env : (filter_mode(v) >= 2 ? 9 : 32);
     // millions of query-rows.  Round 2's one-term filter moved the crossover down: 16 / 64 queries x 100k x 768 take 0.17 / 0.18 ms here against
     // 0.30 / 0.57 ms on the exact multi-query scan, x 400k rows 0.36 / 0.37 against 0.59 / 1.65 (8 M query-rows was the three-term crossover)
     static const int min_work_m = env_int("QV_MFMA_MIN_MROWS", 1);
@@ -1102,10 +1105,10 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
 // (258 workgroups on 256 CUs: a second round), as 4 blocks 3.4 ms.
 // With the one-term filter 65-128 queries as two blocks took 1.24-1.33 ms on the per-wave kernel against 1.0 ms for 256 on the shared one:
 // there everything above one block is padded to whole workgroups of four.
-static uint32_t batched_nq_pad(uint32_t nq, uint32_t dim) { return nq <= 64 ? 64u : (nq <= 128 && filter_mode(dim) != 3 ? 128u : (nq + 255) / 256 * 256); }
+static uint32_t batched_nq_pad(uint32_t nq, const IndexView& v) { return nq <= 64 ? 64u : (nq <= 128 && filter_mode(v) != 3 ? 128u : (nq + 255) / 256 * 256); }
 
 size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t nq, uint32_t k) {
-    const uint32_t nq_pad = batched_nq_pad(nq, v.dim);
+    const uint32_t nq_pad = batched_nq_pad(nq, v);
     size_t b = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);   // sample scan (partials + query blocks)
     b = (b + 255) / 256 * 256;
     b += (size_t)nq_pad * (v.dim4 + 4) * 16;                 // Qt (chunk count padded to even) / the bf16 hi + lo planes (padded to 4 chunks)
@@ -1114,7 +1117,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     b += (size_t)nq * 8;                                     // counters, overflow flags
     b += (size_t)nq * k * 8;                                 // sample rows/dist
     b += (size_t)nq * k * 16 + 256;                          // k_sample_bound's partial lists (up to four parts per query)
-    b += (size_t)nq_pad * batched_sample_rows(v.n_rows, k, v.dim) * 4 + 256;   // the sample's scores (bfloat16 filter: bound without an exact scan)
+    b += (size_t)nq_pad * batched_sample_rows(v, k) * 4 + 256;   // the sample's scores (bfloat16 filter: bound without an exact scan)
     return b + 1024;
 }
 
@@ -1125,7 +1128,7 @@ static uint32_t grid_multiple(uint32_t want, uint32_t unit) { const uint32_t g =
 hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k, void* d_ws,
                           uint32_t* d_rows_out, float* d_dist_out, uint32_t** d_overflow_out, int cus, hipStream_t s,
                           hipEvent_t ev0, hipEvent_t ev1) {
-    const uint32_t nq_pad = batched_nq_pad(nq, v.dim);
+    const uint32_t nq_pad = batched_nq_pad(nq, v);
     char* w = static_cast<char*>(d_ws);
     size_t off = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);
     off = (off + 255) / 256 * 256;
@@ -1143,11 +1146,11 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     const uint32_t bparts = nq <= 64 ? 4u : (nq <= 128 ? 2u : 1u);       // (four parts at 256 queries: 44 -> 74 us, every workgroup stages its query again)
     // 1. per-query upper bound U_q of the k-th distance from a sample (the first rows)
     IndexView vs = v;
-    vs.n_rows = batched_sample_rows(v.n_rows, k, v.dim);
+    vs.n_rows = batched_sample_rows(v, k);
     vs.n_tiles = (vs.n_rows + 63) / 64;
     // QV_MFMA_FILTER: 1 = fp32 MFMA (BASELINE configs[2] as written), 2 = bf16 x 3 (default: same candidates up to the margin,
-    // a quarter of the matrix cycles); read per call so that one process can compare the two
-    const int fmode = filter_mode(v.dim);
+    // a quarter of the matrix cycles); the index's choice (qv_index_set_filter), so one process can compare them
+    const int fmode = filter_mode(v);
     const int bf = fmode >= 2 ? 1 : 0;                                 // bfloat16 operand layout
     static const int sample_gemm = env_int("QV_MFMA_SAMPLE_GEMM", 1);
     static const int share_env = env_int("QV_MFMA_SHARE_ROWS", 1);

@@ -34,6 +34,7 @@ struct IndexView {
     uint32_t  n_rows;     // rows ever added
     uint32_t  n_tiles;    // ceil(n_rows/64)
     int       metric;
+    int       filter;     // batched path's filter kernel: 0 = the library's rule, 1 fp32 MFMA chain, 2 bfloat16 x 3, 3 bfloat16 x 1 (qv_index_set_filter)
 };
 
 struct GraphView {
@@ -101,6 +102,8 @@ hipError_t launch_generate(const IndexView& v, uint64_t seed, uint64_t gen_row0,
 hipError_t launch_set_alive(const IndexView& v, const uint32_t* d_rows, uint32_t n, int alive, hipStream_t s);
 // tile layout -> row-major (one row)
 hipError_t launch_fetch_row(const IndexView& v, uint32_t row, float* d_out, hipStream_t s);
+// tile layout -> row-major, n listed rows -> d_out [n][dim]
+hipError_t launch_fetch_rows(const IndexView& v, const uint32_t* d_rows, uint32_t n, float* d_out, hipStream_t s);
 
 // --- search ---------------------------------------------------------------------
 // Flat scan + fused top-k for k <= kMaxFusedK.  d_queries [nq][dim] float32 on device.
@@ -112,7 +115,17 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
                             hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // merge n_lists lists of k (dist, row) pairs -> k best by (dist, row)
 hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t k,
-                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, bool planar = false);
+                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, uint32_t planes = 0 /* 0: [nq][2][k] per shard; >= 2: [planes][nq][k] */);
+// The same merge for lists of any length (k > kMaxFusedK: a filtered search asks every shard for its full ranking): the valid
+// entries of the G sorted lists [planes][nq][kcap] of query q become 64-bit keys (distance, global row), one stable radix sort
+// orders them, the first k_out are written (padded with 0xFFFFFFFF / +inf).  d_ws: merge_ranked_workspace_bytes(G * kcap).
+size_t merge_ranked_workspace_bytes(uint64_t n_keys);
+hipError_t launch_merge_ranked(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t q, uint32_t kcap, uint32_t planes,
+                               uint32_t k_out, void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
+// payload lookup after a merge: out[i] = payload plane `plane` of the list entry that produced merged global row rows[i]
+// (shard = the one whose base range holds the row; entry found by its local row), +inf for padding rows
+hipError_t launch_lookup_payload(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t q, uint32_t kcap, uint32_t planes,
+                                 uint32_t plane, const uint32_t* d_rows, uint32_t n, float* d_out, hipStream_t s);
 hipError_t launch_merge_pairs(const float* d_dist, const uint32_t* d_rows, uint32_t n_lists, uint32_t k,
                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 
@@ -164,6 +177,8 @@ hipError_t launch_build_links(const BuildView& b, uint32_t first, uint32_t n, in
 // distance of one query to n listed rows (lane == listed row, sequential accumulation)
 hipError_t launch_distance_rows(const IndexView& v, const float* d_query, const uint32_t* d_rows, uint32_t n,
                                 float* d_dist_out, hipStream_t s);
+// one pair on the HOST (qv_distance_pair): the kernels' own pair_distance<M> compiled for the CPU
+float host_pair_distance(int metric, const float* a, const float* b, uint32_t dim);
 // n independent pairs a[i], b[i] (row-major [n][dim])
 hipError_t launch_distance_pairs(int metric, const float* d_a, const float* d_b, uint32_t n, uint32_t dim,
                                  float* d_out, hipStream_t s);

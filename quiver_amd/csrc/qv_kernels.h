@@ -109,7 +109,7 @@ template <> struct MT<QV_DOT_F32>    { using Q = float;  using A = float;  stati
 template <> struct MT<QV_L2SQ_F64>   { using Q = double; using A = double; static constexpr bool needs_rnorm = false; };
 
 // one element: a = query element (already in the metric's Q type), b = row element
-template <int M> __device__ __forceinline__ void acc1(typename MT<M>::A& acc, typename MT<M>::Q a, float b) {
+template <int M> __host__ __device__ __forceinline__ void acc1(typename MT<M>::A& acc, typename MT<M>::Q a, float b) {
     if constexpr (M == QV_COSINE || M == QV_DOT) {
         acc = __builtin_fma(a, (double)b, acc);                       // distances.go:19 / :84
     } else if constexpr (M == QV_L2) {
@@ -149,7 +149,7 @@ template <int M, typename T> __device__ __forceinline__ QConst query_const(const
 // rn = stored per-row norm (see k_ingest): sqrt(mb) for COSINE; for COSINE_F32 the
 // float32 value float32(sqrt(float64(nb))) widened, negative if nb == 0 cannot occur,
 // so rn == 0 <=> nb == 0 only when the sqrt underflows; we store nb's zero-ness in the sign bit
-template <int M> __device__ __forceinline__ float finalize(typename MT<M>::A acc, const QConst& qc, double rn) {
+template <int M> __host__ __device__ __forceinline__ float finalize(typename MT<M>::A acc, const QConst& qc, double rn) {
     if constexpr (M == QV_COSINE) {
         if (qc.qn == 0.0 || rn == 0.0) return 1.0f;                   // distances.go:25-27
         double sim = acc / (qc.qn * rn);                              // :30
@@ -174,6 +174,35 @@ template <int M> __device__ __forceinline__ float finalize(typename MT<M>::A acc
     } else {
         return 1.0f - acc;                                            // adapter.go:164
     }
+}
+
+// One pair (a, b) of plain row-major vectors: the whole DistanceFunc (pkg/vectortypes/surface.go:8) in the reference's element
+// order — the body of k_distance_pairs on the device, and of the host entry point qv_distance_pair (the same source
+// compiled for the host: ONE statement of the arithmetic).
+template <int M> __host__ __device__ __forceinline__ float pair_distance(const float* pa, const float* pb, uint32_t dim) {
+    using Q = typename MT<M>::Q;
+    typename MT<M>::A acc = 0;
+    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+    double rn = 0.0;
+    if constexpr (M == QV_COSINE) {
+        double ma = 0.0, mb = 0.0;
+        for (uint32_t j = 0; j < dim; j++) {                           // distances.go:18-22, one pass, element order
+            double x = pa[j], y = pb[j];
+            acc = __builtin_fma(x, y, acc); ma = __builtin_fma(x, x, ma); mb = __builtin_fma(y, y, mb);
+        }
+        qc.qn = __builtin_sqrt(ma); rn = __builtin_sqrt(mb);
+    } else if constexpr (M == QV_COSINE_F32) {
+        float na = 0.0f, nb = 0.0f;
+        for (uint32_t j = 0; j < dim; j++) {                           // adapter.go:116-120
+            float x = pa[j], y = pb[j];
+            float p0 = x * y; acc = acc + p0; float p1 = x * x; na = na + p1; float p2 = y * y; nb = nb + p2;
+        }
+        qc.qn = (double)na; qc.qn32 = (float)__builtin_sqrt((double)na);
+        rn = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
+    } else {
+        for (uint32_t j = 0; j < dim; j++) acc1<M>(acc, (Q)pa[j], pb[j]);
+    }
+    return finalize<M>(acc, qc, rn);
 }
 
 // stage the query into LDS in the metric's Q type, zero-padded to dim4*4

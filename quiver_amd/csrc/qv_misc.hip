@@ -34,33 +34,15 @@ k_distance_rows(IndexView v, const float* __restrict__ query, const uint32_t* __
 template <int M>
 __global__ void __launch_bounds__(64)
 k_distance_pairs(const float* __restrict__ a, const float* __restrict__ b, uint32_t n, uint32_t dim, float* __restrict__ out) {
-    using Q = typename MT<M>::Q;
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
-    const float* pa = a + (size_t)i * dim;
-    const float* pb = b + (size_t)i * dim;
-    typename MT<M>::A acc = 0;
-    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
-    double rn = 0.0;
-    if constexpr (M == QV_COSINE) {
-        double ma = 0.0, mb = 0.0;
-        for (uint32_t j = 0; j < dim; j++) {
-            double x = pa[j], y = pb[j];
-            acc = __builtin_fma(x, y, acc); ma = __builtin_fma(x, x, ma); mb = __builtin_fma(y, y, mb);
-        }
-        qc.qn = __builtin_sqrt(ma); rn = __builtin_sqrt(mb);
-    } else if constexpr (M == QV_COSINE_F32) {
-        float na = 0.0f, nb = 0.0f;
-        for (uint32_t j = 0; j < dim; j++) {
-            float x = pa[j], y = pb[j];
-            float p0 = x * y; acc = acc + p0; float p1 = x * x; na = na + p1; float p2 = y * y; nb = nb + p2;
-        }
-        qc.qn = (double)na; qc.qn32 = (float)__builtin_sqrt((double)na);
-        rn = nb == 0.0f ? -1.0 : (double)(float)__builtin_sqrt((double)nb);
-    } else {
-        for (uint32_t j = 0; j < dim; j++) acc1<M>(acc, (Q)pa[j], pb[j]);
-    }
-    out[i] = finalize<M>(acc, qc, rn);
+    out[i] = pair_distance<M>(a + (size_t)i * dim, b + (size_t)i * dim, dim);
+}
+
+// the same arithmetic on the host, for ONE pair: qv_distance_pair (include/qv.h)
+float host_pair_distance(int metric, const float* a, const float* b, uint32_t dim) {
+    QV_DISPATCH_METRIC(metric, { return pair_distance<MM>(a, b, dim); });
+    return 0.0f;
 }
 
 // ---------------------------------------------------------------- ingest -----------
@@ -306,6 +288,23 @@ hipError_t launch_generate(const IndexView& v, uint64_t seed, uint64_t gen_row0,
 hipError_t launch_set_alive(const IndexView& v, const uint32_t* d_rows, uint32_t n, int alive, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_set_alive, dim3((n + 255) / 256), dim3(256), 0, s, v, d_rows, n, alive);
+    return hipGetLastError();
+}
+
+// n listed rows -> row-major [n][dim]: blockIdx.y = listed row, one thread per element (a row's elements sit 64 floats apart in
+// its tile: a gather by nature; this is the Save / GetVector path, not a scan)
+__global__ void k_fetch_rows(IndexView v, const uint32_t* __restrict__ rows, float* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= v.dim) return;
+    const uint32_t row = rows[blockIdx.y];
+    out[(size_t)blockIdx.y * v.dim + j] = v.tiles[((size_t)(row >> 6) * v.dim4 + (j >> 2)) * 256 + (row & 63) * 4 + (j & 3)];
+}
+
+hipError_t launch_fetch_rows(const IndexView& v, const uint32_t* d_rows, uint32_t n, float* d_out, hipStream_t s) {
+    for (uint32_t done = 0; done < n; done += 65535) {                    // gridDim.y limit
+        const uint32_t m = n - done < 65535 ? n - done : 65535;
+        hipLaunchKernelGGL(k_fetch_rows, dim3((v.dim + 255) / 256, m), dim3(256), 0, s, v, d_rows + done, d_out + (size_t)done * v.dim);
+    }
     return hipGetLastError();
 }
 

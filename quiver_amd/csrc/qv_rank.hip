@@ -166,6 +166,69 @@ hipError_t launch_radix_sort_hi32(uint64_t* a, uint64_t* b, uint32_t n, uint32_t
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- merge of ranked shard lists (any k) -----
+// keys of query q from the gathered per-shard lists [G][planes][nq][kcap] (plane 0: local rows, 0xFFFFFFFF = padding; plane 1:
+// distance bits).  Key i = entry i % kcap of shard i / kcap: every shard's list is ascending in (distance, local row) and the
+// shards' bases ascend, so equal distances already appear in global-row order and the stable sort on the distance bits
+// alone leaves the full (distance, global row) order a single index produces.
+__global__ void __launch_bounds__(256)
+k_shard_keys(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ bases, uint32_t n_lists, uint32_t nq, uint32_t q, uint32_t kcap,
+             uint32_t planes, uint64_t* __restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)n_lists * kcap) return;
+    const uint32_t g = (uint32_t)(i / kcap), j = (uint32_t)(i - (uint64_t)g * kcap);
+    const uint32_t* blk = packed + (size_t)g * planes * nq * kcap + (size_t)q * kcap;
+    const uint32_t row = blk[j];
+    keys[i] = row == 0xFFFFFFFFu ? kDeadKey : make_key(__uint_as_float(blk[(size_t)nq * kcap + j]), bases[g] + row);
+}
+
+size_t merge_ranked_workspace_bytes(uint64_t n_keys) {
+    return 2 * n_keys * sizeof(uint64_t) + radix_hist_words((uint32_t)n_keys) * sizeof(uint32_t) + 256;
+}
+
+hipError_t launch_merge_ranked(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t q, uint32_t kcap, uint32_t planes,
+                               uint32_t k_out, void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    const uint64_t n64 = (uint64_t)n_lists * kcap;
+    if (n_lists == 0 || kcap == 0 || k_out == 0 || planes < 2 || n64 > 0xFFFFFF00ull) return hipErrorInvalidValue;
+    const uint32_t n = (uint32_t)n64;
+    uint64_t* ka = static_cast<uint64_t*>(d_ws);
+    uint64_t* kb = ka + n;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(kb + n);
+    hipLaunchKernelGGL(k_shard_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_packed, d_bases, n_lists, nq, q, kcap, planes, ka);
+    uint64_t* in = nullptr;
+    hipError_t e = launch_radix_sort_hi32(ka, kb, n, hist, &in, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_emit_topk, dim3((k_out + 255) / 256), dim3(256), 0, s, in, n, k_out, d_rows_out, d_dist_out);
+    return hipGetLastError();
+}
+
+// merged global row -> the payload its shard computed for it (e.g. the distance to a negative example): thread i finds
+// row rows[i] in the list of the shard whose id range holds it
+__global__ void __launch_bounds__(256)
+k_lookup_payload(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ bases, uint32_t n_lists, uint32_t nq, uint32_t q, uint32_t kcap,
+                 uint32_t planes, uint32_t plane, const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rows[i];
+    float v = __uint_as_float(0x7F800000u);
+    if (r != 0xFFFFFFFFu) {
+        uint32_t g = 0;
+        while (g + 1 < n_lists && bases[g + 1] <= r) g++;
+        const uint32_t local = r - bases[g];
+        const uint32_t* blk = packed + (size_t)g * planes * nq * kcap + (size_t)q * kcap;
+        for (uint32_t j = 0; j < kcap; j++)
+            if (blk[j] == local) { v = __uint_as_float(blk[(size_t)plane * nq * kcap + j]); break; }
+    }
+    out[i] = v;
+}
+
+hipError_t launch_lookup_payload(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t q, uint32_t kcap, uint32_t planes,
+                                 uint32_t plane, const uint32_t* d_rows, uint32_t n, float* d_out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lookup_payload, dim3((n + 255) / 256), dim3(256), 0, s, d_packed, d_bases, n_lists, nq, q, kcap, planes, plane, d_rows, n, d_out);
+    return hipGetLastError();
+}
+
 size_t full_sort_workspace_bytes(uint32_t n_tiles) {
     size_t n = (size_t)n_tiles * 64;
     size_t nblocks = (n + kRadixTile - 1) / kRadixTile;

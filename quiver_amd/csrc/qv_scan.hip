@@ -394,7 +394,7 @@ k_merge_pairs(const float* __restrict__ dist, const uint32_t* __restrict__ rows,
 // between).  packed = [n_lists][nq][2][k]; one workgroup per query.
 __global__ void __launch_bounds__(kMergeBlock)
 k_merge_shards(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ bases, uint32_t n_lists, uint32_t nq, uint32_t k,
-               uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, bool planar) {
+               uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t planes) {
     __shared__ uint64_t wl[kMergeBlock / 64][64];
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -407,11 +407,12 @@ k_merge_shards(const uint32_t* __restrict__ packed, const uint32_t* __restrict__
         uint64_t key = kDeadKey;
         if (i < total) {
             const uint32_t g = i / k, j = i - g * k;
-            // interleaved: per shard [nq][2][k];  planar: per shard [2][nq][k] (rows of all queries, then distances of all
-            // queries — a shard's multi-query scan writes both halves in place, no repacking before the all-gather)
-            const uint32_t* blk = packed + (planar ? (size_t)g * 2 * nq * k + (size_t)q * k : ((size_t)g * nq + q) * 2 * k);
+            // planes == 0, interleaved: per shard [nq][2][k];  planes >= 2, planar: per shard [planes][nq][k] (rows of all
+            // queries, then distances of all queries, then payload planes the merge does not read — a shard's multi-query
+            // scan writes both halves in place, no repacking before the all-gather)
+            const uint32_t* blk = packed + (planes ? (size_t)g * planes * nq * k + (size_t)q * k : ((size_t)g * nq + q) * 2 * k);
             const uint32_t row = blk[j];
-            if (row != 0xFFFFFFFFu) key = make_key(__uint_as_float(blk[(planar ? (size_t)nq * k : k) + j]), bases[g] + row);
+            if (row != 0xFFFFFFFFu) key = make_key(__uint_as_float(blk[(planes ? (size_t)nq * k : k) + j]), bases[g] + row);
         }
         list_insert(list, thr, key, kth, lane);
     }
@@ -466,11 +467,11 @@ hipError_t launch_merge_pairs(const float* d_dist, const uint32_t* d_rows, uint3
 }
 
 hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t k,
-                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, bool planar) {
-    if (k == 0 || k > (uint32_t)kMaxFusedK || n_lists == 0 || nq == 0) return hipErrorInvalidValue;
+                               uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, uint32_t planes) {
+    if (k == 0 || k > (uint32_t)kMaxFusedK || n_lists == 0 || nq == 0 || planes == 1) return hipErrorInvalidValue;
     uint32_t total = n_lists * k;
     uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
-    hipLaunchKernelGGL(k_merge_shards, dim3(nq), dim3(mblock), 0, s, d_packed, d_bases, n_lists, nq, k, d_rows_out, d_dist_out, planar);
+    hipLaunchKernelGGL(k_merge_shards, dim3(nq), dim3(mblock), 0, s, d_packed, d_bases, n_lists, nq, k, d_rows_out, d_dist_out, planes);
     return hipGetLastError();
 }
 

@@ -15,12 +15,17 @@ def _f32c(a) -> np.ndarray:
 
 
 class DeviceIndex:
-    def __init__(self, dim: int, metric="cosine", device: int = 0, rowmajor: bool = False, bf16_rows: bool = False):
+    default_filter = "auto"        # the filter kernel new indexes choose (set_filter); tests and bench.py compare the kernels through it
+
+    def __init__(self, dim: int, metric="cosine", device: int = 0, rowmajor: bool = False, bf16_rows: bool = False, filter=None):
         self._h = C.c_void_p()
         self.dim = int(dim)
         self.metric = metric_id(metric)
         self.device = device
         check(lib().qv_index_create(C.byref(self._h), self.dim, self.metric, device, (_lib.QV_FLAG_ROWMAJOR if rowmajor else 0) | (_lib.QV_FLAG_BF16_ROWS if bf16_rows else 0)))
+        f = filter if filter is not None else DeviceIndex.default_filter
+        if f not in ("auto", 0):
+            self.set_filter(f)
 
     # ---- lifecycle ----
     def close(self):
@@ -87,6 +92,13 @@ class DeviceIndex:
         check(lib().qv_index_get_row(self._h, row, out.ctypes.data))
         return out
 
+    def get_rows(self, rows) -> np.ndarray:
+        """[n, dim]: the listed rows in one device pass (qv_index_get_rows)"""
+        r = np.ascontiguousarray(rows, dtype=np.uint32).ravel()
+        out = np.empty((r.size, self.dim), dtype=np.float32)
+        check(lib().qv_index_get_rows(self._h, r.ctypes.data, r.size, out.ctypes.data))
+        return out
+
     def search(self, queries, k: int, batched: bool = False):
         """-> (rows [nq,k] uint32, dist [nq,k] float32, count [nq] uint32)"""
         q = _f32c(queries)
@@ -143,6 +155,12 @@ class DeviceIndex:
     def distance_rows_device(self, d_query: int, d_rows: int, n: int, d_out: int, stream: int = 0):
         check(lib().qv_distance_rows_device(self._h, d_query, d_rows, n, d_out, stream))
 
+
+    FILTERS = {"auto": 0, "fp32": 1, "bf16x3": 2, "bf16x1": 3}
+
+    def set_filter(self, filter):
+        """the batched path's filter kernel: "auto", "fp32" (fp32 MFMA chain), "bf16x3", "bf16x1" (qv_index_set_filter)"""
+        check(lib().qv_index_set_filter(self._h, self.FILTERS.get(filter, filter)))
 
     def profile(self, enable: bool):
         check(lib().qv_index_profile(self._h, 1 if enable else 0))
@@ -256,6 +274,44 @@ class DeviceGraph:
             pass
 
 
+class GraphReplicas:
+    """HNSW over the GPUs of a node: graph traversal is sequentially dependent (hnsw.go:471-580), so the graph does
+    not shard by rows — REPLICAS ONLY: one complete index + graph per listed device, built from the same rows and levels (the
+    device build is deterministic, so the replicas are identical), the queries of a batch cut into one contiguous slice per
+    replica and walked concurrently.  A device may be listed more than once (two replicas on one GPU: how a 1-GPU box tests it)."""
+
+    def __init__(self, rows, levels, metric="cosine", devices=(0,), m: int = 16, max_m0: int = 0, ef_construction: int = 200,
+                 batch_max: int = 16384, ramp_div: int = 16):
+        rows = _f32c(rows)
+        self.dim = rows.shape[1]
+        self.indexes, self.graphs = [], []
+        for d in devices:
+            idx = DeviceIndex(self.dim, metric, device=int(d), rowmajor=True)
+            idx.add(rows)
+            self.indexes.append(idx)
+            self.graphs.append(DeviceGraph.build(idx, levels, m=m, max_m0=max_m0, ef_construction=ef_construction, batch_max=batch_max, ramp_div=ramp_div))
+
+    def search(self, queries, k: int, ef_search: int):
+        """-> (rows [nq, k], dist [nq, k], count [nq]): DeviceGraph.search of each query slice on its replica, concurrently"""
+        from concurrent.futures import ThreadPoolExecutor
+        q = _f32c(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, R = q.shape[0], len(self.graphs)
+        cuts = [i * nq // R for i in range(R + 1)]
+        jobs = [(g, q[cuts[i]:cuts[i + 1]]) for i, g in enumerate(self.graphs) if cuts[i + 1] > cuts[i]]
+        with ThreadPoolExecutor(max_workers=max(len(jobs), 1)) as pool:           # ctypes drops the GIL: the replicas' calls overlap
+            parts = list(pool.map(lambda job: job[0].search(job[1], k, ef_search), jobs))
+        return tuple(np.concatenate([p[j] for p in parts]) for j in range(3))
+
+    def close(self):
+        for g in self.graphs:
+            g.close()
+        for i in self.indexes:
+            i.close()
+        self.graphs, self.indexes = [], []
+
+
 class ShardedIndex:
     """One corpus over several GPUs behind ONE C-ABI handle (qv_sharded_* of include/qv.h): a shard (exact index) per device,
     one RCCL all-gather of the per-shard top-k per search, merge on the first device.  `devices` may repeat a device only
@@ -325,6 +381,68 @@ class ShardedIndex:
 
     def search_device(self, d_queries: int, nq: int, k: int, d_rows_out: int, d_dist_out: int, stream: int = 0):
         check(lib().qv_sharded_search_device(self._h, d_queries, nq, k, d_rows_out, d_dist_out, stream or None))
+
+    def _q(self, queries):
+        q = _f32c(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.dim:
+            raise ValueError(f"query dimension mismatch: expected {self.dim}, got {q.shape[1]}")
+        return q
+
+    def rows(self) -> int:
+        return int(lib().qv_sharded_rows(self._h))
+
+    def update(self, global_row: int, vec):
+        vec = _f32c(vec)
+        if vec.size != self.dim:
+            raise ValueError(f"vector dimension mismatch: expected {self.dim}, got {vec.size}")
+        check(lib().qv_sharded_update(self._h, int(global_row), vec.ctypes.data))
+
+    def get_row(self, global_row: int) -> np.ndarray:
+        out = np.empty(self.dim, dtype=np.float32)
+        check(lib().qv_sharded_get_row(self._h, int(global_row), out.ctypes.data))
+        return out
+
+    def get_rows(self, global_rows) -> np.ndarray:
+        r = np.ascontiguousarray(global_rows, dtype=np.uint32).ravel()
+        out = np.empty((r.size, self.dim), dtype=np.float32)
+        check(lib().qv_sharded_get_rows(self._h, r.ctypes.data, r.size, out.ctypes.data))
+        return out
+
+    def search_masked(self, queries, k: int, selected_global_rows):
+        """exact top-k among the listed rows (global ids): the filtered search, qv_sharded_search_masked"""
+        q = self._q(queries)
+        sel = np.ascontiguousarray(selected_global_rows, dtype=np.uint32).ravel()
+        nq, kk = q.shape[0], max(int(k), 0)
+        rows = np.full((nq, max(kk, 1)), 0xFFFFFFFF, dtype=np.uint32); dist = np.full((nq, max(kk, 1)), np.inf, dtype=np.float32)
+        count = np.zeros(nq, dtype=np.uint32)
+        check(lib().qv_sharded_search_masked(self._h, q.ctypes.data, nq, kk, sel.ctypes.data, sel.size, rows.ctypes.data, dist.ctypes.data, count.ctypes.data))
+        return rows[:, :kk], dist[:, :kk], count
+
+    def search_negative(self, query, negative, k_fetch: int):
+        """-> (rows [k_fetch], dist, neg_dist, count): qv_sharded_search_negative"""
+        q, n = self._q(query), self._q(negative)
+        kk = max(int(k_fetch), 0)
+        rows = np.full(max(kk, 1), 0xFFFFFFFF, dtype=np.uint32); dist = np.full(max(kk, 1), np.inf, dtype=np.float32)
+        nd = np.full(max(kk, 1), np.inf, dtype=np.float32); cnt = C.c_uint32(0)
+        check(lib().qv_sharded_search_negative(self._h, q.ctypes.data, n.ctypes.data, kk, rows.ctypes.data, dist.ctypes.data, nd.ctypes.data, C.byref(cnt)))
+        return rows[:kk], dist[:kk], nd[:kk], int(cnt.value)
+
+    def distance_rows(self, query, global_rows) -> np.ndarray:
+        q = self._q(query)
+        r = np.ascontiguousarray(global_rows, dtype=np.uint32).ravel()
+        out = np.empty(r.size, dtype=np.float32)
+        check(lib().qv_sharded_distance_rows(self._h, q.ctypes.data, r.ctypes.data, r.size, out.ctypes.data))
+        return out
+
+    def set_filter(self, filter):
+        check(lib().qv_sharded_set_filter(self._h, DeviceIndex.FILTERS.get(filter, filter)))
+
+    def profile_read_shard(self, g: int):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(lib().qv_sharded_profile_read_shard(self._h, g, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     def sync(self):
         check(lib().qv_sharded_sync(self._h))
@@ -413,6 +531,23 @@ def distance_pairs(metric, a, b, device: int = 0) -> np.ndarray:
     out = np.empty(a.shape[0], dtype=np.float32)
     check(lib().qv_distance_pairs(metric_id(metric), a.ctypes.data, b.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data, device))
     return out
+
+
+def runtime_info() -> str:
+    """which HIP runtime and RCCL the process bound (qv_runtime_info)"""
+    buf = C.create_string_buffer(1024)
+    check(lib().qv_runtime_info(buf, 1024))
+    return buf.value.decode()
+
+
+def distance_pair(metric, a, b) -> float:
+    """one DistanceFunc call on the host (qv_distance_pair): the kernels' per-pair arithmetic compiled for the CPU"""
+    a, b = _f32c(a).ravel(), _f32c(b).ravel()
+    if a.size != b.size:
+        raise ValueError("vectors must have the same length")  # distances.go:13-15 (the reference panics)
+    out = C.c_float(0)
+    check(lib().qv_distance_pair(metric_id(metric), a.ctypes.data, b.ctypes.data, a.size, C.byref(out)))
+    return float(np.float32(out.value))
 
 
 def device_info(device: int = 0):

@@ -38,11 +38,30 @@ def _res(pairs):
     return [BasicSearchResult(i, d) for i, d in pairs]
 
 
-class ExactIndex:
-    """pkg/hybrid/exact.go:14-160"""
+# Where new ExactIndex / HybridIndex objects keep their rows when the caller does not say: None = one device, or a dict
+# {"Devices": [...], "PeerCopy": bool, "Bf16Rows": bool}.  The GPU tests run the host mirror over several placements through it.
+DEFAULT_PLACEMENT = None
 
-    def __init__(self, dist_func=None, device: int = 0):
-        self._h = hlib().qvh_exact_new(_metric_of(dist_func), device)
+
+def _devs(devices):
+    d = np.ascontiguousarray(list(devices), dtype=np.int32)
+    if d.size == 0:
+        raise ValueError("device list is empty")
+    return d
+
+
+class ExactIndex:
+    """pkg/hybrid/exact.go:14-160.  `devices`: shard the rows over a device list (qv_sharded_*) instead of one
+    `device`; peer_copy: point-to-point exchange (shards may then share a device); bf16_rows: QV_FLAG_BF16_ROWS."""
+
+    def __init__(self, dist_func=None, device: int = 0, devices=None, peer_copy: bool = False, bf16_rows: bool = False):
+        if devices is None and not peer_copy and not bf16_rows and DEFAULT_PLACEMENT:
+            devices, peer_copy, bf16_rows = DEFAULT_PLACEMENT.get("Devices"), DEFAULT_PLACEMENT.get("PeerCopy", False), DEFAULT_PLACEMENT.get("Bf16Rows", False)
+        if devices is None and not peer_copy and not bf16_rows:
+            self._h = hlib().qvh_exact_new(_metric_of(dist_func), device)
+        else:
+            d = _devs(devices if devices is not None else [device])
+            self._h = hlib().qvh_exact_new_placed(_metric_of(dist_func), d.ctypes.data, d.size, int(peer_copy), int(bf16_rows))
 
     def __del__(self):
         try:
@@ -90,6 +109,11 @@ class IndexConfig:                     # types.go:27-45
     # not in the reference: its level RNG / exploration RNG are wall-clock / global seeded
     Seed: int = 1
     ExplorationFactor: float = 0.1     # DefaultAdaptiveConfig, types.go:93
+    # not in the reference (one process on CPU cores): where the exact index keeps its rows — a device list shards them
+    # (qv_sharded_*), the HNSW graph stays on the first device; PeerCopy lets shards share a device; Bf16Rows = QV_FLAG_BF16_ROWS
+    Devices: object = None
+    PeerCopy: bool = False
+    Bf16Rows: bool = False
 
 
 def DefaultIndexConfig() -> IndexConfig:
@@ -171,8 +195,15 @@ class HybridIndex:
     def __init__(self, config: Optional[IndexConfig] = None, device: int = 0):
         c = config or IndexConfig()
         h = c.HNSWConfig
-        self._h = hlib().qvh_hybrid_new(_metric_of(c.DistanceFunc), device, h.M, h.MaxM0, h.EfConstruction, h.EfSearch,
-                                        c.ExactThreshold, c.ExplorationFactor, c.Seed)
+        if c.Devices is None and not c.PeerCopy and not c.Bf16Rows and DEFAULT_PLACEMENT:
+            c = IndexConfig(**{**c.__dict__, **{k: DEFAULT_PLACEMENT[k] for k in ("Devices", "PeerCopy", "Bf16Rows") if k in DEFAULT_PLACEMENT}})
+        if c.Devices is None and not c.PeerCopy and not c.Bf16Rows:
+            self._h = hlib().qvh_hybrid_new(_metric_of(c.DistanceFunc), device, h.M, h.MaxM0, h.EfConstruction, h.EfSearch,
+                                            c.ExactThreshold, c.ExplorationFactor, c.Seed)
+        else:
+            d = _devs(c.Devices if c.Devices is not None else [device])
+            self._h = hlib().qvh_hybrid_new_placed(_metric_of(c.DistanceFunc), d.ctypes.data, d.size, int(c.PeerCopy), int(c.Bf16Rows), h.M, h.MaxM0,
+                                                   h.EfConstruction, h.EfSearch, c.ExactThreshold, c.ExplorationFactor, c.Seed)
 
     def __del__(self):
         try:

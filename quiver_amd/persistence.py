@@ -42,6 +42,8 @@ class Collection:
         self._id_of: Dict[int, str] = {}
         self._free: List[int] = []
         self._meta: Dict[str, Dict[str, str]] = {}
+        self._host: Dict[str, np.ndarray] = {}                       # distanceFunc == nil: the reference still stores, returns and deletes
+                                                                     # vectors (collection.go:99-208); only Search errors.  No device index then.
         self.dirty = False
 
     def GetName(self) -> str:
@@ -64,11 +66,20 @@ class Collection:
             else:
                 row = self._idx.add(v)
                 self._row_of[id], self._id_of[row] = row, id
+        else:
+            self._host[id] = v.copy()
         if metadata is not None:
             self._meta[id] = dict(metadata)
         self.dirty = True
 
     def DeleteVector(self, id: str) -> None:                         # collection.go:151-182
+        if self._idx is None:
+            if id not in self._host:
+                raise GoError(f"vector with ID {id} not found")
+            del self._host[id]
+            self._meta.pop(id, None)
+            self.dirty = True
+            return
         if id not in self._row_of:
             raise GoError(f"vector with ID {id} not found")
         row = self._row_of.pop(id)
@@ -79,13 +90,14 @@ class Collection:
         self.dirty = True
 
     def GetVector(self, id: str):                                    # collection.go:185-208
-        if id not in self._row_of:
+        if id not in self._row_of and id not in self._host:
             raise GoError(f"vector with ID {id} not found")
         meta = self._meta.get(id)
-        return self._idx.get_row(self._row_of[id]), (dict(meta) if meta is not None else None)
+        vec = self._host[id].copy() if self._idx is None else self._idx.get_row(self._row_of[id])
+        return vec, (dict(meta) if meta is not None else None)
 
     def Count(self) -> int:                                          # collection.go:281-285
-        return len(self._row_of)
+        return len(self._row_of) + len(self._host)
 
     def Search(self, query, limit: int) -> List[SearchResult]:       # collection.go:226-261
         if self._idx is None:

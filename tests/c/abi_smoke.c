@@ -11,6 +11,9 @@
 
 int main(void) {
     if (qv_abi_version() != QV_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
+    /* the DistanceFunc contract for one pair is host code: works with or without a device.  distances_test.go:151-156 */
+    { const float a[3] = {2, 0, 0}, b[3] = {3, 0, 0}; float d = 0;
+      if (qv_distance_pair(QV_DOT, a, b, 3, &d) != QV_OK || d != -5.0f) { fprintf(stderr, "distance_pair: %g\n", d); return 30; } }
     qv_index* idx = NULL;
     int rc = qv_index_create(&idx, 4, QV_L2, 0, 0);
     if (qv_device_count() <= 0) {
@@ -55,6 +58,19 @@ int main(void) {
     uint32_t gids[3];
     if (qv_sharded_add(sh, &rows[0][0], 3, gids) != QV_OK || qv_sharded_size(sh) != 3) { fprintf(stderr, "sharded add: %s\n", qv_last_error()); return 17; }
     if (qv_sharded_search(sh, q, 1, 2, out_rows, out_dist, &count) != QV_OK || count != 2 || out_rows[0] != gids[0] || out_rows[1] != gids[1]) { fprintf(stderr, "sharded search: %s\n", qv_last_error()); return 18; }
+    /* the rest of core.Index on the sharded handle: update (Collection.Update), get, filtered search, a ranking deeper than
+     * the fused top-k, negative example, listed-row distances */
+    { const float moved[4] = {0.5f, 0.5f, 0, 0}; float back[4]; uint32_t big_rows[70], cnt70 = 0; float big_dist[70], nd[3], dr[2];
+      if (qv_sharded_update(sh, gids[2], moved) != QV_OK || qv_sharded_get_row(sh, gids[2], back) != QV_OK || back[0] != 0.5f) { fprintf(stderr, "sharded update/get: %s\n", qv_last_error()); return 19; }
+      if (qv_sharded_search(sh, q, 1, 70, big_rows, big_dist, &cnt70) != QV_OK || cnt70 != 3 || big_rows[0] != gids[0] || big_rows[1] != gids[2] || big_rows[3] != 0xFFFFFFFFu) { fprintf(stderr, "sharded k=70: %s\n", qv_last_error()); return 20; }
+      const uint32_t sel[2] = {gids[1], gids[2]};
+      if (qv_sharded_search_masked(sh, q, 1, 2, sel, 2, out_rows, out_dist, &count) != QV_OK || count != 2 || out_rows[0] != gids[2] || out_rows[1] != gids[1]) { fprintf(stderr, "sharded masked: %s\n", qv_last_error()); return 21; }
+      const float neg[4] = {0, 1, 0, 0}; uint32_t nrows[3], ncnt = 0; float ndist[3];
+      if (qv_sharded_search_negative(sh, q, neg, 3, nrows, ndist, nd, &ncnt) != QV_OK || ncnt != 3 || nrows[0] != gids[0] || !(fabsf(nd[0] - 1.41421354f) < 1e-6f)) { fprintf(stderr, "sharded negative: %s\n", qv_last_error()); return 22; }
+      if (qv_sharded_distance_rows(sh, q, sel, 2, dr) != QV_OK || dr[0] != out_dist[1] || dr[1] != out_dist[0]) { fprintf(stderr, "sharded distance_rows: %s\n", qv_last_error()); return 23; }
+      char rt[512];
+      if (qv_runtime_info(rt, sizeof rt) != QV_OK || !strstr(rt, "rccl=")) { fprintf(stderr, "runtime info\n"); return 24; }
+      if (qv_sharded_set_filter(sh, QV_FILTER_BF16X3) != QV_OK || qv_sharded_set_filter(sh, 9) != QV_ERR_INVALID_ARG) { fprintf(stderr, "set_filter\n"); return 25; } }
     qv_sharded_destroy(sh);
     printf("ok: [%u %u] d0=%g graph [%u %u %u]\n", 1u, out_rows[1], out_dist[0], gr[0], gr[1], gr[2]);
     return 0;

@@ -32,12 +32,17 @@ def _has_gpu() -> bool:
 
 def pytest_collection_modifyitems(config, items):
     if _has_gpu():
-        # a wedged collective or device call must fail ONE test, not stall the whole run (seen once: the RCCL communicator of
-        # test_gpu_sharded_abi's first test never came up after the multi-process tests before it)
+        # a wedged collective or device call must fail loudly instead of stalling the whole run (seen once in round 2: the RCCL
+        # communicator of test_gpu_sharded_abi's first test never came up after the multi-process tests before it; not
+        # reproduced since — profiles/r03_rccl_loop.md).  method="thread": a thread blocked inside hipStreamSynchronize or
+        # ncclCommInitAll (through ctypes) never returns to the interpreter, so the signal method would not fire; the thread
+        # method dumps every stack and ends the process with a non-zero status.
         if config.pluginmanager.hasplugin("timeout"):
             for item in items:
                 if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
-                    item.add_marker(pytest.mark.timeout(600))
+                    item.add_marker(pytest.mark.timeout(600, method="thread"))
+        else:
+            sys.stderr.write("conftest: pytest-timeout is not installed: a wedged device call will stall this run\n")
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:

@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["bf16x3", "fp32", "bf16x1"], autouse=True)
 def filter_kernel(request, monkeypatch):
-    """every case runs with the three filter kernels: bfloat16 x 3 (QV_MFMA_FILTER=2), the fp32 MFMA chain (=1, BASELINE
-    configs[2] as written) and the one-term bfloat16 filter (=3); the library reads the variable per call"""
-    monkeypatch.setenv("QV_MFMA_FILTER", {"bf16x3": "2", "fp32": "1", "bf16x1": "3"}[request.param])
+    """every case runs with the three filter kernels: bfloat16 x 3, the fp32 MFMA chain (BASELINE configs[2] as written) and
+    the one-term bfloat16 filter; each index chooses through qv_index_set_filter (DeviceIndex.default_filter here)"""
+    import quiver_amd
+    monkeypatch.setattr(quiver_amd.DeviceIndex, "default_filter", request.param)
     return request.param
 
 

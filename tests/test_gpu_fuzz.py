@@ -161,20 +161,56 @@ def test_random_hnsw_histories_match_the_oracle(seed):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_random_sharded_histories_match_the_oracle(seed):
-    """qv_sharded_* with 1..5 co-located shards (point-to-point exchange): add / remove / search in random order; the answer is
-    the oracle's over the live rows keyed by global row id, (distance, global row) order, float32 bits"""
+    """qv_sharded_* with 1..8 co-located shards (point-to-point exchange): add / remove / update / search (any k) / filtered search /
+    negative-example fetch / listed-row distances in random order; the answer is the oracle's over the live rows keyed by global
+    row id, (distance, global row) order, float32 bits"""
     from quiver_amd import ShardedIndex
     rng = np.random.default_rng(9000 + seed)
     metric = METRICS[seed % len(METRICS)]
     mid = quiver_amd.metric_id(metric)
     dim = int(rng.choice([3, 8, 20, 64]))
-    shards = int(rng.integers(1, 6))
+    shards = int(rng.integers(1, 9))
     style = seed % 3
     idx = ShardedIndex(dim, metric, devices=[0] * shards, peer_copy=True)
-    live = {}
-    for step in range(25):
-        op = rng.choice(["add", "add", "remove", "search", "search"]) if live else "add"
-        if op == "add":
+    live, dead = {}, []
+    for step in range(40):
+        op = rng.choice(["add", "add", "remove", "search", "search", "update", "masked", "ranked", "negative", "rows"]) if live else "add"
+        if op == "update":                                       # overwrite a live row, or revive a tombstoned one
+            g = dead.pop() if dead and rng.random() < 0.5 else list(live)[int(rng.integers(len(live)))]
+            x = _vectors(rng, 1, dim, style)[0]
+            idx.update(g, x)
+            live[g] = x
+        elif op in ("masked", "ranked", "negative", "rows"):
+            gids = np.array(sorted(live), dtype=np.uint32)
+            mat = np.stack([live[g] for g in gids])
+            q = _vectors(rng, 1, dim, style)[0]
+            if op == "masked":
+                sel = rng.random(gids.size) < rng.choice([0.05, 0.5, 1.0])
+                extra = np.array(dead[:3], dtype=np.uint32)        # tombstoned rows among the candidates are ignored
+                k = int(rng.choice([1, 10, 100]))
+                r, d, c = idx.search_masked(q, k, np.concatenate([gids[sel], extra]))
+                if sel.sum() == 0:
+                    assert c[0] == 0
+                else:
+                    er, ed = O.exact_search(mid, mat[sel], q, k)
+                    assert int(c[0]) == er.size and r[0, :er.size].tolist() == gids[sel][er].tolist() and d[0, :er.size].tobytes() == ed.tobytes(), step
+            elif op == "ranked":
+                k = int(rng.choice([65, 200, gids.size, gids.size + 7]))
+                r, d, c = idx.search(q, k)
+                er, ed = O.exact_search(mid, mat, q, k)
+                assert int(c[0]) == er.size and r[0, :er.size].tolist() == gids[er].tolist() and d[0, :er.size].tobytes() == ed.tobytes(), step
+            elif op == "negative":
+                neg = _vectors(rng, 1, dim, style)[0]
+                kf = int(rng.choice([30, 64, 90]))
+                r, d, nd, c = idx.search_negative(q, neg, kf)
+                er, ed = O.exact_search(mid, mat, q, kf)
+                assert c == er.size and r[:c].tolist() == gids[er].tolist() and d[:c].tobytes() == ed.tobytes(), step
+                assert nd[:c].tobytes() == O.all_distances(mid, mat[er], neg).tobytes(), step
+            else:
+                pick = rng.integers(0, gids.size, size=int(rng.choice([1, 5, 40])))
+                assert idx.distance_rows(q, gids[pick]).tobytes() == O.all_distances(mid, mat[pick], q).tobytes(), step
+                assert idx.get_rows(gids[pick]).tobytes() == mat[pick].tobytes(), step
+        elif op == "add":
             x = _vectors(rng, int(rng.choice([1, 2, 7, 64, 300])), dim, style)
             gids = idx.add(x)
             assert len(set(gids.tolist()) & set(live)) == 0
@@ -184,6 +220,7 @@ def test_random_sharded_histories_match_the_oracle(seed):
             idx.remove(who)
             for g in who:
                 del live[g]
+            dead.extend(who)
         elif live:
             gids = np.array(sorted(live), dtype=np.uint32)
             mat = np.stack([live[g] for g in gids])
@@ -212,6 +249,9 @@ def test_random_hybrid_histories(seed):
     cfg = hybrid.IndexConfig(DistanceFunc=metric, Seed=seed + 1, ExplorationFactor=0.0)
     cfg.HNSWConfig = hybrid.HNSWConfig(M=int(rng.choice([4, 16])), MaxM0=0, EfConstruction=int(rng.choice([20, 100])), EfSearch=int(rng.choice([16, 64])))
     cfg.HNSWConfig.MaxM0 = 2 * cfg.HNSWConfig.M
+    n_shards = (1, 3, 8)[seed % 3]                                # the exact index on one device, or sharded (co-located shards)
+    if n_shards > 1:
+        cfg.Devices, cfg.PeerCopy = [0] * n_shards, True
     idx = hybrid.HybridIndex(cfg)
     live, nxt = {}, 0
     for step in range(22):

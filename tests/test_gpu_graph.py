@@ -142,3 +142,28 @@ def test_update_and_remove_reach_the_row_major_copy_the_traversal_reads():
     # the flat scan (tile layout) agrees
     fr, fd, _ = idx.search(q, 1)
     assert fr[0, 0] == far and fd[0, 0] == d[0, 0]
+
+
+def test_graph_replicas_round_robin_equals_one_graph():
+    """HNSW across GPUs = replicas only: one graph per device (two replicas co-located on device 0 here), a batch
+    cut over them and walked concurrently; same answer, query for query, as one graph walking the whole batch"""
+    import quiver_amd
+    from quiver_amd.device_index import DeviceGraph, GraphReplicas, random_levels
+    n, dim, k, ef = 4000, 48, 7, 40
+    rows = O.gen_rows(901, 0, n, dim)
+    levels = random_levels(n, 16, 5)
+    reps = GraphReplicas(rows, levels, "cosine", devices=[0, 0, 0], m=8, max_m0=16, ef_construction=60)
+    one_idx = quiver_amd.DeviceIndex(dim, "cosine", rowmajor=True)
+    one_idx.add(rows)
+    one = DeviceGraph.build(one_idx, levels, m=8, max_m0=16, ef_construction=60)
+    for a, b in zip(reps.graphs[0].export(), one.export()):
+        assert np.array_equal(a, b)                                   # the build is deterministic: replicas are copies
+    qs = O.gen_rows(902, 0, 50, dim)
+    r, d, c = reps.search(qs, k, ef)
+    r1, d1, c1 = one.search(qs, k, ef)
+    assert np.array_equal(c, c1)
+    for i in range(50):
+        assert np.array_equal(r[i, :c[i]], r1[i, :c1[i]]) and d[i, :c[i]].tobytes() == d1[i, :c1[i]].tobytes()
+    r2, d2, c2 = reps.search(qs[:2], k, ef)                           # fewer queries than replicas
+    assert np.array_equal(r2[:, :k], r[:2, :k])
+    reps.close(); one.close(); one_idx.close()

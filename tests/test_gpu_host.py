@@ -18,6 +18,19 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+# The exact index behind ExactIndex / HybridIndex / Collection on one device (a qv_index) and sharded over 3 and 8 row shards
+# (a qv_sharded handle; co-located on device 0 with the point-to-point exchange, which is how a 1-GPU box runs several
+# shards): the host mirror and its reference tables must not notice the difference.
+PLACEMENTS = {"1dev": None, "3shards": {"Devices": [0, 0, 0], "PeerCopy": True}, "8shards": {"Devices": [0] * 8, "PeerCopy": True}}
+
+
+@pytest.fixture(params=list(PLACEMENTS))
+def placement(request, monkeypatch):
+    from quiver_amd import hybrid
+    monkeypatch.setattr(hybrid, "DEFAULT_PLACEMENT", PLACEMENTS[request.param])
+    return request.param
+
+
 # ------------------------------------------------------------------ vectortypes ---
 
 def test_vectortypes_distance_funcs_kats():                     # distances_test.go:9-204
@@ -55,6 +68,7 @@ def test_vectortypes_lookup_and_surfaces():                     # types_test.go:
 
 # ------------------------------------------------------------------ hybrid.ExactIndex ---
 
+@pytest.mark.usefixtures("placement")
 def test_exact_index_insert_delete_semantics():                 # exact_test.go:13-95
     from quiver_amd import hybrid, vectortypes as vt
     from quiver_amd._host import GoError
@@ -86,6 +100,7 @@ def test_exact_index_insert_delete_semantics():                 # exact_test.go:
 
 
 @pytest.mark.parametrize("kat", KATS["exact_search"], ids=lambda k: k["src"])
+@pytest.mark.usefixtures("placement")
 def test_exact_index_search_kats(kat):                          # exact_test.go:97-205
     from quiver_amd import hybrid
     idx = hybrid.ExactIndex(kat["metric"])
@@ -111,6 +126,7 @@ def _hybrid(metric="cosine", **kw):
     return hybrid.HybridIndex(cfg)
 
 
+@pytest.mark.usefixtures("placement")
 def test_hybrid_forced_exact_and_batch_insert():                # hybrid_index_test.go:270-311
     from quiver_amd import hybrid
     idx = _hybrid()
@@ -122,6 +138,7 @@ def test_hybrid_forced_exact_and_batch_insert():                # hybrid_index_t
     assert resp.Results[0].ID == "vec2"                          # hybrid_index_test.go:349-360
 
 
+@pytest.mark.usefixtures("placement")
 def test_hybrid_errors_and_rollback():
     from quiver_amd import hybrid
     from quiver_amd._host import GoError
@@ -151,6 +168,7 @@ def test_hybrid_errors_and_rollback():
     idx.Insert("n", [1, 2])                                      # dimension resets (hybrid_index.go:282-284)
 
 
+@pytest.mark.usefixtures("placement")
 def test_hybrid_exact_distances_l2_unit_axes():                 # hybrid_property_test.go:443-461
     idx = _hybrid("euclidean")
     idx.Insert("a", [1, 0, 0]); idx.Insert("b", [0, 1, 0]); idx.Insert("c", [0, 0, 1])
@@ -160,6 +178,7 @@ def test_hybrid_exact_distances_l2_unit_axes():                 # hybrid_propert
 
 
 @pytest.mark.parametrize("kat", KATS["negative_rerank"], ids=lambda k: k["src"])
+@pytest.mark.usefixtures("placement")
 def test_hybrid_negative_example_kats(kat):                     # hybrid_index_test.go:541-656; hybrid_index_rerank_test.go:9-47
     from quiver_amd import hybrid
     idx = _hybrid(kat["metric"])
@@ -186,6 +205,7 @@ def test_hybrid_negative_example_kats(kat):                     # hybrid_index_t
     assert [r.ID for r in fres.Results] == [r.ID for r in res]
 
 
+@pytest.mark.usefixtures("placement")
 def test_hybrid_negative_rerank_random_vs_oracle():
     from quiver_amd import hybrid
     rows = O.gen_rows(61, 0, 500, 24)
@@ -203,6 +223,7 @@ def test_hybrid_negative_rerank_random_vs_oracle():
             assert np.array_equal(_bits([r.Distance for r in res]), _bits(ed))
 
 
+@pytest.mark.usefixtures("placement")
 def test_hybrid_batch_search_equals_single_searches():          # hybrid_index.go:677-811
     from quiver_amd import hybrid
     from quiver_amd._host import GoError
@@ -320,6 +341,7 @@ def test_hnsw_adapter_fill_and_negative():                       # adapter.go:41
 
 # ------------------------------------------------------------------ core.Collection surface ---
 
+@pytest.mark.usefixtures("placement")
 def test_collection_add_search_fluent_filters():                # collection_test.go; collection.go:133-331, 637-807, 886-1108
     from quiver_amd import core, hybrid
     idx = _hybrid("cosine")
@@ -353,6 +375,7 @@ def test_collection_add_search_fluent_filters():                # collection_tes
         c.Search(core.SearchRequest(Vector=q[:3], TopK=1))
 
 
+@pytest.mark.usefixtures("placement")
 def test_collection_filtered_search_is_a_full_ranking():        # collection.go:679-682: searchK = Index.Size()
     from quiver_amd import core, hybrid
     rows = O.gen_rows(121, 0, 300, 8)
@@ -551,6 +574,7 @@ def test_hnsw_insert_batch_duplicate_id_is_rejected_before_anything_changes():
     assert h.Size() == 6 and h.nodes() == 6
 
 
+@pytest.mark.usefixtures("placement")
 def test_hybrid_insert_batch_is_two_device_calls_and_searches_agree():
     from quiver_amd import hybrid, hnsw
     n, dim = 1200, 24
@@ -570,6 +594,7 @@ def test_hybrid_insert_batch_is_two_device_calls_and_searches_agree():
         assert [r.ID for r in ex.Results[i]] == ["v%d" % j for j in er]
 
 
+@pytest.mark.usefixtures("placement")
 def test_exact_index_reuses_tombstoned_rows_under_churn():
     """Collection.Update = Delete + Insert (collection.go): the device index must not grow with every update"""
     from quiver_amd import hybrid
@@ -593,6 +618,7 @@ def test_exact_index_reuses_tombstoned_rows_under_churn():
     assert len(set(ed.tolist())) < 7 or [r.ID for r in got] == [names[j] for j in er]
 
 
+@pytest.mark.usefixtures("placement")
 def test_concurrent_searches_on_one_hybrid_index_are_consistent():
     """Collection.Search holds only a read lock (collection.go:647): many Index.Search calls run at once.  ctypes drops the GIL,
     so Python threads really do enter the C++ mirror concurrently."""
@@ -701,6 +727,8 @@ def test_arrow_graph_search_table(kat):                          # arrowindex/gr
     assert arrowindex.Graph(2).Search([0.0, 0.0], 3) == []       # empty graph: nil, nil (:474-476)
     with pytest.raises(ValueError, match="not float32-representable"):
         g.Add(9, [0.1, 0.2])
+    with pytest.raises(ValueError, match="not float32-representable"):
+        g.Search([0.1, 0.2], 1)                                  # a query is refused by the same rule, never rounded
 
 
 def test_persistence_collection_search_tables():                 # persistence/collection_test.go:259-325, 355-383

@@ -77,9 +77,8 @@ def test_fewer_rows_than_shards_and_k_larger_than_corpus():
     with pytest.raises(quiver_amd.QvError) as e:
         idx.search(rows[0], 0)
     assert "k must be positive" in str(e.value)
-    with pytest.raises(quiver_amd.QvError) as e:
-        idx.search(rows[0], 65)
-    assert e.value.code == quiver_amd._lib.QV_ERR_UNSUPPORTED
+    r, d, c = idx.search(rows[0], 65)                            # any k: clamped to the corpus, the rest padded
+    assert c[0] == 2 and (r[0, 2:] == 0xFFFFFFFF).all() and sorted(r[0, :2].tolist()) == sorted(gids.tolist())
 
 
 def test_rccl_refuses_a_device_listed_twice():

@@ -127,3 +127,29 @@ def test_filter_value_semantics():                  # collection.go:530-632
     assert matchesFilter(md, Filter("n", "not_in", "oops"))       # not a list -> true (collection.go:562-571)
     assert not matchesFilter(md, Filter("n", "in", "oops"))
     assert not matchesFilter(md, Filter("n", "~", 1))
+
+
+def test_persistence_collection_without_a_distance_function_still_stores_vectors():
+    """pkg/persistence/collection.go:99-208: AddVector / GetVector / DeleteVector / Count do not involve distanceFunc; only Search
+    errors with "distance function is not set" (:227-229).  No device index exists then (nothing to offload): runs without a GPU."""
+    import numpy as np
+    import pytest
+    from quiver_amd import persistence as ps
+    c = ps.Collection("plain", 3, None)
+    c.AddVector("a", [1, 2, 3], {"k": "v"})
+    c.AddVector("b", [4, 5, 6])
+    assert c.Count() == 2
+    v, meta = c.GetVector("a")
+    assert np.array_equal(v, np.array([1, 2, 3], np.float32)) and meta == {"k": "v"}
+    c.AddVector("a", [7, 8, 9])                                   # an existing id is overwritten (c.vectors[id] = vecCopy)
+    assert c.Count() == 2 and np.array_equal(c.GetVector("a")[0], np.array([7, 8, 9], np.float32))
+    with pytest.raises(ps.GoError, match="distance function is not set"):
+        c.Search([1, 2, 3], 1)
+    c.DeleteVector("a")
+    assert c.Count() == 1
+    with pytest.raises(ps.GoError, match="vector with ID a not found"):
+        c.DeleteVector("a")
+    with pytest.raises(ps.GoError, match="vector with ID a not found"):
+        c.GetVector("a")
+    with pytest.raises(ps.GoError, match="vector dimension mismatch: got 2, expected 3"):
+        c.AddVector("z", [1, 2])

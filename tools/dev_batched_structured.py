@@ -39,7 +39,7 @@ for label, centers, spread in (("subspace r=%d" % r, None, 0.0),
     idx.search_device(dq.data_ptr(), nq, k, er.data_ptr(), ed.data_ptr(), sp)
     torch.cuda.synchronize()
     for mode in ("3", "2", "1"):
-        os.environ["QV_MFMA_FILTER"] = mode
+        idx.set_filter(int(mode))
         dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
         fl = torch.zeros((nq,), dtype=torch.int32, device="cuda")
         idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), sp)
