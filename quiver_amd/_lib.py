@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqv.so")
+LIB_PATH = os.environ.get("QV_LIB_PATH") or os.path.join(_HERE, "lib", "libqv.so")   # QV_LIB_PATH: a measurement build of the library (tools/)
 
 QV_OK = 0
 QV_ERR_INVALID_ARG, QV_ERR_DIM_MISMATCH, QV_ERR_K_NOT_POSITIVE, QV_ERR_OUT_OF_RANGE = -1, -2, -3, -4

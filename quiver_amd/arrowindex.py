@@ -162,7 +162,11 @@ class Graph:
     def GetVector(self, idx: int):                                 # graph.go:897-901
         return self._idx.get_row(idx).astype(np.float64) if 0 <= idx < len(self._ids) else None
 
-    def Search(self, query, k: int) -> List[int]:                  # graph.go:467-488
+    def Search(self, query, k: int, strict: bool = False) -> List[int]:   # graph.go:467-488
+        """Stored vectors must be float32-representable (AddBatch refuses others).  A QUERY that is not — the reference's own
+        table queries (0.1, 0.1), graph_test.go:10-28 — is rounded to the nearest float32 before the device call and a
+        RuntimeWarning says so (never silently): distances then differ from the reference's by at most one float32 rounding of
+        each query component, which can reorder only near-ties.  strict=True refuses instead, like AddBatch."""
         q = np.asarray(query, dtype=np.float64).ravel()
         if q.size != self.dim:
             raise ValueError(f"query dimension mismatch: got {q.size}, want {self.dim}")
@@ -171,7 +175,11 @@ class Graph:
             return []
         k = min(k, n)                                              # :478-480
         q32 = q.astype(np.float32)
-        if not np.array_equal(q32.astype(np.float64), q):          # the same rule AddBatch applies: refused, never rounded
-            raise ValueError("query vector is not float32-representable (device arithmetic starts from float32 values)")
+        if not np.array_equal(q32.astype(np.float64), q):
+            if strict:
+                raise ValueError("query vector is not float32-representable (device arithmetic starts from float32 values)")
+            import warnings
+            warnings.warn("arrowindex.Graph.Search: query rounded to float32 for the device (max component change %.3g)"
+                          % float(np.max(np.abs(q32.astype(np.float64) - q))), RuntimeWarning, stacklevel=2)
         rows, _, count = self._idx.search(q32, k)                  # exhaustiveSearch (:490-506): every node, nearest k
         return [self._ids[int(rows[0, i])] for i in range(int(count[0]))]

@@ -143,11 +143,11 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
                 const double T = metric == QV_L2 ? U * U * (1.0 + 4e-7) : U * (1.0 + gamma + 2e-6);
                 c = n2 * (1.0 - 2e-6) - T;                           // A_q; test: 2S~ >= A_q + (1-2e-6)|r|^2 - B_q|r|
                 m = 2.0 * (gamma + 1e-6) * qn;                       // B_q
-                if (!(U == U) || U > 1.0e18 || (bf16x3 && qn < 1e-18)) { c = -3.0e38; m = 0.0; }
+                if (!(U == U) || U > 1.0e18 || (bf16x3 && qn < 1e-18) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; }   // (a query norm >= 1e18 or NaN: its float32 scores may overflow)
             } else {
                 c = metric == QV_COSINE ? (1.0 - U - 4e-7) * qn : (1.0 - U - 4e-7 * (1.0 + __builtin_fabs(U)));
                 m = (gamma + 1e-6) * qn;
-                if (!(U == U) || U > 3.0e38 || (bf16x3 && qn < 1e-18)) { c = -3.0e38; m = 0.0; }   // no bound: everything is a candidate (overflow -> exact path); bf16 operands below 2^-126 flush
+                if (!(U == U) || U > 3.0e38 || (bf16x3 && qn < 1e-18) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; }   // no bound: everything is a candidate (overflow -> exact path); bf16 operands below 2^-126 flush
             }
             c_ = f32_down((float)c);                                         // round towards "keep more"
             m_ = f32_up((float)m);
@@ -157,14 +157,135 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
     }
 }
 
-// the filter test on a wave's 64 x 128 scores: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31];
-// a row that may be in some query's top-k goes to that query's candidate list with its score
+// Candidate queue of a wave.  A row that passes the filter test used to be appended to its query's list with a RETURNING global
+// atomic (the slot), inside an epilogue that also spilled around itself.  Vector-memory operations complete in issue order per
+// wave (`s_waitcnt vmcnt` is one counter), so waiting for that slot — or for any vector-memory result: a spill reload is one too
+// — also waits for every row request the wave has in flight, i.e. the prefetch ring of the NEXT row group, issued during the last
+// steps of this one.  Hits now go to a queue in LDS that belongs to the wave (its fill count is a wave-uniform register, the
+// slot is count + the lane's rank in the ballot: no atomic at all, nothing in the append path touches vector memory), and the
+// wave appends its queue to the per-query lists itself when it fills up (rare) and after its last row group.
+constexpr uint32_t kCandQueueWords = 3;                               // {query, row, score bits}
+struct CandQueue { uint32_t* rec; uint32_t cap; };                    // this WAVE's records in LDS (cap >= 64)
+
+__device__ __forceinline__ void cand_append_global(uint32_t q, uint32_t row, float score, uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score,
+                                                   uint32_t* __restrict__ cand_cnt) {
+    const uint32_t slot = atomicAdd(&cand_cnt[q], 1u);
+    if (slot < (uint32_t)kMfmaCandCap) {
+        cand_rows[(size_t)q * kMfmaCandCap + slot] = row;
+        cand_score[(size_t)q * kMfmaCandCap + slot] = score;
+    }
+}
+struct CandOut { uint32_t* rows; float* score; uint32_t* cnt; };      // the per-query candidate lists in global memory
+// every lane of the wave calls this: the wave's n queued records go to the per-query lists
+__device__ __forceinline__ void cand_flush(const CandQueue& cqu, uint32_t n, const CandOut& out) {
+    __threadfence_block();
+    for (uint32_t i = lane_id(); i < n; i += 64)
+        cand_append_global(cqu.rec[kCandQueueWords * i], cqu.rec[kCandQueueWords * i + 1], __uint_as_float(cqu.rec[kCandQueueWords * i + 2]), out.rows, out.score, out.cnt);
+    __threadfence_block();
+}
+// called by ALL lanes of a wave (converged) with the wave's mask m (non-zero) of the lanes that append their record; n = the queue's fill
+__device__ __forceinline__ void cand_push(const CandQueue& cqu, uint32_t& n, uint64_t m, uint32_t q, uint32_t row, float score, const CandOut& out) {
+    const uint32_t lane = lane_id();
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+    if (__builtin_expect(n + cnt > cqu.cap, 0)) { cand_flush(cqu, n, out); n = 0; }
+    if ((m >> lane) & 1ull) {
+        uint32_t* d = cqu.rec + kCandQueueWords * (n + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)));
+        d[0] = q; d[1] = row; d[2] = __float_as_uint(score);
+    }
+    n += cnt;
+}
+#define QV_EPI_DUMP(name, WAVES, CAP)                                         \
+    __shared__ __align__(16) uint32_t name##_area[(WAVES) * (CAP) * kEpiEntryWords]; \
+    const EpiDump name{name##_area + (threadIdx.x >> 6) * (CAP) * kEpiEntryWords, (CAP)}
+#define QV_CAND_QUEUE(name, WAVES, CAP)                                       \
+    __shared__ uint32_t name##_rec[(WAVES) * (CAP) * kCandQueueWords];        \
+    const CandQueue name{name##_rec + (threadIdx.x >> 6) * (CAP) * kCandQueueWords, (CAP)}; \
+    uint32_t name##_n = 0;                                                    \
+    const CandOut name##_out{cand_rows, cand_score, cand_cnt}
+
+// The filter test on a wave's 64 x 128 scores: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31];
+// a row that may be in some query's top-k goes to that query's candidate list with its score.
+//
+// Cost matters here: 128 scores per lane and row group, of which ~1 in 1400 passes, on a lone wave per SIMD that pays ~13 cycles
+// per instruction (nobody to cover its dependencies).  Testing every score against its own query's threshold, and entering an
+// unrolled 16-way append sequence in every block in which any lane hit, was 1 300 instructions per wave and row group: 30 % of the
+// kernel (profiles/r03_batched_epilogue.txt: 855 us with, 594 us without any epilogue).  Three steps now:
+//   level 1, per lane and 16-score block (the part that must touch every score): ONE compare of the block's maximum (8 v_max3)
+//     against a lower bound of the block's 16 thresholds — the smallest c and largest m among the 16 queries of that block and
+//     lane half (EpiConsts, once per wave).  ~1-3 % of the lanes pass.
+//   dump: a lane that passes writes its 16 scores and its row constants to the wave's dump area in LDS (80 bytes).
+//   dense pass, once per row group: the dumped (entry, score) pairs are spread over the 64 lanes — 4 entries per pass — and each
+//     lane does the exact per-query test for its pair and appends.  The sparse work of a few lanes becomes a dense wave's work.
+// No score is NaN or infinite when both norms are below 1e18 (|partial sum| <= |q||r| < 1e36), so overflow is guarded per ROW
+// here (a norm that is NaN, infinite or >= 1e18 passes both tests outright: the exact pass decides) and per QUERY in k_mfma_prep
+// (such a query gets the "everything is a candidate" threshold), not per score.
+struct EpiConsts { float cmin[2], mmax[2]; };
+template <int METRIC>
+__device__ __forceinline__ EpiConsts epi_consts(const float (&s_c)[4][64], const float (&s_m)[4][64], uint32_t wave, uint32_t half) {
+    EpiConsts e;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float cm = __uint_as_float(0x7F800000u), mm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+            cm = fminf(cm, s_c[wave][ql]); mm = fmaxf(mm, s_m[wave][ql]);
+        }
+        e.cmin[i] = cm; e.mmax[i] = mm;
+    }
+    return e;
+}
+template <int METRIC>
+__device__ __forceinline__ float filter_threshold(float c, float m, float rn, float rn2c) {
+    return METRIC == QV_COSINE ? c * rn - 1e-30f : (METRIC == QV_DOT ? c - m * rn : 0.5f * (c + rn2c - m * rn));
+}
+constexpr uint32_t kEpiEntryWords = 20;                               // 16 scores, row, |r| up, (1-2e-6)|r|^2 down, flags (i | half << 1 | unsure << 2)
+struct EpiDump { uint32_t* area; uint32_t cap; };                     // this WAVE's dump area in LDS, cap entries of kEpiEntryWords words (16-byte aligned)
+
+// the dense pass: entries [0, n) of the wave's dump area, 16 (entry, score) pairs per entry, 64 pairs per round
+template <int METRIC>
+__device__ __forceinline__ void epi_dense_pass(const EpiDump& du, uint32_t n, const float (&s_c)[4][64], const float (&s_m)[4][64], uint32_t wave, uint32_t qb64,
+                                               const CandQueue& cqu, uint32_t& cqn, const CandOut& out) {
+    __threadfence_block();                                            // the dump's LDS writes, before other lanes of the wave read them
+    const uint32_t lane = lane_id();
+    for (uint32_t p = lane; p < 16 * n + 63; p += 64) {              // the loop count is wave-uniform (cand_push is a wave operation)
+        bool take = false; uint32_t q = 0, row = 0; float score = 0.f;
+        if (p < 16 * n) {
+            const uint32_t* d = du.area + (p >> 4) * kEpiEntryWords;
+            const uint32_t r = p & 15, fl = d[19];
+            const uint32_t ql = 32 * (fl & 1) + (r & 3) + 8 * (r >> 2) + 4 * ((fl >> 1) & 1);
+            score = __uint_as_float(d[r]); row = d[16];
+            const float c = s_c[wave][ql];
+            const float thr = filter_threshold<METRIC>(c, s_m[wave][ql], __uint_as_float(d[17]), __uint_as_float(d[18]));
+            take = (!(score < thr) || (fl >> 2)) && c < 3.0e38f;      // (padded query slots carry +inf)
+            q = 64 * qb64 + ql;
+        }
+        const uint64_t m = __ballot(take);
+        if (m) cand_push(cqu, cqn, m, q, row, score, out);
+        if (p - lane + 64 >= 16 * n) break;
+    }
+}
+
 template <int METRIC, int NJ>
 __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (&acc)[2][NJ], uint32_t t0, uint32_t t1, const float (&s_c)[4][64], const float (&s_m)[4][64],
-                                                uint32_t wave, uint32_t half, uint32_t l31, uint32_t qb64, float tiny_rn,
-                                                const double (&rnd)[NJ], const uint64_t (&alv)[NJ / 2],
-                                                uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
-        // epilogue: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31]
+                                                uint32_t wave, uint32_t half, uint32_t l31, uint32_t qb64, float tiny_rn, const EpiConsts& ec,
+                                                const double (&rnd)[NJ], const uint64_t (&alv)[NJ / 2], const CandQueue& cqu, uint32_t& cqn, const CandOut& out,
+                                                const EpiDump& du) {
+        uint32_t* const cand_cnt = out.cnt; (void)cand_cnt;
+#if defined(QV_DBG_EPI) && QV_DBG_EPI == 1                               // measurement build: no epilogue (the accumulators stay live through one compare)
+        {
+            float sdbg = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) sdbg += acc[i][j][r];
+            if (sdbg == 1.2345678f) cand_cnt[0] = 1;
+            return;
+        }
+#endif
+        uint32_t n = 0;                                              // entries in the wave's dump area (wave-uniform)
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const uint32_t t = j < 2 ? t0 : t1;
@@ -174,36 +295,42 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
             const float rn = f32_up((float)rnd[j]);
             const float rlo = f32_down((float)rnd[j]);
             const float rn2c = f32_down(f32_down(rlo * rlo) * 0.999998f);   // (1-2e-6)|r|^2, rounded down (L2 family)
-            (void)rn2c;
+            // rows the scores say nothing about: bf16 operands of a vanishing row would flush; a norm that is NaN, infinite or huge
+            // may have overflowed the float32 sums (in either direction, possibly only on the way)
+            const bool unsure = rn < tiny_rn || !(rn < 1.0e18f);
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                bool hit = false;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
-                    // a score that is NaN or infinite (rows or queries near FLT_MAX overflow the float32 sums, in either direction and
-                    // possibly only on the way) says nothing about the row: it counts as a hit and the exact pass decides
-                    hit |= !(acc[i][j][r] < thr) || acc[i][j][r] < -3.0e38f;
-                }
-                hit |= rn < tiny_rn;                                   // bf16 operands of a vanishing row would flush: let the exact pass see it
-                if (hit && live) {                                  // rare: a row that may be in some query's top-k
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const float thr = METRIC == QV_COSINE ? s_c[wave][ql] * rn - 1e-30f : (METRIC == QV_DOT ? s_c[wave][ql] - s_m[wave][ql] * rn : 0.5f * (s_c[wave][ql] + rn2c - s_m[wave][ql] * rn));
-                        if ((!(acc[i][j][r] < thr) || acc[i][j][r] < -3.0e38f || rn < tiny_rn) && s_c[wave][ql] < 3.0e38f) {      // (padded query slots carry +inf)
-                            const uint32_t q = 64 * qb64 + ql;
-                            uint32_t slot = atomicAdd(&cand_cnt[q], 1u);
-                            if (slot < (uint32_t)kMfmaCandCap) {
-                                cand_rows[(size_t)q * kMfmaCandCap + slot] = row;
-                                cand_score[(size_t)q * kMfmaCandCap + slot] = acc[i][j][r];
-                            }
+                const f16v& a = acc[i][j];
+                const float m0 = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(a[3], a[4]), a[5]);
+                const float m2 = __builtin_fmaxf(__builtin_fmaxf(a[6], a[7]), a[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(a[9], a[10]), a[11]);
+                const float m4 = __builtin_fmaxf(__builtin_fmaxf(a[12], a[13]), a[14]);
+                const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), m2), __builtin_fmaxf(__builtin_fmaxf(m3, m4), a[15]));
+                // monotone in c (up) and m (down) operation by operation, so this is a lower bound of every one of the 16 thresholds
+                const float thr_lo = filter_threshold<METRIC>(ec.cmin[i], ec.mmax[i], rn, rn2c);
+                const bool pre = (!(mx < thr_lo) || unsure) && live;
+                const uint64_t pm = __ballot(pre);
+#if defined(QV_DBG_EPI) && QV_DBG_EPI == 2                               // measurement build: level 1 only
+                if (pm == 0x123456789abcull) cand_cnt[0] = 1;
+                continue;
+#endif
+                if (__builtin_expect(pm != 0, 0)) {                 // some row of the block may be in some query's top-k
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(pm), rank = (uint32_t)__builtin_popcountll(pm & ((1ull << lane_id()) - 1ull));
+                    for (uint32_t done = 0; done < cnt;) {          // one round, unless the dump area fills up (wave-uniform loop)
+                        if (n == du.cap) { epi_dense_pass<METRIC>(du, n, s_c, s_m, wave, qb64, cqu, cqn, out); n = 0; __threadfence_block(); }
+                        const uint32_t now = (du.cap - n) < (cnt - done) ? (du.cap - n) : (cnt - done);
+                        if (pre && rank >= done && rank < done + now) {
+                            uint32_t* d = du.area + (n + rank - done) * kEpiEntryWords;
+                            f4* d4 = reinterpret_cast<f4*>(d);
+                            d4[0] = f4{a[0], a[1], a[2], a[3]}; d4[1] = f4{a[4], a[5], a[6], a[7]};
+                            d4[2] = f4{a[8], a[9], a[10], a[11]}; d4[3] = f4{a[12], a[13], a[14], a[15]};
+                            d[16] = row; d[17] = __float_as_uint(rn); d[18] = __float_as_uint(rn2c); d[19] = (uint32_t)i | (half << 1) | ((uint32_t)unsure << 2);
                         }
+                        n += now; done += now;
                     }
                 }
             }
         }
+        if (n) epi_dense_pass<METRIC>(du, n, s_c, s_m, wave, qb64, cqu, cqn, out);
 }
 
 // the group's row norms and alive words, requested before the K loop so that their latency is not the epilogue's
@@ -220,7 +347,9 @@ template <int METRIC>
 __global__ void __launch_bounds__(256, 1)
 k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
               uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
-    __shared__ float s_c[4][64], s_m[4][64];                        // this wave's 64 queries' filter constants
+    __shared__ __align__(16) float s_c[4][64], s_m[4][64];                        // this wave's 64 queries' filter constants
+    QV_CAND_QUEUE(cqu, 4, 512);                                       // 24 KiB
+    QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * 4 + wave, tw = gridDim.x * 4;
@@ -236,6 +365,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
+    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, wave, half);
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     const f4* qt = reinterpret_cast<const f4*>(Qt);
     const uint32_t steps = (v.dim4 + 1) / 2;                       // 8 dims per step
@@ -296,8 +426,9 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
 
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 0.0f, rnd, alv, cand_rows, cand_score, cand_cnt);
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 0.0f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
+    cand_flush(cqu, cqu_n, cqu_out);
 }
 
 // The same filter on the bfloat16 matrix instruction, three products per pair of operands (see filter_gamma): the scores keep
@@ -315,7 +446,9 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
     // score_out != null: no filter — the scores of the SAMPLE, row groups 0, gstep, 2 gstep, ... (score_stride / 128 of them, spread over the
     // corpus so that a corpus stored cluster by cluster still yields a representative bound), are written to
     // score_out[query * score_stride + 128 * (group's place in the sample) + row of the group]
-    __shared__ float s_c[4][64], s_m[4][64];
+    __shared__ __align__(16) float s_c[4][64], s_m[4][64];
+    QV_CAND_QUEUE(cqu, 4, 512);                                       // 24 KiB
+    QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * 4 + wave, tw = gridDim.x * 4;
@@ -331,6 +464,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
+    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, wave, half);
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step
     const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
@@ -437,8 +571,9 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
             }
             continue;
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
+    cand_flush(cqu, cqu_n, cqu_out);
 }
 
 // The same with the row operand shared by the four waves of a workgroup (nq_pad a multiple of 256: the waves of a workgroup then
@@ -451,7 +586,9 @@ template <int METRIC, int TERMS, int RING>
 __global__ void __launch_bounds__(256, 1)
 k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                        uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
-    __shared__ float s_c[4][64], s_m[4][64];
+    __shared__ __align__(16) float s_c[4][64], s_m[4][64];
+    QV_CAND_QUEUE(cqu, 4, 512);                                       // 24 KiB
+    QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     __shared__ uint4 s_b[4][4][2][64];                              // [stage][32-row block][hi, lo][lane]: 32 KiB
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -468,6 +605,7 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
+    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, wave, half);
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step
     const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
@@ -652,8 +790,9 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
             mfma(q0, 0);
         }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
+    cand_flush(cqu, cqu_n, cqu_out);
 }
 
 // The one-term filter reading the index's bfloat16 copy of the rows (QV_FLAG_BF16_ROWS) instead of converting float32 rows on the fly:
@@ -666,7 +805,9 @@ template <int METRIC>
 __global__ void __launch_bounds__(256, 2)
 k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                   uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
-    __shared__ float s_c[4][64], s_m[4][64];
+    __shared__ __align__(16) float s_c[4][64], s_m[4][64];
+    QV_CAND_QUEUE(cqu, 4, 512);                                       // 24 KiB
+    QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     __shared__ uint4 s_b[4][4][64];                                 // [stage][32-row block][lane]: 16 KiB
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -683,6 +824,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
+    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, wave, half);
     const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
     const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step; a multiple of 8 here
     const uint32_t dim8 = (v.dim4 + 1) / 2;
@@ -758,8 +900,9 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
 #pragma unroll
             for (int k8 = 0; k8 < RING; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
+    cand_flush(cqu, cqu_n, cqu_out);
 }
 
 // One query block (9-64 queries, the usual BatchSearch sizes) over an index with the bfloat16 row copy: all eight waves of the
@@ -772,7 +915,9 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
                       uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
     extern __shared__ __align__(16) unsigned char smem_q64[];
     uint4* s_a = reinterpret_cast<uint4*>(smem_q64);                // [step][query half][lane]
-    __shared__ float s_c[4][64], s_m[4][64];                        // row 0 is used (filter_epilogue's shape)
+    __shared__ __align__(16) float s_c[4][64], s_m[4][64];                        // row 0 is used (filter_epilogue's shape)
+    QV_CAND_QUEUE(cqu, 8, 128);                                       // 12 KiB: the query operands take up to 128 KiB of the 160
+    QV_EPI_DUMP(du, 8, 16);                                           // 10 KiB
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step; a multiple of 4 here
@@ -788,6 +933,7 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
     }
     __syncthreads();
     const uint32_t half = lane >> 5, l31 = lane & 31;
+    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, 0u, half);
     const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
     // NB = 4: a row group is two tiles (128 rows), R steps of them in flight; NB = 2: one tile per group and 64 accumulators less, which
     // buys twice the steps in flight (each wave's requests are what feeds the HBM stream: 4.9 TB/s with 16 KB per wave)
@@ -843,8 +989,9 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
                 load_step(rb[k]);
             }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 0u, half, l31, 0u, 1e-18f, rnd, alv, cand_rows, cand_score, cand_cnt);
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 0u, half, l31, 0u, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
+    cand_flush(cqu, cqu_n, cqu_out);
 }
 
 // [lo, hi] containing the reference distance d(q, r) given an approximate score S~ with |S~ - S| <= gamma |q||r| (filter_gamma):

@@ -728,7 +728,9 @@ def test_arrow_graph_search_table(kat):                          # arrowindex/gr
     with pytest.raises(ValueError, match="not float32-representable"):
         g.Add(9, [0.1, 0.2])
     with pytest.raises(ValueError, match="not float32-representable"):
-        g.Search([0.1, 0.2], 1)                                  # a query is refused by the same rule, never rounded
+        g.Search([0.1, 0.2], 1, strict=True)                     # strict: a query is refused by the same rule as a vector
+    with pytest.warns(RuntimeWarning, match="rounded to float32"):
+        g.Search([0.1, 0.2], 1)                                  # default: rounded, and said so (the reference's own table queries need it)
 
 
 def test_persistence_collection_search_tables():                 # persistence/collection_test.go:259-325, 355-383

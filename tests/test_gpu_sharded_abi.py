@@ -130,3 +130,25 @@ def test_sharded_batches_take_the_filter_path_and_equal_the_exact_scan(nq, monke
     bounds = [g * n // 3 for g in range(4)]
     back = np.array([[bounds[int(x) // span] + int(x) % span for x in row] for row in r], dtype=np.uint32)
     assert (c == k).all() and np.array_equal(back, r1) and np.array_equal(d.view(np.uint32), d1.view(np.uint32))
+
+
+def test_two_devices_over_rccl_equal_one_index():
+    """the multi-DEVICE code paths (hipMemcpyPeerAsync between devices, cross-device events, a grouped ncclAllGather over two
+    communicators): runs only where two GPUs are visible — the 1-GPU test box skips it"""
+    if quiver_amd.lib().qv_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    n, dim, k = 100_003, 96, 10
+    for peer in (False, True):
+        sh = ShardedIndex(dim, "cosine", devices=[0, 1], peer_copy=peer)
+        sh.add_synthetic(20260424, 0, n)
+        one = quiver_amd.DeviceIndex(dim, "cosine")
+        one.add_synthetic(20260424, 0, n)
+        qs = O.gen_rows(20260425, 0, 12, dim)
+        span = quiver_amd.lib().qv_sharded_span(2)
+        bounds = [0, n // 2, n]
+        for kk in (k, 300):
+            r, d, c = sh.search(qs, kk)
+            r1, d1, _ = one.search(qs, kk)
+            back = np.array([[bounds[int(x) // span] + int(x) % span for x in row] for row in r], dtype=np.uint32)
+            assert np.array_equal(back, r1) and np.array_equal(d.view(np.uint32), d1.view(np.uint32)), (peer, kk)
+        sh.close(); one.close()
