@@ -220,16 +220,18 @@ __device__ __forceinline__ void cand_push(const CandQueue& cqu, uint32_t& n, uin
 // here (a norm that is NaN, infinite or >= 1e18 passes both tests outright: the exact pass decides) and per QUERY in k_mfma_prep
 // (such a query gets the "everything is a candidate" threshold), not per score.
 struct EpiConsts { float cmin[2], mmax[2]; };
-template <int METRIC>
-__device__ __forceinline__ EpiConsts epi_consts(const float (&s_c)[4][64], const float (&s_m)[4][64], uint32_t wave, uint32_t half) {
+// sc / sm: the workgroup's filter constants in LDS (one float per query); qbase: the wave's first query in them; NI 32-query blocks
+template <int METRIC, int NI = 2>
+__device__ __forceinline__ EpiConsts epi_consts(const float* sc, const float* sm, uint32_t qbase, uint32_t half) {
     EpiConsts e;
+    e.cmin[1] = e.mmax[1] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NI; i++) {
         float cm = __uint_as_float(0x7F800000u), mm = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-            cm = fminf(cm, s_c[wave][ql]); mm = fmaxf(mm, s_m[wave][ql]);
+            cm = fminf(cm, sc[qbase + ql]); mm = fmaxf(mm, sm[qbase + ql]);
         }
         e.cmin[i] = cm; e.mmax[i] = mm;
     }
@@ -244,7 +246,7 @@ struct EpiDump { uint32_t* area; uint32_t cap; };                     // this WA
 
 // the dense pass: entries [0, n) of the wave's dump area, 16 (entry, score) pairs per entry, 64 pairs per round
 template <int METRIC>
-__device__ __forceinline__ void epi_dense_pass(const EpiDump& du, uint32_t n, const float (&s_c)[4][64], const float (&s_m)[4][64], uint32_t wave, uint32_t qb64,
+__device__ __forceinline__ void epi_dense_pass(const EpiDump& du, uint32_t n, const float* sc, const float* sm, uint32_t qbase, uint32_t qglobal,
                                                const CandQueue& cqu, uint32_t& cqn, const CandOut& out) {
     __threadfence_block();                                            // the dump's LDS writes, before other lanes of the wave read them
     const uint32_t lane = lane_id();
@@ -255,10 +257,10 @@ __device__ __forceinline__ void epi_dense_pass(const EpiDump& du, uint32_t n, co
             const uint32_t r = p & 15, fl = d[19];
             const uint32_t ql = 32 * (fl & 1) + (r & 3) + 8 * (r >> 2) + 4 * ((fl >> 1) & 1);
             score = __uint_as_float(d[r]); row = d[16];
-            const float c = s_c[wave][ql];
-            const float thr = filter_threshold<METRIC>(c, s_m[wave][ql], __uint_as_float(d[17]), __uint_as_float(d[18]));
+            const float c = sc[qbase + ql];
+            const float thr = filter_threshold<METRIC>(c, sm[qbase + ql], __uint_as_float(d[17]), __uint_as_float(d[18]));
             take = (!(score < thr) || (fl >> 2)) && c < 3.0e38f;      // (padded query slots carry +inf)
-            q = 64 * qb64 + ql;
+            q = qglobal + ql;
         }
         const uint64_t m = __ballot(take);
         if (m) cand_push(cqu, cqn, m, q, row, score, out);
@@ -266,9 +268,10 @@ __device__ __forceinline__ void epi_dense_pass(const EpiDump& du, uint32_t n, co
     }
 }
 
-template <int METRIC, int NJ>
-__device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (&acc)[2][NJ], uint32_t t0, uint32_t t1, const float (&s_c)[4][64], const float (&s_m)[4][64],
-                                                uint32_t wave, uint32_t half, uint32_t l31, uint32_t qb64, float tiny_rn, const EpiConsts& ec,
+// acc[i][j][r] = S~[query qglobal + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31]; the wave's queries start at sc[qbase] / sm[qbase]
+template <int METRIC, int NI, int NJ>
+__device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (&acc)[NI][NJ], uint32_t t0, uint32_t t1, const float* sc, const float* sm,
+                                                uint32_t qbase, uint32_t half, uint32_t l31, uint32_t qglobal, float tiny_rn, const EpiConsts& ec,
                                                 const double (&rnd)[NJ], const uint64_t (&alv)[NJ / 2], const CandQueue& cqu, uint32_t& cqn, const CandOut& out,
                                                 const EpiDump& du) {
         uint32_t* const cand_cnt = out.cnt; (void)cand_cnt;
@@ -278,7 +281,7 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
 #pragma unroll
             for (int j = 0; j < NJ; j++)
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+                for (int i = 0; i < NI; i++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) sdbg += acc[i][j][r];
             if (sdbg == 1.2345678f) cand_cnt[0] = 1;
@@ -299,7 +302,7 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
             // may have overflowed the float32 sums (in either direction, possibly only on the way)
             const bool unsure = rn < tiny_rn || !(rn < 1.0e18f);
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < NI; i++) {
                 const f16v& a = acc[i][j];
                 const float m0 = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(a[3], a[4]), a[5]);
                 const float m2 = __builtin_fmaxf(__builtin_fmaxf(a[6], a[7]), a[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(a[9], a[10]), a[11]);
@@ -316,7 +319,7 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
                 if (__builtin_expect(pm != 0, 0)) {                 // some row of the block may be in some query's top-k
                     const uint32_t cnt = (uint32_t)__builtin_popcountll(pm), rank = (uint32_t)__builtin_popcountll(pm & ((1ull << lane_id()) - 1ull));
                     for (uint32_t done = 0; done < cnt;) {          // one round, unless the dump area fills up (wave-uniform loop)
-                        if (n == du.cap) { epi_dense_pass<METRIC>(du, n, s_c, s_m, wave, qb64, cqu, cqn, out); n = 0; __threadfence_block(); }
+                        if (n == du.cap) { epi_dense_pass<METRIC>(du, n, sc, sm, qbase, qglobal, cqu, cqn, out); n = 0; __threadfence_block(); }
                         const uint32_t now = (du.cap - n) < (cnt - done) ? (du.cap - n) : (cnt - done);
                         if (pre && rank >= done && rank < done + now) {
                             uint32_t* d = du.area + (n + rank - done) * kEpiEntryWords;
@@ -330,7 +333,7 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
                 }
             }
         }
-        if (n) epi_dense_pass<METRIC>(du, n, s_c, s_m, wave, qb64, cqu, cqn, out);
+        if (n) epi_dense_pass<METRIC>(du, n, sc, sm, qbase, qglobal, cqu, cqn, out);
 }
 
 // the group's row norms and alive words, requested before the K loop so that their latency is not the epilogue's
@@ -365,7 +368,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
-    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, wave, half);
+    const EpiConsts ec = epi_consts<METRIC>(&s_c[0][0], &s_m[0][0], 64 * wave, half);
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     const f4* qt = reinterpret_cast<const f4*>(Qt);
     const uint32_t steps = (v.dim4 + 1) / 2;                       // 8 dims per step
@@ -426,7 +429,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
 
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 0.0f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 0.0f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -464,7 +467,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
-    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, wave, half);
+    const EpiConsts ec = epi_consts<METRIC>(&s_c[0][0], &s_m[0][0], 64 * wave, half);
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step
     const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
@@ -571,7 +574,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
             }
             continue;
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -605,7 +608,7 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
-    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, wave, half);
+    const EpiConsts ec = epi_consts<METRIC>(&s_c[0][0], &s_m[0][0], 64 * wave, half);
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step
     const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
@@ -790,7 +793,190 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
             mfma(q0, 0);
         }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+    }
+    cand_flush(cqu, cqu_n, cqu_out);
+}
+
+// The one-term filter over float32 rows with EIGHT waves per workgroup (round 3; the default for 256 queries and more).
+// k_bf16x3_filter_shared gives each of four waves a 64-query x 128-row tile: 128 accumulators, ~450 registers, so ONE wave per SIMD —
+// and a lone wave pays every dependency itself (~13 cycles per instruction; 880 cycles per 16-dimension step where the matrix work
+// is 256 and the HBM share ~680).  Here wave w owns a 64-query x 64-row tile: queries 64*(w&3) .. +63 of the workgroup's 256 x the
+// rows of tile w>>2 of the 128-row group: 64 accumulators, ~190 registers, TWO waves per SIMD, and per step and wave only one
+// row request (wave w fetches chunk w&3 of tile w>>2: its lane's 4 floats become 4 bfloat16 = 8 bytes of the B image in LDS),
+// two query-operand requests (2 KiB; the wave's partner w^4 asks for the same lines: an L1 hit), two 16-byte LDS reads and four
+// matrix instructions.  HBM and L2 traffic are what they were (rows once, query operands once per 128-row group) and so are
+// the LDS reads (16 KiB per step per CU) — a 32-query x 128-row tile per wave reads every B block from LDS eight times
+// (32 KiB per step) and the eight waves' LDS instructions, all issued right after the barrier, held the matrix instructions
+// behind them up (measured: the same time as the four-wave kernel).  Dimensions that are a multiple of 128, nq_pad of 256.
+template <int METRIC, int RING, int AR, int SPB>
+__global__ void __launch_bounds__(512, 1)
+k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
+                   uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+    // RING, AR: row chunks / query operands in flight, counted in ROUNDS; a round = SPB steps of 16 dimensions between two barriers
+    __shared__ __align__(16) float s_c[256], s_m[256];
+    __shared__ __align__(16) unsigned char s_b[4][SPB][4][1024];        // [stage][step of the round][32-row block][lane * 16 bytes]: 16 KiB per step of a round
+    QV_CAND_QUEUE(cqu, 8, 256);                                      // 24 KiB
+    QV_EPI_DUMP(du, 8, 32);                                          // 20 KiB
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wgs_per_group = nq_pad >> 8;                      // workgroups that share one row group (different query blocks)
+    const uint32_t qb256 = blockIdx.x % wgs_per_group;
+    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    const uint32_t stride = gridDim.x / wgs_per_group;
+    if (threadIdx.x < 256) {
+        const float c = cq[256 * qb256 + threadIdx.x], m = mq[256 * qb256 + threadIdx.x];
+        s_c[threadIdx.x] = METRIC == QV_COSINE ? c - m : c;
+        s_m[threadIdx.x] = m;
+    }
+    __syncthreads();
+    if (stride == 0) return;
+    const uint32_t half = lane >> 5, l31 = lane & 31;
+    const EpiConsts ec = epi_consts<METRIC, 1>(s_c, s_m, 32 * wave, half);
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t rounds = v.dim4 / (4 * SPB);                      // a multiple of RING here
+    // the running request pointers are wave-uniform (scalar registers, advanced by scalar adds); the lane's 16 bytes are an offset
+    // of the request itself — 15 vector instructions per wave and step were pointer arithmetic before
+    const uint4* a0 = Qbf + ((size_t)(8 * qb256 + wave) * rounds * SPB) * 2 * 64;          // the hi plane of 32-query block 8*qb256 + wave
+    struct Raw { f4 c[SPB]; };                                       // this wave's row chunk of every step of a round
+    struct Aop { uint4 h[SPB]; };
+    struct Bset { uint4 h[SPB][4]; };
+    Raw r[RING];                                                     // requested RING + 2 rounds ahead of their use
+    Aop qa[AR];
+    Bset b0, b1;
+    // where this wave's converted chunk goes in a step's image: row lane of tile (wave >> 2) is row lane & 31 of block 2*(wave>>2) + (lane>>5);
+    // chunk c = wave & 3 holds dims 4c .. 4c+3 of the step = bytes 8*(c&1) .. +7 of the lane slot (row, dims 8*(c>>1) .. +7)
+    const uint32_t pub_off = (2 * (wave >> 2) + (lane >> 5)) * 1024 + (l31 + 32 * ((wave & 3) >> 1)) * 16 + ((wave & 3) & 1) * 8;
+    auto rows_of = [&](uint32_t g_) {
+#if defined(QV_DBG_ROWS) && QV_DBG_ROWS == 1                              // measurement build: every group reads the same 16 groups (cache-resident rows)
+        g_ &= 15u;
+#endif
+        const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
+        return tiles + ((size_t)(wave < 4 ? ta : tb) * v.dim4 + (wave & 3)) * 64;             // wave-uniform: the lane is added in the request
+    };
+    const f4* lp = nullptr;
+    const uint4* ap = a0;
+    auto load_b_run = [&](Raw& o) {
+#pragma unroll
+        for (int u = 0; u < SPB; u++) { o.c[u] = __builtin_nontemporal_load(lp + lane); lp += 256; }      // next step: four chunks on
+    };
+    auto load_a_run = [&](Aop& o) {
+#pragma unroll
+        for (int u = 0; u < SPB; u++) { o.h[u] = ap[lane]; ap += 128; }
+    };
+    auto publish = [&](const Raw& o, uint32_t stage) {
+#pragma unroll
+        for (int u = 0; u < SPB; u++) {
+            uint2 h; h.x = pack_bf16(o.c[u].x, o.c[u].y); h.y = pack_bf16(o.c[u].z, o.c[u].w);
+            *reinterpret_cast<uint2*>(&s_b[stage][u][0][0] + pub_off) = h;
+        }
+    };
+    auto read_b = [&](uint32_t stage, Bset& b) {
+#pragma unroll
+        for (int u = 0; u < SPB; u++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) b.h[u][j] = *reinterpret_cast<const uint4*>(&s_b[stage][u][j][lane * 16]);
+    };
+    bool primed = false;
+    for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
+        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
+        const f4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
+        f16v acc[1][4];
+        double rnd[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, alv);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
+        if (!primed) {                                              // the workgroup's first group: fill the rings
+            primed = true;
+            lp = rows_of(g);
+#pragma unroll
+            for (int i = 0; i < RING; i++) load_b_run(r[i]);
+#pragma unroll
+            for (int i = 0; i < AR - 1; i++) load_a_run(qa[i]);
+            publish(r[0], 0); publish(r[1], 1);
+            load_b_run(r[0]); load_b_run(r[1]);
+            __syncthreads();
+            read_b(0, b0);
+        }
+        // round s: barrier (round s+1 is published); publish round s+2 (requested RING rounds ago) and re-request its ring slot (rows
+        // of round s+2+RING); read the B operands of round s+1; request the query operands of round s+AR-1; then the matrix
+        // instructions of round s.  Requests that run past the end of the group are the first rounds of this workgroup's next group.
+        // The LDS write goes FIRST after the barrier (its stage was last read three rounds ago) so that it and the reads drain under
+        // the matrix instructions: with the write after them every round ended in "wait for my LDS write, then the barrier".
+        // The scheduling barriers matter: without them the compiler hoists the conversions of LATER ring entries into this round's
+        // matrix gaps, which moves their s_waitcnt up to vmcnt(1..3) — the wave then waits for rows it requested a step or two ago.
+#if defined(QV_DBG_STAMP)
+#define QV_STAMP(i) if (stamping && k8 == 2) { stamp[i] = __builtin_amdgcn_s_memtime(); }
+        const bool stamping = blockIdx.x == 7 && g == blockIdx.x / wgs_per_group + 3 * stride;
+        uint64_t stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+#define QV_STAMP(i)
+#endif
+        auto pstep = [&](uint32_t s_, int k8, const Bset& b_use, Bset& b_next) {
+            __builtin_amdgcn_sched_barrier(0);
+            QV_STAMP(0)
+            __syncthreads();
+#if defined(QV_DBG_STAMP)
+            if (stamping && k8 == 3) { stamp[6] = __builtin_amdgcn_s_memtime(); }
+#endif
+            QV_STAMP(1)
+            publish(r[(k8 + 2) & (RING - 1)], (uint32_t)(k8 + 2) & 3);
+            if (s_ + RING + 2 == rounds) lp = bwn;
+            load_b_run(r[(k8 + 2) & (RING - 1)]);
+            read_b((uint32_t)(k8 + 1) & 3, b_next);
+            if (s_ + (AR - 1) == rounds) ap = a0;
+            load_a_run(qa[(k8 + AR - 1) & (AR - 1)]);
+#if defined(QV_DBG_STAMP)
+            __builtin_amdgcn_sched_barrier(0);
+            QV_STAMP(2)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            QV_STAMP(3)
+#endif
+#pragma unroll
+            for (int u = 0; u < SPB; u++) {
+                const bf8 ah = __builtin_bit_cast(bf8, qa[k8 & (AR - 1)].h[u]);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf8, b_use.h[u][j]), acc[0][j], 0, 0, 0);
+            }
+#if !defined(QV_DBG_STAMP)
+            // The eight waves leave the barrier together and the CU's vector memory path takes one 1-KiB request per 16 cycles: with
+            // all requests in front of the matrix instructions a wave queued ~300 cycles before its first one (in-kernel stamps,
+            // profiles/r03_batched_w8.txt).  One memory / LDS instruction per matrix-instruction gap instead: while a wave waits for
+            // the memory path to take its request, its SIMD partner's matrix instructions run.
+#pragma unroll
+            for (int u = 0; u < SPB; u++) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // the conversion (2 VALU)
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // ... and the LDS write of round s+2
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // matrix
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // row request
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two B operands of round s+1
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // query operand request
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the other two B operands
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#if defined(QV_DBG_STAMP)
+            QV_STAMP(4)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            QV_STAMP(5)
+#endif
+        };
+        for (uint32_t st = 0; st < rounds; st += RING) {
+#pragma unroll
+            for (int k8 = 0; k8 < RING; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
+        }
+#if defined(QV_DBG_STAMP)
+        if (stamping && lane == 0)
+            printf("stamp wave %u: barrier-in 0, barrier-out %llu, issued %llu, A ready %llu, mfma issued %llu, lds drained %llu, next step start %llu\n", wave,
+                   stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0]);
+#endif
+        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -824,7 +1010,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
-    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, wave, half);
+    const EpiConsts ec = epi_consts<METRIC>(&s_c[0][0], &s_m[0][0], 64 * wave, half);
     const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
     const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step; a multiple of 8 here
     const uint32_t dim8 = (v.dim4 + 1) / 2;
@@ -900,7 +1086,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
 #pragma unroll
             for (int k8 = 0; k8 < RING; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, wave, half, l31, qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -933,7 +1119,7 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
     }
     __syncthreads();
     const uint32_t half = lane >> 5, l31 = lane & 31;
-    const EpiConsts ec = epi_consts<METRIC>(s_c, s_m, 0u, half);
+    const EpiConsts ec = epi_consts<METRIC>(&s_c[0][0], &s_m[0][0], 0u, half);
     const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
     // NB = 4: a row group is two tiles (128 rows), R steps of them in flight; NB = 2: one tile per group and 64 accumulators less, which
     // buys twice the steps in flight (each wave's requests are what feeds the HBM stream: 4.9 TB/s with 16 KB per wave)
@@ -989,7 +1175,7 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
                 load_step(rb[k]);
             }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 0u, half, l31, 0u, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 0u, half, l31, 0u, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -1353,7 +1539,13 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t fsteps = (v.dim4 + 3) / 4;
         static const int bfrows_env = env_int("QV_MFMA_BF16_ROWS", 1);                        // 2 = ignore the index's bfloat16 plane
         const bool bfrows = gmode == 2 && v.bf16 != nullptr && bfrows_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;
+        static const int w8_env = env_int("QV_MFMA_W8", 1);                                   // 2 = the four-wave kernel (k_bf16x3_filter_shared<., 1>)
+        const bool w8 = w8_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;       // rounds of two steps, four in flight: a multiple of 4 rounds, at least 6
+        static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // measurement: 2 = query operands 15 steps ahead, 3 = that and rows 18 steps ahead
 #define QV_FS(MMM) { if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (gmode == 2 && w8) { if (w8_shape == 2) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 16, 1>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8_shape == 3 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 16, 1>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); } \
                      else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 3, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         if (v.metric == QV_COSINE) QV_FS(QV_COSINE) else if (v.metric == QV_DOT) QV_FS(QV_DOT) else QV_FS(QV_L2)
