@@ -809,7 +809,9 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
 // the LDS reads (16 KiB per step per CU) — a 32-query x 128-row tile per wave reads every B block from LDS eight times
 // (32 KiB per step) and the eight waves' LDS instructions, all issued right after the barrier, held the matrix instructions
 // behind them up (measured: the same time as the four-wave kernel).  Dimensions that are a multiple of 128, nq_pad of 256.
-template <int METRIC, int RING, int AR, int SPB>
+// BF: the rows come from the index's bfloat16 copy (QV_FLAG_BF16_ROWS): a wave's 1-KiB request IS one 32-row B operand of one step,
+// no conversion; a round is then two steps (eight pieces, one per wave: piece w = step w>>2 of the round, block w&3).
+template <int METRIC, int RING, int AR, int SPB, bool BF>
 __global__ void __launch_bounds__(512, 1)
 k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                    uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
@@ -838,7 +840,8 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
     // the running request pointers are wave-uniform (scalar registers, advanced by scalar adds); the lane's 16 bytes are an offset
     // of the request itself — 15 vector instructions per wave and step were pointer arithmetic before
     const uint4* a0 = Qbf + ((size_t)(8 * qb256 + wave) * rounds * SPB) * 2 * 64;          // the hi plane of 32-query block 8*qb256 + wave
-    struct Raw { f4 c[SPB]; };                                       // this wave's row chunk of every step of a round
+    static_assert(!BF || SPB == 2, "the bfloat16 plane is read in rounds of two steps");
+    struct Raw { f4 c[BF ? 1 : SPB]; };                              // this wave's row chunk of every step of a round (BF: its one piece of the round)
     struct Aop { uint4 h[SPB]; };
     struct Bset { uint4 h[SPB][4]; };
     Raw r[RING];                                                     // requested RING + 2 rounds ahead of their use
@@ -846,25 +849,33 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
     Bset b0, b1;
     // where this wave's converted chunk goes in a step's image: row lane of tile (wave >> 2) is row lane & 31 of block 2*(wave>>2) + (lane>>5);
     // chunk c = wave & 3 holds dims 4c .. 4c+3 of the step = bytes 8*(c&1) .. +7 of the lane slot (row, dims 8*(c>>1) .. +7)
-    const uint32_t pub_off = (2 * (wave >> 2) + (lane >> 5)) * 1024 + (l31 + 32 * ((wave & 3) >> 1)) * 16 + ((wave & 3) & 1) * 8;
+    const uint32_t pub_off = BF ? ((wave >> 2) * 4 + (wave & 3)) * 1024 + lane * 16
+                                : (2 * (wave >> 2) + (lane >> 5)) * 1024 + (l31 + 32 * ((wave & 3) >> 1)) * 16 + ((wave & 3) & 1) * 8;
     auto rows_of = [&](uint32_t g_) {
 #if defined(QV_DBG_ROWS) && QV_DBG_ROWS == 1                              // measurement build: every group reads the same 16 groups (cache-resident rows)
         g_ &= 15u;
 #endif
         const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
-        return tiles + ((size_t)(wave < 4 ? ta : tb) * v.dim4 + (wave & 3)) * 64;             // wave-uniform: the lane is added in the request
+        if constexpr (BF)      // plane: [tile][step][row block][half][32 rows] x 16 bytes; this wave's piece: step (wave >> 2) of the round, block wave & 3
+            return reinterpret_cast<const f4*>(v.bf16) + ((((size_t)((wave & 2) ? tb : ta) * (v.dim4 / 4)) + (wave >> 2)) * 2 + (wave & 1)) * 64;
+        else
+            return tiles + ((size_t)(wave < 4 ? ta : tb) * v.dim4 + (wave & 3)) * 64;         // wave-uniform: the lane is added in the request
     };
     const f4* lp = nullptr;
     const uint4* ap = a0;
     auto load_b_run = [&](Raw& o) {
+        if constexpr (BF) { o.c[0] = __builtin_nontemporal_load(lp + lane); lp += 256; }           // next round: two steps of 128 x 16 bytes on
+        else {
 #pragma unroll
-        for (int u = 0; u < SPB; u++) { o.c[u] = __builtin_nontemporal_load(lp + lane); lp += 256; }      // next step: four chunks on
+            for (int u = 0; u < SPB; u++) { o.c[u] = __builtin_nontemporal_load(lp + lane); lp += 256; }      // next step: four chunks on
+        }
     };
     auto load_a_run = [&](Aop& o) {
 #pragma unroll
         for (int u = 0; u < SPB; u++) { o.h[u] = ap[lane]; ap += 128; }
     };
     auto publish = [&](const Raw& o, uint32_t stage) {
+        if constexpr (BF) { *reinterpret_cast<f4*>(&s_b[stage][0][0][0] + pub_off) = o.c[0]; return; }
 #pragma unroll
         for (int u = 0; u < SPB; u++) {
             uint2 h; h.x = pack_bf16(o.c[u].x, o.c[u].y); h.y = pack_bf16(o.c[u].z, o.c[u].w);
@@ -946,6 +957,22 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
             // all requests in front of the matrix instructions a wave queued ~300 cycles before its first one (in-kernel stamps,
             // profiles/r03_batched_w8.txt).  One memory / LDS instruction per matrix-instruction gap instead: while a wave waits for
             // the memory path to take its request, its SIMD partner's matrix instructions run.
+            if constexpr (BF) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // the LDS write of round s+2
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // row request
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // query operand request
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            } else
 #pragma unroll
             for (int u = 0; u < SPB; u++) {
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // the conversion (2 VALU)
@@ -967,9 +994,10 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
             QV_STAMP(5)
 #endif
         };
-        for (uint32_t st = 0; st < rounds; st += RING) {
+        constexpr int UNR = RING > AR ? RING : AR;                  // both rings are indexed by the unrolled step number: the loop body covers the longer one
+        for (uint32_t st = 0; st < rounds; st += UNR) {
 #pragma unroll
-            for (int k8 = 0; k8 < RING; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
+            for (int k8 = 0; k8 < UNR; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
         }
 #if defined(QV_DBG_STAMP)
         if (stamping && lane == 0)
@@ -1541,11 +1569,14 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const bool bfrows = gmode == 2 && v.bf16 != nullptr && bfrows_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;
         static const int w8_env = env_int("QV_MFMA_W8", 1);                                   // 2 = the four-wave kernel (k_bf16x3_filter_shared<., 1>)
         const bool w8 = w8_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;       // rounds of two steps, four in flight: a multiple of 4 rounds, at least 6
-        static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // measurement: 2 = query operands 15 steps ahead, 3 = that and rows 18 steps ahead
-#define QV_FS(MMM) { if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                     else if (gmode == 2 && w8) { if (w8_shape == 2) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 16, 1>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8_shape == 3 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 16, 1>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); } \
+        static const int w8_bf = env_int("QV_MFMA_W8_BF", 2);                                  // 1 = the eight-wave kernel on the bfloat16 plane too (measured: 485 against 474 us for k_bf16rows_filter)
+        static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // measurement: 3 = rows 18 and query operands 15 steps ahead, 4 = query operands 15 steps ahead (644.6 against 648.6 us: kept at 3)
+#define QV_FS(MMM) { if (bfrows && w8 && w8_bf) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 4, 8, 2, true>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (gmode == 2 && w8) { if (w8_shape == 2) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8_shape == 3 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 16, 1, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8_shape == 4 && fsteps % 16 == 0) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 16, 1, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); } \
                      else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 3, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         if (v.metric == QV_COSINE) QV_FS(QV_COSINE) else if (v.metric == QV_DOT) QV_FS(QV_DOT) else QV_FS(QV_L2)
