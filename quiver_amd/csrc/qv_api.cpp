@@ -96,6 +96,7 @@ int ensure_rows(qv_index* idx, uint64_t rows, bool exact) {
     hipError_t e = regrow(&idx->d_tiles, used_tiles * tb, new_tiles * tb);
     if (e == hipSuccess) e = regrow(&idx->d_rnorm, used_tiles * 64 * sizeof(double), new_tiles * 64 * sizeof(double));
     if (e == hipSuccess) e = regrow(&idx->d_alive, used_tiles * sizeof(uint64_t), new_tiles * sizeof(uint64_t));
+    if (e == hipSuccess) e = regrow(&idx->d_rres, used_tiles * 64 * sizeof(float), new_tiles * 64 * sizeof(float));
     if (e == hipSuccess && (idx->flags & QV_FLAG_ROWMAJOR))
         e = regrow(&idx->d_rowmaj, (size_t)idx->n_rows * idx->dim * sizeof(float), new_tiles * 64 * (size_t)idx->dim * sizeof(float));
     if (e == hipSuccess && (idx->flags & QV_FLAG_BF16_ROWS))
@@ -177,7 +178,7 @@ void qv_index_destroy(qv_index* idx) {
     (void)hipDeviceSynchronize();
     for (SearchCtx* c : idx->all_ctx) { c->release(); delete c; }
     for (auto& kv : idx->stream_ws) { kv.second->ws.release(); delete kv.second; }
-    (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rowmaj); (void)hipFree(idx->d_bf16);
+    (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rres); (void)hipFree(idx->d_rowmaj); (void)hipFree(idx->d_bf16);
     idx->mut_stage.release();
     delete idx;
 }

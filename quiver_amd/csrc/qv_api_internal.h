@@ -78,6 +78,7 @@ struct qv_index {
     float* d_tiles = nullptr;
     double* d_rnorm = nullptr;
     uint64_t* d_alive = nullptr;
+    float* d_rres = nullptr;                   // |r - bf16(r)| per row: refreshed by every call that writes rows
     float* d_rowmaj = nullptr;
     uint16_t* d_bf16 = nullptr;                // QV_FLAG_BF16_ROWS: refreshed by every call that writes rows
     std::vector<uint64_t> alive_host;          // mirror of d_alive, for size bookkeeping and validation
@@ -96,7 +97,7 @@ struct qv_index {
 
     qv::IndexView view() const {
         qv::IndexView v;
-        v.tiles = d_tiles; v.rnorm = d_rnorm; v.alive = d_alive; v.rowmaj = d_rowmaj; v.bf16 = d_bf16;
+        v.tiles = d_tiles; v.rnorm = d_rnorm; v.alive = d_alive; v.rres = d_rres; v.rowmaj = d_rowmaj; v.bf16 = d_bf16;
         v.dim = dim; v.dim4 = dim4; v.n_rows = n_rows; v.n_tiles = (n_rows + 63) / 64; v.metric = metric; v.filter = filter;
         return v;
     }

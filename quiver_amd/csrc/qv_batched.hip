@@ -45,6 +45,17 @@ constexpr int kMfmaCandCap = 4096;        // candidate slots per query
 //   bf16 x 1 (k_bf16x3_filter_shared<.., 1>, mode 2 here): only qh*xh.  Dropped: (q - qh)*x + qh*(x - xh), at most (2 * 2^-8 + 2^-16)
 //     |q_i||x_i| per element, hence 7.83e-3 |q||r|; K + 2 additions.  A third of the matrix work for a filter that passes ~8 rows
 //     per query instead of ~1 on unstructured 768-d data (the exact re-score decides either way).
+//     Round 3: that 7.83e-3 is a worst case over operands (every element at the far end of its rounding interval, q and r
+//     parallel in absolute value).  The dropped part is bounded just as rigorously by what the operands REALLY lose,
+//       |(q - qh).r + qh.(r - rh)| <= |q - qh| |r| + |qh| |r - rh|        (Cauchy-Schwarz on each term),
+//     with |q - qh|, |qh| computed per query (k_mfma_prep) and |r - rh| kept per row (IndexView::rres, k_row_residual): round to
+//     nearest leaves ~0.38 * 2^-8 of a vector's norm on ordinary data, so the window is 2.6 x narrower — a third of the rows pass
+//     the filter at the same sample bound and a quarter survive the interval test into the exact pass.  filter_gamma(., 2) is
+//     then only the accumulation part (filter_gamma_acc); the 7.83e-3 stays for callers without per-row data.
+__host__ __device__ static inline double filter_gamma_acc(uint32_t dim) {     // K + 2 float32 additions of the one-term kernel
+    const double g = (double)(dim + 2) * 1.1920928955078125e-7;
+    return 1.008 * g / (1.0 - g);
+}
 __host__ __device__ static inline double filter_gamma(uint32_t dim, int mode /* 0 fp32, 1 bf16 x 3, 2 bf16 x 1 */) {
     if (!mode) { const double g = (double)(dim + 2) * 5.9604644775390625e-8; return g / (1.0 - g); }
     if (mode == 2) { const double g = (double)(dim + 2) * 1.1920928955078125e-7; return 1.008 * g / (1.0 - g) + 7.83e-3; }
@@ -79,7 +90,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float x0, float x1) { const bf2 h 
 // Qt[qb32][chunk][32 queries][4 dims] (zero padded), per-query filter constants, counters reset
 __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t dim4,
                             const float* __restrict__ sample_dist /*[nq][k], or [nq][parts][k] ascending partial lists*/, uint32_t parts, uint32_t k, int metric,
-                            float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq,
+                            float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq /*[2][nq_pad]: m_q, b_q*/, float* __restrict__ eq /*[nq_pad][2]*/,
                             uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what) {
     // what: 1 = operand layout only, 2 = filter constants only (needs sample_dist), 3 = both
     const uint32_t q = blockIdx.x;                     // one block per (padded) query
@@ -109,15 +120,28 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
         }
         reinterpret_cast<f4*>(Qt)[((size_t)(q >> 5) * dim4p + c) * 32 + (q & 31)] = x;
     }
-    double n2 = 0.0;                                                // |q|^2: the block is one wave
-    if ((what & 2) && q < nq) {
-        for (uint32_t i = threadIdx.x; i < dim; i += 64) { const double a = queries[(size_t)q * dim + i]; n2 = __builtin_fma(a, a, n2); }
-        n2 = wave_sum_f64(n2);
+    double n2 = 0.0, d2 = 0.0, h2 = 0.0;                            // |q|^2, |q - qh|^2, |qh|^2 (qh = bf16(q)): the block is one wave
+    if (q < nq) {
+        for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+            const float af = queries[(size_t)q * dim + i];
+            float hf = (float)(__bf16)af;
+            if (__builtin_fabsf(hf) < 1.17549435e-38f) hf = 0.f;            // an operand the matrix core may flush
+            const double a = af, h = hf;
+            n2 = __builtin_fma(a, a, n2); d2 = __builtin_fma(a - h, a - h, d2); h2 = __builtin_fma(h, h, h2);
+        }
+        n2 = wave_sum_f64(n2); d2 = wave_sum_f64(d2); h2 = wave_sum_f64(h2);
     }
+    if (threadIdx.x == 0 && what == 1) cq[q] = q < nq ? f32_up((float)__builtin_sqrt(n2)) : 0.f;   // the sample pass reads |q| here (rounded up)
     if (threadIdx.x == 0 && (what & 2)) {
-        float c_ = __uint_as_float(0x7F800000u), m_ = 0.f;       // padded queries: +inf threshold, nothing passes
+        float c_ = __uint_as_float(0x7F800000u), m_ = 0.f, b_ = 0.f;       // padded queries: +inf threshold, nothing passes
+        float ea_ = 0.f, eb_ = 0.f;
         if (q < nq) {
             const double qn = __builtin_sqrt(n2);
+            // |S~ - S| <= ea |r| + eb |r - rh|: per query what the filter's scores can be off by (one-term filter: the query's own
+            // rounding loss and |qh|; the others: gamma |q|, nothing per row)
+            const double ea = bf16x3 == 2 ? filter_gamma_acc(dim) * qn + __builtin_sqrt(d2) * (1.0 + 1e-9) : filter_gamma(dim, bf16x3) * qn;
+            const double eb = bf16x3 == 2 ? __builtin_sqrt(h2) * (1.0 + 1e-9) : 0.0;
+            ea_ = f32_up((float)ea); eb_ = f32_up((float)eb);
             double U;                                                          // +inf if the sample held < k live rows
             if (parts <= 1) U = (double)sample_dist[(size_t)q * k + (k - 1)];
             else {                                                             // k-th smallest over the parts' ascending lists (k_sample_bound)
@@ -134,25 +158,28 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
                 }
                 U = (double)best;
             }
-            const double gamma = filter_gamma(dim, bf16x3);
+            const double gref = filter_gamma(dim, 0);                          // the REFERENCE's float32 accumulation error (QV_L2SQ), not the filter's
             double c, m;
             if (metric == QV_L2 || metric == QV_L2SQ) {
                 // squared domain: real d^2 = |q|^2 + |r|^2 - 2S.  The reference value D relates to the real d by
                 // D = d(1+eta), |eta| <= 1.3e-7 (QV_L2: float32 differences, float64 sum, sqrt, one rounding) or
                 // D = d^2(1+eta), |eta| <= (K+2)u (QV_L2SQ: float32 accumulation), so D <= U implies d^2 <= T:
-                const double T = metric == QV_L2 ? U * U * (1.0 + 4e-7) : U * (1.0 + gamma + 2e-6);
-                c = n2 * (1.0 - 2e-6) - T;                           // A_q; test: 2S~ >= A_q + (1-2e-6)|r|^2 - B_q|r|
-                m = 2.0 * (gamma + 1e-6) * qn;                       // B_q
-                if (!(U == U) || U > 1.0e18 || (bf16x3 && qn < 1e-18) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; }   // (a query norm >= 1e18 or NaN: its float32 scores may overflow)
+                const double T = metric == QV_L2 ? U * U * (1.0 + 4e-7) : U * (1.0 + gref + 2e-6);
+                c = n2 * (1.0 - 2e-6) - T;                           // A_q; test: 2S~ >= A_q + (1-2e-6)|r|^2 - B_q|r| - 2 eb |r - rh|
+                m = 2.0 * (ea + 1e-6 * qn);                          // B_q
+                b_ = f32_up((float)(2.0 * eb));
+                if (!(U == U) || U > 1.0e18 || (bf16x3 && qn < 1e-18) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; b_ = 0.f; }   // (a query norm >= 1e18 or NaN: its float32 scores may overflow)
             } else {
                 c = metric == QV_COSINE ? (1.0 - U - 4e-7) * qn : (1.0 - U - 4e-7 * (1.0 + __builtin_fabs(U)));
-                m = (gamma + 1e-6) * qn;
-                if (!(U == U) || U > 3.0e38 || (bf16x3 && qn < 1e-18) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; }   // no bound: everything is a candidate (overflow -> exact path); bf16 operands below 2^-126 flush
+                m = ea + 1e-6 * qn;
+                b_ = f32_up((float)eb);
+                if (!(U == U) || U > 3.0e38 || (bf16x3 && qn < 1e-18) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; b_ = 0.f; }   // no bound: everything is a candidate (overflow -> exact path); bf16 operands below 2^-126 flush
             }
             c_ = f32_down((float)c);                                         // round towards "keep more"
             m_ = f32_up((float)m);
         }
-        cq[q] = c_; mq[q] = m_;
+        cq[q] = c_; mq[q] = m_; mq[nq_pad + q] = b_;
+        eq[2 * q] = ea_; eq[2 * q + 1] = eb_;
         if (q < nq) { cand_cnt[q] = 0; overflow[q] = 0; }
     }
 }
@@ -219,29 +246,36 @@ __device__ __forceinline__ void cand_push(const CandQueue& cqu, uint32_t& n, uin
 // No score is NaN or infinite when both norms are below 1e18 (|partial sum| <= |q||r| < 1e36), so overflow is guarded per ROW
 // here (a norm that is NaN, infinite or >= 1e18 passes both tests outright: the exact pass decides) and per QUERY in k_mfma_prep
 // (such a query gets the "everything is a candidate" threshold), not per score.
-struct EpiConsts { float cmin[2], mmax[2]; };
+struct EpiConsts { float cmin[2], mmax[2], bmax[2]; };
+constexpr uint32_t kEpiQ = 256;                                      // query slots of a workgroup's constants: sm[0..256) = m_q, sm[256..512) = b_q
 // sc / sm: the workgroup's filter constants in LDS (one float per query); qbase: the wave's first query in them; NI 32-query blocks
 template <int METRIC, int NI = 2>
 __device__ __forceinline__ EpiConsts epi_consts(const float* sc, const float* sm, uint32_t qbase, uint32_t half) {
     EpiConsts e;
-    e.cmin[1] = e.mmax[1] = 0.f;
+    e.cmin[1] = e.mmax[1] = e.bmax[1] = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-        float cm = __uint_as_float(0x7F800000u), mm = 0.f;
+        float cm = __uint_as_float(0x7F800000u), mm = 0.f, bm = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-            cm = fminf(cm, sc[qbase + ql]); mm = fmaxf(mm, sm[qbase + ql]);
+            cm = fminf(cm, sc[qbase + ql]); mm = fmaxf(mm, sm[qbase + ql]); bm = fmaxf(bm, sm[kEpiQ + qbase + ql]);
         }
-        e.cmin[i] = cm; e.mmax[i] = mm;
+        e.cmin[i] = cm; e.mmax[i] = mm; e.bmax[i] = bm;
     }
     return e;
 }
 template <int METRIC>
-__device__ __forceinline__ float filter_threshold(float c, float m, float rn, float rn2c) {
-    return METRIC == QV_COSINE ? c * rn - 1e-30f : (METRIC == QV_DOT ? c - m * rn : 0.5f * (c + rn2c - m * rn));
+__device__ __forceinline__ float filter_threshold(float c, float m, float b, float rn, float rn2c, float rho) {
+    // rho = |r - bf16(r)| and b = the query's |qh| (one-term filter; b = 0 for the others): see filter_gamma
+    return METRIC == QV_COSINE ? c * rn - b * rho - 1e-30f : (METRIC == QV_DOT ? c - m * rn - b * rho : 0.5f * (c + rn2c - m * rn - b * rho));
 }
-constexpr uint32_t kEpiEntryWords = 20;                               // 16 scores, row, |r| up, (1-2e-6)|r|^2 down, flags (i | half << 1 | unsure << 2)
+// (1-2e-6)|r|^2 rounded down, from rn = the row norm rounded to float32 and one step up (L2 family)
+__device__ __forceinline__ float rn2c_of(float rn) {
+    const float rlo = f32_down(f32_down(rn));
+    return f32_down(f32_down(rlo * rlo) * 0.999998f);
+}
+constexpr uint32_t kEpiEntryWords = 20;                               // 16 scores, row, |r| up, |r - bf16(r)| up, flags (i | half << 1 | unsure << 2)
 struct EpiDump { uint32_t* area; uint32_t cap; };                     // this WAVE's dump area in LDS, cap entries of kEpiEntryWords words (16-byte aligned)
 
 // the dense pass: entries [0, n) of the wave's dump area, 16 (entry, score) pairs per entry, 64 pairs per round
@@ -258,7 +292,8 @@ __device__ __forceinline__ void epi_dense_pass(const EpiDump& du, uint32_t n, co
             const uint32_t ql = 32 * (fl & 1) + (r & 3) + 8 * (r >> 2) + 4 * ((fl >> 1) & 1);
             score = __uint_as_float(d[r]); row = d[16];
             const float c = sc[qbase + ql];
-            const float thr = filter_threshold<METRIC>(c, sm[qbase + ql], __uint_as_float(d[17]), __uint_as_float(d[18]));
+            const float rn = __uint_as_float(d[17]);
+            const float thr = filter_threshold<METRIC>(c, sm[qbase + ql], sm[kEpiQ + qbase + ql], rn, rn2c_of(rn), __uint_as_float(d[18]));
             take = (!(score < thr) || (fl >> 2)) && c < 3.0e38f;      // (padded query slots carry +inf)
             q = qglobal + ql;
         }
@@ -269,12 +304,68 @@ __device__ __forceinline__ void epi_dense_pass(const EpiDump& du, uint32_t n, co
 }
 
 // acc[i][j][r] = S~[query qglobal + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31]; the wave's queries start at sc[qbase] / sm[qbase]
+// The epilogue of one row group in pieces — row block J (level 1 + dump), then the dense pass — so that a kernel can run them one
+// at a time between the steps of the NEXT group's K loop (k_bf16x1_filter_w8), where they cost memory-wait time instead of their own.
+// n: entries in the wave's dump area (wave-uniform), carried from block to block.
+template <int METRIC, int NI, int NJ, int J>
+__device__ __forceinline__ void filter_epilogue_block(const f16v (&acc)[NI][NJ], uint32_t t0, uint32_t t1, const float* sc, const float* sm,
+                                                      uint32_t qbase, uint32_t half, uint32_t l31, uint32_t qglobal, float tiny_rn, const EpiConsts& ec,
+                                                      const double (&rnd)[NJ], const float (&rho)[NJ], const uint64_t (&alv)[NJ / 2], const CandQueue& cqu, uint32_t& cqn,
+                                                      const CandOut& out, const EpiDump& du, uint32_t& n) {
+    constexpr int j = J;
+    const uint32_t t = j < 2 ? t0 : t1;
+    if (j >= 2 && t1 == t0) return;
+    const uint32_t row = t * 64 + 32 * (j & 1) + l31;
+    const bool live = (alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull;
+    const float rn = f32_up((float)rnd[j]);
+    const float rn2c = rn2c_of(rn);
+    // rows the scores say nothing about: bf16 operands of a vanishing row would flush; a norm that is NaN, infinite or huge
+    // may have overflowed the float32 sums (in either direction, possibly only on the way)
+    const bool unsure = rn < tiny_rn || !(rn < 1.0e18f);
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const f16v& a = acc[i][j];
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(a[3], a[4]), a[5]);
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(a[6], a[7]), a[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(a[9], a[10]), a[11]);
+        const float m4 = __builtin_fmaxf(__builtin_fmaxf(a[12], a[13]), a[14]);
+        const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), m2), __builtin_fmaxf(__builtin_fmaxf(m3, m4), a[15]));
+        // monotone in c (up), m and b (down) operation by operation, so this is a lower bound of every one of the 16 thresholds
+        const float thr_lo = filter_threshold<METRIC>(ec.cmin[i], ec.mmax[i], ec.bmax[i], rn, rn2c, rho[j]);
+        const bool pre = (!(mx < thr_lo) || unsure) && live;
+        const uint64_t pm = __ballot(pre);
+#if defined(QV_DBG_EPI) && QV_DBG_EPI == 2                               // measurement build: level 1 only
+        if (pm == 0x123456789abcull) out.cnt[0] = 1;
+        continue;
+#endif
+        if (__builtin_expect(pm != 0, 0)) {                 // some row of the block may be in some query's top-k
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(pm), rank = (uint32_t)__builtin_popcountll(pm & ((1ull << lane_id()) - 1ull));
+            for (uint32_t done = 0; done < cnt;) {          // one round, unless the dump area fills up (wave-uniform loop)
+                if (n == du.cap) { epi_dense_pass<METRIC>(du, n, sc, sm, qbase, qglobal, cqu, cqn, out); n = 0; __threadfence_block(); }
+                const uint32_t now = (du.cap - n) < (cnt - done) ? (du.cap - n) : (cnt - done);
+                if (pre && rank >= done && rank < done + now) {
+                    uint32_t* d = du.area + (n + rank - done) * kEpiEntryWords;
+                    f4* d4 = reinterpret_cast<f4*>(d);
+                    d4[0] = f4{a[0], a[1], a[2], a[3]}; d4[1] = f4{a[4], a[5], a[6], a[7]};
+                    d4[2] = f4{a[8], a[9], a[10], a[11]}; d4[3] = f4{a[12], a[13], a[14], a[15]};
+                    d[16] = row; d[17] = __float_as_uint(rn); d[18] = __float_as_uint(rho[j]); d[19] = (uint32_t)i | (half << 1) | ((uint32_t)unsure << 2);
+                }
+                n += now; done += now;
+            }
+        }
+    }
+}
+template <int METRIC>
+__device__ __forceinline__ void filter_epilogue_finish(const float* sc, const float* sm, uint32_t qbase, uint32_t qglobal, const CandQueue& cqu, uint32_t& cqn,
+                                                       const CandOut& out, const EpiDump& du, uint32_t& n) {
+    if (n) epi_dense_pass<METRIC>(du, n, sc, sm, qbase, qglobal, cqu, cqn, out);
+    n = 0;
+}
 template <int METRIC, int NI, int NJ>
 __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (&acc)[NI][NJ], uint32_t t0, uint32_t t1, const float* sc, const float* sm,
                                                 uint32_t qbase, uint32_t half, uint32_t l31, uint32_t qglobal, float tiny_rn, const EpiConsts& ec,
-                                                const double (&rnd)[NJ], const uint64_t (&alv)[NJ / 2], const CandQueue& cqu, uint32_t& cqn, const CandOut& out,
+                                                const double (&rnd)[NJ], const float (&rho)[NJ], const uint64_t (&alv)[NJ / 2], const CandQueue& cqu, uint32_t& cqn, const CandOut& out,
                                                 const EpiDump& du) {
-        uint32_t* const cand_cnt = out.cnt; (void)cand_cnt;
+        uint32_t* const cand_cnt = out.cnt; (void)cand_cnt; (void)v;
 #if defined(QV_DBG_EPI) && QV_DBG_EPI == 1                               // measurement build: no epilogue (the accumulators stay live through one compare)
         {
             float sdbg = 0.f;
@@ -288,59 +379,18 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
             return;
         }
 #endif
-        uint32_t n = 0;                                              // entries in the wave's dump area (wave-uniform)
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const uint32_t t = j < 2 ? t0 : t1;
-            if (j >= 2 && t1 == t0) continue;
-            const uint32_t row = t * 64 + 32 * (j & 1) + l31;
-            const bool live = (alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull;
-            const float rn = f32_up((float)rnd[j]);
-            const float rlo = f32_down((float)rnd[j]);
-            const float rn2c = f32_down(f32_down(rlo * rlo) * 0.999998f);   // (1-2e-6)|r|^2, rounded down (L2 family)
-            // rows the scores say nothing about: bf16 operands of a vanishing row would flush; a norm that is NaN, infinite or huge
-            // may have overflowed the float32 sums (in either direction, possibly only on the way)
-            const bool unsure = rn < tiny_rn || !(rn < 1.0e18f);
-#pragma unroll
-            for (int i = 0; i < NI; i++) {
-                const f16v& a = acc[i][j];
-                const float m0 = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(a[3], a[4]), a[5]);
-                const float m2 = __builtin_fmaxf(__builtin_fmaxf(a[6], a[7]), a[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(a[9], a[10]), a[11]);
-                const float m4 = __builtin_fmaxf(__builtin_fmaxf(a[12], a[13]), a[14]);
-                const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), m2), __builtin_fmaxf(__builtin_fmaxf(m3, m4), a[15]));
-                // monotone in c (up) and m (down) operation by operation, so this is a lower bound of every one of the 16 thresholds
-                const float thr_lo = filter_threshold<METRIC>(ec.cmin[i], ec.mmax[i], rn, rn2c);
-                const bool pre = (!(mx < thr_lo) || unsure) && live;
-                const uint64_t pm = __ballot(pre);
-#if defined(QV_DBG_EPI) && QV_DBG_EPI == 2                               // measurement build: level 1 only
-                if (pm == 0x123456789abcull) cand_cnt[0] = 1;
-                continue;
-#endif
-                if (__builtin_expect(pm != 0, 0)) {                 // some row of the block may be in some query's top-k
-                    const uint32_t cnt = (uint32_t)__builtin_popcountll(pm), rank = (uint32_t)__builtin_popcountll(pm & ((1ull << lane_id()) - 1ull));
-                    for (uint32_t done = 0; done < cnt;) {          // one round, unless the dump area fills up (wave-uniform loop)
-                        if (n == du.cap) { epi_dense_pass<METRIC>(du, n, sc, sm, qbase, qglobal, cqu, cqn, out); n = 0; __threadfence_block(); }
-                        const uint32_t now = (du.cap - n) < (cnt - done) ? (du.cap - n) : (cnt - done);
-                        if (pre && rank >= done && rank < done + now) {
-                            uint32_t* d = du.area + (n + rank - done) * kEpiEntryWords;
-                            f4* d4 = reinterpret_cast<f4*>(d);
-                            d4[0] = f4{a[0], a[1], a[2], a[3]}; d4[1] = f4{a[4], a[5], a[6], a[7]};
-                            d4[2] = f4{a[8], a[9], a[10], a[11]}; d4[3] = f4{a[12], a[13], a[14], a[15]};
-                            d[16] = row; d[17] = __float_as_uint(rn); d[18] = __float_as_uint(rn2c); d[19] = (uint32_t)i | (half << 1) | ((uint32_t)unsure << 2);
-                        }
-                        n += now; done += now;
-                    }
-                }
-            }
-        }
-        if (n) epi_dense_pass<METRIC>(du, n, sc, sm, qbase, qglobal, cqu, cqn, out);
+        uint32_t n = 0;
+#define QV_EPI_BLK(JJ) if constexpr (JJ < NJ) filter_epilogue_block<METRIC, NI, NJ, (JJ < NJ ? JJ : 0)>(acc, t0, t1, sc, sm, qbase, half, l31, qglobal, tiny_rn, ec, rnd, rho, alv, cqu, cqn, out, du, n)
+        QV_EPI_BLK(0); QV_EPI_BLK(1); QV_EPI_BLK(2); QV_EPI_BLK(3);
+#undef QV_EPI_BLK
+        filter_epilogue_finish<METRIC>(sc, sm, qbase, qglobal, cqu, cqn, out, du, n);
 }
 
 // the group's row norms and alive words, requested before the K loop so that their latency is not the epilogue's
 template <int NJ>
-__device__ __forceinline__ void filter_row_consts(const IndexView& v, uint32_t t0, uint32_t t1, uint32_t l31, double (&rnd)[NJ], uint64_t (&alv)[NJ / 2]) {
+__device__ __forceinline__ void filter_row_consts(const IndexView& v, uint32_t t0, uint32_t t1, uint32_t l31, double (&rnd)[NJ], float (&rho)[NJ], uint64_t (&alv)[NJ / 2]) {
 #pragma unroll
-    for (int j = 0; j < NJ; j++) rnd[j] = v.rnorm[(size_t)(j < 2 ? t0 : t1) * 64 + 32 * (j & 1) + l31];
+    for (int j = 0; j < NJ; j++) { const size_t row = (size_t)(j < 2 ? t0 : t1) * 64 + 32 * (j & 1) + l31; rnd[j] = v.rnorm[row]; rho[j] = v.rres[row]; }
     alv[0] = v.alive[t0];
     if constexpr (NJ == 4) alv[1] = v.alive[t1];
 }
@@ -350,7 +400,7 @@ template <int METRIC>
 __global__ void __launch_bounds__(256, 1)
 k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
               uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
-    __shared__ __align__(16) float s_c[4][64], s_m[4][64];                        // this wave's 64 queries' filter constants
+    __shared__ __align__(16) float s_c[4][64], s_m[8][64];                        // this wave's 64 queries' filter constants
     QV_CAND_QUEUE(cqu, 4, 512);                                       // 24 KiB
     QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     const uint32_t lane = lane_id();
@@ -364,6 +414,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
         s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;     // L2 family: A_q (c) and B_q (m)
         s_m[wave][lane] = m;
+        s_m[4 + wave][lane] = mq[nq_pad + 64 * qb64 + lane];
     }
     __syncthreads();
     if (stride == 0) return;
@@ -381,8 +432,8 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         const f4* b0 = tiles + (size_t)t0 * v.dim4 * 64 + l31;
         const f4* b1 = tiles + (size_t)t1 * v.dim4 * 64 + l31;
         f16v acc[2][4];
-        double rnd[4]; uint64_t alv[2];
-        filter_row_consts(v, t0, t1, l31, rnd, alv);
+        double rnd[4]; float rho[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, rho, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -429,9 +480,53 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
 
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 0.0f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 0.0f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
+}
+
+// An UPPER bound of the reference distance from a score, in float32 (the sample pass: 32 768 rows per query): score_interval's
+// formulas with every float32 rounding covered by an explicit allowance — any upper bound of the k-th smallest distance serves as
+// U_q, a looser one only lets a few more rows through.  128 of these per lane and row group, so everything that depends on the
+// query alone or the row alone is prepared once (sample_query_consts / sample_row_consts) and the per-score part is 3-6 instructions
+// without a division.  g = the filter's gamma (|S~ - S| <= g |q||r|); qn, rn rounded UP from float64.  A query or row the scores
+// say nothing about (norm below 1e-18: flushed operands; 1e18 or above: float32 sums may overflow; a row that is gone) carries
+// NaN constants: its bounds come out NaN and are stored as +inf.  With both norms inside that range no score overflows.
+// The L2 family yields the bound on d^2 (one kernel serves QV_L2 and QV_L2SQ); sample_bound_finish takes the SELECTED value into
+// the metric's units — both steps are monotone, so the k-th smallest commutes with them.
+template <int M>
+__device__ __forceinline__ void sample_query_consts(float qn, float g, float& qa, float& qb) {
+    const float nan = __builtin_nanf("");
+    const bool none = (qn != 0.f && qn < 1e-18f) || !(qn < 1.0e18f);
+    if constexpr (M == QV_COSINE) { qa = none ? nan : (qn == 0.f ? 0.f : 1.0f / qn); qb = 0.f; }        // zero norm: the bound becomes 1 + g (the distance is 1)
+    else if constexpr (M == QV_DOT) { qa = none ? nan : g * qn * 1.000001f; qb = 0.f; }
+    else { qa = none ? nan : qn * qn * 1.000001f; qb = 2.0f * g * qn * 1.000002f; }
+}
+template <int M>
+__device__ __forceinline__ void sample_row_consts(float rn, bool gone, float& ra, float& rb) {
+    const float nan = __builtin_nanf("");
+    const bool none = gone || (rn != 0.f && rn < 1e-18f) || !(rn < 1.0e18f);
+    if constexpr (M == QV_COSINE) { ra = none ? nan : (rn == 0.f ? 0.f : 1.0f / rn); rb = 0.f; }
+    else if constexpr (M == QV_DOT) { ra = none ? nan : rn; rb = 0.f; }
+    else { ra = none ? nan : rn * rn * 1.000001f; rb = rn; }
+}
+template <int M>
+__device__ __forceinline__ float sample_upper(float S, float g, float qa, float qb, float ra, float rb) {
+    float hi;
+    if constexpr (M == QV_COSINE) hi = (1.0f - S * (qa * ra)) + (g + 5e-6f);          // |S|/(|q||r|) <= 1 + g: two reciprocals, two products, a difference, a sum: < 1e-6
+    else if constexpr (M == QV_DOT) { const float d = 1.0f - S; hi = d + (qa * ra + 4e-6f * (1.0f + __builtin_fabsf(d))); }
+    else {
+        const float sum = qa + ra;                                   // >= |q|^2 + |r|^2
+        const float h2 = (sum - 2.0f * S) + (qb * rb + 5e-6f * sum);  // 2|S| <= sum: every rounding is of magnitude <= 2 sum
+        hi = h2 > 0.f ? h2 : (h2 == h2 ? 0.f : h2);
+    }
+    return hi == hi ? hi : __builtin_inff();
+}
+template <int M>
+__device__ __forceinline__ float sample_bound_finish(float x, float gref) {
+    if constexpr (M == QV_L2) return __builtin_sqrtf(x) * 1.000002f;
+    else if constexpr (M == QV_L2SQ) return x * (1.0f + gref + 4e-6f);
+    else return x;
 }
 
 // The same filter on the bfloat16 matrix instruction, three products per pair of operands (see filter_gamma): the scores keep
@@ -446,10 +541,13 @@ __global__ void __launch_bounds__(256, 1)
 k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                 uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt,
                 float* __restrict__ score_out, uint32_t score_stride, uint32_t gstep) {
-    // score_out != null: no filter — the scores of the SAMPLE, row groups 0, gstep, 2 gstep, ... (score_stride / 128 of them, spread over the
-    // corpus so that a corpus stored cluster by cluster still yields a representative bound), are written to
-    // score_out[query * score_stride + 128 * (group's place in the sample) + row of the group]
-    __shared__ __align__(16) float s_c[4][64], s_m[4][64];
+    // score_out != null: no filter — the SAMPLE pass.  Row groups 0, gstep, 2 gstep, ... (score_stride / 128 of them, spread over the
+    // corpus so that a corpus stored cluster by cluster still yields a representative bound); what is written to
+    // score_out[query * score_stride + 128 * (group's place in the sample) + row of the group] is the UPPER BOUND of the row's
+    // reference distance that its score implies (score_upper_f32; +inf for rows that are gone or whose score says nothing), so that
+    // k_sample_bound only selects: the row norms and alive words are read once here instead of once per query there.
+    // cq = the queries' norms, rounded up (k_mfma_prep, what = 1).
+    __shared__ __align__(16) float s_c[4][64], s_m[8][64];
     QV_CAND_QUEUE(cqu, 4, 512);                                       // 24 KiB
     QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     const uint32_t lane = lane_id();
@@ -463,7 +561,8 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
         const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
         s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
         s_m[wave][lane] = m;
-    }
+        s_m[4 + wave][lane] = mq[nq_pad + 64 * qb64 + lane];
+    } else sample_query_consts<METRIC>(cq[64 * qb64 + lane], f32_up((float)filter_gamma(v.dim, 1)), s_c[wave][lane], s_m[wave][lane]);
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
@@ -479,8 +578,8 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
         const f4* b0 = tiles + (size_t)t0 * v.dim4 * 64 + l31;
         const f4* b1 = tiles + (size_t)t1 * v.dim4 * 64 + l31;
         f16v acc[2][4];
-        double rnd[4]; uint64_t alv[2];
-        filter_row_consts(v, t0, t1, l31, rnd, alv);
+        double rnd[4]; float rho[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, rho, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -561,20 +660,25 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
             load(st, o0); split(o0, h0); mfma(h0);
         }
         if (score_out) {
+            const float gsm = f32_up((float)filter_gamma(v.dim, 1));
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (j >= 2 && t1 == t0) continue;
                 const uint32_t row = g * 128 + (j < 2 ? 0u : 64u) + 32 * (j & 1) + l31;      // place in the sample
                 if (row >= score_stride) continue;
+                float ra, rb;
+                sample_row_consts<METRIC>(f32_up((float)rnd[j]), !((alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull), ra, rb);
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        score_out[(size_t)(64 * qb64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half) * score_stride + row] = acc[i][j][r];
+                    for (int r = 0; r < 16; r++) {
+                        const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        score_out[(size_t)(64 * qb64 + ql) * score_stride + row] = sample_upper<METRIC>(acc[i][j][r], gsm, s_c[wave][ql], s_m[wave][ql], ra, rb);
+                    }
             }
             continue;
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -589,7 +693,7 @@ template <int METRIC, int TERMS, int RING>
 __global__ void __launch_bounds__(256, 1)
 k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                        uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
-    __shared__ __align__(16) float s_c[4][64], s_m[4][64];
+    __shared__ __align__(16) float s_c[4][64], s_m[8][64];
     QV_CAND_QUEUE(cqu, 4, 512);                                       // 24 KiB
     QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     __shared__ uint4 s_b[4][4][2][64];                              // [stage][32-row block][hi, lo][lane]: 32 KiB
@@ -604,6 +708,7 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
         const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
         s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
         s_m[wave][lane] = m;
+        s_m[4 + wave][lane] = mq[nq_pad + 64 * qb64 + lane];
     }
     __syncthreads();
     if (stride == 0) return;
@@ -637,8 +742,8 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
         const f4* bw = rows_of(g);
         const f4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
         f16v acc[2][4];
-        double rnd[4]; uint64_t alv[2];
-        filter_row_consts(v, t0, t1, l31, rnd, alv);
+        double rnd[4]; float rho[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, rho, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -793,7 +898,7 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
             mfma(q0, 0);
         }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -811,12 +916,12 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
 // behind them up (measured: the same time as the four-wave kernel).  Dimensions that are a multiple of 128, nq_pad of 256.
 // BF: the rows come from the index's bfloat16 copy (QV_FLAG_BF16_ROWS): a wave's 1-KiB request IS one 32-row B operand of one step,
 // no conversion; a round is then two steps (eight pieces, one per wave: piece w = step w>>2 of the round, block w&3).
-template <int METRIC, int RING, int AR, int SPB, bool BF>
+template <int METRIC, int RING, int AR, int SPB, bool BF, bool DEFER>
 __global__ void __launch_bounds__(512, 1)
 k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                    uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
     // RING, AR: row chunks / query operands in flight, counted in ROUNDS; a round = SPB steps of 16 dimensions between two barriers
-    __shared__ __align__(16) float s_c[256], s_m[256];
+    __shared__ __align__(16) float s_c[256], s_m[512];
     __shared__ __align__(16) unsigned char s_b[4][SPB][4][1024];        // [stage][step of the round][32-row block][lane * 16 bytes]: 16 KiB per step of a round
     QV_CAND_QUEUE(cqu, 8, 256);                                      // 24 KiB
     QV_EPI_DUMP(du, 8, 32);                                          // 20 KiB
@@ -830,6 +935,7 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
         const float c = cq[256 * qb256 + threadIdx.x], m = mq[256 * qb256 + threadIdx.x];
         s_c[threadIdx.x] = METRIC == QV_COSINE ? c - m : c;
         s_m[threadIdx.x] = m;
+        s_m[256 + threadIdx.x] = mq[nq_pad + 256 * qb256 + threadIdx.x];
     }
     __syncthreads();
     if (stride == 0) return;
@@ -889,12 +995,19 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
             for (int j = 0; j < 4; j++) b.h[u][j] = *reinterpret_cast<const uint4*>(&s_b[stage][u][j][lane * 16]);
     };
     bool primed = false;
+    // DEFER (a measurement, not the default: 610.7 us against 607.3): the dense pass of a row group's epilogue (the exact per-query tests and the appends, which work from the wave's dump
+    // area in LDS alone) runs after the first eight steps of the NEXT group's K loop.  All eight waves reach the epilogue together
+    // (the barriers keep them in step), so after the loop it is time in which the CU neither computes nor requests rows; between
+    // steps its LDS round trips fill cycles the wave would wait for memory in.  (Carrying the 64 accumulators over as well, so that
+    // level 1 could be deferred too, does not fit: 256 registers at two waves per SIMD, 16 spilled.)
+    constexpr int UNR = RING > AR ? RING : AR;                      // both rings are indexed by the unrolled step number: the loop body covers the longer one
+    uint32_t epn = 0;                                               // entries waiting in the dump area (wave-uniform)
     for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
         const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
         const f4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
         f16v acc[1][4];
-        double rnd[4]; uint64_t alv[2];
-        filter_row_consts(v, t0, t1, l31, rnd, alv);
+        double rnd[4]; float rho[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, rho, alv);
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -994,18 +1107,25 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
             QV_STAMP(5)
 #endif
         };
-        constexpr int UNR = RING > AR ? RING : AR;                  // both rings are indexed by the unrolled step number: the loop body covers the longer one
         for (uint32_t st = 0; st < rounds; st += UNR) {
 #pragma unroll
             for (int k8 = 0; k8 < UNR; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
+            if constexpr (DEFER) {
+                if (st == 0 && epn) filter_epilogue_finish<METRIC>(s_c, s_m, 32 * wave, 256 * qb256 + 32 * wave, cqu, cqu_n, cqu_out, du, epn);
+            }
         }
 #if defined(QV_DBG_STAMP)
         if (stamping && lane == 0)
             printf("stamp wave %u: barrier-in 0, barrier-out %llu, issued %llu, A ready %llu, mfma issued %llu, lds drained %llu, next step start %llu\n", wave,
                    stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0]);
 #endif
-        filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        if constexpr (DEFER) {
+#define QV_W8_BLK(JJ) filter_epilogue_block<METRIC, 1, 4, JJ>(acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du, epn)
+            QV_W8_BLK(0); QV_W8_BLK(1); QV_W8_BLK(2); QV_W8_BLK(3);
+#undef QV_W8_BLK
+        } else filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
+    if constexpr (DEFER) filter_epilogue_finish<METRIC>(s_c, s_m, 32 * wave, 256 * qb256 + 32 * wave, cqu, cqu_n, cqu_out, du, epn);
     cand_flush(cqu, cqu_n, cqu_out);
 }
 
@@ -1019,7 +1139,7 @@ template <int METRIC>
 __global__ void __launch_bounds__(256, 2)
 k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                   uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
-    __shared__ __align__(16) float s_c[4][64], s_m[4][64];
+    __shared__ __align__(16) float s_c[4][64], s_m[8][64];
     QV_CAND_QUEUE(cqu, 4, 512);                                       // 24 KiB
     QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     __shared__ uint4 s_b[4][4][64];                                 // [stage][32-row block][lane]: 16 KiB
@@ -1034,6 +1154,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
         const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
         s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
         s_m[wave][lane] = m;
+        s_m[4 + wave][lane] = mq[nq_pad + 64 * qb64 + lane];
     }
     __syncthreads();
     if (stride == 0) return;
@@ -1067,8 +1188,8 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
         const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
         const uint4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
         f16v acc[2][4];
-        double rnd[4]; uint64_t alv[2];
-        filter_row_consts(v, t0, t1, l31, rnd, alv);
+        double rnd[4]; float rho[4]; uint64_t alv[2];
+        filter_row_consts(v, t0, t1, l31, rnd, rho, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1114,7 +1235,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
 #pragma unroll
             for (int k8 = 0; k8 < RING; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -1129,7 +1250,7 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
                       uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
     extern __shared__ __align__(16) unsigned char smem_q64[];
     uint4* s_a = reinterpret_cast<uint4*>(smem_q64);                // [step][query half][lane]
-    __shared__ __align__(16) float s_c[4][64], s_m[4][64];                        // row 0 is used (filter_epilogue's shape)
+    __shared__ __align__(16) float s_c[4][64], s_m[8][64];                        // row 0 is used (filter_epilogue's shape)
     QV_CAND_QUEUE(cqu, 8, 128);                                       // 12 KiB: the query operands take up to 128 KiB of the 160
     QV_EPI_DUMP(du, 8, 16);                                           // 10 KiB
     const uint32_t lane = lane_id();
@@ -1144,6 +1265,7 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
         const float c = cq[threadIdx.x], m = mq[threadIdx.x];
         s_c[0][threadIdx.x] = METRIC == QV_COSINE ? c - m : c;
         s_m[0][threadIdx.x] = m;
+        s_m[4][threadIdx.x] = mq[nq_pad + threadIdx.x];
     }
     __syncthreads();
     const uint32_t half = lane >> 5, l31 = lane & 31;
@@ -1171,8 +1293,8 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
         const uint4* nb[NB];
         bases(g + tw < n_groups ? g + tw : g, nb);
         f16v acc[2][NB];
-        double rnd[NB]; uint64_t alv[NB / 2];
-        filter_row_consts(v, t0, t1, l31, rnd, alv);
+        double rnd[NB]; float rho[NB]; uint64_t alv[NB / 2];
+        filter_row_consts(v, t0, t1, l31, rnd, rho, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1203,28 +1325,29 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
                 load_step(rb[k]);
             }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 0u, half, l31, 0u, 1e-18f, ec, rnd, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 0u, half, l31, 0u, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
 
-// [lo, hi] containing the reference distance d(q, r) given an approximate score S~ with |S~ - S| <= gamma |q||r| (filter_gamma):
-// qn_cos = the cosine metric's own query norm, qn_l2 = |q|, rn = the stored row norm
+// [lo, hi] containing the reference distance d(q, r) given an approximate score S~ with |S~ - S| <= E (the filter's bound for this
+// query and row: filter_gamma |q||r|, or ea |r| + eb |r - rh| for the one-term filter); gref = the reference's own float32
+// accumulation error (QV_L2SQ); qn_cos = the cosine metric's own query norm, qn_l2 = |q|, rn = the stored row norm
 template <int M>
-__device__ __forceinline__ void score_interval(double S, double qn_cos, double qn_l2, double rn, double gamma, float& lo, float& hi) {
+__device__ __forceinline__ void score_interval(double S, double qn_cos, double qn_l2, double rn, double E, double gref, float& lo, float& hi) {
     if (!(__builtin_fabs(S) < 3.0e38)) { lo = -__builtin_inff(); hi = __builtin_inff(); return; }   // overflowed float32 sum (or NaN): no information
     double d, e;
     if constexpr (M == QV_COSINE) {
         if (qn_cos == 0.0 || rn == 0.0) { d = 1.0; e = 0.0; }
-        else { d = 1.0 - S / (qn_cos * rn); e = gamma + 2e-6; }      // |S~ - S| <= gamma |q||r|
+        else { d = 1.0 - S / (qn_cos * rn); e = E / (qn_cos * rn) + 2e-6; }
     } else if constexpr (M == QV_DOT) {
-        d = 1.0 - S; e = gamma * qn_l2 * rn + 2e-6 * (1.0 + __builtin_fabs(d));
+        d = 1.0 - S; e = E + 2e-6 * (1.0 + __builtin_fabs(d));
     } else {                                                        // QV_L2 / QV_L2SQ: interval on d^2, then into the metric's units
         const double q2 = qn_l2 * qn_l2, r2 = rn * rn;
-        const double d2 = q2 + r2 - 2.0 * S, e2 = 2.0 * gamma * qn_l2 * rn + 2e-6 * (q2 + r2);
+        const double d2 = q2 + r2 - 2.0 * S, e2 = 2.0 * E + 2e-6 * (q2 + r2);
         double l2 = d2 - e2 > 0.0 ? d2 - e2 : 0.0, h2 = d2 + e2 > 0.0 ? d2 + e2 : 0.0;
         if constexpr (M == QV_L2) { l2 = __builtin_sqrt(l2) * (1.0 - 4e-7); h2 = __builtin_sqrt(h2) * (1.0 + 4e-7); }
-        else { l2 = l2 * (1.0 - gamma - 2e-6); h2 = h2 * (1.0 + gamma + 2e-6); }
+        else { l2 = l2 * (1.0 - gref - 2e-6); h2 = h2 * (1.0 + gref + 2e-6); }
         lo = f32_down((float)l2); hi = f32_up((float)h2);
         if (!(d2 == d2)) { lo = -__builtin_inff(); hi = __builtin_inff(); }
         return;
@@ -1233,73 +1356,65 @@ __device__ __forceinline__ void score_interval(double S, double qn_cos, double q
     if (!(d == d)) { lo = -__builtin_inff(); hi = __builtin_inff(); }   // NaN score: keep, the exact pass decides
 }
 
-// The sample bound without an exact scan: the filter kernel's scores of the first `srows` rows give every sampled row an UPPER
-// bound of its reference distance (score_interval), and the k-th smallest of those bounds is at least the k-th smallest true
-// distance over the sample, hence over the corpus.  One workgroup per query; writes U_q where k_mfma_prep reads it.
+// The sample bound without an exact scan: the three-term filter kernel's scores of the sample give every sampled row an UPPER
+// bound of its reference distance (written by that kernel: score_upper_f32), and the k-th smallest of those bounds is at least the
+// k-th smallest true distance over the sample, hence over the corpus.  One workgroup per query (and part); a pure selection.
 template <int M>
 __global__ void __launch_bounds__(1024)
-k_sample_bound(IndexView v, const float* __restrict__ queries, const float* __restrict__ scores, uint32_t srows, uint32_t k, double gamma,
-               float* __restrict__ sample_dist, uint32_t parts, uint32_t gstep) {
+k_sample_bound(const float* __restrict__ bounds, uint32_t srows, uint32_t k, float gref, float* __restrict__ sample_dist, uint32_t parts) {
     __shared__ uint64_t wl[16 * 64];
-    __shared__ double s_qn[2];
+    __shared__ uint64_t s_sorted[64];
+    __shared__ unsigned long long s_thr;                            // the smallest k-th key any wave of the workgroup holds: no key above it is in the answer
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t qi = blockIdx.x;
-    extern __shared__ float s_q[];                                  // the query, staged so that one thread can walk it quickly
-    for (uint32_t i = threadIdx.x; i < v.dim; i += blockDim.x) s_q[i] = queries[(size_t)qi * v.dim + i];
+    if (threadIdx.x < 64) s_sorted[threadIdx.x] = kDeadKey;
+    if (threadIdx.x == 0) s_thr = kDeadKey;
     __syncthreads();
-    if (wave == 0) {
-        // |q|: it only enters score_interval's bounds (2e-6 of slack), so the order of the additions is free
-        double n2 = 0.0;
-        for (uint32_t i = lane; i < v.dim; i += 64) { const double a = (double)s_q[i]; n2 = __builtin_fma(a, a, n2); }
-        n2 = wave_sum_f64(n2);
-        if (lane == 0) { s_qn[0] = __builtin_sqrt(n2); s_qn[1] = s_qn[0]; }
-    }
-    __syncthreads();
-    const double qn_cos = s_qn[0], qn_l2 = s_qn[1];
     const uint32_t kth = k - 1;
-    const float* sc = scores + (size_t)qi * srows;
+    const float* sc = bounds + (size_t)qi * srows;
     // grid (nq, parts): this workgroup takes the rows [r_lo, r_hi) of the sample and writes the k smallest upper bounds it saw, ascending;
     // k_mfma_prep takes the k-th smallest over the parts (a few queries alone would leave most CUs idle: 38 us for 64 queries)
     const uint32_t part = blockIdx.y;
     const uint32_t per_part = ((srows + parts - 1) / parts + 63) / 64 * 64;
     const uint32_t r_lo = part * per_part, r_hi = r_lo + per_part < srows ? r_lo + per_part : srows;
     uint64_t list = kDeadKey, thr = kDeadKey;
-    // eight batches of 64 rows per round: their scores, norms and alive words are requested together (one batch at a time the
-    // loop was a chain of 32 exposed round trips: 60 us per launch at a 32k-row sample)
+    // eight batches of 64 rows per round, requested together
     for (uint32_t base0 = r_lo + wave * 64; base0 < r_hi; base0 += 8 * 16 * 64) {
-        float scv[8]; double rnv[8]; uint64_t alw[8];
+        float scv[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t row = base0 + (uint32_t)j * (16 * 64) + lane;                        // place in the sample
-            const uint32_t arow = (row >> 7) * gstep * 128 + (row & 127);                          // row of the corpus
-            const bool in = row < r_hi && arow < v.n_rows;
-            scv[j] = in ? sc[row] : 0.f; rnv[j] = in ? v.rnorm[arow] : 0.0; alw[j] = in ? v.alive[arow >> 6] : 0ull;
+            scv[j] = row < r_hi ? __builtin_nontemporal_load(&sc[row]) : __builtin_inff();
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t row = base0 + (uint32_t)j * (16 * 64) + lane;
-            const uint32_t arow = (row >> 7) * gstep * 128 + (row & 127);
-            uint64_t key = kDeadKey;
-            if (row < r_hi && arow < v.n_rows && ((alw[j] >> (arow & 63)) & 1ull)) {
-                float lo, hi;
-                score_interval<M>((double)scv[j], qn_cos, qn_l2, rnv[j], gamma, lo, hi);
-                key = make_key(hi, row);
-            }
+            const uint64_t key = row < r_hi && scv[j] < __builtin_inff() ? make_key(scv[j], row) : kDeadKey;
             if (base0 + (uint32_t)j * (16 * 64) >= r_hi) continue;
             if (base0 == r_lo + wave * 64 && j == 0) list_seed(list, thr, key, kth, lane); else list_insert(list, thr, key, kth, lane);
+            // the sixteen waves tighten ONE threshold (each alone would take ~k ln(rows/k) serial inserts: 1 000 per workgroup against ~100)
+            if (lane == 0 && thr < s_thr) atomicMin(&s_thr, (unsigned long long)thr);
+            const uint64_t shared_thr = s_thr;
+            thr = shared_thr < thr ? shared_thr : thr;
         }
     }
     wl[wave * 64 + lane] = list;
     __syncthreads();
+    {   // merge of the sixteen lists by rank: a wave counts, for each of its k keys, the keys of the workgroup below it (keys are
+        // distinct: the row is part of them) and puts those that rank under k in place — no serial inserts
+        const uint64_t mine = lane < k ? list : kDeadKey;
+        uint32_t rank = 0;
+        for (uint32_t w = 0; w < 16; w++)
+            for (uint32_t i = 0; i < k; i++) rank += wl[w * 64 + i] < mine ? 1u : 0u;
+        if (mine != kDeadKey && rank < k) s_sorted[rank] = mine;
+    }
+    __syncthreads();
     if (wave == 0) {
-        for (uint32_t w = 1; w < 16; w++) {
-            const uint64_t key = lane < k ? wl[w * 64 + lane] : kDeadKey;
-            list_insert(list, thr, key, kth, lane);
-        }
-        const uint64_t kk = readlane64(list, kth);
-        if (parts <= 1) { if (lane == 0) sample_dist[(size_t)qi * k + kth] = kk == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(kk >> 32)); }
-        else if (lane < k) sample_dist[((size_t)qi * parts + part) * k + lane] = list == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(list >> 32));
+        const uint64_t mine = s_sorted[lane];
+        const float val = mine == kDeadKey ? __builtin_inff() : sample_bound_finish<M>(unord_f32((uint32_t)(mine >> 32)), gref);
+        if (parts <= 1) { if (lane == kth) sample_dist[(size_t)qi * k + kth] = val; }
+        else if (lane < k) sample_dist[((size_t)qi * parts + part) * k + lane] = val;
     }
 }
 
@@ -1313,7 +1428,7 @@ template <int M, int U>
 __global__ void __launch_bounds__(256)
 k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_score,
                  const uint32_t* __restrict__ cand_cnt, uint32_t k, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out,
-                 uint32_t* __restrict__ overflow, double gamma) {
+                 uint32_t* __restrict__ overflow, const float* __restrict__ eq /*[nq][2]: |S~ - S| <= eq[0] |r| + eq[1] |r - rh| (k_mfma_prep)*/) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
@@ -1349,8 +1464,11 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
     RSTK();
 
     // ---- stage 1: H = k-th smallest upper bound
+    const double ea = (double)eq[2 * qi], eb = (double)eq[2 * qi + 1], gref = filter_gamma(v.dim, 0);
     auto bounds = [&](uint32_t i, float& lo, float& hi) {
-        score_interval<M>((double)cs[i], qc.qn, qn_l2, v.rnorm[cr[i]], gamma, lo, hi);
+        const uint32_t row = cr[i];
+        const double rn = v.rnorm[row];
+        score_interval<M>((double)cs[i], qc.qn, qn_l2, rn, ea * rn + eb * (double)v.rres[row], gref, lo, hi);
     };
     uint64_t list = kDeadKey, thr = kDeadKey;
     for (uint32_t base = wave * 64; base < cnt; base += 4 * 64) {
@@ -1387,8 +1505,12 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
         uint64_t key = kDeadKey;
         if (i < ns) {
             const uint32_t row = surv[i];
-            const f4* p = reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63);
-            typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
+            // a survivor's row out of the tile layout is dim4 separate 16-byte pieces, one memory line each (~80 survivors per query
+            // with the one-term filter: the pass is bound by those lines); the row-major copy, when the index keeps one, holds the
+            // same floats contiguously — same values, same order, same result
+            typename MT<M>::A acc;
+            if (v.rowmaj != nullptr && (v.dim & 3) == 0) acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
+            else acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
             double rn = 0.0;
             if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
             key = make_key(finalize<M>(acc, qc, rn), row);
@@ -1473,7 +1595,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     size_t b = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);   // sample scan (partials + query blocks)
     b = (b + 255) / 256 * 256;
     b += (size_t)nq_pad * (v.dim4 + 4) * 16;                 // Qt (chunk count padded to even) / the bf16 hi + lo planes (padded to 4 chunks)
-    b += (size_t)nq_pad * 8;                                 // cq, mq
+    b += (size_t)nq_pad * 20;                                // cq, mq (m_q and b_q), eq
     b += (size_t)nq * kMfmaCandCap * 8;                      // candidates: rows + fp32 scores
     b += (size_t)nq * 8;                                     // counters, overflow flags
     b += (size_t)nq * k * 8;                                 // sample rows/dist
@@ -1495,7 +1617,8 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     off = (off + 255) / 256 * 256;
     float* Qt = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * (v.dim4 + 4) * 16;
     float* cq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 4;
-    float* mq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 4;
+    float* mq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // m_q, b_q
+    float* eq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // the scores' error bound per query (k_mfma_prep -> k_rescore_select)
     uint32_t* cand = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * kMfmaCandCap * 4;
     float* cscore = reinterpret_cast<float*>(w + off); off += (size_t)nq * kMfmaCandCap * 4;
     uint32_t* cnt = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
@@ -1521,12 +1644,13 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     const bool q64 = bf && fmode == 3 && nq_pad == 64 && v.bf16 != nullptr && q64_env == 1 && (v.dim4 & 3u) == 0 && fsteps0 % 4 == 0 && fsteps0 >= 8 && fsteps0 <= 64;
     const int gmode = !bf ? 0 : (fmode == 3 && (shared || q64) ? 2 : 1);   // which filter_gamma the main pass obeys (one term: the shared kernels and the one-block kernel)
     hipError_t e = hipSuccess;
-    if (bf && sample_gemm == 1) {
-        // the sample's scores by the filter kernel itself, their upper bounds' k-th smallest as U_q (k_sample_bound): 0.08 ms
-        // against 0.24 for an exact scan of the sample
+    if (sample_gemm == 1) {
+        // the sample's scores by the three-term bfloat16 kernel, their upper bounds' k-th smallest as U_q (k_sample_bound): 0.1 ms
+        // against 0.24 for an exact scan of the sample.  The fp32-MFMA filter takes its bound the same way (round 3): the query
+        // operands are laid out as bfloat16 for the sample and then, in the same buffer, as float32 for the main pass
         off = (off + 255) / 256 * 256;
         float* sscore = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * vs.n_rows * 4;
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, cnt, ovf, 1, 1);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, 1, 1);
         const uint32_t nqb64s = nq_pad / 64;
         const uint32_t gs = grid_multiple(std::min<uint32_t>((uint32_t)cus, ((vs.n_tiles + 1) / 2 * nqb64s + 3) / 4), nqb64s / std::gcd(nqb64s, 4u));
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
@@ -1534,16 +1658,16 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t sgroups = (vs.n_rows + 127) / 128, all_groups = v.n_tiles / 2;
         const uint32_t gstep = sgroups && all_groups > sgroups ? all_groups / sgroups : 1u;
 #define QV_SB(MMM) { hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
-                     hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), (size_t)v.dim * sizeof(float), s, v, d_queries, sscore, vs.n_rows, k, filter_gamma(v.dim, 1), bparts > 1 ? sparts : sdist, bparts, gstep); }
+                     hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 ? sparts : sdist, bparts, k, v.metric, Qt, cq, mq, cnt, ovf, gmode, 2);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 ? sparts : sdist, bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, bf ? 2 : 3);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
         e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
         if (e != hipSuccess) return e;
         // 2. query re-layout + filter constants
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, cnt, ovf, gmode, 3);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, 3);
     }
     // 3. MFMA filter
     const uint32_t nqb64 = nq_pad / 64;
@@ -1570,13 +1694,15 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         static const int w8_env = env_int("QV_MFMA_W8", 1);                                   // 2 = the four-wave kernel (k_bf16x3_filter_shared<., 1>)
         const bool w8 = w8_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;       // rounds of two steps, four in flight: a multiple of 4 rounds, at least 6
         static const int w8_bf = env_int("QV_MFMA_W8_BF", 2);                                  // 1 = the eight-wave kernel on the bfloat16 plane too (measured: 485 against 474 us for k_bf16rows_filter)
-        static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // measurement: 3 = rows 18 and query operands 15 steps ahead, 4 = query operands 15 steps ahead (644.6 against 648.6 us: kept at 3)
-#define QV_FS(MMM) { if (bfrows && w8 && w8_bf) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 4, 8, 2, true>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+        static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // measurement (profiles/r03_batched_epilogue.txt): 7 = the epilogue's dense pass deferred into the next group's K loop (610.7 against 607.3 us), 5 / 6 = rows 16 rounds ahead (614 / 613), 3 = rows 18 and query operands 15 steps ahead, 4 = query operands 15 steps ahead (644.6 against 648.6 us: kept at 3)
+#define QV_FS(MMM) { if (bfrows && w8 && w8_bf == 1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 4, 8, 2, true, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                     else if (gmode == 2 && w8) { if (w8_shape == 2) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8_shape == 3 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 16, 1, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8_shape == 4 && fsteps % 16 == 0) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 16, 1, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); } \
+                     else if (gmode == 2 && w8) { if (w8_shape == 3 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 16, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8_shape == 4 && fsteps % 16 == 0) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 16, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8_shape == 5 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 4, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8_shape == 6 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 8, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8_shape == 7) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false, true>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); } \
                      else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 3, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         if (v.metric == QV_COSINE) QV_FS(QV_COSINE) else if (v.metric == QV_DOT) QV_FS(QV_DOT) else QV_FS(QV_L2)
@@ -1595,7 +1721,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     // (8 / 16 / 32 chunks requested per block of the exact pass: 105 / 108 / 112 us — it is bound by the gather of ~80 surviving rows
     // per query out of the tile layout, 192 separate 128-byte lines each, not by the depth of the requests)
 #define QV_RS(MMM) { e = set_lds(k_rescore_select<MMM, 8>, lds); if (e != hipSuccess) return e;                                   \
-        hipLaunchKernelGGL((k_rescore_select<MMM, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, filter_gamma(v.dim, gmode)); }
+        hipLaunchKernelGGL((k_rescore_select<MMM, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, eq); }
     if (v.metric == QV_COSINE) QV_RS(QV_COSINE) else if (v.metric == QV_DOT) QV_RS(QV_DOT) else if (v.metric == QV_L2) QV_RS(QV_L2) else QV_RS(QV_L2SQ)
 #undef QV_RS
     *d_overflow_out = ovf;

@@ -12,6 +12,8 @@
 //   rnorm   double [n_tiles*64]              per-row sqrt(sum b_i^2) in the metric's
 //                                            precision (cosine metrics only)
 //   alive   u64    [n_tiles]                 bit r of word t = row 64t+r is live
+//   rres    float  [n_tiles*64]              per-row |r - bf16(r)|, rounded up: what the one-term bfloat16 filter loses of a row
+//                                            (qv_batched.hip: its error bound is per row and per query, not a worst case)
 //   rowmaj  float  [rows][dim]               optional row-major copy (QV_FLAG_ROWMAJOR)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,6 +29,7 @@ struct IndexView {
     float*    tiles;
     double*   rnorm;
     uint64_t* alive;
+    float*    rres;       // |r - bf16(r)| per row (k_row_residual, after every write of rows)
     float*    rowmaj;     // may be null
     uint16_t* bf16;       // may be null: bfloat16 copy of the rows, [tile][ceil(dim/16)][2 row blocks][2 halves][32 rows][8 values] (QV_FLAG_BF16_ROWS)
     uint32_t  dim;

@@ -254,7 +254,42 @@ k_bf16_plane(IndexView v, uint32_t t0, uint32_t n_tiles) {
         reinterpret_cast<uint4*>(v.bf16)[((((size_t)t * steps8 + (c8 >> 1)) * 2 + (r >> 5)) * 2 + (c8 & 1)) * 32 + (r & 31)] = o;
     }
 }
+// |r - bf16(r)| of the rows of tiles [t0, t0 + n_tiles): what the one-term bfloat16 filter drops of a row (qv_batched.hip: its
+// margin is |q - qh||r| + |qh||r - rh|, a third of the worst case 2 * 2^-8 |q||r| on ordinary data).  Lane == row, one wave per
+// tile, 1 KiB per request; the value only feeds a bound, so it is rounded UP (float64 sum, correctly rounded sqrt, one more
+// float32 step than round-to-nearest) and the order of the additions is free.  Elements below 2^-126 in magnitude count whole:
+// the matrix core may flush such an operand.
+__global__ void __launch_bounds__(64)
+k_row_residual(IndexView v, uint32_t t0) {
+    const uint32_t t = t0 + blockIdx.x, lane = threadIdx.x;
+    const f4* src = reinterpret_cast<const f4*>(v.tiles) + (size_t)t * v.dim4 * 64 + lane;
+    double s2 = 0.0;
+    auto one = [&](float x) {
+        const __bf16 hb = (__bf16)x;
+        float h = (float)hb;
+        if (__builtin_fabsf(h) < 1.17549435e-38f) h = 0.f;
+        const double d = (double)x - (double)h;
+        s2 = __builtin_fma(d, d, s2);
+    };
+    for (uint32_t c = 0; c < v.dim4; c += 4) {
+        f4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = c + u < v.dim4 ? src[(size_t)(c + u) * 64] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; u++) { one(x[u].x); one(x[u].y); one(x[u].z); one(x[u].w); }
+    }
+    const float r = (float)(__builtin_sqrt(s2) * (1.0 + 1e-12));
+    // next float up (NaN / inf stay: such a row's norm is NaN / inf too and the filter passes it on)
+    float up = r;
+    if (r == r && r != __builtin_inff()) up = r == 0.f ? (s2 == 0.0 ? 0.f : __uint_as_float(1u)) : __uint_as_float(__float_as_uint(r) + 1u);
+    v.rres[(size_t)t * 64 + lane] = up;
+}
 static hipError_t refresh_bf16(const IndexView& v, uint32_t t0, uint32_t t1, hipStream_t s) {
+    if (v.rres && (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ)) {
+        hipLaunchKernelGGL(k_row_residual, dim3(t1 - t0 + 1), dim3(64), 0, s, v, t0);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     if (!v.bf16) return hipSuccess;
     const uint64_t total = (uint64_t)(t1 - t0 + 1) * ((v.dim4 + 1) / 2) * 64;
     hipLaunchKernelGGL(k_bf16_plane, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 65536)), dim3(256), 0, s, v, t0, t1 - t0 + 1);
