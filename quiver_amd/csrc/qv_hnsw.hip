@@ -94,6 +94,70 @@ __device__ __forceinline__ void h_max_down(HRes* rs, int i0, int n) {           
     rs[i] = x;
 }
 
+// The same two sifts done by the whole wave (round 3).  The exact-heap kernel is a lone wave whose lane 0 walked these loops level
+// by level through LDS (~130 cycles a level, ~20 sifts per hop: 11.5 us of a 30 us hop).  Same comparisons, same final array:
+//   up(j):   the ancestors of j are known in advance (a_l = ((j + 1) >> l) - 1): lane l reads ancestor l, one ballot finds the first
+//            parent the new element does NOT pass (hnsw.go:121 / :175), the parents below it move down one slot, the element lands.
+//            One LDS read and one LDS write in all.
+//   down():  the element sinks along the path of PREFERRED children (the smaller / larger of each pair, hnsw.go:137-139 / :190-192),
+//            which does not depend on the element.  62 lanes read the five levels below the hole at once, each inner node picks
+//            its preferred child by two lane shuffles, one ballot + a five-step scalar walk gives the path, a second ballot the
+//            first path node the element does not pass (hnsw.go:140 / :193); the path above it moves up one slot.  Five levels per
+//            round: two rounds for a 512-entry result heap, three for 4096 candidates.
+template <bool MAXH>
+__device__ __forceinline__ void wave_heap_up(HRes* rs, int j, HRes x, uint32_t lane) {
+    const int D = 31 - __builtin_clz((uint32_t)j + 1u);              // ancestors a_1 .. a_D (a_D = the root)
+    const int l = (int)lane;
+    HRes p = {0.f, 0u};
+    const bool anc = l >= 1 && l <= D;
+    if (anc) p = rs[(int)(((uint32_t)j + 1u) >> l) - 1];
+    const bool stop = anc && (MAXH ? x.dist <= p.dist : x.dist >= p.dist);
+    const uint64_t m = __ballot(stop);
+    const int L = m ? (int)__builtin_ctzll(m) : D + 1;               // the element stays at ancestor L - 1
+    if (anc && l < L) rs[(int)(((uint32_t)j + 1u) >> (l - 1)) - 1] = p;
+    if (l == 0) rs[(int)(((uint32_t)j + 1u) >> (L - 1)) - 1] = x;
+}
+// x sinks from the root of rs[0..n) (rs[0] is the hole)
+template <bool MAXH>
+__device__ __forceinline__ void wave_heap_down(HRes* rs, int n, HRes x, uint32_t lane) {
+    uint32_t p = 0;                                                   // the hole (wave-uniform)
+    const uint32_t t = lane + 2;                                      // lane m holds local node m + 2 of the subtree below the hole (local 1 = the hole)
+    const uint32_t d = 31u - (uint32_t)__builtin_clz(t);
+    const uint32_t lc = (2 * t - 2) & 63u;                            // lane of this node's left child (nodes of the first four levels: lanes 0..29)
+    for (;;) {
+        if (2 * p + 1 >= (uint32_t)n) break;                          // the hole is a leaf
+        const uint32_t gi = ((p + 1u) << d) - 1u + (t - (1u << d));
+        const bool have = lane < 62 && gi < (uint32_t)n;
+        HRes c = {0.f, 0u};
+        if (have) c = rs[gi];
+        const uint64_t HM = __ballot(have);
+        const float dl = __shfl(c.dist, (int)lc), dr = __shfl(c.dist, (int)((lc + 1) & 63u));
+        const bool right = lane <= 29 && ((HM >> ((lc + 1) & 63u)) & 1ull) && (MAXH ? dr > dl : dr < dl);
+        const uint64_t RB = __ballot(right);
+        const float d0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.dist), 0));
+        const float d1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.dist), 1));
+        const bool right1 = ((HM >> 1) & 1ull) && (MAXH ? d1 > d0 : d1 < d0);
+        uint64_t path = 0; uint32_t tcur = 1, last_lane = 0;
+#pragma unroll
+        for (int step = 0; step < 5; step++) {
+            const uint32_t left = 2 * tcur - 2;
+            if (tcur > 31 || !((HM >> left) & 1ull)) break;           // no child in the heap (or below the five levels read)
+            const uint32_t r = tcur == 1 ? (right1 ? 1u : 0u) : (uint32_t)((RB >> (tcur - 2)) & 1ull);
+            last_lane = left + r;
+            path |= 1ull << last_lane;
+            tcur = last_lane + 2;
+        }
+        const bool onpath = (path >> lane) & 1ull;
+        const bool stop = onpath && (MAXH ? x.dist >= c.dist : x.dist <= c.dist);
+        const uint64_t SM = __ballot(stop);
+        const uint32_t first = SM ? (uint32_t)__builtin_ctzll(SM) : 64u;
+        if (onpath && lane < first) rs[(gi - 1u) >> 1] = c;           // the path above the stopping point moves up one slot
+        if (SM) { p = ((uint32_t)__builtin_amdgcn_readlane((int)gi, (int)first) - 1u) >> 1; break; }
+        p = (uint32_t)__builtin_amdgcn_readlane((int)gi, (int)last_lane);
+    }
+    if (lane == 0) rs[p] = x;
+}
+
 // ---------------------------------------------------------------- HNSW traversal, wave-resident form
 // Same traversal, without the serial LDS heaps.  Observation (no two entries of equal distance):
 //   * a node enters the candidate heap exactly when it enters the result heap (hnsw.go:553-555);
@@ -419,8 +483,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
     float* bd = reinterpret_cast<float*>(batch + kHnswMaxDeg);        // [kHnswMaxDeg]
     const lds_u32* batch_l = (const lds_u32*)((lds_u8*)smem + 2 * slab_bytes<kHnswHeapSlab>() + (size_t)(cand_cap + kHnswEfMax + 1) * sizeof(HRes));
     const Q* q_g = qblk;
-    __shared__ int s_ncand, s_nres, s_state;                           // state: 0 run, 1 done, 2 overflow
-    __shared__ uint32_t s_cur;
+    __shared__ int s_ncand, s_nres;
     const uint32_t lane = threadIdx.x;
     uint32_t* bm = o.vis + (size_t)blockIdx.x * o.vis_cap;            // one bit per node
     const uint32_t bm_words = (g.n_nodes + 31) >> 5;
@@ -450,25 +513,23 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
         eval(1); n_eval += 1;                                          // :492
         if (lane == 0) {
             cand[0] = {bd[0], entry}; res[0] = {bd[0], entry};        // :498-506
-            s_ncand = 1; s_nres = 1; s_state = 0;
+            s_ncand = 1; s_nres = 1;
         }
         __syncthreads();
         for (;;) {
             HTK(5);
-            if (lane == 0) {
-                int nc = s_ncand, nr = s_nres;
-                if (nc == 0) s_state = 1;                              // :509
-                else {
-                    nc--; HRes t = cand[0]; cand[0] = cand[nc]; cand[nc] = t; h_min_down(cand, 0, nc); HRes cur = cand[nc];   // :511 pop
-                    s_ncand = nc;
-                    if (nr >= ef && cur.dist > res[0].dist) s_state = 1;   // :514-516
-                    else s_cur = cur.idx;
-                }
-            }
+            // every lane carries the heap sizes and walks the same branches (the sifts are wave operations)
+            int nc = s_ncand, nr = s_nres;
+            if (nc == 0) break;                                        // :509
+            nc--;
+            const HRes top = cand[0], lastc = cand[nc];                // :511 pop: the last element sinks from the root
             __syncthreads();
+            if (nc > 0) wave_heap_down<false>(cand, nc, lastc, lane);
+            __syncthreads();
+            if (lane == 0) s_ncand = nc;
+            if (nr >= ef && top.dist > res[0].dist) break;             // :514-516
             HTK(0);
-            if (s_state != 0) break;
-            const uint32_t cur = s_cur;
+            const uint32_t cur = top.idx;
             // neighbours of cur at `level` (:523-534).  On level 0 the degree and the (fixed-width) list are requested together,
             // and a graph without tombstones needs no level[] lookups at all: two dependent round trips less per hop for a
             // wave that has a CU to itself.
@@ -502,26 +563,47 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
 #ifdef QV_HNSW_PROF
             hops++;
 #endif
-            if (lane == 0) {
-                int nc = s_ncand, nr = s_nres;
-                for (uint32_t i = 0; i < n; i++) {
+            {
+                bool overflow = false;
+                // once the result heap is full its worst value only decreases: a neighbour that is not below it now never will be,
+                // so one ballot drops those up front (most of a hop) and the admission test (:553) runs for the rest, in adjacency order
+                const float mine = lane < n ? bd[lane] : 0.f;
+                uint64_t pend = __ballot(lane < n && (nr < ef || mine < res[0].dist));
+                while (pend) {
+                    const uint32_t i = (uint32_t)__builtin_ctzll(pend);
+                    pend &= pend - 1;
                     const float cd = bd[i];
                     if (nr < ef || cd < res[0].dist) {                 // :553
-                        if (nc >= (int)cand_cap) { s_state = 2; break; }
-                        cand[nc] = {cd, batch[i]}; h_min_up(cand, nc); nc++;          // :554
-                        res[nr] = {cd, batch[i]}; h_max_up(res, nr); nr++;            // :555
-                        if (nr > ef) { nr--; HRes t = res[0]; res[0] = res[nr]; res[nr] = t; h_max_down(res, 0, nr); }   // :558-560
+                        if (nc >= (int)cand_cap) { overflow = true; break; }
+                        const HRes x = {cd, batch[i]};
+                        wave_heap_up<false>(cand, nc, x, lane); nc++;                 // :554
+                        wave_heap_up<true>(res, nr, x, lane); nr++;                   // :555
+                        __syncthreads();
+                        if (nr > ef) {                                                // :558-560: the last element sinks from the root
+                            nr--;
+                            const HRes lastr = res[nr];
+                            __syncthreads();
+                            wave_heap_down<true>(res, nr, lastr, lane);
+                            __syncthreads();
+                        }
                     }
                 }
-                s_ncand = nc; s_nres = nr;
+                __syncthreads();
+                if (lane == 0) { s_ncand = nc; s_nres = nr; }
+                __syncthreads();
+                if (overflow) return false;
             }
-            __syncthreads();
             HTK(3);
-            if (s_state == 2) return false;
         }
-        if (lane == 0) {                                               // :566-577 heap -> ascending slice, in place
-            int nr = s_nres;
-            for (int m = nr; m > 1; m--) { HRes t = res[0]; res[0] = res[m - 1]; res[m - 1] = t; h_max_down(res, 0, m - 1); }
+        {                                                              // :566-577 heap -> ascending slice, in place: pop after pop
+            const int nr = s_nres;
+            for (int m = nr; m > 1; m--) {
+                const HRes t = res[0], lastr = res[m - 1];
+                __syncthreads();
+                if (lane == 0) res[m - 1] = t;
+                if (m - 1 > 0) wave_heap_down<true>(res, m - 1, lastr, lane);
+                __syncthreads();
+            }
         }
         __syncthreads();
         return true;
