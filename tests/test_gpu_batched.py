@@ -322,3 +322,55 @@ def test_bf16_row_plane_gives_the_same_results_and_follows_every_mutation(metric
     assert e[0][9][0] == 150_000 + 210
     for m, kk in ((44, 7), (9, 10), (64, 1)):          # one query block: k_bf16rows_filter_q64 (queries resident in LDS) where the dimension allows
         assert _eq(_exact(idx, qs[:m], kk), idx.search(qs[:m], kk, batched=True))
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot_product", "euclidean", "squared_euclidean"])
+def test_rows_and_queries_at_the_worst_of_bfloat16_rounding(metric):
+    """The one-term filter's margin is |q - qh||r| + |qh||r - rh| per query and row (IndexView::rres, k_row_residual), not a worst
+    case over operands — so the corpus here IS the worst case: every element sits exactly half way between two bfloat16 values
+    (the largest rounding loss there is, all of the same sign for a row), other rows are exact in bfloat16 (no loss at all: the
+    tightest margin), others have elements below 2^-126 that the matrix core may flush, and rows are updated after ingest (the
+    residual follows).  Queries likewise.  Every filter must still return what the exact scan returns."""
+    import quiver_amd as q
+    rng = np.random.default_rng(77)
+    n, dim, nq, k = 70_000, 768, 64, 10
+
+    def bf16_exact(x):                       # keep the top 16 bits: values exact in bfloat16
+        return (x.astype(np.float32).view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+
+    def half_way(x):                         # bfloat16 value + exactly half a bfloat16 ulp, away from zero
+        return ((x.astype(np.float32).view(np.uint32) & np.uint32(0xFFFF0000)) | np.uint32(0x00008000)).view(np.float32)
+
+    centre = rng.standard_normal(dim).astype(np.float32)
+    base = (centre[None, :] + 0.35 * rng.standard_normal((n, dim))).astype(np.float32)      # a cluster: many near-ties around every query
+    rows = base.copy()
+    rows[0::4] = half_way(base[0::4])
+    rows[1::4] = bf16_exact(base[1::4])
+    rows[2::8] *= np.float32(1e-3)           # mixed norms
+    tiny = rng.integers(0, n, 200)
+    rows[tiny, ::7] = np.float32(1e-41)      # denormal elements inside ordinary rows
+    rows[5] = np.float32(3e-39)              # a whole row below the normal range
+    qs = (centre[None, :] + 0.35 * rng.standard_normal((nq, dim))).astype(np.float32)
+    qs[0::3] = half_way(qs[0::3])
+    qs[1::3] = bf16_exact(qs[1::3])
+    qs[7, ::5] = np.float32(1e-41)
+    idx = q.DeviceIndex(dim, metric)
+    idx.add(rows)
+    assert _eq(_exact(idx, qs, k), idx.search(qs, k, batched=True))
+    # ... and it was the filter that answered, not the exact redo of overflowed candidate buffers
+    import torch
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    fl = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+    idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    print("queries sent back to the exact scan:", int(fl.sum().item()), "of", nq)
+    assert int(fl.sum().item()) <= nq // 4
+    # rows rewritten after ingest: the per-row residual must follow (a stale, smaller one would make the filter drop true neighbours)
+    upd = np.arange(0, 4000, 3, dtype=np.uint32)
+    newv = half_way(qs[rng.integers(0, nq, len(upd))] + 0.01 * rng.standard_normal((len(upd), dim)).astype(np.float32))
+    for r, vrow in zip(upd[:64], newv[:64]):
+        idx.update(int(r), vrow)
+    exact = _exact(idx, qs, k)
+    assert _eq(exact, idx.search(qs, k, batched=True))
+    assert len(np.intersect1d(exact[0].ravel(), upd[:64])) > 0          # the rewritten rows are the nearest ones now
