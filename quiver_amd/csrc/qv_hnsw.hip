@@ -812,12 +812,20 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     }
                     HTICK(0);
                     uint32_t deg = 0; const uint32_t* links = nullptr;
-                    if (alive(cur) && (level == 0 ? (!g.has_dead || g.level[cur] >= 0) : level <= (int)g.level[cur])) {
-                        if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
-                        else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
-                    }
                     uint32_t c = 0xFFFFFFFFu; bool fresh = false;
-                    if (lane < deg) { c = links[lane]; fresh = alive(c); }
+                    if (level == 0 && !g.has_dead && cur < g.n_nodes) {
+                        // level 0 of a graph without tombstones (every graph built on the device): the degree and the fixed-width list
+                        // are requested together — one round trip instead of two dependent ones per hop
+                        deg = g.l0_deg[cur];
+                        const uint32_t cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu;
+                        if (lane < deg) { c = cl; fresh = c < g.n_nodes; }
+                    } else {
+                        if (alive(cur) && (level == 0 ? (!g.has_dead || g.level[cur] >= 0) : level <= (int)g.level[cur])) {
+                            if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
+                            else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
+                        }
+                        if (lane < deg) { c = links[lane]; fresh = alive(c); }
+                    }
                     // a node repeated inside one list (the self-link quirk) is new at its FIRST occurrence: admissions of a hop go
                     // in adjacency order (:537-560), and between two nodes of equal distance that order decides which one a full
                     // result set keeps — so the hash's test-and-set must not pick the winner among a node's repeats
