@@ -338,7 +338,7 @@ def short_runtime(text):
 def pmc_traffic(rows_per_gpu, dim):
     """HBM bytes per k_flat_scan launch from the committed rocprofv3 PMC summary, when it was taken on this exact per-GPU
     workload; else None."""
-    for name in ("r02_10Mx768_pmc.json", "r01_10Mx768_pmc.json"):
+    for name in ("r03_10Mx768_pmc.json", "r02_10Mx768_pmc.json", "r01_10Mx768_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             if rows_per_gpu == 10_000_000 and dim == 768:
