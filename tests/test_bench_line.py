@@ -14,11 +14,14 @@ import bench  # noqa: E402
 RECORDED = os.path.join(ROOT, "profiles", "r02_bench_n1.jsonl")     # full records of round 2's runs (26 KB each)
 
 
+RECORDED_R03 = os.path.join(ROOT, "profiles", "r03_bench_full.json")   # round 3's full record (the sidecar of its 3.7 KB line)
+
+
 def _records():
-    return [json.loads(l) for l in open(RECORDED).read().strip().split("\n")]
+    return [json.loads(l) for l in open(RECORDED).read().strip().split("\n")] + [json.load(open(RECORDED_R03))]
 
 
-@pytest.mark.parametrize("i", range(7))
+@pytest.mark.parametrize("i", range(8))
 def test_line_fits_and_parses(i):
     rec = _records()[i]
     text = bench.compact_line(rec, "gpurun_out/bench_full.json")
