@@ -1111,7 +1111,7 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
 #pragma unroll
             for (int k8 = 0; k8 < UNR; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
             if constexpr (DEFER) {
-                if (st == 0 && epn) filter_epilogue_finish<METRIC>(s_c, s_m, 32 * wave, 256 * qb256 + 32 * wave, cqu, cqu_n, cqu_out, du, epn);
+                if (st == 0 && epn >= 16) filter_epilogue_finish<METRIC>(s_c, s_m, 32 * wave, 256 * qb256 + 32 * wave, cqu, cqu_n, cqu_out, du, epn);   // the dump area holds 32 entries; a group adds ~2
             }
         }
 #if defined(QV_DBG_STAMP)

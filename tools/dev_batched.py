@@ -27,7 +27,7 @@ sp = torch.cuda.current_stream().cuda_stream
 idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), sp)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-reps = 10
+reps = int(os.environ.get("DEV_REPS", "10"))     # (the clocks take ~8 launches to ramp after an idle gap: 50+ for a steady-state mean)
 for _ in range(reps):
     idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), sp)
 torch.cuda.synchronize()

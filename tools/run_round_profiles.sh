@@ -1,6 +1,7 @@
 #!/bin/bash
 # The round's measurement artefacts, on the GPU box: the bench line (+ full record), and rocprofv3 --kernel-trace --stats
 # summaries of (a) the headline command, (b) the default batched path, (c) the fp32-MFMA batched path.
+# (60 timed launches each: after an idle gap the clocks take ~8 launches to come up — k_mfma_filter 3.6 -> 3.03 ms, tools/kcalls.sh)
 # bash tools/run_round_profiles.sh r03
 tag=${1:-rXX}; root=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $root/gpurun_out; cd $root
@@ -10,9 +11,9 @@ export TMPDIR=/tmp
 (cd /tmp && rm -rf /tmp/rp_h && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_h -o h -- python3 $root/bench.py --steps 100 --warmup 10 --no-also --no-cpu-baseline > $root/gpurun_out/${tag}_bench_under_rocprof_10Mx768.jsonl 2>/dev/null)
 cp $(find /tmp/rp_h -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_10Mx768_kernel_stats.csv 2>/dev/null
 for f in "" fp32; do
-  (cd /tmp && rm -rf /tmp/rp_b && DEV_FILTER=$f rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_b -o b -- python3 $root/tools/dev_batched.py cosine 256 1000000 768 10 > /dev/null 2>&1)
+  (cd /tmp && rm -rf /tmp/rp_b && DEV_REPS=60 DEV_FILTER=$f rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_b -o b -- python3 $root/tools/dev_batched.py cosine 256 1000000 768 10 > /dev/null 2>&1)
   cp $(find /tmp/rp_b -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_batched_${f:-default}_256x1Mx768_kernel_stats.csv 2>/dev/null
 done
-(cd /tmp && rm -rf /tmp/rp_b && DEV_BF16_ROWS=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_b -o b -- python3 $root/tools/dev_batched.py cosine 256 1000000 768 10 > /dev/null 2>&1)
+(cd /tmp && rm -rf /tmp/rp_b && DEV_REPS=60 DEV_BF16_ROWS=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_b -o b -- python3 $root/tools/dev_batched.py cosine 256 1000000 768 10 > /dev/null 2>&1)
 cp $(find /tmp/rp_b -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_batched_bf16rows_256x1Mx768_kernel_stats.csv 2>/dev/null
 wc -c gpurun_out/${tag}_bench_n1.jsonl; head -c 3500 gpurun_out/${tag}_bench_n1.jsonl; echo; head -5 gpurun_out/${tag}_10Mx768_kernel_stats.csv; head -4 gpurun_out/${tag}_batched_default_256x1Mx768_kernel_stats.csv; head -3 gpurun_out/${tag}_batched_fp32_256x1Mx768_kernel_stats.csv
