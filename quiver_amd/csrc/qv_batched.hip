@@ -62,6 +62,15 @@ __host__ __device__ static inline double filter_gamma(uint32_t dim, int mode /* 
     const double g = (double)(3 * dim + 2) * 1.1920928955078125e-7;
     return 1.012 * g / (1.0 - g) + 4.63e-5;
 }
+// Norms below which a query or a row bypasses the filter (the row goes to the exact pass whatever its score; the query gets the
+// "everything is a candidate" threshold).  The error model above has no underflow in it: a matrix core may flush operands, products
+// or partial sums below 2^-126, each such product is lost whole (<= 1.2e-38), up to `dim` of them per score.  That stays inside the
+// slack the thresholds keep in reserve (5e-7 |q||r|) as long as |q||r| >= dim * 2.4e-32, i.e. when both norms are at least
+// sqrt(dim * 2.4e-32) (1e-14 up to 4096 dimensions).  Data of that scale is not a workload; the guard makes the claim unconditional.
+__host__ __device__ static inline float filter_tiny_norm(uint32_t dim) {
+    const float t = __builtin_sqrtf((float)dim * 2.4e-32f);
+    return t > 1.0e-14f ? t : 1.0e-14f;
+}
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 // two floats -> (hi pair, lo pair) of bfloat16, packed: hi = bf16(x) (RNE), lo = bf16(x - hi) (x - hi is exact)
@@ -168,12 +177,12 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
                 c = n2 * (1.0 - 2e-6) - T;                           // A_q; test: 2S~ >= A_q + (1-2e-6)|r|^2 - B_q|r| - 2 eb |r - rh|
                 m = 2.0 * (ea + 1e-6 * qn);                          // B_q
                 b_ = f32_up((float)(2.0 * eb));
-                if (!(U == U) || U > 1.0e18 || (bf16x3 && qn < 1e-18) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; b_ = 0.f; }   // (a query norm >= 1e18 or NaN: its float32 scores may overflow)
+                if (!(U == U) || U > 1.0e18 || qn < (double)filter_tiny_norm(dim) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; b_ = 0.f; }   // (a query norm >= 1e18 or NaN: its float32 scores may overflow)
             } else {
                 c = metric == QV_COSINE ? (1.0 - U - 4e-7) * qn : (1.0 - U - 4e-7 * (1.0 + __builtin_fabs(U)));
                 m = ea + 1e-6 * qn;
                 b_ = f32_up((float)eb);
-                if (!(U == U) || U > 3.0e38 || (bf16x3 && qn < 1e-18) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; b_ = 0.f; }   // no bound: everything is a candidate (overflow -> exact path); bf16 operands below 2^-126 flush
+                if (!(U == U) || U > 3.0e38 || qn < (double)filter_tiny_norm(dim) || !(qn < 1.0e18)) { c = -3.0e38; m = 0.0; b_ = 0.f; }   // no bound: everything is a candidate (overflow -> exact path); bf16 operands below 2^-126 flush
             }
             c_ = f32_down((float)c);                                         // round towards "keep more"
             m_ = f32_up((float)m);
@@ -295,6 +304,7 @@ __device__ __forceinline__ void epi_dense_pass(const EpiDump& du, uint32_t n, co
             const float rn = __uint_as_float(d[17]);
             const float thr = filter_threshold<METRIC>(c, sm[qbase + ql], sm[kEpiQ + qbase + ql], rn, rn2c_of(rn), __uint_as_float(d[18]));
             take = (!(score < thr) || (fl >> 2)) && c < 3.0e38f;      // (padded query slots carry +inf)
+            if (fl >> 2) score = __builtin_nanf("");                  // a row the scores say nothing about: the exact pass must not read an interval out of this one either
             q = qglobal + ql;
         }
         const uint64_t m = __ballot(take);
@@ -480,7 +490,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
 
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 0.0f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -490,22 +500,22 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
 // U_q, a looser one only lets a few more rows through.  128 of these per lane and row group, so everything that depends on the
 // query alone or the row alone is prepared once (sample_query_consts / sample_row_consts) and the per-score part is 3-6 instructions
 // without a division.  g = the filter's gamma (|S~ - S| <= g |q||r|); qn, rn rounded UP from float64.  A query or row the scores
-// say nothing about (norm below 1e-18: flushed operands; 1e18 or above: float32 sums may overflow; a row that is gone) carries
+// say nothing about (norm below filter_tiny_norm: flushed operands or products; 1e18 or above: float32 sums may overflow; a row that is gone) carries
 // NaN constants: its bounds come out NaN and are stored as +inf.  With both norms inside that range no score overflows.
 // The L2 family yields the bound on d^2 (one kernel serves QV_L2 and QV_L2SQ); sample_bound_finish takes the SELECTED value into
 // the metric's units — both steps are monotone, so the k-th smallest commutes with them.
 template <int M>
-__device__ __forceinline__ void sample_query_consts(float qn, float g, float& qa, float& qb) {
+__device__ __forceinline__ void sample_query_consts(float qn, float g, float tiny, float& qa, float& qb) {
     const float nan = __builtin_nanf("");
-    const bool none = (qn != 0.f && qn < 1e-18f) || !(qn < 1.0e18f);
+    const bool none = (qn != 0.f && qn < tiny) || !(qn < 1.0e18f);
     if constexpr (M == QV_COSINE) { qa = none ? nan : (qn == 0.f ? 0.f : 1.0f / qn); qb = 0.f; }        // zero norm: the bound becomes 1 + g (the distance is 1)
     else if constexpr (M == QV_DOT) { qa = none ? nan : g * qn * 1.000001f; qb = 0.f; }
     else { qa = none ? nan : qn * qn * 1.000001f; qb = 2.0f * g * qn * 1.000002f; }
 }
 template <int M>
-__device__ __forceinline__ void sample_row_consts(float rn, bool gone, float& ra, float& rb) {
+__device__ __forceinline__ void sample_row_consts(float rn, bool gone, float tiny, float& ra, float& rb) {
     const float nan = __builtin_nanf("");
-    const bool none = gone || (rn != 0.f && rn < 1e-18f) || !(rn < 1.0e18f);
+    const bool none = gone || (rn != 0.f && rn < tiny) || !(rn < 1.0e18f);
     if constexpr (M == QV_COSINE) { ra = none ? nan : (rn == 0.f ? 0.f : 1.0f / rn); rb = 0.f; }
     else if constexpr (M == QV_DOT) { ra = none ? nan : rn; rb = 0.f; }
     else { ra = none ? nan : rn * rn * 1.000001f; rb = rn; }
@@ -562,7 +572,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
         s_c[wave][lane] = METRIC == QV_COSINE ? c - m : c;
         s_m[wave][lane] = m;
         s_m[4 + wave][lane] = mq[nq_pad + 64 * qb64 + lane];
-    } else sample_query_consts<METRIC>(cq[64 * qb64 + lane], f32_up((float)filter_gamma(v.dim, 1)), s_c[wave][lane], s_m[wave][lane]);
+    } else sample_query_consts<METRIC>(cq[64 * qb64 + lane], f32_up((float)filter_gamma(v.dim, 1)), filter_tiny_norm(v.dim), s_c[wave][lane], s_m[wave][lane]);
     __syncthreads();
     if (stride == 0) return;
     const uint32_t half = lane >> 5, l31 = lane & 31;
@@ -667,7 +677,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
                 const uint32_t row = g * 128 + (j < 2 ? 0u : 64u) + 32 * (j & 1) + l31;      // place in the sample
                 if (row >= score_stride) continue;
                 float ra, rb;
-                sample_row_consts<METRIC>(f32_up((float)rnd[j]), !((alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull), ra, rb);
+                sample_row_consts<METRIC>(f32_up((float)rnd[j]), !((alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull), filter_tiny_norm(v.dim), ra, rb);
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -678,7 +688,7 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
             }
             continue;
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -898,7 +908,7 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
             mfma(q0, 0);
         }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -1120,10 +1130,10 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
                    stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0]);
 #endif
         if constexpr (DEFER) {
-#define QV_W8_BLK(JJ) filter_epilogue_block<METRIC, 1, 4, JJ>(acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du, epn)
+#define QV_W8_BLK(JJ) filter_epilogue_block<METRIC, 1, 4, JJ>(acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du, epn)
             QV_W8_BLK(0); QV_W8_BLK(1); QV_W8_BLK(2); QV_W8_BLK(3);
 #undef QV_W8_BLK
-        } else filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
+        } else filter_epilogue<METRIC>(v, acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     if constexpr (DEFER) filter_epilogue_finish<METRIC>(s_c, s_m, 32 * wave, 256 * qb256 + 32 * wave, cqu, cqu_n, cqu_out, du, epn);
     cand_flush(cqu, cqu_n, cqu_out);
@@ -1235,7 +1245,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
 #pragma unroll
             for (int k8 = 0; k8 < RING; k8 += 2) { pstep(st + k8, k8, b0, b1); pstep(st + k8 + 1, k8 + 1, b1, b0); }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -1325,7 +1335,7 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
                 load_step(rb[k]);
             }
         }
-        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 0u, half, l31, 0u, 1e-18f, ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
+        filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 0u, half, l31, 0u, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }

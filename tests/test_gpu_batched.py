@@ -374,3 +374,28 @@ def test_rows_and_queries_at_the_worst_of_bfloat16_rounding(metric):
     exact = _exact(idx, qs, k)
     assert _eq(exact, idx.search(qs, k, batched=True))
     assert len(np.intersect1d(exact[0].ravel(), upd[:64])) > 0          # the rewritten rows are the nearest ones now
+
+
+@pytest.mark.parametrize("scale", [1e-20, 1e-16, 3e-14])
+@pytest.mark.parametrize("metric", ["cosine", "dot_product", "euclidean"])
+def test_rows_too_small_for_the_filter_are_still_found(metric, scale):
+    """Rows whose norm is so small that the matrix core flushes their operands or products (scores come out 0, or off by more than
+    the margin allows for) say nothing to the filter: they must reach the exact pass whatever their score, and the exact pass must
+    not trust that score either.  Under cosine a scaled-down copy of the query is its nearest neighbour."""
+    import quiver_amd as q
+    rng = np.random.default_rng(5)
+    n, dim, nq, k = 40_000, 768, 32, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    for j in range(nq):                                         # three tiny near-copies of every query, spread over the corpus
+        for t in range(3):
+            rows[1000 * j + 37 * t + 5] = (qs[j] + 0.05 * (t + 1) * rng.standard_normal(dim)).astype(np.float32) * np.float32(scale)
+    idx = q.DeviceIndex(dim, metric)
+    idx.add(rows)
+    exact = _exact(idx, qs, k)
+    assert _eq(exact, idx.search(qs, k, batched=True))
+    if metric == "cosine":
+        assert all(1000 * j + 5 in exact[0][j] for j in range(nq))          # the tiny copies ARE the nearest rows
+    # and tiny queries against ordinary rows
+    tq = (qs * np.float32(scale)).astype(np.float32)
+    assert _eq(_exact(idx, tq, k), idx.search(tq, k, batched=True))
