@@ -1173,8 +1173,9 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
     const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
     const uint32_t steps = (v.dim4 + 3) / 4;                        // 16 dims per step; a multiple of 8 here
     const uint32_t dim8 = (v.dim4 + 1) / 2;
-    const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64 + lane;
-    const uint4* a1 = Qbf + ((size_t)(2 * qb64 + 1) * steps) * 2 * 64 + lane;
+    // request pointers are wave-uniform (scalar registers, scalar adds); the lane's 16 bytes are an offset of the request itself
+    const uint4* a0 = Qbf + ((size_t)(2 * qb64) * steps) * 2 * 64;
+    const uint4* a1 = Qbf + ((size_t)(2 * qb64 + 1) * steps) * 2 * 64;
     constexpr int RING = 8;
     uint4 r[RING];
     uint4 qa[4][2];
@@ -1185,11 +1186,11 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
     const uint4* ap0 = a0; const uint4* ap1 = a1;
     auto rows_of = [&](uint32_t g_) {                                // 8-dim group `half` of row 32*(wave&1) + l31 of this wave's tile of group g_
         const uint32_t ta = 2 * g_, tb = (2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
-        return plane + (size_t)(wave < 2 ? ta : tb) * dim8 * 64 + 64 * (wave & 1) + 32 * half + l31;    // dim8 is even here: dim8 * 64 = steps * 128
+        return plane + (size_t)(wave < 2 ? ta : tb) * dim8 * 64 + 64 * (wave & 1);    // + lane (= 32 * half + l31) in the request; dim8 is even here: dim8 * 64 = steps * 128
     };
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto load_b_run = [&](uint4& o) { o = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(lp))); lp += 128; };
-    auto load_a_run = [&](uint4 (&o)[2]) { o[0] = ap0[0]; o[1] = ap1[0]; ap0 += 128; ap1 += 128; };
+    auto load_b_run = [&](uint4& o) { o = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(lp + lane))); lp += 128; };
+    auto load_a_run = [&](uint4 (&o)[2]) { o[0] = ap0[lane]; o[1] = ap1[lane]; ap0 += 128; ap1 += 128; };
     auto read_b = [&](uint32_t stage, Bset& b) {
 #pragma unroll
         for (int j = 0; j < 4; j++) b.h[j] = s_b[stage][j][lane];
