@@ -1520,8 +1520,8 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
             // with the one-term filter: the pass is bound by those lines); the row-major copy, when the index keeps one, holds the
             // same floats contiguously — same values, same order, same result
             typename MT<M>::A acc;
-            if (v.rowmaj != nullptr && (v.dim & 3) == 0) acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
-            else acc = row_accumulate<M, U, false>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
+            if (v.rowmaj != nullptr && (v.dim & 3) == 0) acc = row_accumulate<M, U, false, true>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
+            else acc = row_accumulate<M, U, false, true>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
             double rn = 0.0;
             if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
             key = make_key(finalize<M>(acc, qc, rn), row);
@@ -1729,12 +1729,17 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     if (ev1) (void)hipEventRecord(ev1, s);
     // 4. exact re-scoring + selection
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * sizeof(uint32_t);
-    // (8 / 16 / 32 chunks requested per block of the exact pass: 105 / 108 / 112 us — it is bound by the gather of ~80 surviving rows
-    // per query out of the tile layout, 192 separate 128-byte lines each, not by the depth of the requests)
-#define QV_RS(MMM) { e = set_lds(k_rescore_select<MMM, 8>, lds); if (e != hipSuccess) return e;                                   \
-        hipLaunchKernelGGL((k_rescore_select<MMM, 8>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, eq); }
+    // chunk requests per round of the exact pass, all issued before the round's arithmetic (row_accumulate's BAR): a survivor's row is
+    // a gather of dim4 separate lines and the pass is a chain of dim4 / U dependent round trips — 8 / 16 / 32 / 48 / 64 per round:
+    // 64.4 / 58.0 / 54.2 / 55.3 / 55.6 us per launch at 256 x 1M x 768 (left to the compiler's own schedule, as the streaming scans
+    // are for cosine, deeper rounds were slower: 90 us at 16)
+    static const int rs_u = env_int("QV_MFMA_RESCORE_U", 32);
+#define QV_RS1(MMM, UU) { e = set_lds(k_rescore_select<MMM, UU>, lds); if (e != hipSuccess) return e;                                   \
+        hipLaunchKernelGGL((k_rescore_select<MMM, UU>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, eq); }
+#define QV_RS(MMM) { if (rs_u == 8) QV_RS1(MMM, 8) else QV_RS1(MMM, 32) }
     if (v.metric == QV_COSINE) QV_RS(QV_COSINE) else if (v.metric == QV_DOT) QV_RS(QV_DOT) else if (v.metric == QV_L2) QV_RS(QV_L2) else QV_RS(QV_L2SQ)
 #undef QV_RS
+#undef QV_RS1
     *d_overflow_out = ovf;
     return hipGetLastError();
 }

@@ -215,7 +215,7 @@ template <int M> __device__ __forceinline__ void stage_query(typename MT<M>::Q* 
 // (distances.go:20 magnitudeA += a*a; adapter.go:118 normA += a*a).  It is an independent
 // dependency chain, so riding along with a row's dot product costs no time; a wave does it
 // on its first tile only.
-template <int M, int U, bool QN>
+template <int M, int U, bool QN, bool BAR = false>
 __device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict__ p, uint32_t stride4,
                                                             const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4,
                                                             typename MT<M>::A* qnorm2 = nullptr) {
@@ -237,7 +237,7 @@ __device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict
         // the HBM peak instead of 88 %.  For cosine its own schedule (a rolling window of ~8 loads) beats the hard barrier
         // (89.7 vs 86.6-87.9 % at any batch size 8..32), so the barrier is left out there; tests/test_isa_guard.py checks the
         // compiled loops (>= 16 loads in flight for the barriered metrics, >= 8 for cosine).
-        if constexpr (M != QV_COSINE) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (M != QV_COSINE || BAR) __builtin_amdgcn_sched_barrier(0);   // (BAR: a caller whose loads are gathers, not a stream — k_rescore_select)
 #pragma unroll
         for (int u = 0; u < B; u++) {
             const Q* qq = q_lds + (size_t)(c0 + u) * 4;
