@@ -140,7 +140,13 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
         }
         n2 = wave_sum_f64(n2); d2 = wave_sum_f64(d2); h2 = wave_sum_f64(h2);
     }
-    if (threadIdx.x == 0 && what == 1) cq[q] = q < nq ? f32_up((float)__builtin_sqrt(n2)) : 0.f;   // the sample pass reads |q| here (rounded up)
+    if (threadIdx.x == 0 && what == 1) {
+        // the sample pass reads |q| here (rounded up) and, when it runs on the one-term kernel, that kernel's error constants in eq
+        const double qn1 = __builtin_sqrt(n2);
+        cq[q] = q < nq ? f32_up((float)qn1) : 0.f;
+        eq[2 * q] = q < nq ? f32_up((float)(filter_gamma_acc(dim) * qn1 + __builtin_sqrt(d2) * (1.0 + 1e-9))) : 0.f;
+        eq[2 * q + 1] = q < nq ? f32_up((float)(__builtin_sqrt(h2) * (1.0 + 1e-9))) : 0.f;
+    }
     if (threadIdx.x == 0 && (what & 2)) {
         float c_ = __uint_as_float(0x7F800000u), m_ = 0.f, b_ = 0.f;       // padded queries: +inf threshold, nothing passes
         float ea_ = 0.f, eb_ = 0.f;
@@ -528,6 +534,42 @@ __device__ __forceinline__ float sample_upper(float S, float g, float qa, float 
     else {
         const float sum = qa + ra;                                   // >= |q|^2 + |r|^2
         const float h2 = (sum - 2.0f * S) + (qb * rb + 5e-6f * sum);  // 2|S| <= sum: every rounding is of magnitude <= 2 sum
+        hi = h2 > 0.f ? h2 : (h2 == h2 ? 0.f : h2);
+    }
+    return hi == hi ? hi : __builtin_inff();
+}
+// The same for the ONE-TERM filter's scores (round 3: the sample pass of the one-term path runs on the eight-wave one-term kernel,
+// a third of the three-term kernel's time; its bounds are looser by the difference of the two error bounds, ~0.07 sigma of the
+// scores of 768-d data, i.e. ~1.3 x the candidates): |S~ - S| <= ea |r| + eb |r - rh| with ea, eb per query (k_mfma_prep), so a
+// query and a row contribute three constants each.
+template <int M>
+__device__ __forceinline__ void sample1_query_consts(float qn, float ea, float eb, float tiny, float& qa, float& qb, float& qc) {
+    const float nan = __builtin_nanf("");
+    const bool none = (qn != 0.f && qn < tiny) || !(qn < 1.0e18f);
+    if constexpr (M == QV_COSINE) {
+        const float inv = qn == 0.f ? 0.f : 1.0f / qn;
+        qa = none ? nan : inv; qb = ea * inv * 1.000001f; qc = eb * inv * 1.000001f;
+    } else if constexpr (M == QV_DOT) { qa = none ? nan : ea * 1.000001f; qb = eb * 1.000001f; qc = 0.f; }
+    else { qa = none ? nan : qn * qn * 1.000001f; qb = 2.0f * ea * 1.000002f; qc = 2.0f * eb * 1.000002f; }
+}
+template <int M>
+__device__ __forceinline__ void sample1_row_consts(float rn, float rho, bool gone, float tiny, float& ra, float& rb, float& rc) {
+    const float nan = __builtin_nanf("");
+    const bool none = gone || (rn != 0.f && rn < tiny) || !(rn < 1.0e18f);
+    if constexpr (M == QV_COSINE) {
+        const float inv = rn == 0.f ? 0.f : 1.0f / rn;
+        ra = none ? nan : inv; rb = rho * inv * 1.000001f; rc = 0.f;
+    } else if constexpr (M == QV_DOT) { ra = none ? nan : rn; rb = rho; rc = 0.f; }
+    else { ra = none ? nan : rn * rn * 1.000001f; rb = rn; rc = rho; }
+}
+template <int M>
+__device__ __forceinline__ float sample1_upper(float S, float qa, float qb, float qc, float ra, float rb, float rc) {
+    float hi;
+    if constexpr (M == QV_COSINE) hi = (1.0f - S * (qa * ra)) + ((qb + qc * rb) + 5e-6f);      // E / (|q||r|) = ea/|q| + (eb/|q|)(|r - rh|/|r|)
+    else if constexpr (M == QV_DOT) { const float d = 1.0f - S; hi = d + ((qa * ra + qb * rb) + 4e-6f * (1.0f + __builtin_fabsf(d))); }
+    else {
+        const float sum = qa + ra;
+        const float h2 = (sum - 2.0f * S) + ((qb * rb + qc * rc) + 5e-6f * sum);
         hi = h2 > 0.f ? h2 : (h2 == h2 ? 0.f : h2);
     }
     return hi == hi ? hi : __builtin_inff();
@@ -926,10 +968,14 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
 // behind them up (measured: the same time as the four-wave kernel).  Dimensions that are a multiple of 128, nq_pad of 256.
 // BF: the rows come from the index's bfloat16 copy (QV_FLAG_BF16_ROWS): a wave's 1-KiB request IS one 32-row B operand of one step,
 // no conversion; a round is then two steps (eight pieces, one per wave: piece w = step w>>2 of the round, block w&3).
-template <int METRIC, int RING, int AR, int SPB, bool BF, bool DEFER>
+template <int METRIC, int RING, int AR, int SPB, bool BF, bool DEFER, bool SAMPLE = false>
 __global__ void __launch_bounds__(512, 1)
 k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
-                   uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+                   uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt,
+                   float* __restrict__ score_out = nullptr, uint32_t score_stride = 0, uint32_t gstep = 1) {
+    // SAMPLE: no filter — the sample pass of the one-term path (see k_bf16x3_filter's score_out): row groups 0, gstep, 2 gstep, ... ; cq = the
+    // queries' norms (rounded up), mq = their error constants ea, eb ([nq_pad][2], k_mfma_prep with what = 1); what is written is the upper
+    // bound of the row's reference distance that its one-term score implies (sample1_upper)
     // RING, AR: row chunks / query operands in flight, counted in ROUNDS; a round = SPB steps of 16 dimensions between two barriers
     __shared__ __align__(16) float s_c[256], s_m[512];
     __shared__ __align__(16) unsigned char s_b[4][SPB][4][1024];        // [stage][step of the round][32-row block][lane * 16 bytes]: 16 KiB per step of a round
@@ -939,13 +985,18 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wgs_per_group = nq_pad >> 8;                      // workgroups that share one row group (different query blocks)
     const uint32_t qb256 = blockIdx.x % wgs_per_group;
-    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    const uint32_t n_groups = SAMPLE ? (score_stride + 127) / 128 : (v.n_tiles + 1) / 2;
     const uint32_t stride = gridDim.x / wgs_per_group;
     if (threadIdx.x < 256) {
-        const float c = cq[256 * qb256 + threadIdx.x], m = mq[256 * qb256 + threadIdx.x];
-        s_c[threadIdx.x] = METRIC == QV_COSINE ? c - m : c;
-        s_m[threadIdx.x] = m;
-        s_m[256 + threadIdx.x] = mq[nq_pad + 256 * qb256 + threadIdx.x];
+        if constexpr (SAMPLE) {
+            const uint32_t qq = 256 * qb256 + threadIdx.x;
+            sample1_query_consts<METRIC>(cq[qq], mq[2 * qq], mq[2 * qq + 1], filter_tiny_norm(v.dim), s_c[threadIdx.x], s_m[threadIdx.x], s_m[256 + threadIdx.x]);
+        } else {
+            const float c = cq[256 * qb256 + threadIdx.x], m = mq[256 * qb256 + threadIdx.x];
+            s_c[threadIdx.x] = METRIC == QV_COSINE ? c - m : c;
+            s_m[threadIdx.x] = m;
+            s_m[256 + threadIdx.x] = mq[nq_pad + 256 * qb256 + threadIdx.x];
+        }
     }
     __syncthreads();
     if (stride == 0) return;
@@ -1013,8 +1064,9 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
     constexpr int UNR = RING > AR ? RING : AR;                      // both rings are indexed by the unrolled step number: the loop body covers the longer one
     uint32_t epn = 0;                                               // entries waiting in the dump area (wave-uniform)
     for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
-        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
-        const f4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
+        const uint32_t ga = SAMPLE ? g * gstep : g;                 // the group's place in the corpus
+        const uint32_t t0 = 2 * ga, t1 = (2 * ga + 1 < v.n_tiles) ? 2 * ga + 1 : t0;
+        const f4* bwn = rows_of((g + stride < n_groups ? g + stride : g) * (SAMPLE ? gstep : 1u));
         f16v acc[1][4];
         double rnd[4]; float rho[4]; uint64_t alv[2];
         filter_row_consts(v, t0, t1, l31, rnd, rho, alv);
@@ -1024,7 +1076,7 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
             for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
         if (!primed) {                                              // the workgroup's first group: fill the rings
             primed = true;
-            lp = rows_of(g);
+            lp = rows_of(ga);
 #pragma unroll
             for (int i = 0; i < RING; i++) load_b_run(r[i]);
 #pragma unroll
@@ -1129,7 +1181,21 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
             printf("stamp wave %u: barrier-in 0, barrier-out %llu, issued %llu, A ready %llu, mfma issued %llu, lds drained %llu, next step start %llu\n", wave,
                    stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0]);
 #endif
-        if constexpr (DEFER) {
+        if constexpr (SAMPLE) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j >= 2 && t1 == t0) continue;
+                const uint32_t row = g * 128 + (j < 2 ? 0u : 64u) + 32 * (j & 1) + l31;      // place in the sample
+                if (row >= score_stride) continue;
+                float ra, rb, rc;
+                sample1_row_consts<METRIC>(f32_up((float)rnd[j]), rho[j], !((alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull), filter_tiny_norm(v.dim), ra, rb, rc);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t ql = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    score_out[(size_t)(256 * qb256 + ql) * score_stride + row] = sample1_upper<METRIC>(acc[0][j][r], s_c[ql], s_m[ql], s_m[256 + ql], ra, rb, rc);
+                }
+            }
+        } else if constexpr (DEFER) {
 #define QV_W8_BLK(JJ) filter_epilogue_block<METRIC, 1, 4, JJ>(acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du, epn)
             QV_W8_BLK(0); QV_W8_BLK(1); QV_W8_BLK(2); QV_W8_BLK(3);
 #undef QV_W8_BLK
@@ -1668,7 +1734,13 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         // the sample's row groups are spread evenly over the corpus (a corpus stored cluster by cluster: the first S rows would bound nothing)
         const uint32_t sgroups = (vs.n_rows + 127) / 128, all_groups = v.n_tiles / 2;
         const uint32_t gstep = sgroups && all_groups > sgroups ? all_groups / sgroups : 1u;
-#define QV_SB(MMM) { hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
+        // one-term path: the sample on the eight-wave one-term kernel (QV_MFMA_SAMPLE1=2: on the three-term kernel, as the other filters' samples)
+        static const int sample1_env = env_int("QV_MFMA_SAMPLE1", 1);
+        static const int w8s_env = env_int("QV_MFMA_W8", 1);
+        const bool sample1 = sample1_env == 1 && w8s_env == 1 && gmode == 2 && shared && (v.dim4 & 3u) == 0 && fsteps0 % 8 == 0 && fsteps0 >= 16;
+        const uint32_t gs1 = grid_multiple(std::min<uint32_t>((uint32_t)cus, sgroups * (nq_pad >> 8)), std::max<uint32_t>(nq_pad >> 8, 1u));
+#define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
+                     else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
                      hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
