@@ -399,3 +399,17 @@ def test_rows_too_small_for_the_filter_are_still_found(metric, scale):
     # and tiny queries against ordinary rows
     tq = (qs * np.float32(scale)).astype(np.float32)
     assert _eq(_exact(idx, tq, k), idx.search(tq, k, batched=True))
+
+
+@pytest.mark.parametrize("metric,dim", [("cosine", 1024), ("dot_product", 1536), ("euclidean", 512), ("squared_euclidean", 256), ("cosine", 640), ("cosine", 2048)])
+def test_filter_kernels_at_other_dimensions(metric, dim):
+    """The eight-wave one-term kernel (and its sample mode) runs whenever the dimension is a multiple of 128 with at least 16 steps of
+    16; 640 is not (the four-wave kernels take it) and 2048 is past the one-term rule (three terms by default): every shape against
+    the exact scan, 256 queries (whole workgroups of eight waves) and 64 (one query block)."""
+    import quiver_amd as q
+    n = 70_000
+    idx = q.DeviceIndex(dim, metric)
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, 256, dim)
+    for nq in (256, 64):
+        assert _eq(_exact(idx, qs[:nq], 10), idx.search(qs[:nq], 10, batched=True))
