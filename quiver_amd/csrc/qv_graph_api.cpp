@@ -26,6 +26,8 @@ struct qv_graph {
     Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev;
     PinBuf h_stage[2];                          // pinned bounce buffers for the query upload (pageable callers)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr;              // exact-heap passes of qv_graph_search, beside the next part's wave pass
+    hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_heap = nullptr;
     // build workspace
     Buf b_self, b_keys_a, b_keys_b, b_hist, b_seg, b_redo, b_counters;
     double build_seconds = 0.0; uint64_t build_redo = 0, build_batches = 0;
@@ -155,6 +157,9 @@ void qv_graph_destroy(qv_graph* g) {
     if (g->idx) (void)hipSetDevice(g->idx->device);
     if (g->ev_last) { (void)hipEventSynchronize(g->ev_last); (void)hipEventDestroy(g->ev_last); }
     for (int i = 0; i < 2; i++) { if (g->ev_stage[i]) (void)hipEventDestroy(g->ev_stage[i]); g->h_stage[i].release(); }
+    if (g->stream2) { (void)hipStreamSynchronize(g->stream2); (void)hipStreamDestroy(g->stream2); }
+    for (int i = 0; i < 2; i++) if (g->ev_part[i]) (void)hipEventDestroy(g->ev_part[i]);
+    if (g->ev_heap) (void)hipEventDestroy(g->ev_heap);
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
     (void)hipFree(g->d_level); (void)hipFree(g->d_l0deg); (void)hipFree(g->d_l0links); (void)hipFree(g->d_upoff); (void)hipFree(g->d_uplinks);
     (void)hipFree(g->d_l0dist); (void)hipFree(g->d_updist);
@@ -182,7 +187,6 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     if ((rc = g->d_q.ensure(qbytes)) || (rc = g->d_rows.ensure(obytes)) || (rc = g->d_dist.ensure(obytes)) || (rc = g->d_cnt.ensure(cbytes)) ||
         (rc = g->d_ev.ensure(cbytes)) || (rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4))) || (rc = ensure_visited(g, efx)))
         return rc;
-    const uint32_t grid = std::min(g->grid, nq);
     HIPCHK(hipStreamWaitEvent(g->stream, g->ev_last, 0));               // after any device-form traversal still running on another stream
     static const bool trace = getenv("QV_TRACE") && atoi(getenv("QV_TRACE")) > 0;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -204,47 +208,57 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     if (trace) { (void)hipStreamSynchronize(g->stream); fprintf(stderr, "qv: graph search upload %.3f ms (%zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), qbytes); }
     const auto t_p1 = std::chrono::steady_clock::now();
     // pass 1: wave-resident traversal (list in registers, rows streamed through LDS); queries that meet equal distances / NaN
-    // or outgrow the visited table report 0xFFFFFFFE
-    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, static_cast<const float*>(g->d_q.p), g->d_qblk.p, nq, k, ef_search, wave_opts(g), grid,
-                                               static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
-                                               static_cast<uint32_t*>(g->d_ev.p), g->stream);
+    // or outgrow the visited table report 0xFFFFFFFE.  pass 2: the exact-heap kernel for those (heap pop order under ties depends on
+    // the heap layout), from a work list compacted ON THE DEVICE (as the construction does): no host round trip between the passes.
+    // QV_HNSW_OVERLAP_REDO=1 (a measurement, not the default): large batches in two halves, each pass 1 at eight wave slots per CU — the
+    // traversal rate is flat from 8 to 16 (profiles/r03_hnsw_heap.txt) and that leaves the LDS an exact-heap workgroup needs — so that the
+    // first half's pass 2 (a handful of queries, ~5 ms of pure latency) can run on a second stream beside the second half's pass 1.
+    // Measured at 8192 queries, efSearch 128 / 512: 32.9 / 119.1 ms against 31.5 / 119.4 in one part: nothing gained.
+    static const int overlap_env = getenv("QV_HNSW_OVERLAP_REDO") ? atoi(getenv("QV_HNSW_OVERLAP_REDO")) : 2;
+    const uint32_t parts = nq >= 4096 && overlap_env == 1 ? 2u : 1u;
+    const uint32_t part_n = (nq + parts - 1) / parts;
+    const size_t part_qblk = (qv::hnsw_qblk_bytes(part_n, idx->dim4) + 255) / 256 * 256;
+    if ((rc = g->d_qblk.ensure(part_qblk * parts)) || (rc = g->b_redo.ensure((size_t)nq * 4)) || (rc = g->b_counters.ensure(64))) return rc;
+    if (!g->stream2) HIPCHK(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) if (!g->ev_part[i]) HIPCHK(hipEventCreateWithFlags(&g->ev_part[i], hipEventDisableTiming));
+    if (!g->ev_heap) HIPCHK(hipEventCreateWithFlags(&g->ev_heap, hipEventDisableTiming));
+    uint32_t* counters = static_cast<uint32_t*>(g->b_counters.p);
+    HIPCHK(hipMemsetAsync(counters, 0, 64, g->stream));
+    hipError_t e = hipSuccess;
+    for (uint32_t pi = 0; pi < parts && e == hipSuccess; pi++) {
+        const uint32_t q0 = pi * part_n, n_c = std::min(part_n, nq - q0);
+        if (n_c == 0) break;
+        const float* dq = static_cast<const float*>(g->d_q.p) + (size_t)q0 * idx->dim;
+        void* qblk = static_cast<unsigned char*>(g->d_qblk.p) + part_qblk * pi;
+        uint32_t* d_rows = static_cast<uint32_t*>(g->d_rows.p) + (size_t)q0 * k; float* d_dist = static_cast<float*>(g->d_dist.p) + (size_t)q0 * k;
+        uint32_t* d_cnt = static_cast<uint32_t*>(g->d_cnt.p) + q0; uint32_t* d_ev = static_cast<uint32_t*>(g->d_ev.p) + q0;
+        const uint32_t pgrid = std::min(parts > 1 ? std::min(g->grid, (uint32_t)idx->cus * 8u) : g->grid, n_c);
+        e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, qblk, n_c, k, ef_search, wave_opts(g), pgrid, d_rows, d_dist, d_cnt, d_ev, g->stream);
+        if (e == hipSuccess) e = qv::launch_build_compact_redo(d_cnt, n_c, static_cast<uint32_t*>(g->b_redo.p) + q0, counters + 4 * pi, g->stream);
+        if (e != hipSuccess) break;
+        HIPCHK(hipEventRecord(g->ev_part[pi], g->stream));
+        HIPCHK(hipStreamWaitEvent(g->stream2, g->ev_part[pi], 0));
+        qv::HnswOpts ho = heap_opts(g);
+        ho.redo_idx = static_cast<const uint32_t*>(g->b_redo.p) + q0; ho.redo_n = counters + 4 * pi;
+        const uint32_t hgrid = std::min(std::min(qv::hnsw_grid(idx->cus, efx, n_c), g->vis_bits_slots), n_c);
+        e = qv::launch_hnsw_search(idx->view(), g->g, dq, qblk, n_c, k, ef_search, ho, hgrid, false, d_rows, d_dist, d_cnt, d_ev, g->stream2);
+    }
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+    HIPCHK(hipEventRecord(g->ev_heap, g->stream2));
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_heap, 0));
+    uint32_t hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(rows_out, g->d_rows.p, obytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipMemcpyAsync(dist_out, g->d_dist.p, obytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipMemcpyAsync(count_out, g->d_cnt.p, cbytes, hipMemcpyDeviceToHost, g->stream));
     if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, g->d_ev.p, cbytes, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipMemcpyAsync(hc, counters, 32, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
-    if (trace) fprintf(stderr, "qv: graph search pass 1 + download %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p1).count());
-    const auto t_p2 = std::chrono::steady_clock::now();
-    // pass 2: the exact-heap kernel for the flagged queries (heap pop order under ties depends on the heap layout)
-    std::vector<uint32_t> redo;
-    for (uint32_t q = 0; q < nq; q++) if (count_out[q] == 0xFFFFFFFEu) redo.push_back(q);
-    if (!redo.empty()) {
-        g->tie_reruns += redo.size();
-        const uint32_t m = (uint32_t)redo.size();
-        std::vector<float> rq((size_t)m * idx->dim);
-        for (uint32_t i = 0; i < m; i++) memcpy(&rq[(size_t)i * idx->dim], queries + (size_t)redo[i] * idx->dim, idx->dim * sizeof(float));
-        std::vector<uint32_t> rr((size_t)m * k), rc2(m), rev(m);
-        std::vector<float> rd((size_t)m * k);
-        HIPCHK(hipMemcpyAsync(g->d_q.p, rq.data(), rq.size() * sizeof(float), hipMemcpyHostToDevice, g->stream));
-        const uint32_t hgrid = std::min(qv::hnsw_grid(idx->cus, efx, m), g->vis_bits_slots);
-        e = qv::launch_hnsw_search(idx->view(), g->g, static_cast<const float*>(g->d_q.p), g->d_qblk.p, m, k, ef_search, heap_opts(g), hgrid, true,
-                                   static_cast<uint32_t*>(g->d_rows.p), static_cast<float*>(g->d_dist.p), static_cast<uint32_t*>(g->d_cnt.p),
-                                   static_cast<uint32_t*>(g->d_ev.p), g->stream);
-        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
-        HIPCHK(hipMemcpyAsync(rr.data(), g->d_rows.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipMemcpyAsync(rd.data(), g->d_dist.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipMemcpyAsync(rc2.data(), g->d_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipMemcpyAsync(rev.data(), g->d_ev.p, (size_t)m * 4, hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipStreamSynchronize(g->stream));
-        for (uint32_t i = 0; i < m; i++) {
-            memcpy(rows_out + (size_t)redo[i] * k, &rr[(size_t)i * k], (size_t)k * 4);
-            memcpy(dist_out + (size_t)redo[i] * k, &rd[(size_t)i * k], (size_t)k * 4);
-            count_out[redo[i]] = rc2[i];
-            if (evals_out) evals_out[redo[i]] = rev[i];
-        }
-    }
-    if (trace) fprintf(stderr, "qv: graph search pass 2 (%zu flagged queries) %.3f ms\n", redo.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p2).count());
+    HIPCHK(hipEventRecord(g->ev_last, g->stream));
+    g->tie_reruns += (uint64_t)hc[0] + hc[4];
+    if (trace) fprintf(stderr, "qv: graph search passes 1 + 2 + download %.3f ms (%u + %u flagged queries redone on the device, %u part%s)\n",
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p1).count(), hc[0], hc[4], parts, parts > 1 ? "s" : "");
+    for (uint32_t q = 0; q < nq; q++)
+        if (count_out[q] == 0xFFFFFFFEu) return fail(QV_ERR_DEVICE, "hnsw search: a flagged query was not redone");
     return QV_OK;
 }
 
