@@ -1524,15 +1524,25 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 #else
 #define RSTK()
 #endif
+    __shared__ double s_part[4], s_qn_exact;
     stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
     if (threadIdx.x == 0) s_ns = 0;
     __syncthreads();
-    const QConst qc = query_const<M>(q_lds, v.dim);                 // the metric's own query constant
-    double qn_l2 = qc.qn;                                           // |q| for the error bounds (every lane, same value)
-    if constexpr (M != QV_COSINE) {
+    // |q| for the error bounds: it only enters intervals that carry 2e-6 of slack, so the order of the additions is free — a sum over
+    // the workgroup's 256 threads.  The cosine metric's OWN query norm (a chain of dim rounded fmas in element order, distances.go:20:
+    // 4 us on one lane) is only needed by stage 2's finalize: wave 3 walks it while the other waves are already in stage 1
+    // (every thread used to walk it up front, and the non-cosine metrics walked a second chain for |q|).
+    {
         double n2 = 0.0;
-        for (uint32_t i = 0; i < v.dim; i++) { double a = (double)q_lds[i]; n2 = __builtin_fma(a, a, n2); }
-        qn_l2 = __builtin_sqrt(n2);
+        for (uint32_t i = threadIdx.x; i < v.dim; i += blockDim.x) { const double a = (double)q_lds[i]; n2 = __builtin_fma(a, a, n2); }
+        n2 = wave_sum_f64(n2);
+        if (lane == 0) s_part[wave] = n2;
+    }
+    __syncthreads();
+    const double qn_l2 = __builtin_sqrt((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+    QConst qc; qc.qn = qn_l2; qc.qn32 = 0.f;                        // stage 1: the approximate norm; stage 2 replaces it for cosine
+    if constexpr (M == QV_COSINE) {
+        if (wave == 3) { const QConst t = query_const<M>(q_lds, v.dim); if (lane == 0) s_qn_exact = t.qn; }
     }
     const uint32_t kth = k - 1;
     const uint32_t* cr = cand_rows + (size_t)qi * kMfmaCandCap;
@@ -1542,17 +1552,29 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 
     // ---- stage 1: H = k-th smallest upper bound
     const double ea = (double)eq[2 * qi], eb = (double)eq[2 * qi + 1], gref = filter_gamma(v.dim, 0);
-    auto bounds = [&](uint32_t i, float& lo, float& hi) {
-        const uint32_t row = cr[i];
-        const double rn = v.rnorm[row];
-        score_interval<M>((double)cs[i], qc.qn, qn_l2, rn, ea * rn + eb * (double)v.rres[row], gref, lo, hi);
-    };
     uint64_t list = kDeadKey, thr = kDeadKey;
-    for (uint32_t base = wave * 64; base < cnt; base += 4 * 64) {
-        const uint32_t i = base + lane;
-        uint64_t key = kDeadKey;
-        if (i < cnt) { float lo, hi; bounds(i, lo, hi); key = make_key(hi, i); }
-        if (base == wave * 64) list_seed(list, thr, key, kth, lane); else list_insert(list, thr, key, kth, lane);
+    // four candidates per thread at a time: their scores and rows requested together, then their norms and residuals together (two round
+    // trips per 1024 candidates instead of two per 256); the lower bounds are parked in LDS for the survivor pass
+    float* lo_l = reinterpret_cast<float*>(surv + kMfmaCandCap);                                              // [kMfmaCandCap]
+    for (uint32_t base0 = wave * 64; base0 < cnt; base0 += 4 * 4 * 64) {
+        uint32_t rowv[4]; float scv[4]; double rnv[4]; float rhv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t i = base0 + (uint32_t)j * 256 + lane; rowv[j] = i < cnt ? cr[i] : 0u; scv[j] = i < cnt ? cs[i] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t i = base0 + (uint32_t)j * 256 + lane; rnv[j] = i < cnt ? v.rnorm[rowv[j]] : 0.0; rhv[j] = i < cnt ? v.rres[rowv[j]] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t base = base0 + (uint32_t)j * 256, i = base + lane;
+            if (base >= cnt) break;
+            uint64_t key = kDeadKey;
+            if (i < cnt) {
+                float lo, hi;
+                score_interval<M>((double)scv[j], qc.qn, qn_l2, rnv[j], ea * rnv[j] + eb * (double)rhv[j], gref, lo, hi);
+                lo_l[i] = lo;
+                key = make_key(hi, i);
+            }
+            if (base == wave * 64) list_seed(list, thr, key, kth, lane); else list_insert(list, thr, key, kth, lane);
+        }
     }
     wl[wave * 64 + lane] = list;
     __syncthreads();
@@ -1567,12 +1589,11 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
     __syncthreads();
     RSTK();
     const float H = s_H;
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-        float lo, hi; bounds(i, lo, hi);
-        if (lo <= H) surv[atomicAdd(&s_ns, 1u)] = cr[i];
-    }
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x)
+        if (lo_l[i] <= H) surv[atomicAdd(&s_ns, 1u)] = cr[i];
     __syncthreads();
     const uint32_t ns = s_ns;
+    if constexpr (M == QV_COSINE) qc.qn = s_qn_exact;              // from here on the metric's own norm (wave 3 wrote it before the barriers above)
     RSTK();
 
     // ---- stage 2: exact distances of the survivors, top-k by (distance, row)
@@ -1800,7 +1821,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     else hipLaunchKernelGGL(k_mfma_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter
     if (ev1) (void)hipEventRecord(ev1, s);
     // 4. exact re-scoring + selection
-    const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * sizeof(uint32_t);
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * (sizeof(uint32_t) + sizeof(float));   // query, wave lists, survivors, lower bounds
     // chunk requests per round of the exact pass, all issued before the round's arithmetic (row_accumulate's BAR): a survivor's row is
     // a gather of dim4 separate lines and the pass is a chain of dim4 / U dependent round trips — 8 / 16 / 32 / 48 / 64 per round:
     // 64.4 / 58.0 / 54.2 / 55.3 / 55.6 us per launch at 256 x 1M x 768 (left to the compiler's own schedule, as the streaming scans
