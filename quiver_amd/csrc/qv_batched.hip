@@ -373,6 +373,11 @@ __device__ __forceinline__ void filter_epilogue_block(const f16v (&acc)[NI][NJ],
 template <int METRIC>
 __device__ __forceinline__ void filter_epilogue_finish(const float* sc, const float* sm, uint32_t qbase, uint32_t qglobal, const CandQueue& cqu, uint32_t& cqn,
                                                        const CandOut& out, const EpiDump& du, uint32_t& n) {
+#if defined(QV_DBG_EPI) && QV_DBG_EPI == 3                               // measurement build: level 1 + dump, no dense pass
+    if (n == 0xFFFFFFFFu) out.cnt[0] = 1;
+    n = 0;
+    return;
+#endif
     if (n) epi_dense_pass<METRIC>(du, n, sc, sm, qbase, qglobal, cqu, cqn, out);
     n = 0;
 }
