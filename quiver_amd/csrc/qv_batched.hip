@@ -370,6 +370,36 @@ __device__ __forceinline__ void filter_epilogue_block(const f16v (&acc)[NI][NJ],
         }
     }
 }
+// level 1 of one row block, branch-free: the mask of lanes whose block maximum reaches the lower bound of the block's 16 thresholds
+template <int METRIC>
+__device__ __forceinline__ uint64_t epi_level1(const f16v& a, float cmin, float mmax, float bmax, float rn, float rn2c, float rho, bool unsure, bool live) {
+    const float m0 = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(a[3], a[4]), a[5]);
+    const float m2 = __builtin_fmaxf(__builtin_fmaxf(a[6], a[7]), a[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(a[9], a[10]), a[11]);
+    const float m4 = __builtin_fmaxf(__builtin_fmaxf(a[12], a[13]), a[14]);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), m2), __builtin_fmaxf(__builtin_fmaxf(m3, m4), a[15]));
+    const float thr_lo = filter_threshold<METRIC>(cmin, mmax, bmax, rn, rn2c, rho);
+    return __ballot((!(mx < thr_lo) || unsure) && live);
+}
+// the dump of one row block whose level-1 mask pm is not empty (wave-uniform call)
+template <int METRIC>
+__device__ __forceinline__ void epi_dump(const f16v& a, uint64_t pm, uint32_t row, float rn, float rho, uint32_t i, uint32_t half, bool unsure,
+                                         const float* sc, const float* sm, uint32_t qbase, uint32_t qglobal, const CandQueue& cqu, uint32_t& cqn,
+                                         const CandOut& out, const EpiDump& du, uint32_t& n) {
+    const bool pre = (pm >> lane_id()) & 1ull;
+    const uint32_t cnt = (uint32_t)__builtin_popcountll(pm), rank = (uint32_t)__builtin_popcountll(pm & ((1ull << lane_id()) - 1ull));
+    for (uint32_t done = 0; done < cnt;) {                  // one round, unless the dump area fills up (wave-uniform loop)
+        if (n == du.cap) { epi_dense_pass<METRIC>(du, n, sc, sm, qbase, qglobal, cqu, cqn, out); n = 0; __threadfence_block(); }
+        const uint32_t now = (du.cap - n) < (cnt - done) ? (du.cap - n) : (cnt - done);
+        if (pre && rank >= done && rank < done + now) {
+            uint32_t* d = du.area + (n + rank - done) * kEpiEntryWords;
+            f4* d4 = reinterpret_cast<f4*>(d);
+            d4[0] = f4{a[0], a[1], a[2], a[3]}; d4[1] = f4{a[4], a[5], a[6], a[7]};
+            d4[2] = f4{a[8], a[9], a[10], a[11]}; d4[3] = f4{a[12], a[13], a[14], a[15]};
+            d[16] = row; d[17] = __float_as_uint(rn); d[18] = __float_as_uint(rho); d[19] = i | (half << 1) | ((uint32_t)unsure << 2);
+        }
+        n += now; done += now;
+    }
+}
 template <int METRIC>
 __device__ __forceinline__ void filter_epilogue_finish(const float* sc, const float* sm, uint32_t qbase, uint32_t qglobal, const CandQueue& cqu, uint32_t& cqn,
                                                        const CandOut& out, const EpiDump& du, uint32_t& n) {
@@ -400,10 +430,47 @@ __device__ __forceinline__ void filter_epilogue(const IndexView& v, const f16v (
             return;
         }
 #endif
-        uint32_t n = 0;
-#define QV_EPI_BLK(JJ) if constexpr (JJ < NJ) filter_epilogue_block<METRIC, NI, NJ, (JJ < NJ ? JJ : 0)>(acc, t0, t1, sc, sm, qbase, half, l31, qglobal, tiny_rn, ec, rnd, rho, alv, cqu, cqn, out, du, n)
-        QV_EPI_BLK(0); QV_EPI_BLK(1); QV_EPI_BLK(2); QV_EPI_BLK(3);
+        if constexpr (NI == 1) {
+            // one 32-query block per wave (the eight-wave kernel): block after block measures 1 % faster than the two phases below (608 against 615 us)
+            uint32_t n1 = 0;
+#define QV_EPI_BLK(JJ) if constexpr (JJ < NJ) filter_epilogue_block<METRIC, NI, NJ, (JJ < NJ ? JJ : 0)>(acc, t0, t1, sc, sm, qbase, half, l31, qglobal, tiny_rn, ec, rnd, rho, alv, cqu, cqn, out, du, n1)
+            QV_EPI_BLK(0); QV_EPI_BLK(1); QV_EPI_BLK(2); QV_EPI_BLK(3);
 #undef QV_EPI_BLK
+            filter_epilogue_finish<METRIC>(sc, sm, qbase, qglobal, cqu, cqn, out, du, n1);
+            return;
+        }
+        // Two phases (two 32-query blocks per wave: eight row blocks; k_bf16rows_filter 437 -> 423 us, k_mfma_filter 3.06 -> 3.03 ms).
+        // Level 1 of ALL row blocks first, branch-free: the blocks' max trees and threshold products are independent chains the
+        // compiler can interleave (a wave-uniform branch after each block's ballot kept them one behind the other: ~500 cycles a block on
+        // waves that all sit in their epilogue at the same time).  Then the dumps of the blocks whose mask is not empty.
+        uint32_t n = 0;
+        uint64_t pm[NJ][NI];
+        float rnv[NJ]; bool unsv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const bool live = (alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull;
+            const float rn = f32_up((float)rnd[j]);
+            // rows the scores say nothing about: bf16 operands of a vanishing row would flush; a norm that is NaN, infinite or huge
+            // may have overflowed the float32 sums (in either direction, possibly only on the way)
+            const bool unsure = rn < tiny_rn || !(rn < 1.0e18f);
+            rnv[j] = rn; unsv[j] = unsure;
+            const float rn2c = rn2c_of(rn);
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+                pm[j][i] = (j >= 2 && t1 == t0) ? 0ull : epi_level1<METRIC>(acc[i][j], ec.cmin[i], ec.mmax[i], ec.bmax[i], rn, rn2c, rho[j], unsure, live);
+        }
+#if !(defined(QV_DBG_EPI) && QV_DBG_EPI == 2)                             // (measurement build 2: level 1 only)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t row = (j < 2 ? t0 : t1) * 64 + 32 * (j & 1) + l31;
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+                if (__builtin_expect(pm[j][i] != 0, 0))     // some row of the block may be in some query's top-k
+                    epi_dump<METRIC>(acc[i][j], pm[j][i], row, rnv[j], rho[j], (uint32_t)i, half, unsv[j], sc, sm, qbase, qglobal, cqu, cqn, out, du, n);
+        }
+#else
+        if (pm[0][0] == 0x123456789abcull) cand_cnt[0] = 1;
+#endif
         filter_epilogue_finish<METRIC>(sc, sm, qbase, qglobal, cqu, cqn, out, du, n);
 }
 
