@@ -1277,6 +1277,130 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
     cand_flush(cqu, cqu_n, cqu_out);
 }
 
+// k_bf16x1_filter_w8 with 256 rows per round of the K loop (round 3, late).  In the eight-wave kernel a step is paced by things that do
+// not overlap because the barriers keep the waves in phase — all eight request (the CU's vector-memory path takes one request per 16
+// cycles), then all eight multiply (4 matrix instructions per wave: 130 of a step's ~680 cycles), then LDS drains, then the barrier.
+// Twice the rows per barrier doubles the matrix work a step's fixed costs are spread over (8 instructions per wave, 512 cycles per SIMD)
+// and halves the query-operand requests per row (one 1-KiB A operand per wave and step now serves 256 rows: L2 -> L1 4.7 GB per launch
+// instead of 6.2).  A wave holds 32 queries x 256 rows (128 accumulator registers); wave w converts dims 8(w&1) .. +7 of the step for the
+// 64 rows of tile (w >> 1) of the group — two 16-byte chunks in, ONE 16-byte LDS write out, which is a whole lane slot of a B operand —
+// and the B operands are read from LDS right before their matrix instructions (a second set of 32 registers would not fit).
+template <int METRIC, int RING, int AR>
+__global__ void __launch_bounds__(512, 1)
+k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
+                     uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
+    __shared__ __align__(16) float s_c[256], s_m[512];
+    __shared__ __align__(16) unsigned char s_b[4][8][1024];           // [stage][32-row block of the 256][lane * 16 bytes]: 8 KiB per step
+    QV_CAND_QUEUE(cqu, 8, 256);                                      // 24 KiB
+    QV_EPI_DUMP(du, 8, 32);                                          // 20 KiB
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wgs_per_group = nq_pad >> 8;
+    const uint32_t qb256 = blockIdx.x % wgs_per_group;
+    const uint32_t n_groups = (v.n_tiles + 3) / 4;                   // groups of four tiles = 256 rows
+    const uint32_t stride = gridDim.x / wgs_per_group;
+    if (threadIdx.x < 256) {
+        const float c = cq[256 * qb256 + threadIdx.x], m = mq[256 * qb256 + threadIdx.x];
+        s_c[threadIdx.x] = METRIC == QV_COSINE ? c - m : c;
+        s_m[threadIdx.x] = m;
+        s_m[256 + threadIdx.x] = mq[nq_pad + 256 * qb256 + threadIdx.x];
+    }
+    __syncthreads();
+    if (stride == 0) return;
+    const uint32_t half = lane >> 5, l31 = lane & 31;
+    const EpiConsts ec = epi_consts<METRIC, 1>(s_c, s_m, 32 * wave, half);
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t rounds = v.dim4 / 4;                              // steps of 16 dimensions: a multiple of RING and AR here
+    const uint4* a0 = Qbf + ((size_t)(8 * qb256 + wave) * rounds) * 2 * 64;                // the hi plane of 32-query block 8*qb256 + wave
+    struct Raw { f4 c[2]; };                                         // this wave's two chunks of a step (dims 8(w&1) .. +7 of its tile's 64 rows)
+    Raw r[RING];
+    uint4 qa[AR];
+    const uint32_t tw = wave >> 1, hw = wave & 1;
+    const uint32_t pub_off = (2 * tw + (lane >> 5)) * 1024 + (l31 + 32 * hw) * 16;          // block 2*tw + lane/32, lane slot (row l31, dims 8*hw .. +7)
+    auto tile_of = [&](uint32_t g_, uint32_t t_) { const uint32_t t = 4 * g_ + t_; return t < v.n_tiles ? t : v.n_tiles - 1; };   // past the end: the last tile again (masked below)
+    auto rows_of = [&](uint32_t g_) { return tiles + ((size_t)tile_of(g_, tw) * v.dim4 + 2 * hw) * 64; };   // wave-uniform: the lane is added in the request
+    const f4* lp = nullptr;
+    const uint4* ap = a0;
+    auto load_b_run = [&](Raw& o) { o.c[0] = __builtin_nontemporal_load(lp + lane); o.c[1] = __builtin_nontemporal_load(lp + 64 + lane); lp += 256; };   // next step: four chunks on
+    auto load_a_run = [&](uint4& o) { o = ap[lane]; ap += 128; };
+    auto publish = [&](const Raw& o, uint32_t stage) {
+        uint4 h;
+        h.x = pack_bf16(o.c[0].x, o.c[0].y); h.y = pack_bf16(o.c[0].z, o.c[0].w); h.z = pack_bf16(o.c[1].x, o.c[1].y); h.w = pack_bf16(o.c[1].z, o.c[1].w);
+        *reinterpret_cast<uint4*>(&s_b[stage][0][0] + pub_off) = h;
+    };
+    bool primed = false;
+    constexpr int UNR = RING > AR ? RING : AR;
+    for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
+        const f4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
+        f16v accA[1][4], accB[1][4];                                // tiles 4g, 4g+1 and 4g+2, 4g+3
+        const uint32_t tA0 = 4 * g, tA1 = 4 * g + 1 < v.n_tiles ? 4 * g + 1 : tA0;
+        const bool hasB = 4 * g + 2 < v.n_tiles;
+        const uint32_t tB0 = hasB ? 4 * g + 2 : tA0, tB1 = 4 * g + 3 < v.n_tiles ? 4 * g + 3 : tB0;
+        double rndA[4], rndB[4]; float rhoA[4], rhoB[4]; uint64_t alvA[2], alvB[2];
+        filter_row_consts(v, tA0, tA1, l31, rndA, rhoA, alvA);
+        filter_row_consts(v, tB0, tB1, l31, rndB, rhoB, alvB);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) { accA[0][j][e] = 0.f; accB[0][j][e] = 0.f; }
+        if (!primed) {                                              // the workgroup's first group: fill the rings
+            primed = true;
+            lp = rows_of(g);
+#pragma unroll
+            for (int i = 0; i < RING; i++) load_b_run(r[i]);
+#pragma unroll
+            for (int i = 0; i < AR - 1; i++) load_a_run(qa[i]);
+            publish(r[0], 0); publish(r[1], 1);
+            load_b_run(r[0]); load_b_run(r[1]);
+        }
+        // step s: barrier (steps s and s+1 are published); publish step s+2 (requested RING steps ago) and re-request its ring slot (rows of
+        // step s+2+RING); request the query operand of step s+AR-1; read the B operands of step s and multiply.  One memory or LDS
+        // instruction per matrix-instruction gap, the LDS write first (see k_bf16x1_filter_w8).
+        auto pstep = [&](uint32_t s_, int k8) {
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            publish(r[(k8 + 2) & (RING - 1)], (uint32_t)(k8 + 2) & 3);
+            if (s_ + (AR - 1) == rounds) ap = a0;
+            load_a_run(qa[(k8 + AR - 1) & (AR - 1)]);                // before the row requests: waiting for a step's query operand then waits for no row younger than the ones this step publishes
+            if (s_ + RING + 2 == rounds) lp = bwn;
+            load_b_run(r[(k8 + 2) & (RING - 1)]);
+            uint4 b[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) b[j] = *reinterpret_cast<const uint4*>(&s_b[(uint32_t)k8 & 3][j][lane * 16]);
+            const bf8 ah = __builtin_bit_cast(bf8, qa[k8 & (AR - 1)]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                accA[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf8, b[j]), accA[0][j], 0, 0, 0);
+                accB[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf8, b[4 + j]), accB[0][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // the first two B operands
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);       // the conversion (4 VALU)
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // ... and the LDS write of step s+2
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // query operand request
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // row request
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // row request
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (uint32_t st = 0; st < rounds; st += UNR) {
+#pragma unroll
+            for (int k8 = 0; k8 < UNR; k8++) pstep(st + k8, k8);
+        }
+        filter_epilogue<METRIC>(v, accA, tA0, tA1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, filter_tiny_norm(v.dim), ec, rndA, rhoA, alvA, cqu, cqu_n, cqu_out, du);
+        if (hasB) filter_epilogue<METRIC>(v, accB, tB0, tB1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, filter_tiny_norm(v.dim), ec, rndB, rhoB, alvB, cqu, cqu_n, cqu_out, du);
+    }
+    cand_flush(cqu, cqu_n, cqu_out);
+}
+
 // The one-term filter reading the index's bfloat16 copy of the rows (QV_FLAG_BF16_ROWS) instead of converting float32 rows on the fly:
 // half the row bytes from HBM and through the vector L1s, no conversion work.  Same workgroup shape as k_bf16x3_filter_shared (four
 // query blocks share a 128-row group through LDS); wave w fetches rows 32w .. 32w+31, one 16-byte request per lane and step — which
@@ -1870,6 +1994,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         static const int w8_env = env_int("QV_MFMA_W8", 1);                                   // 2 = the four-wave kernel (k_bf16x3_filter_shared<., 1>)
         const bool w8 = w8_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;       // rounds of two steps, four in flight: a multiple of 4 rounds, at least 6
         static const int w8_bf = env_int("QV_MFMA_W8_BF", 2);                                  // 1 = the eight-wave kernel on the bfloat16 plane too (measured: 485 against 474 us for k_bf16rows_filter)
+        static const int w8x2 = env_int("QV_MFMA_W8X2", 2);                                 // 1 / 3 = 256 rows per round (k_bf16x1_filter_w8x2), rows 4 / 8 steps ahead
         static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // measurement (profiles/r03_batched_epilogue.txt): 7 = the epilogue's dense pass deferred into the next group's K loop (610.7 against 607.3 us), 5 / 6 = rows 16 rounds ahead (614 / 613), 3 = rows 18 and query operands 15 steps ahead, 4 = query operands 15 steps ahead (644.6 against 648.6 us: kept at 3)
 #define QV_FS(MMM) { if (bfrows && w8 && w8_bf == 1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 4, 8, 2, true, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
@@ -1877,6 +2002,8 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
                        else if (w8_shape == 4 && fsteps % 16 == 0) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 16, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                        else if (w8_shape == 5 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 4, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                        else if (w8_shape == 6 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 8, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8x2 == 1) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 4, 4>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                       else if (w8x2 == 3) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 8, 4>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                        else if (w8_shape == 7) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false, true>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                        else hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); } \
                      else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
