@@ -1994,7 +1994,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         static const int w8_env = env_int("QV_MFMA_W8", 1);                                   // 2 = the four-wave kernel (k_bf16x3_filter_shared<., 1>)
         const bool w8 = w8_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;       // rounds of two steps, four in flight: a multiple of 4 rounds, at least 6
         static const int w8_bf = env_int("QV_MFMA_W8_BF", 2);                                  // 1 = the eight-wave kernel on the bfloat16 plane too (measured: 485 against 474 us for k_bf16rows_filter)
-        static const int w8x2 = env_int("QV_MFMA_W8X2", 2);                                 // 1 / 3 = 256 rows per round (k_bf16x1_filter_w8x2), rows 4 / 8 steps ahead
+        static const int w8x2 = env_int("QV_MFMA_W8X2", 1);                                 // 1 = 256 rows per round (k_bf16x1_filter_w8x2; 552 against 607 us), 2 = 128 (k_bf16x1_filter_w8); 3 = 256 with rows 8 steps ahead (spills)
         static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // measurement (profiles/r03_batched_epilogue.txt): 7 = the epilogue's dense pass deferred into the next group's K loop (610.7 against 607.3 us), 5 / 6 = rows 16 rounds ahead (614 / 613), 3 = rows 18 and query operands 15 steps ahead, 4 = query operands 15 steps ahead (644.6 against 648.6 us: kept at 3)
 #define QV_FS(MMM) { if (bfrows && w8 && w8_bf == 1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 4, 8, 2, true, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
