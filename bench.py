@@ -440,7 +440,7 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
             "roofline": ({"bound": "mfma", "kernel": "k_mfma_filter", "kernel_ms": mf_ms, "achieved": flop / (mf_ms * 1e-3) / 1e12,
                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flop / (mf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                           "end_to_end_frac": flop / dtm / 1e12 / MFMA_F32_PEAK_TF, "algorithmic_flop_per_launch": flop} if kernel == "fp32" else
-                         {"bound": "hbm", "kernel": "k_bf16rows_filter" if plane else "k_bf16x1_filter_w8", "kernel_ms": mf_ms,
+                         {"bound": "hbm", "kernel": "k_bf16rows_filter" if plane else "k_bf16x1_filter_w8x2", "kernel_ms": mf_ms,
                           "achieved": rows_n * (dim * (2 if plane else 4) + 8) / (mf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": rows_n * (dim * (2 if plane else 4) + 8) / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "algorithmic_bytes_per_launch": rows_n * (dim * (2 if plane else 4) + 8),
