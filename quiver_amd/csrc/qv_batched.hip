@@ -1395,8 +1395,19 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
 #pragma unroll
             for (int k8 = 0; k8 < UNR; k8++) pstep(st + k8, k8);
         }
-        filter_epilogue<METRIC>(v, accA, tA0, tA1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, filter_tiny_norm(v.dim), ec, rndA, rhoA, alvA, cqu, cqu_n, cqu_out, du);
-        if (hasB) filter_epilogue<METRIC>(v, accB, tB0, tB1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, filter_tiny_norm(v.dim), ec, rndB, rhoB, alvB, cqu, cqu_n, cqu_out, du);
+        {   // the eight row blocks one after the other (see filter_epilogue, NI == 1), ONE dense pass for the group
+            uint32_t n = 0;
+            const float tiny = filter_tiny_norm(v.dim);
+#define QV_X2_BLK(AA, T0, T1, RR, HH, LL, JJ) filter_epilogue_block<METRIC, 1, 4, JJ>(AA, T0, T1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, tiny, ec, RR, HH, LL, cqu, cqu_n, cqu_out, du, n)
+            QV_X2_BLK(accA, tA0, tA1, rndA, rhoA, alvA, 0); QV_X2_BLK(accA, tA0, tA1, rndA, rhoA, alvA, 1);
+            QV_X2_BLK(accA, tA0, tA1, rndA, rhoA, alvA, 2); QV_X2_BLK(accA, tA0, tA1, rndA, rhoA, alvA, 3);
+            if (hasB) {
+                QV_X2_BLK(accB, tB0, tB1, rndB, rhoB, alvB, 0); QV_X2_BLK(accB, tB0, tB1, rndB, rhoB, alvB, 1);
+                QV_X2_BLK(accB, tB0, tB1, rndB, rhoB, alvB, 2); QV_X2_BLK(accB, tB0, tB1, rndB, rhoB, alvB, 3);
+            }
+#undef QV_X2_BLK
+            filter_epilogue_finish<METRIC>(s_c, s_m, 32 * wave, 256 * qb256 + 32 * wave, cqu, cqu_n, cqu_out, du, n);
+        }
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
