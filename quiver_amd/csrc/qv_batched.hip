@@ -1395,6 +1395,17 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
 #pragma unroll
             for (int k8 = 0; k8 < UNR; k8++) pstep(st + k8, k8);
         }
+#if defined(QV_DBG_EPI) && QV_DBG_EPI == 1                               // measurement build: no epilogue (the accumulators stay live through one compare)
+        {
+            float sdbg = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) sdbg += accA[0][j][e] + accB[0][j][e];
+            if (sdbg == 1.2345678f) cand_cnt[0] = 1;
+            continue;
+        }
+#endif
         {   // the eight row blocks one after the other (see filter_epilogue, NI == 1), ONE dense pass for the group
             uint32_t n = 0;
             const float tiny = filter_tiny_norm(v.dim);
