@@ -203,7 +203,7 @@ def compact_line(out, sidecar=None):
             if isinstance(line.get(k), dict):
                 line[k] = {kk: (vv[:80] if isinstance(vv, str) else vv) for kk, vv in line[k].items()}
     if out.get("also"):                                    # the extras get what is left; the sidecar has all of them
-        line["also"] = compact_also(out["also"], MAX_LINE - len(dumps()) - 16)
+        line["also"] = compact_also(out["also"], MAX_LINE - len(dumps()) - 64)      # (the key, its braces and the shed counter come on top)
     text = dumps()
     assert len(text) <= MAX_LINE, len(text)
     return text
