@@ -1356,9 +1356,21 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
         // step s: barrier (steps s and s+1 are published); publish step s+2 (requested RING steps ago) and re-request its ring slot (rows of
         // step s+2+RING); request the query operand of step s+AR-1; read the B operands of step s and multiply.  One memory or LDS
         // instruction per matrix-instruction gap, the LDS write first (see k_bf16x1_filter_w8).
+#if defined(QV_DBG_STAMP)
+        const bool stamping = blockIdx.x == 7 && g == blockIdx.x / wgs_per_group + 3 * stride;
+        uint64_t stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define QV_XSTAMP(i) if (stamping && k8 == 2) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define QV_XSTAMP(i)
+#endif
         auto pstep = [&](uint32_t s_, int k8) {
             __builtin_amdgcn_sched_barrier(0);
+            QV_XSTAMP(0)
             __syncthreads();
+#if defined(QV_DBG_STAMP)
+            if (stamping && k8 == 3) { stamp[6] = __builtin_amdgcn_s_memtime(); }
+#endif
+            QV_XSTAMP(1)
             publish(r[(k8 + 2) & (RING - 1)], (uint32_t)(k8 + 2) & 3);
             if (s_ + (AR - 1) == rounds) ap = a0;
             load_a_run(qa[(k8 + AR - 1) & (AR - 1)]);                // before the row requests: waiting for a step's query operand then waits for no row younger than the ones this step publishes
@@ -1368,11 +1380,22 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
 #pragma unroll
             for (int j = 0; j < 8; j++) b[j] = *reinterpret_cast<const uint4*>(&s_b[(uint32_t)k8 & 3][j][lane * 16]);
             const bf8 ah = __builtin_bit_cast(bf8, qa[k8 & (AR - 1)]);
+#if defined(QV_DBG_STAMP)
+            QV_XSTAMP(2)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            QV_XSTAMP(3)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            QV_XSTAMP(4)
+#endif
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 accA[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf8, b[j]), accA[0][j], 0, 0, 0);
                 accB[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf8, b[4 + j]), accB[0][j], 0, 0, 0);
             }
+#if defined(QV_DBG_STAMP)
+            QV_XSTAMP(5)
+#endif
+#if !defined(QV_DBG_STAMP)
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // the first two B operands
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);       // the conversion (4 VALU)
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // ... and the LDS write of step s+2
@@ -1389,12 +1412,18 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // row request
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         for (uint32_t st = 0; st < rounds; st += UNR) {
 #pragma unroll
             for (int k8 = 0; k8 < UNR; k8++) pstep(st + k8, k8);
         }
+#if defined(QV_DBG_STAMP)
+        if (stamping && lane == 0)
+            printf("x2 stamp wave %u: barrier-in 0, barrier-out %llu, requests + LDS ops issued %llu, A operand + rows to publish here %llu, B operands here %llu, 8 mfma issued %llu, next step's barrier-in %llu\n", wave,
+                   stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0]);
+#endif
 #if defined(QV_DBG_EPI) && QV_DBG_EPI == 1                               // measurement build: no epilogue (the accumulators stay live through one compare)
         {
             float sdbg = 0.f;
