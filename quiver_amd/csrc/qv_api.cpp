@@ -364,8 +364,25 @@ static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, ui
         if (e != hipSuccess) return fail(QV_ERR_DEVICE, "flat scan launch failed: %s", hipGetErrorString(e));
         return QV_OK;
     }
-    // full-ranking path (k > 64, e.g. filtered search asking for k = N, collection.go:679-682),
-    // also used when the output stride differs from the list length
+    // 64 < k <= 8192 (the negative-example branches fetch max(2k, 30), hybrid_index.go:516-522; BatchSearch takes any k,
+    // :677-811), and any shorter list whose output stride differs from its length: one key per row, then a radix SELECT
+    if (kk > (uint32_t)qv::kMaxFusedK && kk <= (uint32_t)qv::kMaxWideK) {
+        // up to 128: the scan's own stream with 2 keys per lane in the wave's list, then a selection over the waves' lists
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (idx->profiling && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {
+            std::lock_guard<std::mutex> g(idx->prof_mu);
+            idx->prof_events.emplace_back(ev0, ev1);
+        }
+        hipError_t e = qv::launch_flat_wide(v, plan, d_queries, nq, kk, k_stride, ws, d_rows_out, d_dist_out, s, ev0, ev1);
+        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "wide scan launch failed: %s", hipGetErrorString(e));
+        return QV_OK;
+    }
+    if (kk <= (uint32_t)qv::kMaxSelectK) {
+        hipError_t e = qv::launch_flat_select(v, plan, d_queries, nq, kk, k_stride, ws, d_rows_out, d_dist_out, s);
+        if (e != hipSuccess) return fail(QV_ERR_DEVICE, "scan + select launch failed: %s", hipGetErrorString(e));
+        return QV_OK;
+    }
+    // full-ranking path (e.g. a filtered search asking for k = N, collection.go:679-682)
     for (uint32_t q = 0; q < nq; q++) {
         hipError_t e = qv::launch_flat_fullsort(v, plan, d_queries + (size_t)q * idx->dim, k_stride, ws,
                                                 d_rows_out + (size_t)q * k_stride, d_dist_out + (size_t)q * k_stride, s);
@@ -379,6 +396,8 @@ static size_t search_ws_bytes(const qv_index* idx, uint32_t nq, uint32_t kk, uin
     const qv::ScanPlan plan = qv::plan_scan(n_tiles, idx->cus);
     if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride)   // partial lists + the multi-query kernels' query blocks
         return qv::scan_workspace_bytes(plan, nq, kk) + std::max((size_t)(nq + 16) * idx->dim4 * 4 * sizeof(double), qv::mq64_workspace_bytes(nq, idx->dim4));
+    if (kk > (uint32_t)qv::kMaxFusedK && kk <= (uint32_t)qv::kMaxWideK) return qv::flat_wide_workspace_bytes(plan, nq, kk);
+    if (kk <= (uint32_t)qv::kMaxSelectK) return qv::flat_select_workspace_bytes(n_tiles, nq, kk);
     return qv::full_sort_workspace_bytes(n_tiles);
 }
 

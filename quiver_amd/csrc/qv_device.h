@@ -23,6 +23,8 @@ namespace qv {
 
 constexpr int kTileRows = 64;          // one wavefront
 constexpr int kMaxFusedK = 64;         // wave-resident top-k list: one key per lane
+constexpr int kMaxWideK = 128;         // wave-resident list of 2 keys per lane (k_flat_scan_wide) + selection over the waves' lists
+constexpr int kMaxSelectK = 8192;      // one key per row + radix select (qv_select.hip): above it, the full ranking (qv_rank.hip)
 constexpr uint64_t kDeadKey = ~0ull;
 
 struct IndexView {
@@ -125,6 +127,11 @@ hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases
 size_t merge_ranked_workspace_bytes(uint64_t n_keys);
 hipError_t launch_merge_ranked(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t q, uint32_t kcap, uint32_t planes,
                                uint32_t k_out, void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
+// The merge for kMaxFusedK < k_out <= kMaxSelectK, every query of the batch in one go: keys of all gathered entries, then the radix
+// selection of the kk = min(k_out, valid entries) smallest (qv_select.hip) — 6 launches for the batch instead of 18 per query.
+size_t merge_select_workspace_bytes(uint32_t n_lists, uint32_t nq, uint32_t kcap, uint32_t k_out);
+hipError_t launch_merge_select(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t kcap, uint32_t planes,
+                               uint32_t k_out, uint32_t kk, void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 // payload lookup after a merge: out[i] = payload plane `plane` of the list entry that produced merged global row rows[i]
 // (shard = the one whose base range holds the row; entry found by its local row), +inf for padding rows
 hipError_t launch_lookup_payload(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t q, uint32_t kcap, uint32_t planes,
@@ -156,6 +163,28 @@ size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4);   // workspace for the conve
 hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
                                    const HnswOpts& o, uint32_t grid, uint32_t* d_rows_out, float* d_dist_out,
                                    uint32_t* d_count_out, uint32_t* d_evals_out, hipStream_t s);
+
+// Selection path, kMaxFusedK < k <= kMaxSelectK (qv_select.hip): the kk smallest of each query's n keys (d_keys + q * stride; n and
+// stride even), written as [nq][k_stride] rows / distances (padded).  ordered: among keys of equal distance, place in the array
+// ascends with the low word (true for the keys of a scan, where place == row) — ties beyond the sort's capacity are then taken
+// front to back; otherwise they are settled by three more radix windows on the low word.
+// window0_counted: the kernel that made the keys also counted the selection's first window (select_prepare before it: qv_select.h)
+struct SelState;
+uint32_t select_cap(uint32_t kk);
+size_t select_workspace_bytes(uint32_t nq, uint32_t kk);
+hipError_t select_prepare(void* d_ws, uint32_t nq, uint32_t kk, SelState** st_out, uint32_t** hist_out, hipStream_t s);
+hipError_t launch_select_topk(const uint64_t* d_keys, size_t stride, uint32_t n, uint32_t nq, uint32_t kk, uint32_t k_stride, void* d_ws,
+                              uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, bool window0_counted = false, bool ordered = true);
+// 64 < kk <= kMaxWideK: the scan with a list of 2 keys per lane (same stream as launch_flat_topk, no key per row written),
+// then the selection over the waves' lists.  ev0 / ev1 as launch_flat_topk.
+size_t flat_wide_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t kk);
+hipError_t launch_flat_wide(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                            void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// scan + selection for nq queries at list length kk <= kMaxSelectK: every query's keys (one 8-byte key per row, k_flat_keys), then
+// launch_select_topk; queries go in groups so that the keys of a group stay under flat_select_group_bytes
+size_t flat_select_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk);
+hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                              void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 
 // Full ranking path (any k): all distances -> 64-bit keys -> stable radix sort -> first k.
 // d_keys_a/d_keys_b: two buffers of n_tiles*64 u64; d_hist: radix histogram workspace.

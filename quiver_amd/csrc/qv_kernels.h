@@ -79,6 +79,32 @@ __device__ __forceinline__ void list_insert(uint64_t& list, uint64_t& thr, uint6
     }
 }
 
+// The same list with R keys per lane: slot r * 64 + lane holds the (r * 64 + lane)-th smallest key seen so far — 64 R slots for
+// k up to 64 R (k_flat_scan_wide: 64 < k <= 256).  An insert shifts every slot from its position up by one: one DPP shift per
+// register, lane 0 of register r taking lane 63 of register r - 1.  kth = k - 1, the slot whose key is the admission threshold.
+template <int R>
+__device__ __forceinline__ void wide_insert(uint64_t (&list)[R], uint64_t& thr, uint64_t key, uint32_t kth, uint32_t lane) {
+    uint64_t mask = __ballot(key < thr);
+    while (mask) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint64_t c = readlane64(key, src);
+        if (c >= thr) continue;                      // threshold tightened since the ballot
+        uint32_t pos = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) pos += (uint32_t)__builtin_popcountll(__ballot(list[r] < c));
+#pragma unroll
+        for (int r = R - 1; r >= 0; r--) {           // top register first: register r - 1 is still the old one when its lane 63 is read
+            uint64_t up = wave_shr1(list[r]);
+            if (r > 0) { const uint64_t carry = readlane64(list[r - 1], 63); if (lane == 0) up = carry; }
+            const uint32_t slot = (uint32_t)r * 64 + lane;
+            list[r] = slot > pos ? up : (slot == pos ? c : list[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) if ((uint32_t)r == (kth >> 6)) thr = readlane64(list[r], kth & 63);
+    }
+}
+
 // ascending bitonic sort of one key per lane across the wave (21 compare-exchange steps)
 __device__ __forceinline__ uint64_t wave_sort64(uint64_t key, uint32_t lane) {
 #pragma unroll

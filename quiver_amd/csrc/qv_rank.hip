@@ -1,34 +1,71 @@
 // qv_rank.hip — full ranking: all keys + stable LSD radix sort
 // (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
-#include "qv_kernels.h"
+#include "qv_select.h"
 
 namespace qv {
 
 // ---------------------------------------------------------------- full ranking -----
 // all keys: keys[row] = (ord(dist), row) or dead
-template <int M, int U>
+// grid = (workgroups, queries): query blockIdx.y, its keys at keys + blockIdx.y * n_tiles * 64
+// HIST: the kernel also counts the first window of the radix selection (qv_select.h) — a tile's 64 keys go into the workgroup's
+// LDS histogram as they are made, so the selection does not read all the keys once more for it (107 us at 10M rows)
+//
+// The keys leave in BATCHES.  A store per tile cost 0.31 ms of a 4.8 ms pass at 10M x 768 (measured with the store compiled out:
+// 4.48 ms) although it is 0.26 % of the bytes: vector-memory operations retire in issue order per wave, so the next tile's first
+// rows cannot be consumed before the store is acknowledged — one such bubble per tile and wave.  A wave parks kKeyBatch tiles'
+// keys in LDS and writes them back to back, non-temporally (4.70 ms), and the end-of-window step no longer fences (qv_select.h:
+// an agent-scope fence behind 80 MB of dirty keys was another 0.2 ms): 4.47 ms, the pass's rate without any store.
+constexpr int kKeyBatch = 8;
+// tiles a wave parks: kKeyBatch, fewer when a very wide query (up to 128 KiB of LDS at 16384 float64 dimensions) leaves less room
+static uint32_t key_batch(int metric, uint32_t dim4, bool hist) {
+    const size_t room = (size_t)160 * 1024 - 1024 - query_lds_bytes(metric, dim4) - (hist ? (size_t)kSelBins * sizeof(uint32_t) : 0);
+    const size_t per = (size_t)kScanWaves * 64 * sizeof(uint64_t);
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(kKeyBatch, room / per));
+}
+template <int M, int U, bool HIST>
 __global__ void __launch_bounds__(kScanBlock)
-k_flat_keys(IndexView v, const float* __restrict__ query, uint64_t* __restrict__ keys) {
+k_flat_keys(IndexView v, const float* __restrict__ queries, uint64_t* __restrict__ keys_all, SelState* __restrict__ st, uint32_t* __restrict__ hist,
+            uint32_t k, uint32_t cap, uint32_t batch /* tiles parked per wave: key_batch() */) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
+    uint64_t* kb_all = reinterpret_cast<uint64_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);   // [kScanWaves][batch][64]
+    uint32_t* h = reinterpret_cast<uint32_t*>(kb_all + (size_t)kScanWaves * batch * 64);                         // [kSelBins] (HIST)
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint64_t* kb = kb_all + (size_t)wave * batch * 64;
+    const float* query = queries + (size_t)blockIdx.y * v.dim;
+    uint64_t* keys = keys_all + (size_t)blockIdx.y * v.n_tiles * 64;
     stage_query<M>(q_lds, query, v.dim, v.dim4);
+    if constexpr (HIST) for (uint32_t b = threadIdx.x; b < (uint32_t)kSelBins; b += blockDim.x) h[b] = 0;
     __syncthreads();
     const QConst qc = query_const<M>(q_lds, v.dim);
     const uint32_t tw = gridDim.x * kScanWaves;
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    uint32_t t_first = blockIdx.x * kScanWaves + wave, parked = 0;    // first tile of the batch in LDS, tiles parked
+    auto flush = [&]() {
+        // (non-temporal: 4.47 against 4.52 ms at 10M x 768 — the keys are read back by other CUs, nothing of them is worth keeping in this L2)
+        for (uint32_t j = 0; j < parked; j++) __builtin_nontemporal_store(kb[j * 64 + lane], &keys[(size_t)(t_first + j * tw) * 64 + lane]);
+        t_first += parked * tw; parked = 0;
+    };
     for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
         const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
-        typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
+        // (the row's norm and the tile's live word are requested FIRST: behind the pinned blocks they would be a round trip of their own per tile)
         const uint32_t row = t * 64 + lane;
         double rn = 0.0;
         if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        const uint64_t am = v.alive[t];
+        // BAR: the block's 16 requests pinned ahead of its arithmetic for every metric — left to itself hipcc waits for each of
+        // the first six chunks of a block alone here
+        typename MT<M>::A acc = row_accumulate<M, U, false, true>(p, 64, q_lds, v.dim4);
         float dist = finalize<M>(acc, qc, rn);
-        uint64_t am = v.alive[t];
-        keys[row] = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+        const uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+        kb[parked * 64 + lane] = key;                                  // (a lane reads back only what it wrote: no barrier)
+        if (++parked == batch) flush();
+        if constexpr (HIST) sel_count<0>(h, key, true, lane);
     }
+    flush();
+    if constexpr (HIST) sel_finish_window<0>(h, hist + (size_t)blockIdx.y * kSelBins, st + blockIdx.y, gridDim.x, k, cap);
 }
 
 // LSD radix sort of 64-bit keys, 8 bits per pass over the 32 distance bits only (the
@@ -182,6 +219,42 @@ k_shard_keys(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ b
     keys[i] = row == 0xFFFFFFFFu ? kDeadKey : make_key(__uint_as_float(blk[(size_t)nq * kcap + j]), bases[g] + row);
 }
 
+// the same keys for every query of the batch at once (grid.y = query), each query's keys padded to an even count `stride`:
+// what the radix SELECT takes (k <= kMaxSelectK).  The order inside a query's keys is (shard, place in the shard's list), i.e.
+// ascending global row among equal distances — the order the selection's tie rule needs.
+__global__ void __launch_bounds__(256)
+k_shard_keys_all(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ bases, uint32_t n_lists, uint32_t nq, uint32_t kcap,
+                 uint32_t planes, uint32_t stride, uint64_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+    if (i >= stride) return;
+    uint64_t key = kDeadKey;
+    if (i < n_lists * kcap) {
+        const uint32_t g = i / kcap, j = i - g * kcap;
+        const uint32_t* blk = packed + (size_t)g * planes * nq * kcap + (size_t)q * kcap;
+        const uint32_t row = blk[j];
+        if (row != 0xFFFFFFFFu) key = make_key(__uint_as_float(blk[(size_t)nq * kcap + j]), bases[g] + row);
+    }
+    keys[(size_t)q * stride + i] = key;
+}
+
+size_t merge_select_workspace_bytes(uint32_t n_lists, uint32_t nq, uint32_t kcap, uint32_t k_out) {
+    const size_t stride = ((size_t)n_lists * kcap + 1) & ~(size_t)1;
+    return (size_t)nq * stride * sizeof(uint64_t) + 256 + select_workspace_bytes(nq, k_out);
+}
+
+// merge of the gathered per-shard lists for kMaxFusedK < k_out <= kMaxSelectK, all nq queries in one go: keys, then the radix
+// selection (qv_select.hip) of the min(k_out, valid entries) smallest; outputs [nq][k_out], padded
+hipError_t launch_merge_select(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t kcap, uint32_t planes,
+                               uint32_t k_out, uint32_t kk, void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    const uint64_t n64 = (uint64_t)n_lists * kcap;
+    if (n_lists == 0 || kcap == 0 || k_out == 0 || kk == 0 || kk > k_out || planes < 2 || n64 > 0x7FFFFF00ull || kk > n64) return hipErrorInvalidValue;
+    const uint32_t stride = ((uint32_t)n64 + 1u) & ~1u;
+    uint64_t* keys = static_cast<uint64_t*>(d_ws);
+    void* sel_ws = static_cast<char*>(d_ws) + ((size_t)nq * stride * sizeof(uint64_t) + 255) / 256 * 256;
+    hipLaunchKernelGGL(k_shard_keys_all, dim3((stride + 255) / 256, nq), dim3(256), 0, s, d_packed, d_bases, n_lists, nq, kcap, planes, stride, keys);
+    return launch_select_topk(keys, stride, stride, nq, kk, k_out, sel_ws, d_rows_out, d_dist_out, s);
+}
+
 size_t merge_ranked_workspace_bytes(uint64_t n_keys) {
     return 2 * n_keys * sizeof(uint64_t) + radix_hist_words((uint32_t)n_keys) * sizeof(uint32_t) + 256;
 }
@@ -229,6 +302,42 @@ hipError_t launch_lookup_payload(const uint32_t* d_packed, const uint32_t* d_bas
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- scan + selection (kMaxFusedK < k <= kMaxSelectK) -----
+// keys of a group of queries live together: 1 GiB of them at most (128 queries of 1M rows, 13 of 10M)
+static uint32_t flat_select_group(uint32_t n_tiles, uint32_t nq) {
+    const size_t per_query = (size_t)n_tiles * 64 * sizeof(uint64_t);
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, ((size_t)1 << 30) / per_query));
+}
+size_t flat_select_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk) {
+    const uint32_t g = flat_select_group(n_tiles, nq);
+    return (size_t)g * n_tiles * 64 * sizeof(uint64_t) + 256 + select_workspace_bytes(g, kk);
+}
+hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                              void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    const uint32_t n = v.n_tiles * 64;
+    const uint32_t g = flat_select_group(v.n_tiles, nq);
+    uint64_t* keys = static_cast<uint64_t*>(d_ws);
+    void* sel_ws = static_cast<char*>(d_ws) + ((size_t)g * n * sizeof(uint64_t) + 255) / 256 * 256;
+    const uint32_t batch = key_batch(v.metric, v.dim4, true);
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * batch * 64 * sizeof(uint64_t) + (size_t)kSelBins * sizeof(uint32_t);
+    for (uint32_t q0 = 0; q0 < nq; q0 += g) {
+        const uint32_t m = std::min(g, nq - q0);
+        SelState* st = nullptr; uint32_t* hist = nullptr;
+        hipError_t e = select_prepare(sel_ws, m, kk, &st, &hist, s);     // states and histograms zeroed: the keys kernel counts window 0
+        if (e != hipSuccess) return e;
+        QV_DISPATCH_METRIC(v.metric, {
+            e = set_lds(k_flat_keys<MM, kUnroll, true>, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_flat_keys<MM, kUnroll, true>), dim3(p.grid, m), dim3(p.block), lds, s, v, d_queries + (size_t)q0 * v.dim, keys, st, hist, kk, select_cap(kk), batch);
+        });
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = launch_select_topk(keys, n, n, m, kk, k_stride, sel_ws, d_rows_out + (size_t)q0 * k_stride, d_dist_out + (size_t)q0 * k_stride, s, true);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 size_t full_sort_workspace_bytes(uint32_t n_tiles) {
     size_t n = (size_t)n_tiles * 64;
     size_t nblocks = (n + kRadixTile - 1) / kRadixTile;
@@ -241,12 +350,13 @@ hipError_t launch_flat_fullsort(const IndexView& v, const ScanPlan& p, const flo
     uint64_t* ka = static_cast<uint64_t*>(d_ws);
     uint64_t* kb = ka + n;
     uint32_t* hist = reinterpret_cast<uint32_t*>(kb + n);
-    const size_t lds = query_lds_bytes(v.metric, v.dim4);
+    const uint32_t batch = key_batch(v.metric, v.dim4, false);
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * batch * 64 * sizeof(uint64_t);
     hipError_t e = hipSuccess;
     QV_DISPATCH_METRIC(v.metric, {
-        e = set_lds(k_flat_keys<MM, kUnroll>, lds);
+        e = set_lds(k_flat_keys<MM, kUnroll, false>, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_flat_keys<MM, kUnroll>), dim3(p.grid), dim3(p.block), lds, s, v, d_query, ka);
+        hipLaunchKernelGGL((k_flat_keys<MM, kUnroll, false>), dim3(p.grid), dim3(p.block), lds, s, v, d_query, ka, (SelState*)nullptr, (uint32_t*)nullptr, 0u, 0u, batch);
     });
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -64,6 +64,63 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
     }
 }
 
+// ---------------------------------------------------------------- flat scan, 64 < k <= 128 --
+// The negative-example branches of the reference fetch max(2k, 30) results (hybrid_index.go:516-522, hnsw/adapter.go:353-359):
+// k = 50 is a 100-key search.  Same stream, same arithmetic as k_flat_scan; the wave's list holds R keys per lane
+// (wide_insert), and every WAVE writes its 64 R slots — a workgroup merge through one wave's serial inserts would cost more
+// than the scan of a short corpus.  (Four keys per lane, k <= 256, measured SLOWER than a key per row + selection: 5.05 against 4.80 ms
+// at 10M x 768 — ~1000 inserts per wave, each a serial ~100-instruction sequence on a wave that has one partner on its SIMD.)
+// The radix selection (qv_select.hip) then takes the k best of the waves' lists: all keys a
+// wave saw beyond its 64 R best are beaten by 64 R >= k others, so the lists hold the answer.
+// Output: lists[((q * gridDim.x + blockIdx.x) * kScanWaves + wave) * 64 R + r * 64 + lane].
+template <int M, int U, int R>
+__global__ void __launch_bounds__(kScanBlock)
+k_flat_scan_wide(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t* __restrict__ lists) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qi = blockIdx.y;
+    stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
+    __syncthreads();
+
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const uint32_t kth = k - 1;
+    uint64_t list[R], thr = kDeadKey;
+#pragma unroll
+    for (int r = 0; r < R; r++) list[r] = kDeadKey;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+
+    auto finish_tile = [&](uint32_t t, typename MT<M>::A acc, bool first) {
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        float dist = finalize<M>(acc, qc, rn);
+        uint64_t am = v.alive[t];                                     // wave-uniform
+        uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+        if (first) list[0] = wave_sort64(key, lane);                  // empty list: sort the tile outright (k > 64: the threshold stays open)
+        else wide_insert<R>(list, thr, key, kth, lane);
+    };
+
+    uint32_t t = blockIdx.x * kScanWaves + wave;
+    if (t < v.n_tiles) {                                              // first tile: query norm rides along
+        typename MT<M>::A qn2 = 0;
+        typename MT<M>::A acc = row_accumulate<M, U, true>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4, &qn2);
+        qc = qconst_from_norm2<M>(qn2);
+        finish_tile(t, acc, true);
+        t += tw;
+    }
+    for (; t < v.n_tiles; t += tw) {
+        typename MT<M>::A acc = row_accumulate<M, U, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4);
+        finish_tile(t, acc, false);
+    }
+    uint64_t* out = lists + (((size_t)qi * gridDim.x + blockIdx.x) * kScanWaves + wave) * (64 * R);
+#pragma unroll
+    for (int r = 0; r < R; r++) out[r * 64 + lane] = list[r];
+}
+
 // ---------------------------------------------------------------- multi-query scan --
 // QB queries share ONE pass over the corpus (HybridIndex.BatchSearch, hybrid_index.go:677-811,
 // is Q independent exact searches; here every 16-byte row chunk a lane loads is used for QB
@@ -473,6 +530,37 @@ hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases
     uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
     hipLaunchKernelGGL(k_merge_shards, dim3(nq), dim3(mblock), 0, s, d_packed, d_bases, n_lists, nq, k, d_rows_out, d_dist_out, planes);
     return hipGetLastError();
+}
+
+// 64 < kk <= kMaxWideK: the scan with R keys per lane, then the selection over the waves' lists
+static uint32_t wide_regs(uint32_t) { return 2u; }
+size_t flat_wide_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t kk) {
+    const size_t n = (size_t)p.grid * kScanWaves * 64 * wide_regs(kk);
+    return (size_t)nq * n * sizeof(uint64_t) + 256 + select_workspace_bytes(nq, kk);
+}
+hipError_t launch_flat_wide(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                            void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (kk <= (uint32_t)kMaxFusedK || kk > (uint32_t)kMaxWideK || nq == 0 || kk > k_stride) return hipErrorInvalidValue;
+    const uint32_t R = wide_regs(kk);
+    const uint32_t n = p.grid * kScanWaves * 64 * R;
+    uint64_t* lists = static_cast<uint64_t*>(d_ws);
+    void* sel_ws = static_cast<char*>(d_ws) + ((size_t)nq * n * sizeof(uint64_t) + 255) / 256 * 256;
+    const size_t lds = query_lds_bytes(v.metric, v.dim4);
+    hipError_t e = hipSuccess;
+#define QV_WIDE(RR)                                                                                              \
+    QV_DISPATCH_METRIC(v.metric, {                                                                                \
+        e = set_lds(k_flat_scan_wide<MM, kUnroll, RR>, lds);                                                      \
+        if (e != hipSuccess) return e;                                                                            \
+        if (ev0) (void)hipEventRecord(ev0, s);                                                                    \
+        hipLaunchKernelGGL((k_flat_scan_wide<MM, kUnroll, RR>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, kk, lists); \
+        if (ev1) (void)hipEventRecord(ev1, s);                                                                    \
+    })
+    QV_WIDE(2);
+#undef QV_WIDE
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // the lists are not in row order: ties beyond the selection's capacity are settled on the row bits (ordered = false)
+    return launch_select_topk(lists, n, n, nq, kk, k_stride, sel_ws, d_rows_out, d_dist_out, s, false, false);
 }
 
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,

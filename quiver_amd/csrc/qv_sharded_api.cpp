@@ -343,7 +343,12 @@ int search_ctx(qv_sharded* s, CallCtx* c, const float* queries_host, const float
     const uint32_t* bases = static_cast<const uint32_t*>(s->d_bases.p);
     hipError_t e = hipSuccess;
     if (!ranked) e = qv::launch_merge_shards(gath, bases, G, nq, k, o_rows, o_dist, c0.stream, planes);
-    else {
+    else if (k <= (uint32_t)qv::kMaxSelectK) {
+        // 64 < k <= 8192 (max(2k, 30) of the negative-example branches, any-k BatchSearch): every shard SELECTED its kcap best
+        // (qv_index_search_device), and the first device selects the k best of the G * kcap gathered keys, all queries at once
+        if ((rc = c->d_sort.ensure(qv::merge_select_workspace_bytes(G, nq, kcap, k)))) return rc;
+        e = qv::launch_merge_select(gath, bases, G, nq, kcap, planes, k, (uint32_t)kk_total, c->d_sort.p, o_rows, o_dist, c0.stream);
+    } else {
         if ((rc = c->d_sort.ensure(qv::merge_ranked_workspace_bytes((uint64_t)G * kcap)))) return rc;
         for (uint32_t q = 0; q < nq && e == hipSuccess; q++)
             e = qv::launch_merge_ranked(gath, bases, G, nq, q, kcap, planes, k, c->d_sort.p, o_rows + (size_t)q * k, o_dist + (size_t)q * k, c0.stream);
