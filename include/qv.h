@@ -134,7 +134,11 @@ int      qv_index_metric(const qv_index* idx);
  *   rows_out [nq][k], dist_out [nq][k]  caller-allocated; entries past count are
  *            row = 0xFFFFFFFF, dist = +inf
  *   count_out[nq] = min(k, live size); empty index -> 0 results, QV_OK (exact.go:96-98)
- * Order of checks follows exact.go:96-106: empty -> ok; then k <= 0 -> error. */
+ * Order of checks follows exact.go:96-106: empty -> ok; then k <= 0 -> error.
+ * How k is served (same result whichever applies): up to 64 results the scan keeps a sorted list per wavefront; up to 128 —
+ * the negative-example branches fetch max(2k, 30), hybrid_index.go:516-522 — two keys per lane in that list; up to 8192 one
+ * key per row and a radix SELECTION of the k smallest; beyond (k = Size() of a filtered search) the full radix ranking.
+ * Batches of 9+ queries go through the matrix-core filter + exact re-score up to 2048 results per query. */
 int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out);
 
@@ -167,7 +171,8 @@ int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, ui
                             uint32_t* rows_out, float* dist_out, uint32_t* count_out);
 
 /* Which filter kernel the batched path of this index uses: QV_FILTER_AUTO (the rule above), QV_FILTER_FP32_MFMA (the dense
- * fp32 GEMM on v_mfma_f32_32x32x2_f32, BASELINE configs[2] as written), QV_FILTER_BF16X3, QV_FILTER_BF16X1.  Results are
+ * fp32 GEMM on v_mfma_f32_32x32x2_f32, BASELINE configs[2] as written), QV_FILTER_BF16X3, QV_FILTER_BF16X1, or QV_FILTER_OFF
+ * (qv_index_search never takes the batched path; qv_index_search_batched* answer QV_ERR_UNSUPPORTED / fall back).  Results are
  * identical whichever runs (the filter only selects candidates for the exact re-score).  Needs external exclusion against
  * running searches, like the mutations.  The environment variable QV_MFMA_FILTER (read once per process) sets the default of
  * indexes that never call this. */
@@ -175,12 +180,13 @@ int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, ui
 #define QV_FILTER_FP32_MFMA 1
 #define QV_FILTER_BF16X3    2
 #define QV_FILTER_BF16X1    3
+#define QV_FILTER_OFF       4   /* no filter: every batch of this index takes the exact scans (what tests of those scans choose) */
 int qv_index_set_filter(qv_index* idx, int filter);
 
 /* Device-pointer form of the batched path: enqueues on `stream`, no sync.  d_redo_flags_out[nq]
  * (uint32) is set to 1 for queries whose candidate buffer overflowed: the caller must redo those
  * with qv_index_search_device (their result rows are unspecified).  Returns QV_ERR_UNSUPPORTED when
- * the MFMA path does not apply (metric, k > 64, small corpus, nq < 32): use qv_index_search_device. */
+ * the MFMA path does not apply (metric, k > 2048, small corpus, too few queries): use qv_index_search_device. */
 int qv_index_search_batched_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
                                    uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_redo_flags_out, void* stream);
 
@@ -308,7 +314,9 @@ int qv_graph_stats(const qv_graph* g, double* build_seconds, uint64_t* build_bat
  *   qv_sharded_add   cuts a batch into one contiguous piece per shard so that the shards' fill evens out
  *                    (qv_sharded_plan_add is the rule); global_rows_out[i] = id of rows[i] (the host maps string ids);
  *                    all-or-nothing like qv_index_add
- *   any k            k <= 64: per-shard fused top-k + one wavefront-list merge.  k > 64 (a filtered Collection.Search asks
+ *   any k            k <= 64: per-shard fused top-k + one wavefront-list merge.  Up to 8192 every shard SELECTS its
+ *                    min(k, rows) best (as qv_index_search_device does) and one radix selection on the first device takes
+ *                    the k best of the gathered lists, the whole batch at once.  Beyond (a filtered Collection.Search asks
  *                    for k = Index.Size(), collection.go:679-682): every shard ranks its rows (radix sort), the sorted runs
  *                    are exchanged and one stable radix sort on the first device merges them
  *   flags            QV_FLAG_ROWMAJOR and QV_FLAG_BF16_ROWS pass through to the shards; QV_SHARDED_PEER_COPY replaces the collective with

@@ -694,7 +694,7 @@ int qv_merge_topk_shards_device(const uint32_t* d_packed_lists, const uint32_t* 
 
 int qv_index_set_filter(qv_index* idx, int filter) {
     if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
-    if (filter < 0 || filter > 3) return fail(QV_ERR_INVALID_ARG, "filter must be 0 (automatic), 1 (fp32 MFMA), 2 (bfloat16 x 3) or 3 (bfloat16 x 1); got %d", filter);
+    if (filter < 0 || filter > QV_FILTER_OFF) return fail(QV_ERR_INVALID_ARG, "filter must be 0 (automatic), 1 (fp32 MFMA), 2 (bfloat16 x 3), 3 (bfloat16 x 1) or 4 (off); got %d", filter);
     idx->filter = filter;
     return QV_OK;
 }

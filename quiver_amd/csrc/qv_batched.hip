@@ -1,7 +1,7 @@
 // qv_batched.hip — batched filter on the matrix cores (fp32 MFMA chain, or three exact-product bfloat16 terms) + exact re-scoring
 // (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
 #include <numeric>
-#include "qv_kernels.h"
+#include "qv_select.h"
 
 namespace qv {
 
@@ -100,9 +100,10 @@ __device__ __forceinline__ uint32_t pack_bf16(float x0, float x1) { const bf2 h 
 __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t dim4,
                             const float* __restrict__ sample_dist /*[nq][k], or [nq][parts][k] ascending partial lists*/, uint32_t parts, uint32_t k, int metric,
                             float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq /*[2][nq_pad]: m_q, b_q*/, float* __restrict__ eq /*[nq_pad][2]*/,
-                            uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what) {
+                            uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what, uint32_t cand_cap) {
     // what: 1 = operand layout only, 2 = filter constants only (needs sample_dist), 3 = both
     const uint32_t q = blockIdx.x;                     // one block per (padded) query
+    if (q == 0 && threadIdx.x == 0) cand_cnt[-1] = cand_cap;           // candidate slots per query, for the filter kernels (CandOut)
     const uint32_t dim4p = (dim4 + 1) & ~1u;           // chunk count padded to even: the MFMA step eats two chunks
     if (!(what & 1)) {
     } else if (bf16x3) {
@@ -209,20 +210,23 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
 constexpr uint32_t kCandQueueWords = 3;                               // {query, row, score bits}
 struct CandQueue { uint32_t* rec; uint32_t cap; };                    // this WAVE's records in LDS (cap >= 64)
 
+// cap: slots per query.  kMfmaCandCap for k <= 64; a batch asking for more per query (k up to kMaxBatchedK) gets batched_cand_cap(k).
+// The filter kernels read it from the word in front of the counters (cand_cnt[-1], written by k_mfma_prep), so that none of their
+// signatures changes with it.
 __device__ __forceinline__ void cand_append_global(uint32_t q, uint32_t row, float score, uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score,
-                                                   uint32_t* __restrict__ cand_cnt) {
+                                                   uint32_t* __restrict__ cand_cnt, uint32_t cap) {
     const uint32_t slot = atomicAdd(&cand_cnt[q], 1u);
-    if (slot < (uint32_t)kMfmaCandCap) {
-        cand_rows[(size_t)q * kMfmaCandCap + slot] = row;
-        cand_score[(size_t)q * kMfmaCandCap + slot] = score;
+    if (slot < cap) {
+        cand_rows[(size_t)q * cap + slot] = row;
+        cand_score[(size_t)q * cap + slot] = score;
     }
 }
-struct CandOut { uint32_t* rows; float* score; uint32_t* cnt; };      // the per-query candidate lists in global memory
+struct CandOut { uint32_t* rows; float* score; uint32_t* cnt; uint32_t cap; };      // the per-query candidate lists in global memory
 // every lane of the wave calls this: the wave's n queued records go to the per-query lists
 __device__ __forceinline__ void cand_flush(const CandQueue& cqu, uint32_t n, const CandOut& out) {
     __threadfence_block();
     for (uint32_t i = lane_id(); i < n; i += 64)
-        cand_append_global(cqu.rec[kCandQueueWords * i], cqu.rec[kCandQueueWords * i + 1], __uint_as_float(cqu.rec[kCandQueueWords * i + 2]), out.rows, out.score, out.cnt);
+        cand_append_global(cqu.rec[kCandQueueWords * i], cqu.rec[kCandQueueWords * i + 1], __uint_as_float(cqu.rec[kCandQueueWords * i + 2]), out.rows, out.score, out.cnt, out.cap);
     __threadfence_block();
 }
 // called by ALL lanes of a wave (converged) with the wave's mask m (non-zero) of the lanes that append their record; n = the queue's fill
@@ -243,7 +247,7 @@ __device__ __forceinline__ void cand_push(const CandQueue& cqu, uint32_t& n, uin
     __shared__ uint32_t name##_rec[(WAVES) * (CAP) * kCandQueueWords];        \
     const CandQueue name{name##_rec + (threadIdx.x >> 6) * (CAP) * kCandQueueWords, (CAP)}; \
     uint32_t name##_n = 0;                                                    \
-    const CandOut name##_out{cand_rows, cand_score, cand_cnt}
+    const CandOut name##_out{cand_rows, cand_score, cand_cnt, cand_cnt[-1]}
 
 // The filter test on a wave's 64 x 128 scores: acc[i][j][r] = S~[query 64*qb64 + 32*i + (r&3)+8*(r>>2)+4*half][row 64*(t0|t1) + 32*(j&1) + l31];
 // a row that may be in some query's top-k goes to that query's candidate list with its score.
@@ -1884,6 +1888,152 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 #undef RSTK
 }
 
+// ---------------------------------------------------------------- batches with 64 < k <= kMaxBatchedK --
+// HybridIndex.BatchSearch takes any k (hybrid_index.go:677-811), and the negative-example branches ask for max(2k, 30)
+// (:516-522).  Up to 64 results per query the wave lists above do every selection; beyond, the same three steps — the sample's
+// bound, the candidates' narrowing, the exact top-k — are radix selections over arrays of keys (qv_select.hip), and the per-query
+// workgroup of k_rescore_select becomes grids over (candidate, query):
+//   k_sample_hist<0>, <1>        the k-th smallest of the sample's upper bounds, to 24 bits (rounded UP to its bucket's edge: a
+//                                 valid bound, 2^-15 looser at most) — two histogram windows straight over the float32 bounds
+//   k_cand_bounds                 every candidate's interval [lo, hi] from its score; keys (hi, slot)
+//   selection                     H = the k-th smallest hi: the true k-th distance is at most H
+//   k_cand_survive                candidates with lo <= H, compacted (typically k + a few dozen of thousands)
+//   k_cand_exact                  their exact distances, the scan's own arithmetic, a lane per row; keys (distance, row)
+//   selection                     the k best of those, in (distance, row) order
+template <int W>
+__global__ void __launch_bounds__(kSelBlock)
+k_sample_hist(const float* __restrict__ bounds, uint32_t srows, uint32_t k, SelState* __restrict__ st, uint32_t* __restrict__ hist) {
+    constexpr int shift = SelWindow<W>::shift;
+    constexpr int wbits = SelWindow<W>::wbits;
+    __shared__ uint32_t h[kSelBins];
+    const uint32_t q = blockIdx.y;
+    SelState* s = st + q;
+    const unsigned long long prefix = W > 0 ? s->prefix : 0ull;
+    SelRun run{0u, 0u};
+    for (uint32_t b = threadIdx.x; b < (uint32_t)kSelBins; b += kSelBlock) h[b] = 0;
+    __syncthreads();
+    const float* src = bounds + (size_t)q * srows;
+    const uint32_t per = ((srows + gridDim.x - 1) / gridDim.x + kSelBlock - 1) / kSelBlock * kSelBlock;
+    const uint32_t lo = blockIdx.x * per, hi = lo + per < srows ? lo + per : srows;
+    for (uint32_t base = lo; base < hi; base += 16 * kSelBlock) {      // sixteen requests per thread and round, lanes contiguous
+        float e[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const uint32_t j = base + (uint32_t)u * kSelBlock + threadIdx.x; e[u] = j < hi ? __builtin_nontemporal_load(&src[j]) : __builtin_inff(); }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            if (base + (uint32_t)u * kSelBlock >= hi) break;
+            const uint32_t j = base + (uint32_t)u * kSelBlock + threadIdx.x;
+            const uint64_t key = (uint64_t)ord_f32(e[u]) << 32;
+            sel_count<W>(h, run, key, j < hi && (W == 0 || (key >> (shift + wbits)) == (prefix >> (shift + wbits))));
+        }
+    }
+    sel_flush(h, run);
+    sel_finish_window<W>(h, hist + (size_t)q * kSelBins, s, gridDim.x, k, 0u);
+}
+// U_q = the upper edge of the 24-bit bucket that holds the k-th smallest bound (+inf when the sample has fewer than k finite ones)
+template <int M>
+__global__ void k_sample_bound_from_state(const SelState* __restrict__ st, uint32_t nq, uint32_t k, float gref, float* __restrict__ sample_dist) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t top = (uint32_t)(st[q].prefix >> 32) | 0xFFu;
+    const float edge = unord_f32(top);
+    sample_dist[(size_t)q * k + (k - 1)] = edge == edge && edge < __builtin_inff() ? sample_bound_finish<M>(edge, gref) : __builtin_inff();
+}
+
+// per query: |q| for the intervals (any order of additions: it only enters bounds with 2e-6 of slack) and, for cosine, the
+// metric's own norm — a chain of dim rounded fmas in element order (distances.go:20) walked by one lane
+template <int M>
+__global__ void __launch_bounds__(64)
+k_cand_qnorms(const float* __restrict__ queries, uint32_t dim, double* __restrict__ qnorms /*[nq][2]: |q| approx, the metric's norm*/) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* ql = reinterpret_cast<float*>(smem);                        // the query, staged with the wave's 64 lanes (one lane walking it from global memory: 30 us)
+    const uint32_t q = blockIdx.x, lane = lane_id();
+    const float* src = queries + (size_t)q * dim;
+    double n2 = 0.0;
+    for (uint32_t i = lane; i < dim; i += 64) { const float x = src[i]; ql[i] = x; const double a = (double)x; n2 = __builtin_fma(a, a, n2); }
+    n2 = wave_sum_f64(n2);
+    __syncthreads();
+    double exact = 0.0;
+    if constexpr (M == QV_COSINE) { if (lane == 0) { double ma = 0.0; for (uint32_t i = 0; i < dim; i++) { const double a = (double)ql[i]; ma = __builtin_fma(a, a, ma); } exact = __builtin_sqrt(ma); } }
+    if (lane == 0) { qnorms[2 * q] = __builtin_sqrt(n2); qnorms[2 * q + 1] = exact; }
+}
+
+// grid (cap / 256, nq)
+template <int M>
+__global__ void __launch_bounds__(256)
+k_cand_bounds(IndexView v, const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_score, const uint32_t* __restrict__ cand_cnt, uint32_t cap,
+              const float* __restrict__ eq, const double* __restrict__ qnorms, uint64_t* __restrict__ keys_hi, float* __restrict__ lo_out,
+              uint32_t* __restrict__ overflow, uint32_t* __restrict__ n_surv) {
+    const uint32_t q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = cand_cnt[q];
+    if (cnt > cap) { if (i == 0) overflow[q] = 1; cnt = 0; }           // the caller redoes this query with the exact scan
+    if (i == 0) n_surv[q] = 0;
+#ifdef QV_LK_PROF
+    if (i == 0 && (q == 0 || q == 100)) printf("large-k re-score q%u: candidates %u of cap %u\n", q, cand_cnt[q], cap);
+#endif
+    if (i >= cap) return;
+    uint64_t key = kDeadKey;
+    if (i < cnt) {
+        const uint32_t row = cand_rows[(size_t)q * cap + i];
+        const double rn = v.rnorm[row], qn = qnorms[2 * q];
+        float lo, hi;
+        score_interval<M>((double)cand_score[(size_t)q * cap + i], qn, qn, rn, (double)eq[2 * q] * rn + (double)eq[2 * q + 1] * (double)v.rres[row], filter_gamma(v.dim, 0), lo, hi);
+        lo_out[(size_t)q * cap + i] = lo;
+        key = make_key(hi, i);
+    }
+    keys_hi[(size_t)q * cap + i] = key;
+}
+
+// survivors: candidates whose lower bound does not exceed H_q = the k-th smallest upper bound (sel_dist[q][k - 1]; +inf = keep all)
+__global__ void __launch_bounds__(256)
+k_cand_survive(const uint32_t* __restrict__ cand_rows, const uint32_t* __restrict__ cand_cnt, uint32_t cap, const float* __restrict__ lo_in,
+               const float* __restrict__ sel_dist, uint32_t k, uint32_t* __restrict__ surv, uint32_t* __restrict__ n_surv) {
+    const uint32_t q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, lane = lane_id();
+    const uint32_t cnt = cand_cnt[q] <= cap ? cand_cnt[q] : 0u;
+    const float H = sel_dist[(size_t)q * k + (k - 1)];
+    const bool take = i < cnt && lo_in[(size_t)q * cap + i] <= H;
+    const uint64_t m = __ballot(take);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&n_surv[q], (uint32_t)__builtin_popcountll(m));
+    base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(m));
+    if (take) surv[(size_t)q * cap + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = cand_rows[(size_t)q * cap + i];
+}
+
+// exact distances of the survivors: the scan's arithmetic, a lane per row (its chunks are a gather: requests pinned per block);
+// keys (distance, row), dead beyond the survivors.
+template <int M, int U>
+__global__ void __launch_bounds__(256)
+k_cand_exact(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ surv, const uint32_t* __restrict__ n_surv, uint32_t cap,
+             const double* __restrict__ qnorms, uint64_t* __restrict__ keys_ex) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    // grid (nq, cap / 256): the query in x.  Only the first slices of a query have work, and workgroups go to the XCDs round-robin
+    // by linear id: with the slice in x the working workgroups (ids 16 q) all landed on ONE XCD — 1.5 ms for 56 k rows
+    const uint32_t q = blockIdx.x, i = blockIdx.y * blockDim.x + threadIdx.x;
+    const uint32_t ns = n_surv[q];
+#ifdef QV_LK_PROF
+    if (i == 0 && (q == 0 || q == 100)) printf("large-k re-score q%u: survivors %u of cap %u\n", q, ns, cap);
+#endif
+    if (blockIdx.y * blockDim.x >= ns) { if (i < cap) keys_ex[(size_t)q * cap + i] = kDeadKey; return; }
+    stage_query<M>(q_lds, queries + (size_t)q * v.dim, v.dim, v.dim4);
+    __syncthreads();
+    uint64_t key = kDeadKey;
+    if (i < ns) {
+        const uint32_t row = surv[(size_t)q * cap + i];
+        QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+        if constexpr (M == QV_COSINE) qc.qn = qnorms[2 * q + 1];
+        typename MT<M>::A acc;
+        if (v.rowmaj != nullptr && (v.dim & 3) == 0) acc = row_accumulate<M, U, false, true>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
+        else acc = row_accumulate<M, U, false, true>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        key = make_key(finalize<M>(acc, qc, rn), row);
+    }
+    if (i < cap) keys_ex[(size_t)q * cap + i] = key;
+}
+
 // 1 = fp32 MFMA chain (BASELINE configs[2] as written), 2 = bfloat16 x 3, 3 = bfloat16 x 1; QV_MFMA_FILTER unset: the one-term
 // filter up to 1536 dimensions, three terms above.  Its window (2 x 7.9e-3 |q||r|) is measured in units of the scores' spread,
 // which shrinks like 1/sqrt(dim) on unstructured data: 256 queries x 3 GB of rows take 1.93 / 1.14 / 1.08 / 1.39 / 1.34 / 2.55 ms at
@@ -1908,9 +2058,12 @@ uint32_t batched_sample_rows(const IndexView& v, uint32_t k) {
     // the one-term bfloat16 filter's window is 2 x 7.9e-3 |q||r| wide — 0.44 sigma of the scores of unstructured 768-d data, which
     // lets ~4.6 x as many rows through at the same bound: four times the sample keeps the candidate count where it was
     const bool one = filter_mode(v) == 3;
-    const uint64_t per = one ? 384 : 1536;
+    // beyond 64 results per query the candidate slots grow with k (batched_cand_cap): half the sample, twice the candidates
+    const uint64_t per = (one ? 384 : 1536) * (k > (uint32_t)kMaxFusedK ? 2 : 1);
     const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / per + 8191) / 8192 * 8192;
-    return (uint32_t)std::min<uint64_t>(n_rows, std::max<uint64_t>(one ? 32768 : 8192, want));
+    uint64_t cap_rows = n_rows;
+    if (k > (uint32_t)kMaxFusedK) cap_rows = std::max<uint64_t>(32768, ((uint64_t)n_rows / 2 + 8191) / 8192 * 8192);   // the sample costs a pass over its rows: half the corpus at most
+    return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n_rows, cap_rows), std::max<uint64_t>(one ? 32768 : 8192, want));
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     // Measured crossover against the exact multi-query scans (256 queries x 768 dims, host pointers for the filter): 12k-16k
@@ -1919,13 +2072,21 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     // with the bfloat16 filter a batch of 9..31 queries over 1M x 768 takes 0.70-0.76 ms against 0.96-1.2 ms for the exact f64-matrix scan
     // (8 queries or fewer share one HBM-bound pass of k_flat_scan_mq: 0.45 ms); the fp32 filter pays off from 32 queries
     static const int min_rows = env_int("QV_MFMA_MIN_ROWS", 32768);
-    const int min_q_env = env_int("QV_MFMA_MIN_QUERIES", 0);          // read per call: tests of the exact scans switch the filter off with it
-    const int min_q = min_q_env > 0 ? min_q_env : (filter_mode(v) >= 2 ? 9 : 32);
+    if (v.filter == QV_FILTER_OFF) return false;                      // the index's choice (qv_index_set_filter): exact scans only
+    const int min_q = filter_mode(v) >= 2 ? 9 : 32;
     // millions of query-rows.  Round 2's one-term filter moved the crossover down: 16 / 64 queries x 100k x 768 take 0.17 / 0.18 ms here against
     // 0.30 / 0.57 ms on the exact multi-query scan, x 400k rows 0.36 / 0.37 against 0.59 / 1.65 (8 M query-rows was the three-term crossover)
     static const int min_work_m = env_int("QV_MFMA_MIN_MROWS", 1);
-    return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxFusedK && nq >= (uint32_t)min_q &&
+    return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxBatchedK && nq >= (uint32_t)min_q &&
            v.n_rows >= (uint32_t)min_rows && (uint64_t)nq * v.n_rows >= (uint64_t)min_work_m * 1000000ull;
+}
+// candidate slots per query: kMfmaCandCap up to 64 results; beyond, 16 k rounded up to a power of two (the sample is capped at
+// half the corpus there, so the expected candidates grow with k: about 2 f k with f ~ 4.6 for the one-term filter)
+uint32_t batched_cand_cap(uint32_t k) {
+    if (k <= (uint32_t)kMaxFusedK) return (uint32_t)kMfmaCandCap;
+    uint32_t c = (uint32_t)kMfmaCandCap;
+    while (c < 16u * k) c <<= 1;
+    return c;
 }
 // queries are padded (zero vector, +inf threshold: nothing passes) to 1, 2 or a multiple of 4 blocks of 64: the four waves of a
 // workgroup then work on the same row group (its tiles are fetched once and hit L1/L2 for the other three) and the wave count
@@ -1940,9 +2101,12 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     size_t b = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);   // sample scan (partials + query blocks)
     b = (b + 255) / 256 * 256;
     b += (size_t)nq_pad * (v.dim4 + 4) * 16;                 // Qt (chunk count padded to even) / the bf16 hi + lo planes (padded to 4 chunks)
+    const size_t ccap = batched_cand_cap(k);
     b += (size_t)nq_pad * 20;                                // cq, mq (m_q and b_q), eq
-    b += (size_t)nq * kMfmaCandCap * 8;                      // candidates: rows + fp32 scores
-    b += (size_t)nq * 8;                                     // counters, overflow flags
+    b += (size_t)nq * ccap * 8;                              // candidates: rows + fp32 scores
+    b += (size_t)nq * 8 + 256;                               // capacity word + counters, overflow flags
+    if (k > (uint32_t)kMaxFusedK)                            // keys of the upper bounds and of the exact distances, lower bounds, survivors, counters, norms, selection
+        b += (size_t)nq * ccap * (8 + 8 + 4 + 4) + (size_t)nq * (4 + 16) + 1024 + select_workspace_bytes(nq, k);
     b += (size_t)nq * k * 8;                                 // sample rows/dist
     b += (size_t)nq * k * 16 + 256;                          // k_sample_bound's partial lists (up to four parts per query)
     b += (size_t)nq_pad * batched_sample_rows(v, k) * 4 + 256;   // the sample's scores (bfloat16 filter: bound without an exact scan)
@@ -1964,10 +2128,26 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     float* cq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 4;
     float* mq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // m_q, b_q
     float* eq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // the scores' error bound per query (k_mfma_prep -> k_rescore_select)
-    uint32_t* cand = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * kMfmaCandCap * 4;
-    float* cscore = reinterpret_cast<float*>(w + off); off += (size_t)nq * kMfmaCandCap * 4;
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
+    const uint32_t ccap = batched_cand_cap(k);
+    const bool large_k = k > (uint32_t)kMaxFusedK;
+    uint32_t* cand = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * ccap * 4;
+    float* cscore = reinterpret_cast<float*>(w + off); off += (size_t)nq * ccap * 4;
+    off = (off + 255) / 256 * 256;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(w + off) + 1; off += (size_t)nq * 4 + 4;   // cnt[-1]: the capacity, for the filter kernels
     uint32_t* ovf = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
+    // large k: the selections' arrays
+    uint64_t* keys_hi = nullptr; uint64_t* keys_ex = nullptr; float* lo_b = nullptr; uint32_t* surv = nullptr; uint32_t* nsurv = nullptr; double* qnorms = nullptr; void* sel_ws = nullptr;
+    if (large_k) {
+        off = (off + 255) / 256 * 256;
+        keys_hi = reinterpret_cast<uint64_t*>(w + off); off += (size_t)nq * ccap * 8;
+        keys_ex = reinterpret_cast<uint64_t*>(w + off); off += (size_t)nq * ccap * 8;
+        lo_b = reinterpret_cast<float*>(w + off); off += (size_t)nq * ccap * 4;
+        surv = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * ccap * 4;
+        qnorms = reinterpret_cast<double*>(w + off); off += (size_t)nq * 16;
+        nsurv = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
+        off = (off + 255) / 256 * 256;
+        sel_ws = w + off; off += select_workspace_bytes(nq, k);
+    }
     uint32_t* srows = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * k * 4;
     float* sdist = reinterpret_cast<float*>(w + off); off += (size_t)nq * k * 4;
     off = (off + 255) / 256 * 256;
@@ -1989,13 +2169,13 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     const bool q64 = bf && fmode == 3 && nq_pad == 64 && v.bf16 != nullptr && q64_env == 1 && (v.dim4 & 3u) == 0 && fsteps0 % 4 == 0 && fsteps0 >= 8 && fsteps0 <= 64;
     const int gmode = !bf ? 0 : (fmode == 3 && (shared || q64) ? 2 : 1);   // which filter_gamma the main pass obeys (one term: the shared kernels and the one-block kernel)
     hipError_t e = hipSuccess;
-    if (sample_gemm == 1) {
+    if (sample_gemm == 1 || large_k) {
         // the sample's scores by the three-term bfloat16 kernel, their upper bounds' k-th smallest as U_q (k_sample_bound): 0.1 ms
         // against 0.24 for an exact scan of the sample.  The fp32-MFMA filter takes its bound the same way (round 3): the query
         // operands are laid out as bfloat16 for the sample and then, in the same buffer, as float32 for the main pass
         off = (off + 255) / 256 * 256;
         float* sscore = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * vs.n_rows * 4;
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, 1, 1);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, 1, 1, ccap);
         const uint32_t nqb64s = nq_pad / 64;
         const uint32_t gs = grid_multiple(std::min<uint32_t>((uint32_t)cus, ((vs.n_tiles + 1) / 2 * nqb64s + 3) / 4), nqb64s / std::gcd(nqb64s, 4u));
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
@@ -2007,18 +2187,25 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         static const int w8s_env = env_int("QV_MFMA_W8", 1);
         const bool sample1 = sample1_env == 1 && w8s_env == 1 && gmode == 2 && shared && (v.dim4 & 3u) == 0 && fsteps0 % 8 == 0 && fsteps0 >= 16;
         const uint32_t gs1 = grid_multiple(std::min<uint32_t>((uint32_t)cus, sgroups * (nq_pad >> 8)), std::max<uint32_t>(nq_pad >> 8, 1u));
+        // large k: the k-th smallest bound by two histogram windows over the bounds (no wave list holds k keys), per-query state in the selection's workspace
+        SelState* sst = nullptr; uint32_t* shist = nullptr;
+        if (large_k) { e = select_prepare(sel_ws, nq, k, &sst, &shist, s); if (e != hipSuccess) return e; }
+        const uint32_t hgrid = std::max(1u, std::min(256u, (vs.n_rows + 16 * kSelBlock - 1) / (16 * kSelBlock)));
 #define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
                      else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
-                     hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
+                     if (large_k) { hipLaunchKernelGGL(k_sample_hist<0>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
+                                    hipLaunchKernelGGL(k_sample_hist<1>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
+                                    hipLaunchKernelGGL(k_sample_bound_from_state<MMM>, dim3((nq + 255) / 256), dim3(256), 0, s, sst, nq, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); } \
+                     else hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 ? sparts : sdist, bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, bf ? 2 : 3);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k ? sparts : sdist, large_k ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, bf ? 2 : 3, ccap);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
         e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
         if (e != hipSuccess) return e;
         // 2. query re-layout + filter constants
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, 3);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, 3, ccap);
     }
     // 3. MFMA filter
     const uint32_t nqb64 = nq_pad / 64;
@@ -2044,23 +2231,35 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const bool bfrows = gmode == 2 && v.bf16 != nullptr && bfrows_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;
         static const int w8_env = env_int("QV_MFMA_W8", 1);                                   // 2 = the four-wave kernel (k_bf16x3_filter_shared<., 1>)
         const bool w8 = w8_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;       // rounds of two steps, four in flight: a multiple of 4 rounds, at least 6
-        static const int w8_bf = env_int("QV_MFMA_W8_BF", 2);                                  // 1 = the eight-wave kernel on the bfloat16 plane too (measured: 485 against 474 us for k_bf16rows_filter)
-        static const int w8x2 = env_int("QV_MFMA_W8X2", 1);                                 // 1 = 256 rows per round (k_bf16x1_filter_w8x2; 552 against 607 us), 2 = 128 (k_bf16x1_filter_w8); 3 = 256 with rows 8 steps ahead (spills)
-        static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // measurement (profiles/r03_batched_epilogue.txt): 7 = the epilogue's dense pass deferred into the next group's K loop (610.7 against 607.3 us), 5 / 6 = rows 16 rounds ahead (614 / 613), 3 = rows 18 and query operands 15 steps ahead, 4 = query operands 15 steps ahead (644.6 against 648.6 us: kept at 3)
-#define QV_FS(MMM) { if (bfrows && w8 && w8_bf == 1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 4, 8, 2, true, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                     else if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                     else if (gmode == 2 && w8) { if (w8_shape == 3 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 16, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8_shape == 4 && fsteps % 16 == 0) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 16, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8_shape == 5 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 4, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8_shape == 6 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 8, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8x2 == 1) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 4, 4>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8x2 == 3) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 8, 4>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else if (w8_shape == 7) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false, true>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                       else hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); } \
+#ifdef QV_VARIANTS
+        // Measurement build only (make VARIANTS=1 -> libqv_dev.so; profiles/r03_batched_epilogue.txt has what each measured): the
+        // shapes of the eight-wave kernel that lost to the shipped one.  The product library instantiates none of them.
+        static const int w8_bf = env_int("QV_MFMA_W8_BF", 2);                                  // 1 = the eight-wave kernel on the bfloat16 plane too (485 against 474 us for k_bf16rows_filter)
+        static const int w8x2 = env_int("QV_MFMA_W8X2", 1);                                 // 2 = 128 rows per round (k_bf16x1_filter_w8: 607 against 552 us); 3 = 256 with rows 8 steps ahead (spills)
+        static const int w8_shape = env_int("QV_MFMA_W8_SHAPE", 1);                           // 7 = the dense pass deferred into the next group's K loop (610.7 against 607.3 us), 5 / 6 = rows 16 rounds ahead (614 / 613), 3 / 4 = query operands 15 steps ahead (644.6 / 648.6)
+#define QV_FS_VARIANTS(MMM)                                                                                                                                                        \
+                     if (bfrows && w8 && w8_bf == 1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 4, 8, 2, true, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (!bfrows && gmode == 2 && w8 && w8_shape == 3 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 16, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (!bfrows && gmode == 2 && w8 && w8_shape == 4 && fsteps % 16 == 0) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 16, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (!bfrows && gmode == 2 && w8 && w8_shape == 5 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 4, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (!bfrows && gmode == 2 && w8 && w8_shape == 6 && fsteps % 16 == 0 && fsteps >= 32) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 16, 8, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (!bfrows && gmode == 2 && w8 && w8x2 == 3) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 8, 4>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (!bfrows && gmode == 2 && w8 && w8x2 != 1 && w8_shape == 7) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false, true>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (!bfrows && gmode == 2 && w8 && w8x2 != 1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM, 8, 4, 1, false, false>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else
+#else
+#define QV_FS_VARIANTS(MMM)
+#endif
+        // shipped: the bfloat16 copy's own kernel when the index keeps one; 256 rows per round on float32 rows (k_bf16x1_filter_w8x2)
+        // where the dimension allows the eight-wave shape; the four-wave shared-row kernels otherwise
+#define QV_FS(MMM) { QV_FS_VARIANTS(MMM)                                                                                                                                           \
+                     if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (gmode == 2 && w8) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 4, 4>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 3, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         if (v.metric == QV_COSINE) QV_FS(QV_COSINE) else if (v.metric == QV_DOT) QV_FS(QV_DOT) else QV_FS(QV_L2)
 #undef QV_FS
+#undef QV_FS_VARIANTS
     } else if (bf) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
         if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u, 1u);
@@ -2080,6 +2279,24 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
 #define QV_RS1(MMM, UU) { e = set_lds(k_rescore_select<MMM, UU>, lds); if (e != hipSuccess) return e;                                   \
         hipLaunchKernelGGL((k_rescore_select<MMM, UU>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, eq); }
 #define QV_RS(MMM) { if (rs_u == 8) QV_RS1(MMM, 8) else QV_RS1(MMM, 32) }
+    if (large_k) {
+        // intervals -> H (k-th smallest upper bound) -> survivors -> exact distances -> the k best; srows / sdist take the first
+        // selection's output (the sample's bound in sdist has been consumed by k_mfma_prep)
+        const dim3 cgrid((ccap + 255) / 256, nq);
+        const size_t lds_x = query_lds_bytes(v.metric, v.dim4);
+#define QV_LK(MMM) { e = set_lds(k_cand_qnorms<MMM>, (size_t)v.dim * 4); if (e != hipSuccess) return e;                                                 \
+        hipLaunchKernelGGL(k_cand_qnorms<MMM>, dim3(nq), dim3(64), (size_t)v.dim * 4, s, d_queries, v.dim, qnorms);                                         \
+        hipLaunchKernelGGL(k_cand_bounds<MMM>, cgrid, dim3(256), 0, s, v, cand, cscore, cnt, ccap, eq, qnorms, keys_hi, lo_b, ovf, nsurv);                 \
+        e = launch_select_topk(keys_hi, ccap, ccap, nq, k, k, sel_ws, srows, sdist, s, false, false); if (e != hipSuccess) return e;                       \
+        hipLaunchKernelGGL(k_cand_survive, cgrid, dim3(256), 0, s, cand, cnt, ccap, lo_b, sdist, k, surv, nsurv);                                          \
+        e = set_lds(k_cand_exact<MMM, 32>, lds_x); if (e != hipSuccess) return e;                                                                           \
+        hipLaunchKernelGGL((k_cand_exact<MMM, 32>), dim3(nq, (ccap + 255) / 256), dim3(256), lds_x, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex);                         \
+        e = launch_select_topk(keys_ex, ccap, ccap, nq, k, k, sel_ws, d_rows_out, d_dist_out, s, false, false); if (e != hipSuccess) return e; }
+        if (v.metric == QV_COSINE) QV_LK(QV_COSINE) else if (v.metric == QV_DOT) QV_LK(QV_DOT) else if (v.metric == QV_L2) QV_LK(QV_L2) else QV_LK(QV_L2SQ)
+#undef QV_LK
+        *d_overflow_out = ovf;
+        return hipGetLastError();
+    }
     if (v.metric == QV_COSINE) QV_RS(QV_COSINE) else if (v.metric == QV_DOT) QV_RS(QV_DOT) else if (v.metric == QV_L2) QV_RS(QV_L2) else QV_RS(QV_L2SQ)
 #undef QV_RS
 #undef QV_RS1

@@ -43,6 +43,7 @@ k_flat_keys(IndexView v, const float* __restrict__ queries, uint64_t* __restrict
     const uint32_t tw = gridDim.x * kScanWaves;
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
     uint32_t t_first = blockIdx.x * kScanWaves + wave, parked = 0;    // first tile of the batch in LDS, tiles parked
+    SelRun run{0u, 0u};
     auto flush = [&]() {
         // (non-temporal: 4.47 against 4.52 ms at 10M x 768 — the keys are read back by other CUs, nothing of them is worth keeping in this L2)
         for (uint32_t j = 0; j < parked; j++) __builtin_nontemporal_store(kb[j * 64 + lane], &keys[(size_t)(t_first + j * tw) * 64 + lane]);
@@ -62,9 +63,10 @@ k_flat_keys(IndexView v, const float* __restrict__ queries, uint64_t* __restrict
         const uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
         kb[parked * 64 + lane] = key;                                  // (a lane reads back only what it wrote: no barrier)
         if (++parked == batch) flush();
-        if constexpr (HIST) sel_count<0>(h, key, true, lane);
+        if constexpr (HIST) sel_count<0>(h, run, key, true);
     }
     flush();
+    if constexpr (HIST) sel_flush(h, run);
     if constexpr (HIST) sel_finish_window<0>(h, hist + (size_t)blockIdx.y * kSelBins, st + blockIdx.y, gridDim.x, k, cap);
 }
 

@@ -35,24 +35,24 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, uint32_t lane) {
     return x;
 }
 
-// One key per lane into the workgroup's LDS histogram h (called by whole waves: it holds ballots).  The keys of a window crowd
-// into a few bins — the distances of unit vectors share their exponent, and a later window only sees the keys of one bucket — so
-// 64 lanes queueing on two or three LDS addresses was the whole cost of the first window (107 us for 10M keys).  Up to four
-// distinct digits are peeled off with one ballot and ONE atomic each; what is left (scattered digits) goes lane by lane.
+// A thread's keys into the workgroup's LDS histogram h, run by run.  The keys of a window crowd into a few bins — the distances of
+// unit vectors share their exponent, and a later window only sees the keys of one bucket — so one LDS atomic per key queued 64
+// lanes on two or three addresses (107 us for the first window over 10M keys), and peeling equal digits off with ballots cost
+// ~25 instructions per key (150 us per window over 67M sample bounds).  A thread instead keeps (digit, count) of its current run
+// of equal digits in registers and touches LDS when the digit changes: long runs where the bins are crowded, and where digits
+// scatter there is no crowd to queue behind.  No cross-lane operation: callers need not be converged.
+struct SelRun { uint32_t d, n; };
 template <int W>
-__device__ __forceinline__ void sel_count(uint32_t* h, uint64_t key, bool match, uint32_t lane) {
+__device__ __forceinline__ void sel_count(uint32_t* h, SelRun& run, uint64_t key, bool match) {
     const uint32_t d = (uint32_t)(key >> SelWindow<W>::shift) & (SelWindow<W>::nb - 1);
-    uint64_t m = __ballot(match);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (m == 0) return;
-        const uint32_t first = (uint32_t)__builtin_ctzll(m);
-        const uint32_t d0 = __builtin_amdgcn_readlane(d, (int)first);
-        const uint64_t same = __ballot(match && d == d0) & m;
-        if (lane == first) atomicAdd(&h[d0], (uint32_t)__builtin_popcountll(same));
-        m &= ~same;
-    }
-    if ((m >> lane) & 1ull) atomicAdd(&h[d], 1u);
+    if (!match) return;
+    if (d == run.d) { run.n++; return; }
+    if (run.n) atomicAdd(&h[run.d], run.n);
+    run.d = d; run.n = 1;
+}
+__device__ __forceinline__ void sel_flush(uint32_t* h, SelRun& run) {
+    if (run.n) atomicAdd(&h[run.d], run.n);
+    run.n = 0;
 }
 
 // End of a window for one workgroup: its bins go to the query's global histogram; the LAST workgroup of the query to arrive

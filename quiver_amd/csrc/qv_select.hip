@@ -36,17 +36,17 @@ k_select_hist(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
     if (s->done || s->bits != 64 - shift - wbits) return;              // decided already (uniform over the query's workgroups), or this window was
                                                                       // taken by the kernel that made the keys (k_flat_keys counts window 0 itself)
     const unsigned long long prefix = W > 0 ? s->prefix : 0ull;
-    const uint32_t lane = lane_id();
     for (uint32_t b = threadIdx.x; b < nb; b += kSelBlock) h[b] = 0;
     __syncthreads();
     const uint64_t* src = keys + (size_t)q * stride;
     // a contiguous slice per workgroup, two keys (16 bytes) per lane and request
     const uint32_t per = ((n + gridDim.x - 1) / gridDim.x + 2 * kSelBlock - 1) / (2 * kSelBlock) * (2 * kSelBlock);
     const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    SelRun run{0u, 0u};
     auto count = [&](uint64_t key, bool valid) {
-        sel_count<W>(h, key, valid && (W == 0 || (key >> (shift + wbits)) == (prefix >> (shift + wbits))), lane);
+        sel_count<W>(h, run, key, valid && (W == 0 || (key >> (shift + wbits)) == (prefix >> (shift + wbits))));
     };
-    for (uint32_t base = lo; base < hi; base += 2 * 4 * kSelBlock) {   // (workgroup-uniform trip counts: sel_count holds ballots)
+    for (uint32_t base = lo; base < hi; base += 2 * 4 * kSelBlock) {
         ulonglong2 v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -60,6 +60,7 @@ k_select_hist(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
             count(v[u].x, j < hi); count(v[u].y, j + 1 < hi);
         }
     }
+    sel_flush(h, run);
     sel_finish_window<W>(h, hist + (size_t)q * kSelBins, s, gridDim.x, k, cap);
 }
 
@@ -329,13 +330,20 @@ size_t select_workspace_bytes(uint32_t nq, uint32_t kk) {
 
 // the workspace's layout: [nq] states, [nq][kSelBins] histogram words, [nq][cap] kept keys.  select_prepare zeroes the first two
 // (a caller whose keys kernel counts window 0 itself does this BEFORE that kernel and passes window0_counted = true below)
+__global__ void __launch_bounds__(256)
+k_select_zero(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
 hipError_t select_prepare(void* d_ws, uint32_t nq, uint32_t kk, SelState** st_out, uint32_t** hist_out, hipStream_t s) {
     char* w = static_cast<char*>(d_ws);
     const size_t st_bytes = ((size_t)nq * sizeof(SelState) + 255) / 256 * 256;
     *st_out = reinterpret_cast<SelState*>(w);
     *hist_out = reinterpret_cast<uint32_t*>(w + st_bytes);
     (void)kk;
-    return hipMemsetAsync(w, 0, st_bytes + (size_t)nq * kSelBins * sizeof(uint32_t), s);
+    // (a kernel of our own: hipMemsetAsync took 43 us for the 4 MB of a 256-query batch)
+    const size_t n16 = (st_bytes + (size_t)nq * kSelBins * sizeof(uint32_t)) / 16;
+    hipLaunchKernelGGL(k_select_zero, dim3((unsigned)std::min<size_t>(1024, (n16 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint4*>(w), n16);
+    return hipGetLastError();
 }
 
 hipError_t launch_select_topk(const uint64_t* d_keys, size_t stride, uint32_t n, uint32_t nq, uint32_t kk, uint32_t k_stride, void* d_ws,

@@ -280,7 +280,7 @@ int search_ctx(qv_sharded* s, CallCtx* c, const float* queries_host, const float
             // batches go through the matrix-core filter + exact re-score where it applies (same results, qv_index_search's own rule);
             // everything else, and whatever the filter declines, through the exact scan (k > 64: the shard's full ranking)
             int rcb = QV_ERR_UNSUPPORTED;
-            if (nq >= 9 && !ranked) {
+            if (nq >= 9) {                                                  // (declines — QV_ERR_UNSUPPORTED — above kMaxBatchedK results per query)
                 if ((rc = b.d_flags.ensure((size_t)nq * 4)) || (rc = b.h_flags.ensure((size_t)nq * 4))) return rc;
                 rcb = qv_index_search_batched_device(x.idx, dq, nq, kcap, pack, pack_dist, static_cast<uint32_t*>(b.d_flags.p), b.stream);
             }

@@ -156,10 +156,10 @@ class DeviceIndex:
         check(lib().qv_distance_rows_device(self._h, d_query, d_rows, n, d_out, stream))
 
 
-    FILTERS = {"auto": 0, "fp32": 1, "bf16x3": 2, "bf16x1": 3}
+    FILTERS = {"auto": 0, "fp32": 1, "bf16x3": 2, "bf16x1": 3, "off": 4}
 
     def set_filter(self, filter):
-        """the batched path's filter kernel: "auto", "fp32" (fp32 MFMA chain), "bf16x3", "bf16x1" (qv_index_set_filter)"""
+        """the batched path's filter kernel: "auto", "fp32" (fp32 MFMA chain), "bf16x3", "bf16x1", or "off" — exact scans only (qv_index_set_filter)"""
         check(lib().qv_index_set_filter(self._h, self.FILTERS.get(filter, filter)))
 
     def profile(self, enable: bool):

@@ -1,13 +1,16 @@
 """Mirror of pkg/vectortypes for the hot path: the DistanceFunc contract
 (surface.go:8 `func(a, b F32) float32`), the five metrics (distances.go:12-104), the
-DistanceType lookup (types.go:36-49) and Surface (surface.go:11-44).  Every function
-computes on the GPU through libqv (qv_distance_pairs); there is no CPU arithmetic here."""
+DistanceType lookup (types.go:36-49) and Surface (surface.go:11-44).  One pair is what a
+DistanceFunc call is (78 ns in the reference, final_bench.txt:47): it goes to libqv's host entry
+point qv_distance_pair — the kernels' own per-pair routine compiled for the CPU, bit-identical to the
+scans — not through a device round trip; arrays of pairs go to the device (qv_distance_pairs).
+There is no arithmetic in this file."""
 from __future__ import annotations
 
 import numpy as np
 
 from ._lib import metric_id
-from .device_index import distance_pairs
+from .device_index import distance_pair, distance_pairs  # noqa: F401
 
 # DistanceType, types.go:15-26
 Cosine, Euclidean, DotProduct, Manhattan = "cosine", "euclidean", "dot_product", "manhattan"
@@ -24,7 +27,7 @@ def _mk(metric: str, device: int = 0):
             raise ValueError("vectors must have the same length")
         if a.size == 0:
             raise ValueError("vectors must not be empty")
-        return np.float32(distance_pairs(mid, a[None, :], b[None, :], device)[0])
+        return np.float32(distance_pair(mid, a, b))
 
     f.metric = metric
     f.metric_id = mid

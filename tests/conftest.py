@@ -34,7 +34,7 @@ def pytest_collection_modifyitems(config, items):
     if _has_gpu():
         # a wedged collective or device call must fail loudly instead of stalling the whole run (seen once in round 2: the RCCL
         # communicator of test_gpu_sharded_abi's first test never came up after the multi-process tests before it; not
-        # reproduced since — profiles/r03_rccl_loop.md).  method="thread": a thread blocked inside hipStreamSynchronize or
+        # reproduced in six back-to-back loops of those files in round 3).  method="thread": a thread blocked inside hipStreamSynchronize or
         # ncclCommInitAll (through ctypes) never returns to the interpreter, so the signal method would not fire; the thread
         # method dumps every stack and ends the process with a non-zero status.
         if config.pluginmanager.hasplugin("timeout"):

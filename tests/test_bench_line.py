@@ -67,3 +67,34 @@ def test_emit_writes_sidecar_and_one_line(tmp_path):
     assert json.loads(p.stdout)["full_record"]
     full = json.loads(side.read_text())
     assert "hnsw_1Mx768_maxlevel1_structured" in full["also"] and len(side.read_text()) > 20000
+
+
+def test_eight_gpus_and_maximum_length_strings_still_emit_the_headline():
+    """the budget can be exceeded by the fixed part alone (8 per-GPU roofline entries, a long runtime string, every CPU leg):
+    the line sheds extras instead of raising after the whole benchmark has run"""
+    rec = _records()[-1]
+    rec["n_gpus"] = 8
+    rec["roofline"]["per_gpu"] = [{"rank": g, "rows": 1250000, "scan_kernel_ms": 0.5512345, "hbm_frac": 0.87123} for g in range(8)]
+    rec["config"].update({k: "y" * 400 for k in ("runtime", "sharding", "exchange", "arithmetic", "workload", "device")})
+    rec["cpu_baseline"]["sample"] = "z" * 3000
+    rec["cpu_baseline"]["others"] = {("leg_%d" % i): {"value": 1.0 / 3, "cores": 64} for i in range(120)}
+    text = bench.compact_line(rec, "gpurun_out/" + "p" * 300)
+    assert len(text) <= bench.MAX_LINE
+    line = json.loads(text)
+    assert line["value"] == pytest.approx(rec["value"], rel=1e-5) and line["n_gpus"] == 8 and line["roofline"]["frac"] > 0
+    assert line["cpu_baseline"]["value"] > 0
+
+
+def test_membership_check_catches_a_skipped_row():
+    """bench.py's verified_against_oracle: a result that misses a better row fails; results beyond the checked rows are ignored"""
+    import numpy as np
+    from tests import _oracle as O
+    rows = O.gen_rows(1, 0, 5000, 32)
+    q = O.gen_rows(2, 0, 1, 32)[0]
+    er, ed = O.exact_search(0, rows, q, 10)
+    assert bench.membership_check(O, 0, q, rows[:3000], 0, er.astype(np.int64), ed)
+    assert bench.membership_check(O, 0, q, rows[100:2000], 100, er.astype(np.int64), ed)
+    er2, ed2 = O.exact_search(0, rows, q, 11)
+    assert not bench.membership_check(O, 0, q, rows, 0, er2[1:].astype(np.int64), ed2[1:])          # the best row is missing
+    bad = ed.copy(); bad[3] = np.nextafter(bad[3], np.float32(2))
+    assert not bench.membership_check(O, 0, q, rows, 0, er.astype(np.int64), bad)                    # a distance one ulp off

@@ -413,3 +413,48 @@ def test_filter_kernels_at_other_dimensions(metric, dim):
     qs = O.gen_rows(20260425, 0, 256, dim)
     for nq in (256, 64):
         assert _eq(_exact(idx, qs[:nq], 10), idx.search(qs[:nq], 10, batched=True))
+
+
+# ---------------------------------------------------------------- more than 64 results per query ---
+# HybridIndex.BatchSearch takes any k (hybrid_index.go:677-811); its negative-example branch asks for max(2k, 30) (:516-522).
+# Beyond the 64-key wave lists the filter + re-score path selects by radix selection (k_sample_hist, k_cand_*): the result must
+# still be the exact scan's, row for row and bit for bit.
+
+@pytest.mark.parametrize("metric,nq,k", [("cosine", 256, 100), ("cosine", 64, 65), ("dot_product", 100, 128), ("euclidean", 40, 300),
+                                         ("squared_euclidean", 256, 129), ("cosine", 16, 1000), ("dot_product", 300, 2048)])
+def test_batched_large_k_equals_exact_scan(metric, nq, k):
+    import quiver_amd as q
+    n, dim = 200_000, 256
+    idx = q.DeviceIndex(dim, metric)
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    exact = _exact(idx, qs, k)                                       # 8 queries at a time: the exact scans (wide lists / one key per row + selection)
+    batched = idx.search(qs, k, batched=True)
+    assert _eq(exact, batched)
+    assert _eq(exact, idx.search(qs, k))
+    corpus = O.gen_rows(20260424, 0, n, dim)
+    for i in (0, nq - 1):
+        er, ed = O.exact_search(q.metric_id(metric), corpus, qs[i], k)
+        assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
+
+
+def test_batched_large_k_ties_tombstones_and_a_clustered_corpus():
+    """duplicated rows (exact ties, resolved by row), dead rows, and a corpus stored cluster by cluster so that the sample's
+    bound is loose for some queries (candidate overflow -> the caller's exact redo)"""
+    import quiver_amd as q
+    dim, nq, k = 64, 48, 200
+    rng = np.random.default_rng(11)
+    centers = rng.standard_normal((8, dim)).astype(np.float32)
+    rows = np.concatenate([c + 0.05 * rng.standard_normal((12_000, dim)).astype(np.float32) for c in centers])
+    rows[5000:5400] = rows[100]                                       # 400 identical rows
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    dead = rng.choice(len(rows), 3000, replace=False).astype(np.uint32)
+    idx.remove(dead)
+    alive = np.ones(len(rows), bool); alive[dead] = False
+    qs = np.concatenate([rows[100:101], centers[3:4], rng.standard_normal((nq - 2, dim)).astype(np.float32)])
+    got = idx.search(qs, k, batched=True)
+    for i in range(nq):
+        er, ed = O.exact_search(0, rows, qs[i], k, alive=alive)
+        assert np.array_equal(got[0][i], er), i
+        assert np.array_equal(_bits(got[1][i]), _bits(ed)), i

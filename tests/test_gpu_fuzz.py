@@ -300,7 +300,7 @@ def test_random_hybrid_histories(seed):
 def test_filter_path_under_random_mutations_equals_the_exact_scan(seed, monkeypatch):
     """the matrix-core filter + re-score (qv_index_search's route for 9+ queries over >= 32768 rows) on indexes that grow, lose and
     replace rows between batches, with and without the bfloat16 row copy: every batch equals the exact multi-query scan of the same
-    index (forced with QV_MFMA_MIN_QUERIES), and a few queries per seed equal the CPU oracle"""
+    index (the filter switched off: qv_index_set_filter), and a few queries per seed equal the CPU oracle"""
     rng = np.random.default_rng(5000 + seed)
     metric = ["cosine", "dot_product", "euclidean", "squared_euclidean"][seed % 4]
     dim = int(rng.choice([32, 64, 128, 200, 256, 768]))
@@ -329,9 +329,9 @@ def test_filter_path_under_random_mutations_equals_the_exact_scan(seed, monkeypa
         qs = _vectors(rng, nq, dim, style)
         qs[0] = m.rows[rng.integers(n)]
         got = idx.search(qs, k)                                    # the filter path (>= 1 M query-rows) or the exact scan below it
-        monkeypatch.setenv("QV_MFMA_MIN_QUERIES", "1000000")
+        idx.set_filter("off")                                      # the exact multi-query scans of the same index
         want = idx.search(qs, k)
-        monkeypatch.delenv("QV_MFMA_MIN_QUERIES")
+        idx.set_filter(quiver_amd.DeviceIndex.default_filter)
         assert np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes() and np.array_equal(got[2], want[2]), (seed, step)
         _compare(m, (got[0][:2], got[1][:2], got[2][:2]), qs[:2], k)
     idx.close()

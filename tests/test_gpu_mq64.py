@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def exact_scans_only(monkeypatch):
     """qv_index_search hands batches of >= 9 queries over >= 8M query-rows to the filter + re-score path; these tests are about
-    the exact multi-query scan, so the filter is switched off (the library reads the variable per call)"""
-    monkeypatch.setenv("QV_MFMA_MIN_QUERIES", "1000000")
+    the exact multi-query scan, so every index made here chooses "no filter" (qv_index_set_filter(QV_FILTER_OFF))"""
+    monkeypatch.setattr(quiver_amd.DeviceIndex, "default_filter", "off")
 
 
 def _check(idx, rows, alive, metric, qs, k):
@@ -74,7 +74,7 @@ def test_long_cosine_scans_with_9_or_more_queries_run_on_the_f64_matrix_kernel()
     """the parity cases above must really be the MFMA kernel: QV_TRACE=1 names the scan kernel on stderr"""
     import os, subprocess, sys
     code = ("import numpy as np, quiver_amd\n"
-            "idx = quiver_amd.DeviceIndex(16, 'cosine'); idx.add_synthetic(1, 0, 530000)\n"
+            "idx = quiver_amd.DeviceIndex(16, 'cosine', filter='off'); idx.add_synthetic(1, 0, 530000)\n"
             "q = np.random.default_rng(0).standard_normal((12, 16)).astype(np.float32)\n"
             "idx.search(q, 10); idx.search(q[:4], 10)\n")
     env = dict(os.environ, QV_TRACE="1")
@@ -92,7 +92,7 @@ def test_a_bound_that_admits_everything_takes_the_fallback():
     import os, subprocess, sys
     code = ("import numpy as np, quiver_amd\n"
             "n = 530000\n"
-            "idx = quiver_amd.DeviceIndex(16, 'dot'); idx.add_synthetic(1, 0, n)\n"
+            "idx = quiver_amd.DeviceIndex(16, 'dot', filter='off'); idx.add_synthetic(1, 0, n)\n"
             "nt = (n + 63) // 64; ns = min(256, nt // 8) // 8 * 8; step = nt // ns\n"
             "dead = np.concatenate([np.arange(t * step * 64, (t * step + 1) * 64, dtype=np.uint32) for t in range(ns)])\n"
             "idx.remove(dead)\n"

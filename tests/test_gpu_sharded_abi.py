@@ -122,9 +122,8 @@ def test_sharded_batches_take_the_filter_path_and_equal_the_exact_scan(nq, monke
     one = quiver_amd.DeviceIndex(dim, "cosine")
     one.add_synthetic(20260424, 0, n)
     qs = O.gen_rows(20260425, 0, nq, dim)
-    monkeypatch.setenv("QV_MFMA_MIN_QUERIES", "1000000")           # the reference: the exact multi-query scan
+    one.set_filter("off")                                          # the reference: the exact multi-query scan
     r1, d1, _ = one.search(qs, k)
-    monkeypatch.delenv("QV_MFMA_MIN_QUERIES")
     r, d, c = sh.search(qs, k)
     span = quiver_amd.lib().qv_sharded_span(3)
     bounds = [g * n // 3 for g in range(4)]

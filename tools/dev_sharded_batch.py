@@ -19,9 +19,8 @@ qi = quiver_amd.DeviceIndex(dim, "cosine"); qi.add_synthetic(20260425, 0, nq)
 dq = torch.from_numpy(np.stack([qi.get_row(i) for i in range(nq)])).cuda()
 dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
 sp = torch.cuda.current_stream().cuda_stream
-for env in ("1000000", None):
-    if env: os.environ["QV_MFMA_MIN_QUERIES"] = env
-    else: os.environ.pop("QV_MFMA_MIN_QUERIES", None)
+for env in ("off", None):
+    sh.set_filter("off" if env else "auto")
     sh.search_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), sp); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
