@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--abi-sharded", action="store_true",
                     help="one process, qv_sharded_* over --gpus devices (RCCL all-gather inside libqv) instead of one process per GPU")
     ap.add_argument("--peer-copy", action="store_true", help="with --abi-sharded: point-to-point exchange (allows shards to share a device)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="check the multi-GPU plumbing and exit (no corpus): device count, peer-access matrix, the HIP/RCCL pair libqv bound, "
+                         "communicators created, one tiny all-gather, communicators destroyed; non-zero exit with the reason on failure")
     return ap.parse_args()
 
 
@@ -610,6 +613,76 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
     return also
 
 
+# ---------------------------------------------------------------------------------------------- preflight
+def _say(msg):
+    sys.stderr.write("[preflight] %s\n" % msg)
+    sys.stderr.flush()
+
+
+def preflight_devices(torch, need, rank=0):
+    """device count and the peer-access matrix (rank 0 prints); raises SystemExit with the reason when `need` devices are not there"""
+    ndev = torch.cuda.device_count()
+    if rank == 0:
+        _say("visible devices: %d (need %d); HSA_ENABLE_IPC_MODE_LEGACY=%s" % (ndev, need, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
+        if ndev > 1:
+            rows = []
+            for i in range(ndev):
+                rows.append(" ".join("-" if i == j else ("1" if torch.cuda.can_device_access_peer(i, j) else "0") for j in range(ndev)))
+            _say("peer access (row = from, column = to):\n    " + "\n    ".join(rows))
+    return ndev
+
+
+def preflight_abi(a):
+    """one process, qv_sharded_*: the handle over --gpus devices created (ncclCommInitAll, or peer access with --peer-copy), one
+    search on a 64-row-per-shard corpus checked against one index, destroyed"""
+    import torch
+    import quiver_amd
+    from quiver_amd.device_index import runtime_info
+    t0 = time.perf_counter()
+    ndev = preflight_devices(torch, a.gpus)
+    _say("libqv bound: " + runtime_info())
+    if ndev < a.gpus and not a.peer_copy:
+        raise SystemExit("[preflight] FAILED: --abi-sharded --gpus %d needs %d devices, %d visible (--peer-copy co-locates shards for a dry run)" % (a.gpus, a.gpus, ndev))
+    devices = [g % max(ndev, 1) for g in range(a.gpus)]
+    try:
+        sh = quiver_amd.ShardedIndex(a.dim, a.metric, devices=devices, peer_copy=a.peer_copy)
+        _say("qv_sharded_create over devices %s: ok (%s exchange), %.1f s" % (devices, "point-to-point" if a.peer_copy else "RCCL all-gather", time.perf_counter() - t0))
+        sh.add_synthetic(CORPUS_SEED, 0, 64 * a.gpus)
+        one = quiver_amd.DeviceIndex(a.dim, a.metric, device=devices[0])
+        one.add_synthetic(CORPUS_SEED, 0, 64 * a.gpus)
+        q = one.get_row(3)
+        r, d, _ = sh.search(q, a.k)
+        r1, d1, _ = one.search(q, a.k)
+        span = quiver_amd.lib().qv_sharded_span(a.gpus)
+        back = np.array([(int(x) // span) * 64 + int(x) % span for x in r[0]], dtype=np.uint32)
+        if not (np.array_equal(back, r1[0]) and np.array_equal(d.view(np.uint32), d1.view(np.uint32))):
+            raise SystemExit("[preflight] FAILED: the %d-shard handle and one index disagree on a 64-rows-per-shard corpus" % a.gpus)
+        sh.close(); one.close()
+    except quiver_amd.QvError as ex:
+        raise SystemExit("[preflight] FAILED: %s" % ex)
+    _say("one search through %d shards equals one index; handle destroyed; %.1f s in all" % (a.gpus, time.perf_counter() - t0))
+
+
+def preflight_ranks(torch, dist, rank, world, device_id, backend, full):
+    """one rank of `world`: the process group is up (the caller made it); one tiny all-gather with the rank numbers, checked.
+    full (--preflight): also print libqv's runtime pair; the caller destroys the group and exits"""
+    t0 = time.perf_counter()
+    dev = "cuda" if backend == "nccl" else "cpu"          # (gloo: host tensors, as quiver_amd.sharded does when ranks share a device)
+    x = torch.full((4,), float(rank), device=dev)
+    out = torch.empty((world * 4,), device=dev)
+    dist.all_gather_into_tensor(out, x)
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    want = torch.arange(world, device=dev, dtype=torch.float32).repeat_interleave(4)
+    if not torch.equal(out, want):
+        raise SystemExit("[preflight] FAILED on rank %d: all-gather over %s returned %s" % (rank, backend, out.tolist()))
+    if rank == 0:
+        _say("process group (%s, %d ranks) up, one all-gather correct, %.2f s" % (backend, world, time.perf_counter() - t0))
+        if full:
+            from quiver_amd.device_index import runtime_info
+            _say("libqv bound: " + runtime_info())
+
+
 # ---------------------------------------------------------------------------------------------- one process, C-ABI sharding
 def run_abi_sharded(a):
     import torch
@@ -712,6 +785,8 @@ def main():
         return self_launch(a)
     quiet_stdout()
     if a.abi_sharded:
+        if a.preflight:
+            return preflight_abi(a)
         return run_abi_sharded(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -723,15 +798,32 @@ def main():
     shared_devices = world > ndev                        # dry run: more ranks than GPUs
     device_id = local_rank % ndev
     torch.cuda.set_device(device_id)
-    use_pg = world > 1 or a.force_exchange
+    use_pg = world > 1 or a.force_exchange or a.preflight
     backend = "gloo" if shared_devices else "nccl"
+    if world > 1 or a.preflight:                             # before anything is generated: a failed scaling run says why in seconds
+        preflight_devices(torch, world, rank)
+        if shared_devices and rank == 0:
+            _say("%d ranks on %d device(s): ranks share devices, the exchange runs over gloo (RCCL needs one device per rank)" % (world, ndev))
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_id))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_id), timeout=datetime.timedelta(seconds=180))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+        except Exception as ex:                                # noqa: BLE001
+            raise SystemExit("[preflight] FAILED on rank %d: init_process_group(%s, world %d, MASTER %s:%s): %s" % (
+                rank, backend, world, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"), ex))
+        if world > 1 or a.preflight:
+            preflight_ranks(torch, dist, rank, world, device_id, backend, a.preflight)
+        if a.preflight:
+            dist.barrier()
+            dist.destroy_process_group()
+            if rank == 0:
+                _say("process group destroyed: ok")
+            return
 
     import quiver_amd
     from quiver_amd.device_index import device_info, runtime_info

@@ -34,6 +34,7 @@ type GraphConfig struct {
 
 // NewGraph creates the vector storage (a qv_index with a row-major copy for the per-hop gathers) and an empty graph over it.
 func NewGraph(dim int, m Metric, device int, capacity int, cfg GraphConfig) (*Graph, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	var idx *C.qv_index
 	if C.qv_index_create(&idx, C.uint32_t(dim), C.qv_metric(m), C.int(device), C.QV_FLAG_ROWMAJOR) != C.QV_OK {
 		return nil, lastErr()
@@ -66,6 +67,7 @@ func (h *Graph) Close() {
 // batchMax = 1 reproduces n sequential Inserts exactly; 0 = the library's default (16384, ramped up from 1).
 // Returns the node index of the first inserted vector.
 func (h *Graph) InsertBatch(flat []float32, levels []int8, batchMax int) (uint32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	h.mu.Lock()
 	defer h.mu.Unlock()
 	n := len(levels)
@@ -102,6 +104,7 @@ type GraphResult struct {
 // (hnsw.go:676) is completed like the reference's brute-force top-up (hnsw.go:676-710) by ONE exact scan call for all
 // such queries — the exact top-k over all live nodes under (distance, node) order.
 func (h *Graph) SearchBatch(qs []float32, k int) ([][]GraphResult, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	h.mu.RLock()
 	defer h.mu.RUnlock()
 	if k <= 0 {
@@ -158,6 +161,7 @@ func (h *Graph) SearchBatch(qs []float32, k int) ([][]GraphResult, error) {
 // Delete tombstones a node (hnsw.go:829 Nodes[idx] = nil).  The device graph keeps walking through it until the caller
 // re-uploads the adjacency its Go-side Delete produced (hnsw.go:741-842 unlinks the node); see FromAdjacency.
 func (h *Graph) Delete(node uint32) error {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	h.mu.Lock()
 	defer h.mu.Unlock()
 	if C.qv_index_remove(h.idx, &[]C.uint32_t{C.uint32_t(node)}[0], 1) != C.QV_OK {
@@ -180,6 +184,7 @@ type Adjacency struct {
 
 // Export copies the device graph back (what HNSW.Nodes[i].Connections holds) for Delete and persistence on the Go side.
 func (h *Graph) Export() (*Adjacency, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	h.mu.RLock()
 	defer h.mu.RUnlock()
 	var n, nb, m0, m, ep C.uint32_t
@@ -202,6 +207,7 @@ func (h *Graph) Export() (*Adjacency, error) {
 // FromAdjacency uploads a graph built (or edited: Delete) on the Go side over the vectors already in this Graph's storage,
 // replacing the device graph; MakeBuildable lets InsertBatch extend it afterwards (it scores every link once).
 func (h *Graph) FromAdjacency(a *Adjacency, efConstruction int) error {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	h.mu.Lock()
 	defer h.mu.Unlock()
 	n := len(a.Levels)

@@ -50,6 +50,7 @@ type Index struct {
 // (collection.go:105): the dimension lock-in of the first Insert (exact.go:43-47) happens here.
 // flags: C.QV_FLAG_BF16_ROWS for collections that serve BatchSearch traffic (+50 % device memory, faster batches).
 func New(dim int, m Metric, device int, flags uint64) (*Index, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	var h *C.qv_index
 	if C.qv_index_create(&h, C.uint32_t(dim), C.qv_metric(m), C.int(device), C.uint64_t(flags)) != C.QV_OK {
 		return nil, lastErr()
@@ -358,6 +359,7 @@ func u32p(s []uint32) *C.uint32_t {
 func (d *oneGPU) close() { C.qv_index_destroy(d.h); d.h = nil }
 
 func (d *oneGPU) add(flat []float32, n int) ([]uint32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	var first C.uint32_t
 	if C.qv_index_add(d.h, f32p(flat), C.uint32_t(n), &first) != C.QV_OK {
 		return nil, lastErr()
@@ -370,6 +372,7 @@ func (d *oneGPU) add(flat []float32, n int) ([]uint32, error) {
 }
 
 func (d *oneGPU) update(row uint32, v []float32) error {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	if C.qv_index_update(d.h, C.uint32_t(row), f32p(v)) != C.QV_OK {
 		return lastErr()
 	}
@@ -377,6 +380,7 @@ func (d *oneGPU) update(row uint32, v []float32) error {
 }
 
 func (d *oneGPU) remove(rows []uint32) error {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	if C.qv_index_remove(d.h, u32p(rows), C.uint32_t(len(rows))) != C.QV_OK {
 		return lastErr()
 	}
@@ -384,6 +388,7 @@ func (d *oneGPU) remove(rows []uint32) error {
 }
 
 func (d *oneGPU) search(qs []float32, nq, k int) ([]uint32, []float32, []uint32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	rows, dist, count := make([]uint32, nq*k), make([]float32, nq*k), make([]uint32, nq)
 	// qv_index_search routes big batches to the matrix-core filter + exact re-score by itself (identical results)
 	if C.qv_index_search(d.h, f32p(qs), C.uint32_t(nq), C.uint32_t(k), u32p(rows), f32p(dist), u32p(count)) != C.QV_OK {
@@ -393,6 +398,7 @@ func (d *oneGPU) search(qs []float32, nq, k int) ([]uint32, []float32, []uint32,
 }
 
 func (d *oneGPU) searchSelected(qs []float32, nq, k int, selected []uint32) ([]uint32, []float32, []uint32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	words := (int(C.qv_index_rows(d.h)) + 63) / 64
 	mask := make([]uint64, words+1)
 	for _, r := range selected {
@@ -407,6 +413,7 @@ func (d *oneGPU) searchSelected(qs []float32, nq, k int, selected []uint32) ([]u
 }
 
 func (d *oneGPU) searchNegative(q, neg []float32, kFetch int) ([]uint32, []float32, []float32, int, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	rows, dist, nd := make([]uint32, kFetch), make([]float32, kFetch), make([]float32, kFetch)
 	var n C.uint32_t
 	if C.qv_index_search_negative(d.h, f32p(q), f32p(neg), C.uint32_t(kFetch), u32p(rows), f32p(dist), f32p(nd), &n) != C.QV_OK {
@@ -416,6 +423,7 @@ func (d *oneGPU) searchNegative(q, neg []float32, kFetch int) ([]uint32, []float
 }
 
 func (d *oneGPU) distanceRows(q []float32, rows []uint32) ([]float32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	out := make([]float32, len(rows))
 	if C.qv_distance_rows(d.h, f32p(q), u32p(rows), C.uint32_t(len(rows)), f32p(out)) != C.QV_OK {
 		return nil, lastErr()
@@ -424,6 +432,7 @@ func (d *oneGPU) distanceRows(q []float32, rows []uint32) ([]float32, error) {
 }
 
 func (d *oneGPU) getRows(rows []uint32) ([]float32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	out := make([]float32, len(rows)*d.dim)
 	if C.qv_index_get_rows(d.h, u32p(rows), C.uint32_t(len(rows)), f32p(out)) != C.QV_OK {
 		return nil, lastErr()

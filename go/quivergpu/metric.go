@@ -10,6 +10,7 @@ import "C"
 import (
 	"errors"
 	"fmt"
+	"runtime"
 	"unsafe"
 
 	"github.com/TFMV/quiver/pkg/hnsw"
@@ -31,7 +32,16 @@ const (
 	L2SqF64    Metric = C.QV_L2SQ_F64
 )
 
+// lastErr reads libqv's message for the call that just failed.  The message is THREAD-local and a goroutine may be moved to
+// another OS thread between two cgo calls, so every function that can reach lastErr pins itself first (pinned): the failing call
+// and this read then run on one thread.
 func lastErr() error { return errors.New(C.GoString(C.qv_last_error())) }
+
+// pinned locks the calling goroutine to its OS thread until the returned function runs: `defer pinned()()`.
+func pinned() func() {
+	runtime.LockOSThread()
+	return runtime.UnlockOSThread
+}
 
 // MetricOf identifies a vectortypes.DistanceFunc the way DB.CreateCollection does — by comparing function pointers
 // printed with %p (pkg/core/db.go:326-334, 359-367).  ok == false: an arbitrary closure, which cannot be offloaded; the
@@ -95,7 +105,8 @@ func DistanceFunc(m Metric) vectortypes.DistanceFunc {
 			pa, pb = (*C.float)(unsafe.Pointer(&a[0])), (*C.float)(unsafe.Pointer(&b[0]))
 		}
 		if C.qv_distance_pair(C.qv_metric(m), pa, pb, C.uint32_t(len(a)), &out) != C.QV_OK {
-			panic(lastErr())
+			// (only an unknown metric or a null vector gets here; the per-pair path does not pin its thread for the message)
+			panic(fmt.Sprintf("qv_distance_pair failed for metric %d on %d dimensions", int(m), len(a)))
 		}
 		return float32(out)
 	}
@@ -114,7 +125,7 @@ func HNSWDistanceFunction(m Metric) hnsw.DistanceFunction {
 			pa, pb = (*C.float)(unsafe.Pointer(&a[0])), (*C.float)(unsafe.Pointer(&b[0]))
 		}
 		if C.qv_distance_pair(C.qv_metric(m), pa, pb, C.uint32_t(len(a)), &out) != C.QV_OK {
-			return 0, lastErr()
+			return 0, fmt.Errorf("qv_distance_pair failed for metric %d on %d dimensions", int(m), len(a))
 		}
 		return float32(out), nil
 	}
@@ -122,6 +133,7 @@ func HNSWDistanceFunction(m Metric) hnsw.DistanceFunction {
 
 // DistancePairs evaluates n independent pairs a[i], b[i] (each dim long, packed row-major) on the device.
 func DistancePairs(m Metric, a, b []float32, dim, device int) ([]float32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	if dim <= 0 || len(a) != len(b) || len(a)%dim != 0 {
 		return nil, errors.New("vectors must have the same length")
 	}

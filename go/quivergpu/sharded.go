@@ -14,6 +14,7 @@ import "C"
 // flags: C.QV_FLAG_BF16_ROWS passes through to every shard; C.QV_SHARDED_PEER_COPY replaces the collective with
 // point-to-point copies into the first device (and allows a device to be listed more than once).
 func NewSharded(dim int, m Metric, devices []int, flags uint64) (*Index, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	devs := make([]C.int, len(devices))
 	for i, d := range devices {
 		devs[i] = C.int(d)
@@ -46,6 +47,7 @@ type node struct {
 func (d *node) close() { C.qv_sharded_destroy(d.h); d.h = nil }
 
 func (d *node) add(flat []float32, n int) ([]uint32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	out := make([]uint32, n)
 	if C.qv_sharded_add(d.h, f32p(flat), C.uint32_t(n), u32p(out)) != C.QV_OK { // all-or-nothing; out[i] = global row of vector i
 		return nil, lastErr()
@@ -54,6 +56,7 @@ func (d *node) add(flat []float32, n int) ([]uint32, error) {
 }
 
 func (d *node) update(row uint32, v []float32) error {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	if C.qv_sharded_update(d.h, C.uint32_t(row), f32p(v)) != C.QV_OK {
 		return lastErr()
 	}
@@ -61,6 +64,7 @@ func (d *node) update(row uint32, v []float32) error {
 }
 
 func (d *node) remove(rows []uint32) error {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	if C.qv_sharded_remove(d.h, u32p(rows), C.uint32_t(len(rows))) != C.QV_OK {
 		return lastErr()
 	}
@@ -68,6 +72,7 @@ func (d *node) remove(rows []uint32) error {
 }
 
 func (d *node) search(qs []float32, nq, k int) ([]uint32, []float32, []uint32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	rows, dist, count := make([]uint32, nq*k), make([]float32, nq*k), make([]uint32, nq)
 	if C.qv_sharded_search(d.h, f32p(qs), C.uint32_t(nq), C.uint32_t(k), u32p(rows), f32p(dist), u32p(count)) != C.QV_OK {
 		return nil, nil, nil, lastErr()
@@ -76,6 +81,7 @@ func (d *node) search(qs []float32, nq, k int) ([]uint32, []float32, []uint32, e
 }
 
 func (d *node) searchSelected(qs []float32, nq, k int, selected []uint32) ([]uint32, []float32, []uint32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	rows, dist, count := make([]uint32, nq*k), make([]float32, nq*k), make([]uint32, nq)
 	if C.qv_sharded_search_masked(d.h, f32p(qs), C.uint32_t(nq), C.uint32_t(k), u32p(selected), C.uint32_t(len(selected)),
 		u32p(rows), f32p(dist), u32p(count)) != C.QV_OK {
@@ -85,6 +91,7 @@ func (d *node) searchSelected(qs []float32, nq, k int, selected []uint32) ([]uin
 }
 
 func (d *node) searchNegative(q, neg []float32, kFetch int) ([]uint32, []float32, []float32, int, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	rows, dist, nd := make([]uint32, kFetch), make([]float32, kFetch), make([]float32, kFetch)
 	var n C.uint32_t
 	if C.qv_sharded_search_negative(d.h, f32p(q), f32p(neg), C.uint32_t(kFetch), u32p(rows), f32p(dist), f32p(nd), &n) != C.QV_OK {
@@ -94,6 +101,7 @@ func (d *node) searchNegative(q, neg []float32, kFetch int) ([]uint32, []float32
 }
 
 func (d *node) distanceRows(q []float32, rows []uint32) ([]float32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	out := make([]float32, len(rows))
 	if C.qv_sharded_distance_rows(d.h, f32p(q), u32p(rows), C.uint32_t(len(rows)), f32p(out)) != C.QV_OK {
 		return nil, lastErr()
@@ -102,6 +110,7 @@ func (d *node) distanceRows(q []float32, rows []uint32) ([]float32, error) {
 }
 
 func (d *node) getRows(rows []uint32) ([]float32, error) {
+	defer pinned()() // qv_last_error is thread-local: the failing call and the read of its message stay on one OS thread
 	out := make([]float32, len(rows)*d.dim)
 	if C.qv_sharded_get_rows(d.h, u32p(rows), C.uint32_t(len(rows)), f32p(out)) != C.QV_OK {
 		return nil, lastErr()

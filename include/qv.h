@@ -325,7 +325,13 @@ int qv_graph_stats(const qv_graph* g, double* build_seconds, uint64_t* build_bat
  * Threading: as qv_index — searches, qv_sharded_distance_rows and qv_sharded_get_row(s) may run concurrently from many
  * threads (the reference searches under a read lock, collection.go:647): every call works in a context of its own
  * (streams, staging and exchange buffers from a pool); add / remove / update / reserve take the handle exclusively
- * (they wait for running searches); destroy needs external exclusion. */
+ * (they wait for running searches); destroy needs external exclusion.
+ * What has run on hardware (state of round 4; no box with more than one GPU was available to the authors): concurrent callers
+ * with the point-to-point exchange (QV_SHARDED_PEER_COPY, shards co-located) and with RCCL at ONE rank.  With RCCL over several
+ * devices every context enqueues its grouped all-gather on the shared per-device communicators under one lock, each on streams of
+ * its own — within RCCL's rules, but first exercised by tests/test_gpu_sharded_abi.py::test_concurrent_callers_on_one_rccl_handle_*,
+ * which needs two GPUs.  Until that has passed on the target node, callers that want no exposure serialise searches on an RCCL
+ * handle or create it with QV_SHARDED_PEER_COPY. */
 typedef struct qv_sharded qv_sharded;
 #define QV_SHARDED_PEER_COPY (1ull << 32)
 uint32_t qv_sharded_span(int n_shards);

@@ -25,7 +25,11 @@
 #include "qv_api_internal.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <shared_mutex>
+#include <thread>
 
 #include <dlfcn.h>
 #include <limits.h>
@@ -73,12 +77,69 @@ struct CallCtx {
     PinBuf h_q, h_rows, h_dist, h_aux;
     Buf d_out_rows, d_out_dist, d_aux, d_sort;   // first device: merged results, payload, radix-sort workspace
     hipEvent_t ev_merged = nullptr;      // this context's previous search has read the gather buffer
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;   // qv_sharded_search_device: the caller's stream before / after the search (pooled: two
+                                         // hipEventCreate + hipEventDestroy per call were on the path whose whole budget at 8 GPUs is a 0.48 ms scan)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // profiling: scans enqueued / exchange enqueued / merge enqueued / done
+};
+
+// Per-shard host work of one search, optionally issued in parallel.  One thread walking the shards makes ~10 HIP calls per shard
+// (wait, copy, two launches, copy, record, ...): 172-226 us per search at 8 shards (tools/dev_sharded_hostcost.py,
+// profiles/r04_sharded_hostcost.md) against a 480 us scan per shard at 10M x 768 over 8 GPUs — hidden while searches are
+// pipelined, not for a lone one.  With QV_SHARDED_WORKERS=1 a handle of more than two shards keeps G - 1 workers; the caller's
+// thread takes shard 0 and the parts that must stay on one thread (the grouped collective, the merge).  Workers spin briefly after
+// a job before they block, so a stream of searches finds them awake.
+struct ShardJob {
+    std::function<int(uint32_t)> fn;
+    std::atomic<uint32_t> remaining{0};
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+};
+struct ShardPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::pair<ShardJob*, uint32_t>> q;
+    bool stop = false;
+    void start(uint32_t n) {
+        for (uint32_t i = 0; i < n; i++) th.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        for (;;) {
+            std::pair<ShardJob*, uint32_t> item{nullptr, 0};
+            for (int spin = 0; spin < 4000 && !item.first; spin++) {          // ~100 us of polling before sleeping
+                if (m.try_lock()) {
+                    if (!q.empty()) { item = q.front(); q.pop_front(); }
+                    const bool st = stop;
+                    m.unlock();
+                    if (st && !item.first) return;
+                }
+                if (!item.first) { for (int p = 0; p < 16; p++) __builtin_ia32_pause(); }
+            }
+            if (!item.first) {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [this] { return stop || !q.empty(); });
+                if (q.empty()) return;                                           // stop
+                item = q.front(); q.pop_front();
+            }
+            ShardJob* j = item.first;
+            const int rc = j->fn(item.second);
+            j->rc[item.second] = rc;
+            if (rc != QV_OK) j->msg[item.second] = qv_last_error();            // the message is thread-local: carry it to the caller
+            j->remaining.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    void shutdown() {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+    }
 };
 
 }  // namespace
 
 struct qv_sharded {
+    ShardPool pool;
     uint32_t dim = 0; int metric = 0; uint64_t flags = 0;
     uint32_t span = 0;
     std::vector<Shard> sh;
@@ -114,6 +175,29 @@ void plan_add(const uint64_t* have, uint32_t G, uint64_t n, uint64_t* give) {
     for (uint32_t g = 0; g < G && left; g++) { give[g] += left; left = 0; }     // only when a shard already exceeds the level
 }
 
+// fn(g) for every shard: shard 0 on this thread, the others on the pool's workers (or all here when the handle has no pool).
+// Returns the first failure with its message.
+int for_shards(qv_sharded* s, const std::function<int(uint32_t)>& fn) {
+    const uint32_t G = (uint32_t)s->sh.size();
+    if (s->pool.th.empty()) {
+        for (uint32_t g = 0; g < G; g++) { const int rc = fn(g); if (rc != QV_OK) return rc; }
+        return QV_OK;
+    }
+    ShardJob job;
+    job.fn = fn; job.rc.assign(G, QV_OK); job.msg.resize(G);
+    job.remaining.store(G - 1, std::memory_order_relaxed);
+    {
+        std::lock_guard<std::mutex> l(s->pool.m);
+        for (uint32_t g = 1; g < G; g++) s->pool.q.emplace_back(&job, g);
+    }
+    s->pool.cv.notify_all();
+    job.rc[0] = fn(0);
+    if (job.rc[0] != QV_OK) job.msg[0] = qv_last_error();
+    while (job.remaining.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    for (uint32_t g = 0; g < G; g++) if (job.rc[g] != QV_OK) return fail(job.rc[g], "%s", job.msg[g].c_str());
+    return QV_OK;
+}
+
 uint64_t total_live(const qv_sharded* s) { uint64_t t = 0; for (auto& x : s->sh) t += qv_index_size(x.idx); return t; }
 
 int acquire_ctx(qv_sharded* s, CallCtx** out) {
@@ -136,6 +220,8 @@ int acquire_ctx(qv_sharded* s, CallCtx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev2);
     if (e == hipSuccess) e = hipEventCreate(&c->ev3);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_merged, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(c->ev_merged, c->sh[0].stream);
     std::lock_guard<std::mutex> g(s->ctx_mu);
     s->all_ctx.push_back(c);                                              // destroyed with the handle whatever happened above
@@ -155,7 +241,7 @@ void destroy_ctx(qv_sharded* s, CallCtx* c) {
     (void)hipSetDevice(s->sh[0].device);
     c->h_q.release(); c->h_rows.release(); c->h_dist.release(); c->h_aux.release();
     c->d_out_rows.release(); c->d_out_dist.release(); c->d_aux.release(); c->d_sort.release();
-    for (hipEvent_t ev : {c->ev_merged, c->ev0, c->ev1, c->ev2, c->ev3}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {c->ev_merged, c->ev_in, c->ev_out, c->ev0, c->ev1, c->ev2, c->ev3}) if (ev) (void)hipEventDestroy(ev);
     delete c;
 }
 
@@ -241,74 +327,83 @@ int search_ctx(qv_sharded* s, CallCtx* c, const float* queries_host, const float
         if (mode.negative) memcpy(static_cast<char*>(c->h_q.p) + qbytes, mode.negative, (size_t)s->dim * sizeof(float));
     }
     const size_t up_bytes = qbytes + (mode.negative ? (size_t)s->dim * sizeof(float) : 0);
-    // ---- queries to every device
-    for (uint32_t g = 0; g < G; g++) {
+    // ---- the query block on the first device (device-resident queries): placed by this thread BEFORE the other shards' work is
+    // issued, because they wait on the event recorded here (a wait captures the event's state at the call)
+    if (!queries_host) {
+        HIPCHK(hipSetDevice(s0.device));
+        HIPCHK(hipStreamWaitEvent(c0.stream, c->ev_merged, 0));           // this context's previous gather buffer has been consumed
+        if ((rc = c0.d_q.ensure(up_bytes))) return rc;
+        HIPCHK(hipMemcpyAsync(c0.d_q.p, d_queries_dev0, qbytes, hipMemcpyDeviceToDevice, c0.stream));
+        HIPCHK(hipEventRecord(c0.ev_done, c0.stream));
+    }
+    HIPCHK(hipSetDevice(s0.device));
+    if ((rc = c0.d_gath.ensure(words * 4 * G))) return rc;                // (before the shards' tasks: with the point-to-point exchange they all write into it)
+    if (prof) HIPCHK(hipEventRecord(c->ev0, c0.stream));
+    // ---- per shard, in parallel (for_shards): queries in, scan, hand-backs of the batched filter redone, and — point-to-point
+    // exchange — the shard's packed lists on their way to the first device's gather buffer
+    rc = for_shards(s, [&](uint32_t g) -> int {
         Shard& x = s->sh[g]; ShardBufs& b = c->sh[g];
+        int rc2;
         HIPCHK(hipSetDevice(x.device));
-        HIPCHK(hipStreamWaitEvent(b.stream, c->ev_merged, 0));             // this context's previous gather buffer has been consumed
-        if ((rc = b.d_q.ensure(up_bytes)) || (rc = b.d_pack.ensure(words * 4))) return rc;
-        if (s->rccl || g == 0) { if ((rc = b.d_gath.ensure(words * 4 * G))) return rc; }
+        if (queries_host || g != 0) HIPCHK(hipStreamWaitEvent(b.stream, c->ev_merged, 0));
+        if ((rc2 = b.d_q.ensure(up_bytes)) || (rc2 = b.d_pack.ensure(words * 4))) return rc2;
+        if (s->rccl && g != 0) { if ((rc2 = b.d_gath.ensure(words * 4 * G))) return rc2; }
         if (queries_host) HIPCHK(hipMemcpyAsync(b.d_q.p, c->h_q.p, up_bytes, hipMemcpyHostToDevice, b.stream));
-        else if (g == 0) HIPCHK(hipMemcpyAsync(b.d_q.p, d_queries_dev0, qbytes, hipMemcpyDeviceToDevice, b.stream));
-        else {                                                             // device-resident queries live on the first device
+        else if (g != 0) {                                                 // device-resident queries live on the first device
             HIPCHK(hipStreamWaitEvent(b.stream, c0.ev_done, 0));
             if (x.device == s0.device) HIPCHK(hipMemcpyAsync(b.d_q.p, c0.d_q.p, qbytes, hipMemcpyDeviceToDevice, b.stream));
             else HIPCHK(hipMemcpyPeerAsync(b.d_q.p, x.device, c0.d_q.p, s0.device, qbytes, b.stream));
         }
-        if (g == 0 && !queries_host) HIPCHK(hipEventRecord(c0.ev_done, c0.stream));   // the query block is on the first device
         if (mode.masked && matching[g]) {
             const size_t mb = (((size_t)qv_index_rows(x.idx) + 63) / 64) * 8;
             HIPCHK(hipMemcpyAsync(b.d_mask.p, b.h_mask.p, mb, hipMemcpyHostToDevice, b.stream));
         }
-    }
-    if (prof) { HIPCHK(hipSetDevice(s0.device)); HIPCHK(hipEventRecord(c->ev0, c0.stream)); }
-    // ---- scans
-    std::vector<char> filtered(G, 0);
-    for (uint32_t g = 0; g < G; g++) {
-        Shard& x = s->sh[g]; ShardBufs& b = c->sh[g];
+        // -- scan
         uint32_t* pack = static_cast<uint32_t*>(b.d_pack.p);
         float* pack_dist = reinterpret_cast<float*>(pack + (size_t)nq * kcap);
         const float* dq = static_cast<const float*>(b.d_q.p);
+        bool filtered = false;
         if (matching[g] == 0) {                                            // no candidates here: no results (0xFFFFFFFF rows are skipped by the merge)
-            HIPCHK(hipSetDevice(x.device));
             HIPCHK(hipMemsetAsync(pack, 0xFF, words * 4, b.stream));
-            continue;
-        }
-        if (mode.masked) {
-            if ((rc = qv_internal_search_candidates_device(x.idx, dq, nq, kcap, static_cast<const uint64_t*>(b.d_mask.p), matching[g], pack, pack_dist, b.stream))) return rc;
+        } else if (mode.masked) {
+            if ((rc2 = qv_internal_search_candidates_device(x.idx, dq, nq, kcap, static_cast<const uint64_t*>(b.d_mask.p), matching[g], pack, pack_dist, b.stream))) return rc2;
         } else {
             // batches go through the matrix-core filter + exact re-score where it applies (same results, qv_index_search's own rule);
-            // everything else, and whatever the filter declines, through the exact scan (k > 64: the shard's full ranking)
+            // everything else, and whatever the filter declines, through the exact scan
             int rcb = QV_ERR_UNSUPPORTED;
             if (nq >= 9) {                                                  // (declines — QV_ERR_UNSUPPORTED — above kMaxBatchedK results per query)
-                if ((rc = b.d_flags.ensure((size_t)nq * 4)) || (rc = b.h_flags.ensure((size_t)nq * 4))) return rc;
+                if ((rc2 = b.d_flags.ensure((size_t)nq * 4)) || (rc2 = b.h_flags.ensure((size_t)nq * 4))) return rc2;
                 rcb = qv_index_search_batched_device(x.idx, dq, nq, kcap, pack, pack_dist, static_cast<uint32_t*>(b.d_flags.p), b.stream);
             }
-            if (rcb == QV_OK) filtered[g] = 1;
+            if (rcb == QV_OK) filtered = true;
             else if (rcb != QV_ERR_UNSUPPORTED) return rcb;
-            else if ((rc = qv_index_search_device(x.idx, dq, nq, kcap, pack, pack_dist, b.stream))) return rc;
+            else if ((rc2 = qv_index_search_device(x.idx, dq, nq, kcap, pack, pack_dist, b.stream))) return rc2;
         }
-        if (mode.negative) {                                               // hybrid_index.go:536-546: distFunc(vector, negative) for this shard's candidates
+        if (filtered) {                                                    // queries whose candidate buffer overflowed: the exact scan, one by one (rare)
+            HIPCHK(hipMemcpyAsync(b.h_flags.p, b.d_flags.p, (size_t)nq * 4, hipMemcpyDeviceToHost, b.stream));
+            HIPCHK(hipStreamSynchronize(b.stream));
+            const uint32_t* fl = static_cast<const uint32_t*>(b.h_flags.p);
+            for (uint32_t q = 0; q < nq; q++) {
+                if (!fl[q]) continue;
+                if ((rc2 = qv_index_search_device(x.idx, dq + (size_t)q * s->dim, 1, kcap, pack + (size_t)q * kcap, pack_dist + (size_t)q * kcap, b.stream))) return rc2;
+            }
+        }
+        if (mode.negative && matching[g]) {                                // hybrid_index.go:536-546: distFunc(vector, negative) for this shard's candidates
             const uint32_t valid = (uint32_t)std::min<uint64_t>(kcap, matching[g]);
             hipError_t e = qv::launch_distance_rows(x.idx->view(), dq + (size_t)nq * s->dim, pack, valid, reinterpret_cast<float*>(pack + (size_t)2 * nq * kcap), b.stream);
             if (e != hipSuccess) return fail(QV_ERR_DEVICE, "distance_rows launch failed: %s", hipGetErrorString(e));
         }
-    }
-    for (uint32_t g = 0; g < G; g++) {                                      // queries whose candidate buffer overflowed: the exact scan, one by one (rare)
-        if (!filtered[g]) continue;
-        Shard& x = s->sh[g]; ShardBufs& b = c->sh[g];
-        HIPCHK(hipSetDevice(x.device));
-        HIPCHK(hipMemcpyAsync(b.h_flags.p, b.d_flags.p, (size_t)nq * 4, hipMemcpyDeviceToHost, b.stream));
-        HIPCHK(hipStreamSynchronize(b.stream));
-        const uint32_t* fl = static_cast<const uint32_t*>(b.h_flags.p);
-        uint32_t* pack = static_cast<uint32_t*>(b.d_pack.p);
-        for (uint32_t q = 0; q < nq; q++) {
-            if (!fl[q]) continue;
-            if ((rc = qv_index_search_device(x.idx, static_cast<const float*>(b.d_q.p) + (size_t)q * s->dim, 1, kcap, pack + (size_t)q * kcap,
-                                             reinterpret_cast<float*>(pack + (size_t)nq * kcap) + (size_t)q * kcap, b.stream)))
-                return rc;
+        // -- point-to-point exchange: this shard's lists into the first device's gather buffer
+        if (!s->rccl) {
+            HIPCHK(hipSetDevice(x.device));
+            unsigned char* dst = static_cast<unsigned char*>(c0.d_gath.p) + (size_t)g * words * 4;
+            if (x.device == s0.device) HIPCHK(hipMemcpyAsync(dst, b.d_pack.p, words * 4, hipMemcpyDeviceToDevice, b.stream));
+            else HIPCHK(hipMemcpyPeerAsync(dst, s0.device, b.d_pack.p, x.device, words * 4, b.stream));
+            if (g != 0) HIPCHK(hipEventRecord(b.ev_done, b.stream));
         }
-    }
+        return QV_OK;
+    });
+    if (rc != QV_OK) return rc;
     // ---- exchange
     if (prof) { HIPCHK(hipSetDevice(s0.device)); HIPCHK(hipEventRecord(c->ev1, c0.stream)); }
     if (s->rccl) {
@@ -320,14 +415,6 @@ int search_ctx(qv_sharded* s, CallCtx* c, const float* queries_host, const float
         }
         NCCLCHK(ncclGroupEnd());
     } else {
-        for (uint32_t g = 0; g < G; g++) {
-            Shard& x = s->sh[g]; ShardBufs& b = c->sh[g];
-            HIPCHK(hipSetDevice(x.device));
-            unsigned char* dst = static_cast<unsigned char*>(c0.d_gath.p) + (size_t)g * words * 4;
-            if (x.device == s0.device) HIPCHK(hipMemcpyAsync(dst, b.d_pack.p, words * 4, hipMemcpyDeviceToDevice, b.stream));
-            else HIPCHK(hipMemcpyPeerAsync(dst, s0.device, b.d_pack.p, x.device, words * 4, b.stream));
-            if (g != 0) HIPCHK(hipEventRecord(b.ev_done, b.stream));
-        }
         HIPCHK(hipSetDevice(s0.device));
         for (uint32_t g = 1; g < G; g++) HIPCHK(hipStreamWaitEvent(c0.stream, c->sh[g].ev_done, 0));
     }
@@ -454,12 +541,18 @@ int qv_sharded_create(qv_sharded** out, uint32_t dim, qv_metric metric, const in
         if (rc == QV_OK && e != hipSuccess) rc = fail(QV_ERR_DEVICE, "setup on device %d failed: %s", devices[0], hipGetErrorString(e));
     }
     if (rc != QV_OK) { char keep[512]; snprintf(keep, sizeof(keep), "%s", qv_last_error()); qv_sharded_destroy(s); return fail(rc, "%s", keep); }
+    // Workers for the per-shard host work of a search: OPT-IN (QV_SHARDED_WORKERS=1, read at create).  Measured with 8 shards
+    // co-located on ONE device they do not help (207 against 189 us per search: HIP calls on one device serialise on that device's
+    // lock — four caller threads only reach 1.9 x); whether they pay off on 8 distinct devices has to be measured on such a node.
+    const char* wk = getenv("QV_SHARDED_WORKERS");
+    if (n_devices > 2 && wk && atoi(wk) == 1) s->pool.start((uint32_t)n_devices - 1);
     *out = s;
     return QV_OK;
 }
 
 void qv_sharded_destroy(qv_sharded* s) {
     if (!s) return;
+    s->pool.shutdown();
     for (CallCtx* c : s->all_ctx) destroy_ctx(s, c);
     for (auto& x : s->sh) {
         (void)hipSetDevice(x.device);
@@ -692,17 +785,11 @@ int qv_sharded_search_device(qv_sharded* s, const float* d_queries, uint32_t nq,
     HIPCHK(hipSetDevice(s->sh[0].device));
     hipStream_t cs = static_cast<hipStream_t>(stream);
     hipStream_t s0 = c->sh[0].stream;
-    {                                                                      // order after the caller's earlier work on its stream
-        hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(ev, cs)); HIPCHK(hipStreamWaitEvent(s0, ev, 0)); (void)hipEventDestroy(ev);
-    }
+    HIPCHK(hipEventRecord(c->ev_in, cs)); HIPCHK(hipStreamWaitEvent(s0, c->ev_in, 0));   // order after the caller's earlier work on its stream
     rc = search_ctx(s, c, nullptr, d_queries, nq, k, SearchMode{}, nullptr, nullptr, nullptr, d_rows_out, d_dist_out);
     if (rc != QV_OK) return rc;
     HIPCHK(hipSetDevice(s->sh[0].device));
-    {
-        hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(ev, s0)); HIPCHK(hipStreamWaitEvent(cs, ev, 0)); (void)hipEventDestroy(ev);
-    }
+    HIPCHK(hipEventRecord(c->ev_out, s0)); HIPCHK(hipStreamWaitEvent(cs, c->ev_out, 0));
     return QV_OK;
 }
 

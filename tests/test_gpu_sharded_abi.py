@@ -151,3 +151,54 @@ def test_two_devices_over_rccl_equal_one_index():
             back = np.array([[bounds[int(x) // span] + int(x) % span for x in row] for row in r], dtype=np.uint32)
             assert np.array_equal(back, r1) and np.array_equal(d.view(np.uint32), d1.view(np.uint32)), (peer, kk)
         sh.close(); one.close()
+
+
+def test_concurrent_callers_on_one_rccl_handle_over_every_visible_device():
+    """ADVICE (round 3): include/qv.h promises concurrent searches on one handle.  On the RCCL exchange every call context drives
+    the shared per-device communicators from streams of its own (only the group enqueue is serialised): eight threads of
+    qv_sharded_search and qv_sharded_search_device on ONE handle over all visible GPUs against a single index.  Needs >= 2 GPUs
+    (the 1-GPU test box skips it; with one rank the same test runs in test_gpu_sharded_index.py)."""
+    import threading
+    import torch
+    ndev = quiver_amd.lib().qv_device_count()
+    if ndev < 2:
+        pytest.skip("needs two or more GPUs")
+    n, dim, k = 200_003, 64, 10
+    sh = ShardedIndex(dim, "cosine", devices=list(range(ndev)))            # RCCL exchange
+    sh.add_synthetic(20260424, 0, n)
+    one = quiver_amd.DeviceIndex(dim, "cosine")
+    one.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, 32, dim)
+    r1, d1, _ = one.search(qs, k)
+    span = quiver_amd.lib().qv_sharded_span(ndev)
+    bounds = [g * n // ndev for g in range(ndev + 1)]
+    errs = []
+
+    def back(r):
+        return np.array([bounds[int(x) // span] + int(x) % span for x in r], dtype=np.uint32)
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream(device=0)
+            dq = torch.from_numpy(qs).cuda()
+            dr = torch.empty((1, k), dtype=torch.int32, device="cuda"); dd = torch.empty((1, k), dtype=torch.float32, device="cuda")
+            for rep in range(40):
+                i = (t * 7 + rep) % len(qs)
+                if rep % 2:
+                    r, d, _ = sh.search(qs[i], k)
+                    r, d = r[0], d[0]
+                else:
+                    sh.search_device(dq[i].data_ptr(), 1, k, dr.data_ptr(), dd.data_ptr(), st.cuda_stream)
+                    st.synchronize()
+                    r, d = dr.cpu().numpy().view(np.uint32)[0], dd.cpu().numpy()[0]
+                if not (np.array_equal(back(r), r1[i]) and np.array_equal(d.view(np.uint32), d1[i].view(np.uint32))):
+                    errs.append((t, rep))
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:5]
+    sh.close(); one.close()
