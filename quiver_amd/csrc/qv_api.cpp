@@ -9,6 +9,8 @@
 // a HIP kernel, and a missing/failed HIP runtime is a loud error, never a fallback.
 #include "qv_api_internal.h"
 
+#include <atomic>
+
 namespace {
 thread_local char g_err[512] = "";
 }
@@ -48,7 +50,7 @@ struct CtxGuard {
 // The workspace of a caller stream.  Returns with `hold` locked on that workspace: the caller keeps it until its launches
 // are enqueued, so that another thread using the same stream cannot grow (free) the buffer between "fetch the pointer" and
 // "launch" — once enqueued, stream order protects the kernels (a grow drains the stream first).
-int stream_workspace(qv_index* idx, hipStream_t s, size_t bytes, void** out, std::unique_lock<std::mutex>* hold) {
+int stream_workspace(qv_index* idx, hipStream_t s, size_t bytes, void** out, std::unique_lock<std::mutex>* hold, uint32_t** tickets_out = nullptr) {
     Workspace* w;
     {
         std::lock_guard<std::mutex> g(idx->ws_mu);
@@ -65,6 +67,14 @@ int stream_workspace(qv_index* idx, hipStream_t s, size_t bytes, void** out, std
         if (rc != QV_OK) return rc;
     }
     *out = w->ws.p;
+    if (tickets_out) {                                                 // the single-launch small scan's tickets: zeroed once, left zero by the kernel
+        if (!w->tickets.p) {
+            int rc = w->tickets.ensure(256);
+            if (rc != QV_OK) return rc;
+            HIPCHK(hipMemset(w->tickets.p, 0, 256));
+        }
+        *tickets_out = static_cast<uint32_t*>(w->tickets.p);
+    }
     return QV_OK;
 }
 
@@ -177,7 +187,7 @@ void qv_index_destroy(qv_index* idx) {
     (void)hipSetDevice(idx->device);
     (void)hipDeviceSynchronize();
     for (SearchCtx* c : idx->all_ctx) { c->release(); delete c; }
-    for (auto& kv : idx->stream_ws) { kv.second->ws.release(); delete kv.second; }
+    for (auto& kv : idx->stream_ws) { kv.second->ws.release(); kv.second->tickets.release(); delete kv.second; }
     (void)hipFree(idx->d_tiles); (void)hipFree(idx->d_rnorm); (void)hipFree(idx->d_alive); (void)hipFree(idx->d_rres); (void)hipFree(idx->d_rowmaj); (void)hipFree(idx->d_bf16);
     idx->mut_stage.release();
     delete idx;
@@ -347,7 +357,9 @@ int qv_index_get_rows(qv_index* idx, const uint32_t* rows, uint32_t n, float* ou
 // (kk = min(k, live)), results written with row stride k_stride
 static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
                           void* ws, size_t ws_bytes, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
-                          const uint64_t* d_candidates = nullptr /* row bitmap replacing the tombstone bitmap (filtered search) */) {
+                          const uint64_t* d_candidates = nullptr /* row bitmap replacing the tombstone bitmap (filtered search) */,
+                          uint32_t* d_tickets = nullptr /* the stream's tickets: allows the single-launch small scan */,
+                          uint32_t* done_flag = nullptr, uint32_t done_seq = 0, bool* flag_used = nullptr) {
     qv::IndexView v = idx->view();
     if (d_candidates) v.alive = const_cast<uint64_t*>(d_candidates);   // read-only in every scan kernel
     const qv::ScanPlan plan = qv::plan_scan(v.n_tiles, idx->cus);
@@ -359,6 +371,12 @@ static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, ui
                 std::lock_guard<std::mutex> g(idx->prof_mu);
                 idx->prof_events.emplace_back(ev0, ev1);
             } else { ev0 = ev1 = nullptr; }
+        }
+        if (d_tickets && qv::flat_small_applies(v, nq, kk)) {           // small collection: scan + merge in one launch
+            hipError_t e = qv::launch_flat_small(v, d_queries, nq, kk, ws, d_tickets, d_rows_out, d_dist_out, nq == 1 ? done_flag : nullptr, done_seq, s, ev0, ev1);
+            if (e != hipSuccess) return fail(QV_ERR_DEVICE, "small scan launch failed: %s", hipGetErrorString(e));
+            if (flag_used) *flag_used = nq == 1 && done_flag != nullptr;
+            return QV_OK;
         }
         hipError_t e = qv::launch_flat_topk(v, plan, d_queries, nq, kk, ws, d_rows_out, d_dist_out, s, ev0, ev1);
         if (e != hipSuccess) return fail(QV_ERR_DEVICE, "flat scan launch failed: %s", hipGetErrorString(e));
@@ -394,8 +412,9 @@ static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, ui
 static size_t search_ws_bytes(const qv_index* idx, uint32_t nq, uint32_t kk, uint32_t k_stride) {
     const uint32_t n_tiles = (idx->n_rows + 63) / 64;
     const qv::ScanPlan plan = qv::plan_scan(n_tiles, idx->cus);
-    if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride)   // partial lists + the multi-query kernels' query blocks
-        return qv::scan_workspace_bytes(plan, nq, kk) + std::max((size_t)(nq + 16) * idx->dim4 * 4 * sizeof(double), qv::mq64_workspace_bytes(nq, idx->dim4));
+    if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride)   // partial lists + the multi-query kernels' query blocks (the small scan's lists fit in them)
+        return std::max(qv::flat_small_workspace_bytes(std::min(nq, 4u), kk),
+                        qv::scan_workspace_bytes(plan, nq, kk) + std::max((size_t)(nq + 16) * idx->dim4 * 4 * sizeof(double), qv::mq64_workspace_bytes(nq, idx->dim4)));
     if (kk > (uint32_t)qv::kMaxFusedK && kk <= (uint32_t)qv::kMaxWideK) return qv::flat_wide_workspace_bytes(plan, nq, kk);
     if (kk <= (uint32_t)qv::kMaxSelectK) return qv::flat_select_workspace_bytes(n_tiles, nq, kk);
     return qv::full_sort_workspace_bytes(n_tiles);
@@ -441,14 +460,35 @@ static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, u
     const bool direct = (size_t)nq * kk <= 1024;
     const bool q_direct = direct && nq <= 4 && idx->n_rows <= 262144;
     if (!q_direct) HIPCHK(hipMemcpyAsync(c->d_q.p, c->h_q.p, qbytes, hipMemcpyHostToDevice, c->stream));
+    // small collections: one launch for scan + merge, and the host polls a sequence number the kernel writes behind its results
+    // instead of waiting for the stream
+    uint32_t* tickets = nullptr; uint32_t* flag = nullptr; bool flag_used = false;
+    if (direct && q_direct) {
+        if (!c->tickets.p) { if ((rc = c->tickets.ensure(256))) return rc; HIPCHK(hipMemset(c->tickets.p, 0, 256)); }
+        if (!c->h_flag.p) { if ((rc = c->h_flag.ensure(64))) return rc; *static_cast<volatile uint32_t*>(c->h_flag.p) = 0; }
+        tickets = static_cast<uint32_t*>(c->tickets.p); flag = static_cast<uint32_t*>(c->h_flag.p);
+        c->flag_seq++;
+    }
     rc = enqueue_search(idx, static_cast<const float*>(q_direct ? c->h_q.p : c->d_q.p), nq, kk, kk, c->ws.p, c->ws.cap,
-                        static_cast<uint32_t*>(direct ? c->h_rows.p : c->d_rows.p), static_cast<float*>(direct ? c->h_dist.p : c->d_dist.p), c->stream);
+                        static_cast<uint32_t*>(direct ? c->h_rows.p : c->d_rows.p), static_cast<float*>(direct ? c->h_dist.p : c->d_dist.p), c->stream,
+                        nullptr, tickets, flag, c->flag_seq, &flag_used);
     if (rc != QV_OK) return rc;
     if (!direct) {
         HIPCHK(hipMemcpyAsync(c->h_rows.p, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_dist.p, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    bool seen = false;
+    if (flag_used) {
+        const volatile uint32_t* f = static_cast<const volatile uint32_t*>(c->h_flag.p);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spin = 0; !(seen = *f == c->flag_seq); spin++) {
+            __builtin_ia32_pause();
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;   // something else holds the GPU: wait properly
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (seen && (c->flag_seq & 63u) == 0) HIPCHK(hipStreamSynchronize(c->stream));   // (lets the runtime retire its finished commands now and then)
+    }
+    if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
     const uint32_t* hr = static_cast<const uint32_t*>(c->h_rows.p);
     const float* hd = static_cast<const float*>(c->h_dist.p);
     for (uint32_t q = 0; q < nq; q++) {
@@ -586,9 +626,10 @@ int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, u
     const uint32_t kk = std::min(k, idx->n_live);
     void* ws = nullptr;
     std::unique_lock<std::mutex> ws_hold;
-    int rc = stream_workspace(idx, s, search_ws_bytes(idx, nq, kk, k), &ws, &ws_hold);
+    uint32_t* tickets = nullptr;
+    int rc = stream_workspace(idx, s, search_ws_bytes(idx, nq, kk, k), &ws, &ws_hold, &tickets);
     if (rc != QV_OK) return rc;
-    return enqueue_search(idx, d_queries, nq, kk, k, ws, 0, d_rows_out, d_dist_out, s);
+    return enqueue_search(idx, d_queries, nq, kk, k, ws, 0, d_rows_out, d_dist_out, s, nullptr, tickets);
 }
 
 }  // extern "C"

@@ -41,13 +41,15 @@ struct PinBuf {         // growable pinned host buffer
         if (bytes <= cap) return QV_OK;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         size_t want = std::max(bytes, (size_t)4096);
-        HIPCHK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        // coherent (fine-grained): a kernel's stores are visible to the host while the kernel is still running — the single-launch
+        // small scan writes its results and then a sequence number here, and the host polls that instead of waiting for the stream
+        HIPCHK(hipHostMalloc(&p, want, hipHostMallocCoherent));
         cap = want; return QV_OK;
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-struct Workspace { Buf ws; std::mutex mu; };
+struct Workspace { Buf ws; Buf tickets; std::mutex mu; };      // tickets: 64 zeroed words of the single-launch small scan (k_flat_scan_small)
 
 // qv_api.cpp, for qv_sharded_api.cpp: exact scan over the rows of a device-resident candidate bitmap (see the definition)
 int qv_internal_search_candidates_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k_stride, const uint64_t* d_candidates,
@@ -55,11 +57,12 @@ int qv_internal_search_candidates_device(qv_index* idx, const float* d_queries, 
 
 struct SearchCtx {
     hipStream_t stream = nullptr;
-    Buf d_q, d_rows, d_dist, d_ids, d_mask, ws;
-    PinBuf h_q, h_rows, h_dist, h_ids, h_mask;
+    Buf d_q, d_rows, d_dist, d_ids, d_mask, ws, tickets;
+    PinBuf h_q, h_rows, h_dist, h_ids, h_mask, h_flag;
+    uint32_t flag_seq = 0;                   // sequence number the small scan writes into h_flag when its results are in h_rows / h_dist
     void release() {
-        d_q.release(); d_rows.release(); d_dist.release(); d_ids.release(); d_mask.release(); ws.release();
-        h_q.release(); h_rows.release(); h_dist.release(); h_ids.release(); h_mask.release();
+        d_q.release(); d_rows.release(); d_dist.release(); d_ids.release(); d_mask.release(); ws.release(); tickets.release();
+        h_q.release(); h_rows.release(); h_dist.release(); h_ids.release(); h_mask.release(); h_flag.release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }

@@ -119,6 +119,13 @@ hipError_t launch_fetch_rows(const IndexView& v, const uint32_t* d_rows, uint32_
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
                             hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// Small collections (<= 256 tiles, <= 4 queries, k <= 16): scan + merge in ONE launch (the last workgroup to finish merges).
+// d_ws: flat_small_workspace_bytes (partial lists); d_tickets: 64 zeroed words that belong to the caller's stream alone (the kernel
+// leaves them zero).  done_flag (optional, device-visible host memory): receives done_seq after the results have been written.
+bool flat_small_applies(const IndexView& v, uint32_t nq, uint32_t k);
+size_t flat_small_workspace_bytes(uint32_t nq, uint32_t k);
+hipError_t launch_flat_small(const IndexView& v, const float* d_queries, uint32_t nq, uint32_t k, void* d_ws, uint32_t* d_tickets, uint32_t* d_rows_out, float* d_dist_out,
+                             uint32_t* done_flag, uint32_t done_seq, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // merge n_lists lists of k (dist, row) pairs -> k best by (dist, row)
 hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases, uint32_t n_lists, uint32_t nq, uint32_t k,
                                uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, uint32_t planes = 0 /* 0: [nq][2][k] per shard; >= 2: [planes][nq][k] */);

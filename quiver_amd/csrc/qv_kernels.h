@@ -241,7 +241,9 @@ template <int M> __device__ __forceinline__ void stage_query(typename MT<M>::Q* 
 // (distances.go:20 magnitudeA += a*a; adapter.go:118 normA += a*a).  It is an independent
 // dependency chain, so riding along with a row's dot product costs no time; a wave does it
 // on its first tile only.
-template <int M, int U, bool QN, bool BAR = false>
+// NT: non-temporal requests (a corpus streamed once per query must not displace the query and the partial lists from L2); false
+// for collections small enough to STAY in L2 between calls (k_flat_scan_small)
+template <int M, int U, bool QN, bool BAR = false, bool NT = true>
 __device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict__ p, uint32_t stride4,
                                                             const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4,
                                                             typename MT<M>::A* qnorm2 = nullptr) {
@@ -257,7 +259,7 @@ __device__ __forceinline__ typename MT<M>::A row_accumulate(const f4* __restrict
         constexpr int B = decltype(Bc)::value;
         f4 v[B];
 #pragma unroll
-        for (int u = 0; u < B; u++) v[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * stride4]);
+        for (int u = 0; u < B; u++) { if constexpr (NT) v[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * stride4]); else v[u] = p[(size_t)(c0 + u) * stride4]; }
         // Keep all loads of the block ahead of the arithmetic: left alone, hipcc (ROCm 7.2) sinks them next to their uses for
         // every metric but cosine — 2 loads in flight instead of 16: dot / Euclidean 78 %, squared Euclidean / Manhattan 52 % of
         // the HBM peak instead of 88 %.  For cosine its own schedule (a rolling window of ~8 loads) beats the hard barrier

@@ -64,6 +64,147 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
     }
 }
 
+__device__ __forceinline__ uint64_t wave_min64(uint64_t x) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)x, off), hi = __shfl_xor((uint32_t)(x >> 32), off);
+        uint64_t y = ((uint64_t)hi << 32) | lo;
+        x = y < x ? y : x;
+    }
+    return x;
+}
+
+// ---------------------------------------------------------------- small collections: scan + merge in ONE launch --
+// configs[0] of BASELINE.json is 10k x 128: 5 MB of rows, a scan of a few microseconds — what a query costs there is launches and
+// the wait for the stream (31 us per query in round 3: scan launch + merge launch + hipStreamSynchronize; the reference's own
+// ExactIndex.Search bench at 1000 x 64 is 38 us on a laptop core, final_bench.txt:28).  Up to kSmallTiles tiles the scan's
+// workgroups hand their lists to the LAST one to finish (a ticket), which merges them and writes the final rows / distances
+// itself — and, for the host-pointer entry point, a sequence number into pinned memory that the host polls instead of waiting
+// for the stream.  Same arithmetic and (distance, row) order as k_flat_scan + k_merge_lists.
+// Nothing crosses workgroups through a fence (an agent-scope fence writes the XCD's L2 back, qv_select.h): the lists are published
+// with returning atomic exchanges (returned = performed at the memory side), then the ticket; the last workgroup reads them with
+// agent-scope atomic loads.  grid (workgroups, nq); partial [nq][grid][k]; tickets [nq], zero before the first launch and left zero.
+constexpr uint32_t kSmallTiles = 256;                  // 16k rows: 64 workgroups of one tile per wave (at 30k rows the two-launch path measured faster: 25.7 against 32.6 us)
+constexpr uint32_t kSmallPerThread = 64 * 16 / kScanBlock;    // keys a thread of the last workgroup holds: 64 lists of up to 16 keys over 256 threads
+constexpr uint32_t kSmallSurv = 512;                   // survivors of the bound ranked by counting (more: one wave inserts the lists)
+template <int M, int U>
+__global__ void __launch_bounds__(kScanBlock)
+k_flat_scan_small(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t* __restrict__ partial, uint32_t* __restrict__ tickets,
+                  uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* done_flag, uint32_t done_seq) {
+    using Q = typename MT<M>::Q;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);  // [kScanWaves][64]
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qi = blockIdx.y;
+    stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
+    __syncthreads();
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const uint32_t kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+    bool first = true;
+    for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
+        typename MT<M>::A qn2 = 0, acc;
+        // the row's norm and the tile's live word first, then all of a 128-dimension row's chunks in ONE round of requests (U = 32,
+        // pinned), temporal: a collection this small stays in its XCD's L2 from call to call (the same workgroup, hence the same XCD,
+        // reads the same tiles every time) — what a query costs here is round trips, not bytes
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        const uint64_t am = v.alive[t];
+        if (first) { acc = row_accumulate<M, U, true, true, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4, &qn2); qc = qconst_from_norm2<M>(qn2); }
+        else acc = row_accumulate<M, U, false, true, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4);
+        const float dist = finalize<M>(acc, qc, rn);
+        const uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+        if (first) { list = wave_sort64(key, lane); thr = readlane64(list, kth); first = false; }
+        else list_insert(list, thr, key, kth, lane);
+    }
+    wl[wave * 64 + lane] = list;
+    __syncthreads();
+    __shared__ uint32_t s_last, s_ns;
+    __shared__ unsigned long long s_bound;
+    __shared__ uint64_t surv[kSmallSurv];
+    uint64_t* mine = partial + ((size_t)qi * gridDim.x + blockIdx.x) * k;
+    if (wave == 0) {
+        for (uint32_t w = 1; w < kScanWaves; w++) list_insert(list, thr, lane < k ? wl[w * 64 + lane] : kDeadKey, kth, lane);
+        uint32_t last = 1;
+        if (gridDim.x > 1) {
+            if (lane < k) (void)atomicExch(reinterpret_cast<unsigned long long*>(&mine[lane]), (unsigned long long)list);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every lane's exchange has returned: the list is at the memory side
+            if (lane == 0) last = atomicAdd(&tickets[qi], 1u) == gridDim.x - 1 ? 1u : 0u;
+            last = __builtin_amdgcn_readfirstlane(last);
+            if (last && lane == 0) tickets[qi] = 0;                    // for the next launch on this workspace (stream order)
+        }
+        if (lane == 0) { s_last = last; s_ns = 0; s_bound = kDeadKey; }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (gridDim.x > 1) {
+        // The last workgroup merges, all four waves: (1) B = the smallest k-th key of any list — that list alone holds k keys <= B, so
+        // nothing above B is in the answer; (2) the keys <= B (a few dozen of grid * k) go to LDS; (3) every survivor counts the
+        // survivors below it: that count is its place.  (One wave inserting 400 keys one by one was 8 of the kernel's 20 us.)
+        const uint64_t* all = partial + (size_t)qi * gridDim.x * k;
+        const uint32_t total = gridDim.x * k;
+        uint64_t b = kDeadKey;
+        for (uint32_t w = threadIdx.x; w < gridDim.x; w += kScanBlock) { const uint64_t x = __hip_atomic_load(&all[(size_t)w * k + kth], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b = x < b ? x : b; }
+        uint64_t keys[kSmallPerThread];
+#pragma unroll
+        for (uint32_t u = 0; u < kSmallPerThread; u++) {
+            const uint32_t i = threadIdx.x + u * kScanBlock;
+            keys[u] = i < total ? __hip_atomic_load(&all[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kDeadKey;
+        }
+        b = wave_min64(b);
+        if (lane == 0 && b != kDeadKey) atomicMin(&s_bound, (unsigned long long)b);
+        __syncthreads();
+        const uint64_t bound = s_bound;
+#pragma unroll
+        for (uint32_t u = 0; u < kSmallPerThread; u++)
+            if (keys[u] != kDeadKey && keys[u] <= bound) { const uint32_t pos = atomicAdd(&s_ns, 1u); if (pos < kSmallSurv) surv[pos] = keys[u]; }
+        __syncthreads();
+        const uint32_t ns = s_ns < kSmallSurv ? s_ns : kSmallSurv;     // (more than kSmallSurv keys <= B needs > 32 lists with k-th keys tied at B: the first kSmallSurv still hold the answer's
+                                                                      //  keys only if none is lost — so that case takes the serial path below)
+        if (s_ns <= kSmallSurv) {
+            list = kDeadKey;
+            for (uint32_t i = threadIdx.x; i < ns; i += kScanBlock) {
+                const uint64_t me = surv[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < ns; j++) rank += surv[j] < me ? 1u : 0u;
+                if (rank < k) wl[rank] = me;                           // keys are distinct: ranks are too
+            }
+            __syncthreads();
+            if (wave != 0) return;
+            list = lane < (ns < k ? ns : k) ? wl[lane] : kDeadKey;
+        } else {
+            if (wave != 0) return;
+            for (uint32_t base = 0; base < total; base += 64) {
+                const uint32_t i = base + lane;
+                uint64_t key = kDeadKey;
+                if (i < total && i / k != blockIdx.x) key = __hip_atomic_load(&all[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                list_insert(list, thr, key, kth, lane);
+            }
+        }
+    } else if (wave != 0) return;
+    const bool dead = list == kDeadKey;
+    const uint32_t r_out = dead ? 0xFFFFFFFFu : (uint32_t)list;
+    const float d_out = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+    if (!done_flag) {
+        if (lane < k) { rows_out[(size_t)qi * k + lane] = r_out; dist_out[(size_t)qi * k + lane] = d_out; }
+    } else {
+        // The host polls a sequence number instead of waiting for the stream (nq == 1 for this use).  The results go out as
+        // SYSTEM-scope stores (write-through whatever the page's cache policy: plain stores sat in L2 until the kernel ended and
+        // the host read the previous call's rows); once they are acknowledged the sequence number follows on the same path.
+        if (lane < k) {
+            __hip_atomic_store(&rows_out[(size_t)qi * k + lane], r_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dist_out[(size_t)qi * k + lane], d_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---------------------------------------------------------------- flat scan, 64 < k <= 128 --
 // The negative-example branches of the reference fetch max(2k, 30) results (hybrid_index.go:516-522, hnsw/adapter.go:353-359):
 // k = 50 is a 100-key search.  Same stream, same arithmetic as k_flat_scan; the wave's list holds R keys per lane
@@ -271,15 +412,6 @@ constexpr int kMergeBlock = 1024;
 constexpr int kMergeCap = 2048;                       // survivors kept in LDS; more -> general path
 constexpr int kMergeHeads = 128;                      // sampled list heads ranked in LDS
 
-__device__ __forceinline__ uint64_t wave_min64(uint64_t x) {
-#pragma unroll
-    for (int off = 32; off; off >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)x, off), hi = __shfl_xor((uint32_t)(x >> 32), off);
-        uint64_t y = ((uint64_t)hi << 32) | lo;
-        x = y < x ? y : x;
-    }
-    return x;
-}
 
 __global__ void __launch_bounds__(kMergeBlock)
 k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k,
@@ -529,6 +661,28 @@ hipError_t launch_merge_shards(const uint32_t* d_packed, const uint32_t* d_bases
     uint32_t total = n_lists * k;
     uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
     hipLaunchKernelGGL(k_merge_shards, dim3(nq), dim3(mblock), 0, s, d_packed, d_bases, n_lists, nq, k, d_rows_out, d_dist_out, planes);
+    return hipGetLastError();
+}
+
+// (k <= 16: with 64 keys per list the bound lets hundreds through and the two-launch path's 1024-thread merge is faster — 55 against ~30 us at 10k x 128)
+bool flat_small_applies(const IndexView& v, uint32_t nq, uint32_t k) { return v.n_tiles <= kSmallTiles && nq >= 1 && nq <= 4 && k >= 1 && k <= 16; }
+size_t flat_small_workspace_bytes(uint32_t nq, uint32_t k) { return (size_t)nq * 64 * std::min(k, 16u) * sizeof(uint64_t); }
+// d_tickets: 64 words of the caller's own (one set per stream), zero before the first launch; the kernel leaves them zero.
+hipError_t launch_flat_small(const IndexView& v, const float* d_queries, uint32_t nq, uint32_t k, void* d_ws, uint32_t* d_tickets, uint32_t* d_rows_out, float* d_dist_out,
+                             uint32_t* done_flag, uint32_t done_seq, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (!flat_small_applies(v, nq, k)) return hipErrorInvalidValue;
+    const uint32_t grid = std::max(1u, (v.n_tiles + kScanWaves - 1) / kScanWaves);
+    uint32_t* tickets = d_tickets;
+    uint64_t* partial = static_cast<uint64_t*>(d_ws);
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
+    hipError_t e = hipSuccess;
+    QV_DISPATCH_METRIC(v.metric, {
+        e = set_lds(k_flat_scan_small<MM, 32>, lds);
+        if (e != hipSuccess) return e;
+        if (ev0) (void)hipEventRecord(ev0, s);
+        hipLaunchKernelGGL((k_flat_scan_small<MM, 32>), dim3(grid, nq), dim3(kScanBlock), lds, s, v, d_queries, k, partial, tickets, d_rows_out, d_dist_out, done_flag, done_seq);
+        if (ev1) (void)hipEventRecord(ev1, s);
+    });
     return hipGetLastError();
 }
 
