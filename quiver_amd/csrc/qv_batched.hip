@@ -100,7 +100,8 @@ __device__ __forceinline__ uint32_t pack_bf16(float x0, float x1) { const bf2 h 
 __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint32_t nq_pad, uint32_t dim, uint32_t dim4,
                             const float* __restrict__ sample_dist /*[nq][k], or [nq][parts][k] ascending partial lists*/, uint32_t parts, uint32_t k, int metric,
                             float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq /*[2][nq_pad]: m_q, b_q*/, float* __restrict__ eq /*[nq_pad][2]*/,
-                            uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what, uint32_t cand_cap) {
+                            uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what, uint32_t cand_cap,
+                            uint32_t steps_pad /* bfloat16 layout: steps of 16 dimensions per query block, zero padded (0 = ceil(dim / 16)) */) {
     // what: 1 = operand layout only, 2 = filter constants only (needs sample_dist), 3 = both
     const uint32_t q = blockIdx.x;                     // one block per (padded) query
     if (q == 0 && threadIdx.x == 0) cand_cnt[-1] = cand_cap;           // candidate slots per query, for the filter kernels (CandOut)
@@ -108,8 +109,9 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
     if (!(what & 1)) {
     } else if (bf16x3) {
         // Qbf[(qb32 * steps + s) * 2 + {hi, lo}][64 lanes] x 16 bytes: lane 32h + j holds dims 16s + 8h .. +7 of query 32 qb32 + j
-        const uint32_t steps = (dim4 + 3) / 4;
+        const uint32_t steps = steps_pad ? steps_pad : (dim4 + 3) / 4;
         uint4* Qbf = reinterpret_cast<uint4*>(Qt);
+        if (steps_pad && q == 0) Qbf[(size_t)(nq_pad >> 5) * steps * 128 + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);   // (64 threads) the padded kernel's KiB of zeros
         for (uint32_t i = threadIdx.x; i < steps * 2; i += blockDim.x) {
             const uint32_t st = i >> 1, h = i & 1;
             float x[8];
@@ -1289,7 +1291,12 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
 // instead of 6.2).  A wave holds 32 queries x 256 rows (128 accumulator registers); wave w converts dims 8(w&1) .. +7 of the step for the
 // 64 rows of tile (w >> 1) of the group — two 16-byte chunks in, ONE 16-byte LDS write out, which is a whole lane slot of a B operand —
 // and the B operands are read from LDS right before their matrix instructions (a second set of 32 registers would not fit).
-template <int METRIC, int RING, int AR>
+__host__ __device__ static inline uint32_t w8x2_rounds(uint32_t dim4) { const uint32_t r = ((dim4 + 3) / 4 + 3) / 4 * 4; return r < 8 ? 8 : r; }
+// PAD (round 4): any dimension.  The K loop runs over `rounds` = the steps of 16 dimensions rounded up to a multiple of four (eight at
+// least); a chunk past the row's last one is requested from the row's first chunk instead (a valid address) and replaced by zeros,
+// and k_mfma_prep pads the query operands with zeros to the same count: +0 terms, the scores and their error bounds are unchanged.
+// The predicates are wave-uniform (scalar compares) and exist only in this instantiation.
+template <int METRIC, int RING, int AR, bool PAD = false>
 __global__ void __launch_bounds__(512, 1)
 k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                      uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
@@ -1314,7 +1321,7 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
     const uint32_t half = lane >> 5, l31 = lane & 31;
     const EpiConsts ec = epi_consts<METRIC, 1>(s_c, s_m, 32 * wave, half);
     const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
-    const uint32_t rounds = v.dim4 / 4;                              // steps of 16 dimensions: a multiple of RING and AR here
+    const uint32_t rounds = PAD ? w8x2_rounds(v.dim4) : v.dim4 / 4;   // steps of 16 dimensions: a multiple of RING and AR here
     const uint4* a0 = Qbf + ((size_t)(8 * qb256 + wave) * rounds) * 2 * 64;                // the hi plane of 32-query block 8*qb256 + wave
     struct Raw { f4 c[2]; };                                         // this wave's two chunks of a step (dims 8(w&1) .. +7 of its tile's 64 rows)
     Raw r[RING];
@@ -1325,7 +1332,21 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
     auto rows_of = [&](uint32_t g_) { return tiles + ((size_t)tile_of(g_, tw) * v.dim4 + 2 * hw) * 64; };   // wave-uniform: the lane is added in the request
     const f4* lp = nullptr;
     const uint4* ap = a0;
-    auto load_b_run = [&](Raw& o) { o.c[0] = __builtin_nontemporal_load(lp + lane); o.c[1] = __builtin_nontemporal_load(lp + 64 + lane); lp += 256; };   // next step: four chunks on
+    uint32_t lstep = 0;                                              // PAD: the step (of its group) the next row request belongs to
+    const f4* zeros = reinterpret_cast<const f4*>(Qbf + (size_t)(nq_pad >> 5) * rounds * 128);   // PAD: 64 x 16 bytes of zeros behind the operand planes
+    auto load_b_run = [&](Raw& o) {                                  // next step: four chunks on
+        if constexpr (PAD) {
+            // a chunk past the row's end comes from a KiB of zeros behind the query operands (k_mfma_prep): only the wave-uniform
+            // address differs — two scalar selects per request, no vector instruction (selecting the VALUES measured 862 us against
+            // 550 for the unpadded kernel at 960 dimensions, where nothing is padded at all: the loop's hand-placed schedule
+            // counts its vector instructions)
+            const uint32_t c0 = 4 * lstep + 2 * hw;
+            o.c[0] = __builtin_nontemporal_load((c0 < v.dim4 ? lp : zeros) + lane);
+            o.c[1] = __builtin_nontemporal_load((c0 + 1 < v.dim4 ? lp + 64 : zeros) + lane);
+            lstep++;
+        } else { o.c[0] = __builtin_nontemporal_load(lp + lane); o.c[1] = __builtin_nontemporal_load(lp + 64 + lane); }
+        lp += 256;
+    };
     auto load_a_run = [&](uint4& o) { o = ap[lane]; ap += 128; };
     auto publish = [&](const Raw& o, uint32_t stage) {
         uint4 h;
@@ -1349,7 +1370,7 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
             for (int e = 0; e < 16; e++) { accA[0][j][e] = 0.f; accB[0][j][e] = 0.f; }
         if (!primed) {                                              // the workgroup's first group: fill the rings
             primed = true;
-            lp = rows_of(g);
+            lp = rows_of(g); lstep = 0;
 #pragma unroll
             for (int i = 0; i < RING; i++) load_b_run(r[i]);
 #pragma unroll
@@ -1378,7 +1399,7 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
             publish(r[(k8 + 2) & (RING - 1)], (uint32_t)(k8 + 2) & 3);
             if (s_ + (AR - 1) == rounds) ap = a0;
             load_a_run(qa[(k8 + AR - 1) & (AR - 1)]);                // before the row requests: waiting for a step's query operand then waits for no row younger than the ones this step publishes
-            if (s_ + RING + 2 == rounds) lp = bwn;
+            if (s_ + RING + 2 == rounds) { lp = bwn; lstep = 0; }
             load_b_run(r[(k8 + 2) & (RING - 1)]);
             uint4 b[8];
 #pragma unroll
@@ -2100,7 +2121,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     const uint32_t nq_pad = batched_nq_pad(nq, v);
     size_t b = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);   // sample scan (partials + query blocks)
     b = (b + 255) / 256 * 256;
-    b += (size_t)nq_pad * (v.dim4 + 4) * 16;                 // Qt (chunk count padded to even) / the bf16 hi + lo planes (padded to 4 chunks)
+    b += (size_t)nq_pad * (v.dim4 + 36) * 16 + 1024;         // Qt (chunk count padded to even) / the bf16 hi + lo planes (padded to whole steps; up to eight steps at least for the padded eight-wave kernel)
     const size_t ccap = batched_cand_cap(k);
     b += (size_t)nq_pad * 20;                                // cq, mq (m_q and b_q), eq
     b += (size_t)nq * ccap * 8;                              // candidates: rows + fp32 scores
@@ -2124,7 +2145,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     char* w = static_cast<char*>(d_ws);
     size_t off = scan_workspace_bytes(p, nq, k) + (size_t)(nq + 16) * v.dim4 * 4 * sizeof(double);
     off = (off + 255) / 256 * 256;
-    float* Qt = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * (v.dim4 + 4) * 16;
+    float* Qt = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * (v.dim4 + 36) * 16 + 1024;
     float* cq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 4;
     float* mq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // m_q, b_q
     float* eq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // the scores' error bound per query (k_mfma_prep -> k_rescore_select)
@@ -2168,6 +2189,11 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     const uint32_t fsteps0 = (v.dim4 + 3) / 4;
     const bool q64 = bf && fmode == 3 && nq_pad == 64 && v.bf16 != nullptr && q64_env == 1 && (v.dim4 & 3u) == 0 && fsteps0 % 4 == 0 && fsteps0 >= 8 && fsteps0 <= 64;
     const int gmode = !bf ? 0 : (fmode == 3 && (shared || q64) ? 2 : 1);   // which filter_gamma the main pass obeys (one term: the shared kernels and the one-block kernel)
+    // one-term filter on float32 rows at a dimension the eight-wave kernel's loop does not divide: its zero-padded form (round 4);
+    // the query operands are then laid out once more, padded, after the sample pass has read them in its own layout
+    static const int w8_env0 = env_int("QV_MFMA_W8", 1);
+    const bool w8_exact = (v.dim4 & 3u) == 0 && fsteps0 % 8 == 0 && fsteps0 >= 16;
+    const bool pad_main = gmode == 2 && shared && !q64 && w8_env0 == 1 && !w8_exact;
     hipError_t e = hipSuccess;
     if (sample_gemm == 1 || large_k) {
         // the sample's scores by the three-term bfloat16 kernel, their upper bounds' k-th smallest as U_q (k_sample_bound): 0.1 ms
@@ -2175,7 +2201,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         // operands are laid out as bfloat16 for the sample and then, in the same buffer, as float32 for the main pass
         off = (off + 255) / 256 * 256;
         float* sscore = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * vs.n_rows * 4;
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, 1, 1, ccap);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, 1, 1, ccap, 0u);
         const uint32_t nqb64s = nq_pad / 64;
         const uint32_t gs = grid_multiple(std::min<uint32_t>((uint32_t)cus, ((vs.n_tiles + 1) / 2 * nqb64s + 3) / 4), nqb64s / std::gcd(nqb64s, 4u));
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
@@ -2199,13 +2225,13 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
                      else hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k ? sparts : sdist, large_k ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, bf ? 2 : 3, ccap);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k ? sparts : sdist, large_k ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
         e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
         if (e != hipSuccess) return e;
         // 2. query re-layout + filter constants
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, 3, ccap);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, sdist, 1u, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, 3, ccap, 0u);
     }
     // 3. MFMA filter
     const uint32_t nqb64 = nq_pad / 64;
@@ -2255,6 +2281,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
 #define QV_FS(MMM) { QV_FS_VARIANTS(MMM)                                                                                                                                           \
                      if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (gmode == 2 && w8) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 4, 4>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     else if (pad_main) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 4, 4, true>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 3, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         if (v.metric == QV_COSINE) QV_FS(QV_COSINE) else if (v.metric == QV_DOT) QV_FS(QV_DOT) else QV_FS(QV_L2)

@@ -401,11 +401,15 @@ def test_rows_too_small_for_the_filter_are_still_found(metric, scale):
     assert _eq(_exact(idx, tq, k), idx.search(tq, k, batched=True))
 
 
-@pytest.mark.parametrize("metric,dim", [("cosine", 1024), ("dot_product", 1536), ("euclidean", 512), ("squared_euclidean", 256), ("cosine", 640), ("cosine", 2048)])
+@pytest.mark.parametrize("metric,dim", [("cosine", 1024), ("dot_product", 1536), ("euclidean", 512), ("squared_euclidean", 256), ("cosine", 640), ("cosine", 2048),
+                                        # round 4: every other width goes through the eight-wave kernel's zero-padded form
+                                        ("cosine", 64), ("dot_product", 100), ("euclidean", 128), ("cosine", 192), ("squared_euclidean", 200), ("cosine", 300),
+                                        ("dot_product", 320), ("cosine", 960), ("euclidean", 1000), ("cosine", 17), ("dot_product", 4), ("cosine", 1)])
 def test_filter_kernels_at_other_dimensions(metric, dim):
-    """The eight-wave one-term kernel (and its sample mode) runs whenever the dimension is a multiple of 128 with at least 16 steps of
-    16; 640 is not (the four-wave kernels take it) and 2048 is past the one-term rule (three terms by default): every shape against
-    the exact scan, 256 queries (whole workgroups of eight waves) and 64 (one query block)."""
+    """The eight-wave one-term kernel (and its sample mode) runs as it is whenever the dimension is a multiple of 128 with at least 16
+    steps of 16; at any other width its zero-padded form takes the float32 rows (the K loop runs to the next multiple of 64
+    dimensions, eight steps at least; a chunk past the row's end is replaced by zeros); 2048 is past the one-term rule (three terms
+    by default): every shape against the exact scan, 256 queries (whole workgroups of eight waves) and 64 (one query block)."""
     import quiver_amd as q
     n = 70_000
     idx = q.DeviceIndex(dim, metric)
