@@ -147,6 +147,9 @@ def compact_also(also, budget):
             c[short] = o
         elif key == "batched_small_1Mx768":
             c["b_small_1Mx768_ms"] = {k2.replace("_queries_", "q_").replace("float32", "f32"): _r(v2.get("batch_ms"), 3) for k2, v2 in e.items() if isinstance(v2, dict)}
+        elif key == "k_above_64":
+            c["k_gt_64_ms"] = {k2[:-3]: _r(v2, 4) for k2, v2 in e.items() if k2.endswith("_ms")}
+            c["k_gt_64_ms"]["same"] = all(v2 for k2, v2 in e.items() if k2.endswith("_same"))
         elif key == "pcie_inclusive_single_query":
             c["pcie_inclusive_qps"] = _r(e.get("qps"), 4)
         else:
@@ -370,7 +373,7 @@ def short_runtime(text):
 def pmc_traffic(rows_per_gpu, dim):
     """HBM bytes per k_flat_scan launch from the committed rocprofv3 PMC summary, when it was taken on this exact per-GPU
     workload; else None."""
-    for name in ("r03_10Mx768_pmc.json", "r02_10Mx768_pmc.json", "r01_10Mx768_pmc.json"):
+    for name in ("r04_10Mx768_pmc.json", "r03_10Mx768_pmc.json", "r02_10Mx768_pmc.json", "r01_10Mx768_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             if rows_per_gpu == 10_000_000 and dim == 768:
@@ -483,6 +486,38 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
                           "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 3.0 * flop / (mf_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
                           "matrix_flop_per_launch": 3.0 * flop, "fp32_equivalent_tflops_end_to_end": flop / dtm / 1e12,
                           "times_the_fp32_mfma_peak_end_to_end": flop / dtm / 1e12 / MFMA_F32_PEAK_TF})}
+    # more than 64 results per query (round 4): the negative-example branches fetch max(2k, 30) (hybrid_index.go:516-522), BatchSearch
+    # takes any k (:677-811).  k = 100 and 1000, one query (10M and 1M rows) and 256 queries x 1M rows; checked against the full ranking.
+    try:
+        ks_entry = {"workload": "k above the 64-key wave list: single query (wide wave lists to 128, one key per row + radix selection to 8192) and "
+                                "256-query batches (filter + re-score with radix selections to 2048); ms per call, device-resident"}
+        for label_k, index_k, rows_k in (("1x%dM" % (a.rows // 1_000_000), idx, a.rows), ("1x1M", idx1, 1_000_000)):
+            full_r = torch.empty((1, rows_k), dtype=torch.int32, device="cuda"); full_d = torch.empty((1, rows_k), dtype=torch.float32, device="cuda")
+            index_k.search_device(d_q.data_ptr(), 1, rows_k, full_r.data_ptr(), full_d.data_ptr(), sp)      # the full ranking (radix sort): the checker
+            for kk_ in (10, 100, 1000):
+                rr_ = torch.empty((1, kk_), dtype=torch.int32, device="cuda"); dd_ = torch.empty((1, kk_), dtype=torch.float32, device="cuda")
+                index_k.search_device(d_q.data_ptr(), 1, kk_, rr_.data_ptr(), dd_.data_ptr(), sp)
+                torch.cuda.synchronize()
+                t4 = time.perf_counter()
+                for _ in range(20):
+                    index_k.search_device(d_q.data_ptr(), 1, kk_, rr_.data_ptr(), dd_.data_ptr(), sp)
+                torch.cuda.synchronize()
+                ks_entry["%s_k%d_ms" % (label_k, kk_)] = (time.perf_counter() - t4) / 20 * 1e3
+                ks_entry["%s_k%d_same" % (label_k, kk_)] = bool(torch.equal(rr_, full_r[:, :kk_]) and torch.equal(dd_.view(torch.int32), full_d[:, :kk_].view(torch.int32)))
+            del full_r, full_d
+        for kk_ in (10, 64, 100, 1000):
+            rb_ = torch.empty((nqb, kk_), dtype=torch.int32, device="cuda"); db_ = torch.empty((nqb, kk_), dtype=torch.float32, device="cuda")
+            fl_ = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
+            idx1.search_batched_device(d_q.data_ptr(), nqb, kk_, rb_.data_ptr(), db_.data_ptr(), fl_.data_ptr(), sp)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(10):
+                idx1.search_batched_device(d_q.data_ptr(), nqb, kk_, rb_.data_ptr(), db_.data_ptr(), fl_.data_ptr(), sp)
+            torch.cuda.synchronize()
+            ks_entry["256x1M_k%d_ms" % kk_] = (time.perf_counter() - t4) / 10 * 1e3
+        also["k_above_64"] = ks_entry
+    except Exception as ex:                                # noqa: BLE001
+        also["k_above_64"] = {"error": str(ex)}
     also["batched_256x1Mx768_mfma"] = mfma_entry(idx1, "cosine", exact_rows, exact_dist, kernel="fp32")
     also["batched_256x1Mx768_bf16x3"] = mfma_entry(idx1, "cosine", exact_rows, exact_dist)
     also["batched_256x1Mx768_bf16x1"] = mfma_entry(idx1, "cosine", exact_rows, exact_dist, kernel="bf16x1")

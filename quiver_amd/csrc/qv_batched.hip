@@ -2066,6 +2066,13 @@ int filter_mode(const IndexView& v) {
     const int m = v.filter >= 1 && v.filter <= 3 ? v.filter : env_default;
     return m == 1 ? 1 : (m == 2 ? 2 : (m == 3 ? 3 : (v.dim <= 1536 ? 3 : 2)));
 }
+// From how many results per query the batch's selections are radix selections over key arrays (k_sample_hist, k_cand_*) instead of
+// the 64-key wave lists (k_sample_bound, k_rescore_select).  Above 64 there is no choice; QV_BATCHED_SELECT_FROM (read once) moves
+// the switch down for measurements.
+static bool batched_large_k(uint32_t k) {
+    static const int from = env_int("QV_BATCHED_SELECT_FROM", kMaxFusedK + 1);
+    return k > (uint32_t)kMaxFusedK || (int)k >= from;
+}
 // ---- MFMA batched path --------------------------------------------------------------
 // Rows of the exact sample scan that bounds each query's k-th distance.  A sample of S of N rows lets about k*N/S rows through
 // the filter per query; the candidate buffer holds kMfmaCandCap (4096), so S grows with N and k to keep that near 1536
@@ -2080,10 +2087,10 @@ uint32_t batched_sample_rows(const IndexView& v, uint32_t k) {
     // lets ~4.6 x as many rows through at the same bound: four times the sample keeps the candidate count where it was
     const bool one = filter_mode(v) == 3;
     // beyond 64 results per query the candidate slots grow with k (batched_cand_cap): half the sample, twice the candidates
-    const uint64_t per = (one ? 384 : 1536) * (k > (uint32_t)kMaxFusedK ? 2 : 1);
+    const uint64_t per = (one ? 384 : 1536) * (batched_large_k(k) ? 2 : 1);
     const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / per + 8191) / 8192 * 8192;
     uint64_t cap_rows = n_rows;
-    if (k > (uint32_t)kMaxFusedK) cap_rows = std::max<uint64_t>(32768, ((uint64_t)n_rows / 2 + 8191) / 8192 * 8192);   // the sample costs a pass over its rows: half the corpus at most
+    if (batched_large_k(k)) cap_rows = std::max<uint64_t>(32768, ((uint64_t)n_rows / 2 + 8191) / 8192 * 8192);   // the sample costs a pass over its rows: half the corpus at most
     return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n_rows, cap_rows), std::max<uint64_t>(one ? 32768 : 8192, want));
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
@@ -2104,7 +2111,7 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
 // candidate slots per query: kMfmaCandCap up to 64 results; beyond, 16 k rounded up to a power of two (the sample is capped at
 // half the corpus there, so the expected candidates grow with k: about 2 f k with f ~ 4.6 for the one-term filter)
 uint32_t batched_cand_cap(uint32_t k) {
-    if (k <= (uint32_t)kMaxFusedK) return (uint32_t)kMfmaCandCap;
+    if (!batched_large_k(k)) return (uint32_t)kMfmaCandCap;
     uint32_t c = (uint32_t)kMfmaCandCap;
     while (c < 16u * k) c <<= 1;
     return c;
@@ -2126,7 +2133,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     b += (size_t)nq_pad * 20;                                // cq, mq (m_q and b_q), eq
     b += (size_t)nq * ccap * 8;                              // candidates: rows + fp32 scores
     b += (size_t)nq * 8 + 256;                               // capacity word + counters, overflow flags
-    if (k > (uint32_t)kMaxFusedK)                            // keys of the upper bounds and of the exact distances, lower bounds, survivors, counters, norms, selection
+    if (batched_large_k(k))                                  // keys of the upper bounds and of the exact distances, lower bounds, survivors, counters, norms, selection
         b += (size_t)nq * ccap * (8 + 8 + 4 + 4) + (size_t)nq * (4 + 16) + 1024 + select_workspace_bytes(nq, k);
     b += (size_t)nq * k * 8;                                 // sample rows/dist
     b += (size_t)nq * k * 16 + 256;                          // k_sample_bound's partial lists (up to four parts per query)
@@ -2150,7 +2157,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     float* mq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // m_q, b_q
     float* eq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // the scores' error bound per query (k_mfma_prep -> k_rescore_select)
     const uint32_t ccap = batched_cand_cap(k);
-    const bool large_k = k > (uint32_t)kMaxFusedK;
+    const bool large_k = batched_large_k(k);
     uint32_t* cand = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * ccap * 4;
     float* cscore = reinterpret_cast<float*>(w + off); off += (size_t)nq * ccap * 4;
     off = (off + 255) / 256 * 256;

@@ -24,7 +24,7 @@ namespace qv {
 constexpr int kTileRows = 64;          // one wavefront
 constexpr int kMaxFusedK = 64;         // wave-resident top-k list: one key per lane
 constexpr int kMaxWideK = 128;         // wave-resident list of 2 keys per lane (k_flat_scan_wide) + selection over the waves' lists
-constexpr int kMaxBatchedK = 2048;     // filter + re-score batches: beyond 64 results per query their selections are radix selections (qv_batched.hip)
+constexpr int kMaxBatchedK = 4096;     // filter + re-score batches: beyond 64 results per query their selections are radix selections (qv_batched.hip)
 constexpr int kMaxSelectK = 8192;      // one key per row + radix select (qv_select.hip): above it, the full ranking (qv_rank.hip)
 constexpr uint64_t kDeadKey = ~0ull;
 

@@ -425,7 +425,7 @@ def test_filter_kernels_at_other_dimensions(metric, dim):
 # still be the exact scan's, row for row and bit for bit.
 
 @pytest.mark.parametrize("metric,nq,k", [("cosine", 256, 100), ("cosine", 64, 65), ("dot_product", 100, 128), ("euclidean", 40, 300),
-                                         ("squared_euclidean", 256, 129), ("cosine", 16, 1000), ("dot_product", 300, 2048)])
+                                         ("squared_euclidean", 256, 129), ("cosine", 16, 1000), ("dot_product", 300, 2048), ("cosine", 32, 4096)])
 def test_batched_large_k_equals_exact_scan(metric, nq, k):
     import quiver_amd as q
     n, dim = 200_000, 256
