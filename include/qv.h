@@ -138,7 +138,7 @@ int      qv_index_metric(const qv_index* idx);
  * How k is served (same result whichever applies): up to 64 results the scan keeps a sorted list per wavefront; up to 128 —
  * the negative-example branches fetch max(2k, 30), hybrid_index.go:516-522 — two keys per lane in that list; up to 8192 one
  * key per row and a radix SELECTION of the k smallest; beyond (k = Size() of a filtered search) the full radix ranking.
- * Batches of 9+ queries go through the matrix-core filter + exact re-score up to 2048 results per query. */
+ * Batches of 9+ queries go through the matrix-core filter + exact re-score up to 4096 results per query. */
 int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out);
 
@@ -186,7 +186,7 @@ int qv_index_set_filter(qv_index* idx, int filter);
 /* Device-pointer form of the batched path: enqueues on `stream`, no sync.  d_redo_flags_out[nq]
  * (uint32) is set to 1 for queries whose candidate buffer overflowed: the caller must redo those
  * with qv_index_search_device (their result rows are unspecified).  Returns QV_ERR_UNSUPPORTED when
- * the MFMA path does not apply (metric, k > 2048, small corpus, too few queries): use qv_index_search_device. */
+ * the MFMA path does not apply (metric, k > 4096, small corpus, too few queries): use qv_index_search_device. */
 int qv_index_search_batched_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
                                    uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_redo_flags_out, void* stream);
 

@@ -651,6 +651,20 @@ int qv_internal_search_candidates_device(qv_index* idx, const float* d_queries, 
     return enqueue_search(idx, d_queries, nq, kk, k_stride, ws, 0, d_rows_out, d_dist_out, s, d_candidates);
 }
 
+void qv_internal_drop_stream_workspace(qv_index* idx, void* stream) {
+    if (!idx) return;
+    Workspace* w = nullptr;
+    {
+        std::lock_guard<std::mutex> g(idx->ws_mu);
+        auto it = idx->stream_ws.find(static_cast<hipStream_t>(stream));
+        if (it == idx->stream_ws.end()) return;
+        w = it->second;
+        idx->stream_ws.erase(it);
+    }
+    { std::lock_guard<std::mutex> hold(w->mu); w->ws.release(); w->tickets.release(); }   // (hipFree waits for the device: nothing of the stream's is still running on it)
+    delete w;
+}
+
 extern "C" {
 
 // The filter walks the corpus once per 256 queries, so 257-320 queries cost two walks (2.6 ms against 1.4 ms at 1M x 768) while

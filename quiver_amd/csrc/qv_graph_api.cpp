@@ -26,8 +26,10 @@ struct qv_graph {
     Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev;
     PinBuf h_stage[2];                          // pinned bounce buffers for the query upload (pageable callers)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
-    hipStream_t stream2 = nullptr;              // exact-heap passes of qv_graph_search, beside the next part's wave pass
+    hipStream_t stream2 = nullptr;              // exact-heap passes of qv_graph_search beside the next part's wave pass: only QV_HNSW_OVERLAP_REDO=1 creates it
     hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_heap = nullptr;
+    Buf s_redo, s_counters;                     // qv_graph_search's own redo list and counters (the construction has b_redo / b_counters)
+    PinBuf h_counters;                          // counters read back: a pinned member, never the stack (an early return must not leave a copy in flight into a dead frame)
     // build workspace
     Buf b_self, b_keys_a, b_keys_b, b_hist, b_seg, b_redo, b_counters;
     double build_seconds = 0.0; uint64_t build_redo = 0, build_batches = 0;
@@ -165,6 +167,7 @@ void qv_graph_destroy(qv_graph* g) {
     (void)hipFree(g->d_l0dist); (void)hipFree(g->d_updist);
     g->vis_hash.release(); g->vis_bits.release();
     g->d_q.release(); g->d_qblk.release(); g->d_rows.release(); g->d_dist.release(); g->d_cnt.release(); g->d_ev.release();
+    g->s_redo.release(); g->s_counters.release(); g->h_counters.release();
     g->b_self.release(); g->b_keys_a.release(); g->b_keys_b.release(); g->b_hist.release(); g->b_seg.release(); g->b_redo.release(); g->b_counters.release();
     delete g;
 }
@@ -218,11 +221,14 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     const uint32_t parts = nq >= 4096 && overlap_env == 1 ? 2u : 1u;
     const uint32_t part_n = (nq + parts - 1) / parts;
     const size_t part_qblk = (qv::hnsw_qblk_bytes(part_n, idx->dim4) + 255) / 256 * 256;
-    if ((rc = g->d_qblk.ensure(part_qblk * parts)) || (rc = g->b_redo.ensure((size_t)nq * 4)) || (rc = g->b_counters.ensure(64))) return rc;
-    if (!g->stream2) HIPCHK(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) if (!g->ev_part[i]) HIPCHK(hipEventCreateWithFlags(&g->ev_part[i], hipEventDisableTiming));
-    if (!g->ev_heap) HIPCHK(hipEventCreateWithFlags(&g->ev_heap, hipEventDisableTiming));
-    uint32_t* counters = static_cast<uint32_t*>(g->b_counters.p);
+    if ((rc = g->d_qblk.ensure(part_qblk * parts)) || (rc = g->s_redo.ensure((size_t)nq * 4)) || (rc = g->s_counters.ensure(64)) || (rc = g->h_counters.ensure(64))) return rc;
+    if (parts > 1) {                                                    // the two-part mode alone needs a second stream and its events
+        if (!g->stream2) HIPCHK(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) if (!g->ev_part[i]) HIPCHK(hipEventCreateWithFlags(&g->ev_part[i], hipEventDisableTiming));
+        if (!g->ev_heap) HIPCHK(hipEventCreateWithFlags(&g->ev_heap, hipEventDisableTiming));
+    }
+    hipStream_t heap_stream = parts > 1 ? g->stream2 : g->stream;
+    uint32_t* counters = static_cast<uint32_t*>(g->s_counters.p);
     HIPCHK(hipMemsetAsync(counters, 0, 64, g->stream));
     hipError_t e = hipSuccess;
     for (uint32_t pi = 0; pi < parts && e == hipSuccess; pi++) {
@@ -234,19 +240,23 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
         uint32_t* d_cnt = static_cast<uint32_t*>(g->d_cnt.p) + q0; uint32_t* d_ev = static_cast<uint32_t*>(g->d_ev.p) + q0;
         const uint32_t pgrid = std::min(parts > 1 ? std::min(g->grid, (uint32_t)idx->cus * 8u) : g->grid, n_c);
         e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, qblk, n_c, k, ef_search, wave_opts(g), pgrid, d_rows, d_dist, d_cnt, d_ev, g->stream);
-        if (e == hipSuccess) e = qv::launch_build_compact_redo(d_cnt, n_c, static_cast<uint32_t*>(g->b_redo.p) + q0, counters + 4 * pi, g->stream);
+        if (e == hipSuccess) e = qv::launch_build_compact_redo(d_cnt, n_c, static_cast<uint32_t*>(g->s_redo.p) + q0, counters + 4 * pi, g->stream);
         if (e != hipSuccess) break;
-        HIPCHK(hipEventRecord(g->ev_part[pi], g->stream));
-        HIPCHK(hipStreamWaitEvent(g->stream2, g->ev_part[pi], 0));
+        if (parts > 1) {
+            HIPCHK(hipEventRecord(g->ev_part[pi], g->stream));
+            HIPCHK(hipStreamWaitEvent(g->stream2, g->ev_part[pi], 0));
+        }
         qv::HnswOpts ho = heap_opts(g);
-        ho.redo_idx = static_cast<const uint32_t*>(g->b_redo.p) + q0; ho.redo_n = counters + 4 * pi;
+        ho.redo_idx = static_cast<const uint32_t*>(g->s_redo.p) + q0; ho.redo_n = counters + 4 * pi;
         const uint32_t hgrid = std::min(std::min(qv::hnsw_grid(idx->cus, efx, n_c), g->vis_bits_slots), n_c);
-        e = qv::launch_hnsw_search(idx->view(), g->g, dq, qblk, n_c, k, ef_search, ho, hgrid, false, d_rows, d_dist, d_cnt, d_ev, g->stream2);
+        e = qv::launch_hnsw_search(idx->view(), g->g, dq, qblk, n_c, k, ef_search, ho, hgrid, false, d_rows, d_dist, d_cnt, d_ev, heap_stream);
     }
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
-    HIPCHK(hipEventRecord(g->ev_heap, g->stream2));
-    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_heap, 0));
-    uint32_t hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (parts > 1) {
+        HIPCHK(hipEventRecord(g->ev_heap, g->stream2));
+        HIPCHK(hipStreamWaitEvent(g->stream, g->ev_heap, 0));
+    }
+    uint32_t* hc = static_cast<uint32_t*>(g->h_counters.p);
     HIPCHK(hipMemcpyAsync(rows_out, g->d_rows.p, obytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipMemcpyAsync(dist_out, g->d_dist.p, obytes, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipMemcpyAsync(count_out, g->d_cnt.p, cbytes, hipMemcpyDeviceToHost, g->stream));
@@ -440,7 +450,8 @@ int qv_graph_insert(qv_graph* g, uint32_t first_row, uint32_t n, const int8_t* l
         g->g.n_nodes = at + B;
     }
     HIPCHK(hipEventRecord(g->ev_last, s));
-    uint32_t hc[4] = {0, 0, 0, 0};
+    if ((rc = g->h_counters.ensure(64))) return rc;
+    uint32_t* hc = static_cast<uint32_t*>(g->h_counters.p);
     HIPCHK(hipMemcpyAsync(hc, counters, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     g->build_redo += hc[3];

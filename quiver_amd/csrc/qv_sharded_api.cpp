@@ -229,13 +229,24 @@ int acquire_ctx(qv_sharded* s, CallCtx** out) {
     *out = c;
     return QV_OK;
 }
-void release_ctx(qv_sharded* s, CallCtx* c) { std::lock_guard<std::mutex> g(s->ctx_mu); s->free_ctx.push_back(c); }
+void destroy_ctx(qv_sharded* s, CallCtx* c);
+// A burst of concurrent searches leaves as many contexts as it had callers, each with streams, staging buffers and — on every
+// shard's index — a workspace per stream: beyond kKeepCtx idle contexts the extra ones are destroyed instead of pooled.
+constexpr size_t kKeepCtx = 8;
+void release_ctx(qv_sharded* s, CallCtx* c) {
+    {
+        std::lock_guard<std::mutex> g(s->ctx_mu);
+        if (s->free_ctx.size() < kKeepCtx) { s->free_ctx.push_back(c); return; }
+        s->all_ctx.erase(std::find(s->all_ctx.begin(), s->all_ctx.end(), c));
+    }
+    destroy_ctx(s, c);
+}
 struct CtxGuard { qv_sharded* s; CallCtx* c; ~CtxGuard() { if (c) release_ctx(s, c); } };
 
 void destroy_ctx(qv_sharded* s, CallCtx* c) {
     for (size_t g = 0; g < c->sh.size(); g++) {
         (void)hipSetDevice(s->sh[g].device);
-        if (c->sh[g].stream) (void)hipStreamSynchronize(c->sh[g].stream);
+        if (c->sh[g].stream) { (void)hipStreamSynchronize(c->sh[g].stream); qv_internal_drop_stream_workspace(s->sh[g].idx, c->sh[g].stream); }
         c->sh[g].release();
     }
     (void)hipSetDevice(s->sh[0].device);
