@@ -285,7 +285,7 @@ R max_pop(std::vector<R>& h) { int n = (int)h.size() - 1; std::swap(h[0], h[n]);
 // neighbour's distance unconditionally and only the heap admission depends on earlier
 // neighbours of the hop, so one batched device call per hop followed by the sequential
 // admission in adjacency order is exactly the reference's behaviour.
-Error HNSW::searchLayer(const float* q, uint32_t entry, int ef, int level, std::vector<Res>* out) {
+Error HNSW::searchLayer(const float* q, uint32_t entry, int ef, int level, std::vector<Res>* out, const std::vector<float>* table) {
     out->clear();
     if (nodes_.empty()) return "";                                     // :473-475
     if (!ok(entry)) return fmt("invalid entry point ID: %u", entry);   // :478-480
@@ -300,7 +300,13 @@ Error HNSW::searchLayer(const float* q, uint32_t entry, int ef, int level, std::
     visited_[entry] = epoch_;
     std::vector<uint32_t> batch; std::vector<float> bd;
     batch.push_back(entry);
-    Error e = distancesLocked(q, batch, &bd);                                // :492
+    auto distances = [&]() -> Error {                                  // the hop's batch: from the table when the caller made one, else one device call
+        if (!table) return distancesLocked(q, batch, &bd);
+        bd.resize(batch.size());
+        for (size_t i = 0; i < batch.size(); i++) bd[i] = (*table)[batch[i]];
+        return "";
+    };
+    Error e = distances();                                             // :492
     if (!e.empty()) return e;
     std::vector<R> cand, res;
     min_push(cand, {bd[0], entry}); max_push(res, {bd[0], entry});     // :498-506
@@ -316,7 +322,7 @@ Error HNSW::searchLayer(const float* q, uint32_t entry, int ef, int level, std::
             if (visited_[c] != epoch_) { visited_[c] = epoch_; batch.push_back(c); }   // :543-544
         }
         if (batch.empty()) continue;
-        e = distancesLocked(q, batch, &bd);                                  // :548, batched
+        e = distances();                                               // :548, batched
         if (!e.empty()) return e;
         for (size_t i = 0; i < batch.size(); i++) {
             float cd = bd[i];
@@ -602,13 +608,26 @@ Error HNSW::searchLocked(const float* q, uint32_t len, int k, std::vector<HNSWRe
         if (i == nodes_.size()) return "";                             // :632-634
     }
     std::vector<Res> buf;
+    int ef = std::max(efS_, k);                                        // :660-663
+    // A walk this wide (the device traversal stops at 512; a filtered Collection.Search asks k = Size(), collection.go:679-682,
+    // adapter.go:41-52) takes thousands of hops: ONE device call for the distance of the query to every row (the same kernel, the
+    // same bits as a hop's batch) instead of one ~20 us call per hop — 1M nodes at k = Size(): minutes -> under a second.
+    std::vector<float> table;
+    const std::vector<float>* tp = nullptr;
+    static const bool table_off = getenv("QV_HOST_WALK_TABLE") && atoi(getenv("QV_HOST_WALK_TABLE")) == 0;   // (measurement: one device call per hop, as before round 4)
+    if (ef > 512 && nodes_.size() >= 64 && !table_off) {
+        std::vector<uint32_t> all(nodes_.size());
+        for (uint32_t i = 0; i < all.size(); i++) all[i] = i;
+        Error te = distancesLocked(q, all, &table);
+        if (!te.empty()) return te;
+        tp = &table;
+    }
     for (int level = cur_level_; level > 0; level--) {                 // :649-657 (errors swallowed)
-        Error e = searchLayer(q, entry, 1, level, &buf);
+        Error e = searchLayer(q, entry, 1, level, &buf, tp);
         if (!e.empty() || buf.empty()) continue;
         entry = buf[0].idx;
     }
-    int ef = std::max(efS_, k);                                        // :660-663
-    Error e = searchLayer(q, entry, ef, 0, &buf);                      // :664
+    Error e = searchLayer(q, entry, ef, 0, &buf, tp);                  // :664
     if (!e.empty()) return e;
     if ((int)buf.size() > k) buf.resize(k);                            // :670-672
     if ((int)buf.size() < k) {                                         // :676 under-filled: exact top-up
@@ -617,7 +636,8 @@ Error HNSW::searchLocked(const float* q, uint32_t len, int k, std::vector<HNSWRe
         std::vector<uint32_t> rest;
         for (uint32_t i = 0; i < nodes_.size(); i++) if (nodes_[i].alive && !have[i]) rest.push_back(i);   // :682-688
         std::vector<float> d;
-        e = distancesLocked(q, rest, &d);                                    // :690
+        if (tp) { d.resize(rest.size()); for (size_t i = 0; i < rest.size(); i++) d[i] = table[rest[i]]; }
+        else e = distancesLocked(q, rest, &d);                               // :690
         if (!e.empty()) return e;
         for (size_t i = 0; i < rest.size(); i++) buf.push_back({d[i], rest[i]});
         std::sort(buf.begin(), buf.end(), [&](const Res& a, const Res& b) {   // :699-704 (Distance, VectorID)

@@ -160,7 +160,9 @@ public:
 private:
     struct Node { std::string id; std::vector<float> vec; int level = 0; std::vector<std::vector<uint32_t>> conn; bool alive = false; };
     struct Res { float dist; uint32_t idx; };
-    Error searchLayer(const float* q, uint32_t entry, int ef, int level, std::vector<Res>* out);   // hnsw.go:471-580
+    // table (optional): distance of the query to EVERY row, computed in one device call — the host-driven walk of a search with k or
+    // efSearch above the device traversal's 512 (a filtered Collection.Search asks k = Size()) then makes no device call per hop
+    Error searchLayer(const float* q, uint32_t entry, int ef, int level, std::vector<Res>* out, const std::vector<float>* table = nullptr);   // hnsw.go:471-580
     Error connectNode(uint32_t nodeIdx, const float* v, int level, int graphLevel);                // hnsw.go:337-468
     static int selectNeighbors(std::vector<Res>& c, int k);                                        // hnsw.go:583-599
     bool ok(uint32_t i) const { return i < nodes_.size() && nodes_[i].alive; }

@@ -770,3 +770,28 @@ def test_persistence_collection_search_tables():                 # persistence/c
     assert np.array_equal(_bits([r.Distance for r in top]), _bits(ed)) and (len(set(ed.tolist())) < 5 or [r.ID for r in top] == [names[j] for j in er])
     with pytest.raises(ps.GoError, match="vector with ID nope not found"):
         c2.DeleteVector("nope")
+
+
+def test_hnsw_search_wider_than_the_device_traversal_uses_one_distance_table():
+    """k above 512 (a filtered Collection.Search over an HNSW-backed collection asks k = Size(), collection.go:679-682 ->
+    adapter.go:41-52): the host-driven walk takes its distances from ONE device call over every row instead of one call per hop —
+    same results as the oracle's walk, and far fewer device calls than hops"""
+    import time
+    from quiver_amd import hnsw
+    n, dim = 2500, 24
+    rows = O.gen_rows(71, 0, n, dim)
+    h = hnsw.HNSW(hnsw.Config(M=8, EfConstruction=60, EfSearch=50, MaxLevel=2, DistanceFunc="hnsw_cosine", Seed=5))
+    o = O.HNSW(5, dim, M=8, efConstruction=60, efSearch=50, maxLevel=2, seed=5)
+    for i in range(n):                                                # node by node on both sides: the same graph
+        h.Insert("p%05d" % i, rows[i]); o.insert(rows[i])            # (zero-padded ids: the top-up's (Distance, VectorID) order, hnsw.go:699-704, compares
+                                                                      #  the id STRINGS — "p1765" < "p24" — and the oracle's ids are the indices)
+    qs = O.gen_rows(72, 0, 3, dim)
+    for k in (600, n):
+        t0 = time.perf_counter()
+        out = h.SearchBatch(qs, k)
+        dt = time.perf_counter() - t0
+        for i, q in enumerate(qs):
+            ro, do = o.search(q, k)
+            assert [r.VectorIndex for r in out[i]] == ro.tolist(), (k, i)
+            assert np.array_equal(np.array([r.Distance for r in out[i]], np.float32).view(np.uint32), do.view(np.uint32))
+        assert dt < 20.0
