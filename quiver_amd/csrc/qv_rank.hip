@@ -15,7 +15,10 @@ namespace qv {
 // rows cannot be consumed before the store is acknowledged — one such bubble per tile and wave.  A wave parks kKeyBatch tiles'
 // keys in LDS and writes them back to back, non-temporally (4.70 ms), and the end-of-window step no longer fences (qv_select.h:
 // an agent-scope fence behind 80 MB of dirty keys was another 0.2 ms): 4.47 ms, the pass's rate without any store.
-constexpr int kKeyBatch = 8;
+#ifndef QV_KEY_BATCH
+#define QV_KEY_BATCH 8
+#endif
+constexpr int kKeyBatch = QV_KEY_BATCH;
 // tiles a wave parks: kKeyBatch, fewer when a very wide query (up to 128 KiB of LDS at 16384 float64 dimensions) leaves less room
 static uint32_t key_batch(int metric, uint32_t dim4, bool hist) {
     const size_t room = (size_t)160 * 1024 - 1024 - query_lds_bytes(metric, dim4) - (hist ? (size_t)kSelBins * sizeof(uint32_t) : 0);
@@ -51,14 +54,15 @@ k_flat_keys(IndexView v, const float* __restrict__ queries, uint64_t* __restrict
     };
     for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
         const f4* p = tiles + (size_t)t * v.dim4 * 64 + lane;
-        // (the row's norm and the tile's live word are requested FIRST: behind the pinned blocks they would be a round trip of their own per tile)
+        // The tile loop has k_flat_scan's shape on purpose: the row walk first (cosine on hipcc's own rolling window of ~8 requests,
+        // the other metrics pinned per block — row_accumulate), the row's norm and the tile's live word after it.  Measured at
+        // 10M x 768 by compiling the differences out one by one (round 4): pinned blocks + norm requested first 4.47 ms, this shape
+        // 4.40, the same without writing any key 4.29 (= k_flat_scan).  tests/test_isa_guard.py holds the compiled loop to it.
+        typename MT<M>::A acc = row_accumulate<M, U, false>(p, 64, q_lds, v.dim4);
         const uint32_t row = t * 64 + lane;
         double rn = 0.0;
         if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
         const uint64_t am = v.alive[t];
-        // BAR: the block's 16 requests pinned ahead of its arithmetic for every metric — left to itself hipcc waits for each of
-        // the first six chunks of a block alone here
-        typename MT<M>::A acc = row_accumulate<M, U, false, true>(p, 64, q_lds, v.dim4);
         float dist = finalize<M>(acc, qc, rn);
         const uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
         kb[parked * 64 + lane] = key;                                  // (a lane reads back only what it wrote: no barrier)
