@@ -101,7 +101,8 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
                             const float* __restrict__ sample_dist /*[nq][k], or [nq][parts][k] ascending partial lists*/, uint32_t parts, uint32_t k, int metric,
                             float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq /*[2][nq_pad]: m_q, b_q*/, float* __restrict__ eq /*[nq_pad][2]*/,
                             uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what, uint32_t cand_cap,
-                            uint32_t steps_pad /* bfloat16 layout: steps of 16 dimensions per query block, zero padded (0 = ceil(dim / 16)) */) {
+                            uint32_t steps_pad /* bfloat16 layout: steps of 16 dimensions per query block, zero padded (0 = ceil(dim / 16)) */,
+                            const float* __restrict__ group_min = nullptr, uint32_t n_groups = 0 /* the sample's per-group minima [nq_pad][n_groups]: the bound is selected here */) {
     // what: 1 = operand layout only, 2 = filter constants only (needs sample_dist), 3 = both
     const uint32_t q = blockIdx.x;                     // one block per (padded) query
     if (q == 0 && threadIdx.x == 0) cand_cnt[-1] = cand_cap;           // candidate slots per query, for the filter kernels (CandOut)
@@ -150,6 +151,27 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
         eq[2 * q] = q < nq ? f32_up((float)(filter_gamma_acc(dim) * qn1 + __builtin_sqrt(d2) * (1.0 + 1e-9))) : 0.f;
         eq[2 * q + 1] = q < nq ? f32_up((float)(__builtin_sqrt(h2) * (1.0 + 1e-9))) : 0.f;
     }
+    __shared__ float s_U;
+    if ((what & 2) && group_min && q < nq) {
+        // the k-th smallest of the sample's group minima (k_bf16x1_filter_w8's sample mode): a wave-resident list over n_groups values,
+        // here instead of in a kernel of its own (k_sample_bound: one more launch on the batch's critical path)
+        const uint32_t lane = threadIdx.x, kth = k - 1;
+        uint64_t list = kDeadKey, thr = kDeadKey;
+        for (uint32_t base = 0; base < n_groups; base += 64) {
+            const uint32_t i = base + lane;
+            const float x = i < n_groups ? group_min[(size_t)q * n_groups + i] : __builtin_inff();
+            const uint64_t key = x < __builtin_inff() ? make_key(x, i) : kDeadKey;
+            if (base == 0) list_seed(list, thr, key, kth, lane); else list_insert(list, thr, key, kth, lane);
+        }
+        const uint64_t kk = readlane64(list, kth);
+        if (lane == 0) {
+            float x = kk == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(kk >> 32));
+            const float gref = (float)filter_gamma(dim, 0) * 1.000001f;
+            if (x < __builtin_inff()) x = metric == QV_L2 ? __builtin_sqrtf(x) * 1.000002f : (metric == QV_L2SQ ? x * (1.0f + gref + 4e-6f) : x);   // sample_bound_finish
+            s_U = x;
+        }
+    }
+    __syncthreads();
     if (threadIdx.x == 0 && (what & 2)) {
         float c_ = __uint_as_float(0x7F800000u), m_ = 0.f, b_ = 0.f;       // padded queries: +inf threshold, nothing passes
         float ea_ = 0.f, eb_ = 0.f;
@@ -161,7 +183,8 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
             const double eb = bf16x3 == 2 ? __builtin_sqrt(h2) * (1.0 + 1e-9) : 0.0;
             ea_ = f32_up((float)ea); eb_ = f32_up((float)eb);
             double U;                                                          // +inf if the sample held < k live rows
-            if (parts <= 1) U = (double)sample_dist[(size_t)q * k + (k - 1)];
+            if (group_min) U = (double)s_U;                                    // selected by the whole wave below
+            else if (parts <= 1) U = (double)sample_dist[(size_t)q * k + (k - 1)];
             else {                                                             // k-th smallest over the parts' ascending lists (k_sample_bound)
                 const float* sp = sample_dist + (size_t)q * parts * k;
                 uint32_t at[4] = {0, 0, 0, 0};
@@ -1050,7 +1073,7 @@ template <int METRIC, int RING, int AR, int SPB, bool BF, bool DEFER, bool SAMPL
 __global__ void __launch_bounds__(512, 1)
 k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                    uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt,
-                   float* __restrict__ score_out = nullptr, uint32_t score_stride = 0, uint32_t gstep = 1) {
+                   float* __restrict__ score_out = nullptr, uint32_t score_stride = 0, uint32_t gstep = 1, uint32_t group_min = 0) {
     // SAMPLE: no filter — the sample pass of the one-term path (see k_bf16x3_filter's score_out): row groups 0, gstep, 2 gstep, ... ; cq = the
     // queries' norms (rounded up), mq = their error constants ea, eb ([nq_pad][2], k_mfma_prep with what = 1); what is written is the upper
     // bound of the row's reference distance that its one-term score implies (sample1_upper)
@@ -1260,6 +1283,31 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
                    stamp[1] - stamp[0], stamp[2] - stamp[0], stamp[3] - stamp[0], stamp[4] - stamp[0], stamp[5] - stamp[0], stamp[6] - stamp[0]);
 #endif
         if constexpr (SAMPLE) {
+            // group_min (round 4, k <= 64): per query only the SMALLEST upper bound of the group's 128 rows leaves the kernel —
+            // score_out[query][group].  The k-th smallest of those minima is still an upper bound of the k-th smallest distance (they
+            // belong to k different rows), nearly as tight as the k-th smallest of all bounds while the groups outnumber k several
+            // times (the k best rows rarely share a group), and k_sample_bound then selects among S / 128 values per query instead
+            // of S: 29 -> 5 us at 256 x 32768, and 33 MB of scores are neither written nor read.
+            if (group_min) {
+                float ra[4], rb[4], rc[4];                                 // the four row blocks' constants first (+inf bounds for rows that are not there),
+#pragma unroll
+                for (int j = 0; j < 4; j++) {                              // then one query at a time: min over the blocks, min over the half-wave's 32 rows
+                    const uint32_t row = g * 128 + (j < 2 ? 0u : 64u) + 32 * (j & 1) + l31;
+                    const bool gone = (j >= 2 && t1 == t0) || row >= score_stride || !((alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull);
+                    sample1_row_consts<METRIC>(f32_up((float)rnd[j]), rho[j], gone, filter_tiny_norm(v.dim), ra[j], rb[j], rc[j]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t ql = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float qa_ = s_c[ql], qb_ = s_m[ql], qc_ = s_m[256 + ql];
+                    float m = __builtin_inff();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) m = fminf(m, sample1_upper<METRIC>(acc[0][j][r], qa_, qb_, qc_, ra[j], rb[j], rc[j]));
+#pragma unroll
+                    for (int off = 1; off < 32; off <<= 1) m = fminf(m, __shfl_xor(m, off));
+                    if (l31 == 0) score_out[(size_t)(256 * qb256 + ql) * n_groups + g] = m;
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (j >= 2 && t1 == t0) continue;
@@ -1272,6 +1320,7 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
                     const uint32_t ql = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
                     score_out[(size_t)(256 * qb256 + ql) * score_stride + row] = sample1_upper<METRIC>(acc[0][j][r], s_c[ql], s_m[ql], s_m[256 + ql], ra, rb, rc);
                 }
+            }
             }
         } else if constexpr (DEFER) {
 #define QV_W8_BLK(JJ) filter_epilogue_block<METRIC, 1, 4, JJ>(acc, t0, t1, s_c, s_m, 32 * wave, half, l31, 256 * qb256 + 32 * wave, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du, epn)
@@ -2224,15 +2273,20 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         SelState* sst = nullptr; uint32_t* shist = nullptr;
         if (large_k) { e = select_prepare(sel_ws, nq, k, &sst, &shist, s); if (e != hipSuccess) return e; }
         const uint32_t hgrid = std::max(1u, std::min(256u, (vs.n_rows + 16 * kSelBlock - 1) / (16 * kSelBlock)));
-#define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
+        // the eight-wave sample kernel hands out one value per query and 128-row group when the groups outnumber k at least four times
+        const uint32_t sample_groups = (vs.n_rows + 127) / 128;
+        static const int gmin_env = env_int("QV_MFMA_SAMPLE_GROUP_MIN", 1);                      // 2 = every row's bound (round 3)
+        const bool group_min = sample1 && !large_k && gmin_env == 1 && sample_groups >= 4 * k;
+#define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? 1u : 0u); \
                      else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
                      if (large_k) { hipLaunchKernelGGL(k_sample_hist<0>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_hist<1>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_bound_from_state<MMM>, dim3((nq + 255) / 256), dim3(256), 0, s, sst, nq, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); } \
+                     else if (group_min) { /* the bound is selected inside k_mfma_prep from the group minima */ } \
                      else hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k ? sparts : sdist, large_k ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k && !group_min ? sparts : sdist, large_k || group_min ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u, group_min ? sscore : nullptr, sample_groups);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
         e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
