@@ -384,7 +384,7 @@ static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, ui
     }
     // 64 < k <= 8192 (the negative-example branches fetch max(2k, 30), hybrid_index.go:516-522; BatchSearch takes any k,
     // :677-811), and any shorter list whose output stride differs from its length: one key per row, then a radix SELECT
-    if (kk > (uint32_t)qv::kMaxFusedK && kk <= (uint32_t)qv::kMaxWideK) {
+    if (kk > (uint32_t)qv::kMaxFusedK && kk <= (uint32_t)qv::kMaxWideK && nq == 1) {   // (several queries: shared corpus passes through the key-per-row path below)
         // up to 128: the scan's own stream with 2 keys per lane in the wave's list, then a selection over the waves' lists
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (idx->profiling && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) {
@@ -415,8 +415,8 @@ static size_t search_ws_bytes(const qv_index* idx, uint32_t nq, uint32_t kk, uin
     if (kk <= (uint32_t)qv::kMaxFusedK && kk == k_stride)   // partial lists + the multi-query kernels' query blocks (the small scan's lists fit in them)
         return std::max(qv::flat_small_workspace_bytes(std::min(nq, 4u), kk),
                         qv::scan_workspace_bytes(plan, nq, kk) + std::max((size_t)(nq + 16) * idx->dim4 * 4 * sizeof(double), qv::mq64_workspace_bytes(nq, idx->dim4)));
-    if (kk > (uint32_t)qv::kMaxFusedK && kk <= (uint32_t)qv::kMaxWideK) return qv::flat_wide_workspace_bytes(plan, nq, kk);
-    if (kk <= (uint32_t)qv::kMaxSelectK) return qv::flat_select_workspace_bytes(n_tiles, nq, kk);
+    if (kk > (uint32_t)qv::kMaxFusedK && kk <= (uint32_t)qv::kMaxWideK && nq == 1) return qv::flat_wide_workspace_bytes(plan, nq, kk);
+    if (kk <= (uint32_t)qv::kMaxSelectK) return qv::flat_select_workspace_bytes(n_tiles, nq, kk, idx->dim4);
     return qv::full_sort_workspace_bytes(n_tiles);
 }
 

@@ -188,9 +188,12 @@ hipError_t launch_select_topk(const uint64_t* d_keys, size_t stride, uint32_t n,
 size_t flat_wide_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t kk);
 hipError_t launch_flat_wide(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// keys [nq][n_tiles * 64] of nq >= 2 queries, QB (4 or 8) queries per corpus pass (k_flat_keys_mq); d_qws: flat_keys_mq_workspace_bytes
+size_t flat_keys_mq_workspace_bytes(uint32_t nq, uint32_t dim4);
+hipError_t launch_flat_keys_mq(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint64_t* d_keys, void* d_qws, hipStream_t s);
 // scan + selection for nq queries at list length kk <= kMaxSelectK: every query's keys (one 8-byte key per row, k_flat_keys), then
 // launch_select_topk; queries go in groups so that the keys of a group stay under flat_select_group_bytes
-size_t flat_select_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk);
+size_t flat_select_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk, uint32_t dim4);
 hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
                               void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 

@@ -314,9 +314,9 @@ static uint32_t flat_select_group(uint32_t n_tiles, uint32_t nq) {
     const size_t per_query = (size_t)n_tiles * 64 * sizeof(uint64_t);
     return (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, ((size_t)1 << 30) / per_query));
 }
-size_t flat_select_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk) {
+size_t flat_select_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk, uint32_t dim4) {
     const uint32_t g = flat_select_group(n_tiles, nq);
-    return (size_t)g * n_tiles * 64 * sizeof(uint64_t) + 256 + select_workspace_bytes(g, kk);
+    return (size_t)g * n_tiles * 64 * sizeof(uint64_t) + 256 + select_workspace_bytes(g, kk) + 256 + (g >= 2 ? flat_keys_mq_workspace_bytes(g, dim4) : 0);
 }
 hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
                               void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
@@ -326,8 +326,18 @@ hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float
     void* sel_ws = static_cast<char*>(d_ws) + ((size_t)g * n * sizeof(uint64_t) + 255) / 256 * 256;
     const uint32_t batch = key_batch(v.metric, v.dim4, true);
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * batch * 64 * sizeof(uint64_t) + (size_t)kSelBins * sizeof(uint32_t);
+    void* qws = static_cast<char*>(sel_ws) + (select_workspace_bytes(g, kk) + 255) / 256 * 256;
     for (uint32_t q0 = 0; q0 < nq; q0 += g) {
         const uint32_t m = std::min(g, nq - q0);
+        if (m >= 2) {
+            // several queries: they share corpus passes (4 or 8 per pass) instead of reading the corpus once each — 8 queries at
+            // k = 100 over 1M x 768: one ~0.6 ms pass instead of eight 0.46 ms ones; the selection counts its first window itself
+            hipError_t e2 = launch_flat_keys_mq(v, p, d_queries + (size_t)q0 * v.dim, m, keys, qws, s);
+            if (e2 != hipSuccess) return e2;
+            e2 = launch_select_topk(keys, n, n, m, kk, k_stride, sel_ws, d_rows_out + (size_t)q0 * k_stride, d_dist_out + (size_t)q0 * k_stride, s, false);
+            if (e2 != hipSuccess) return e2;
+            continue;
+        }
         SelState* st = nullptr; uint32_t* hist = nullptr;
         hipError_t e = select_prepare(sel_ws, m, kk, &st, &hist, s);     // states and histograms zeroed: the keys kernel counts window 0
         if (e != hipSuccess) return e;

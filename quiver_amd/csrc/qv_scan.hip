@@ -404,6 +404,65 @@ k_flat_scan_mq(IndexView v, const float* __restrict__ queries, const typename MT
     }
 }
 
+// The multi-query scan writing ONE KEY PER ROW AND QUERY instead of keeping lists: the front end of the radix selection
+// (qv_select.hip) for batches that ask for more than 64 results per query and do not go through the matrix-core filter (2 - 8
+// queries, or a metric the filter does not take).  QB queries share a corpus pass, their values arrive as scalar operands
+// (k_flat_scan_mq's SQ form); keys_all [nq][n_tiles * 64].  grid = (workgroups, ceil(nq / QB)).
+template <int M, int U, int QB>
+__global__ void __launch_bounds__(kScanBlock, 2)
+k_flat_keys_mq(IndexView v, const typename MT<M>::Q* __restrict__ qblk, uint32_t nq, uint64_t* __restrict__ keys_all) {
+    using Q = typename MT<M>::Q;
+    using A = typename MT<M>::A;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t q0 = blockIdx.y * QB;
+    const Q* q_lds = qblk + (size_t)blockIdx.y * v.dim4 * 4 * QB;                // global, uniform -> scalar loads
+    const uint32_t tw = gridDim.x * kScanWaves;
+    const size_t n = (size_t)v.n_tiles * 64;
+    QConst qc[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) { qc[j].qn = 0.0; qc[j].qn32 = 0.0f; }
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    bool first = true;
+    for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
+        A acc[QB], qa[QB];
+        if (first) {
+            mq_tile<M, U, QB, true>(tiles + (size_t)t * v.dim4 * 64 + lane, q_lds, v.dim4, acc, qa);
+#pragma unroll
+            for (int j = 0; j < QB; j++) qc[j] = qconst_from_norm2<M>(qa[j]);
+            first = false;
+        } else mq_tile<M, U, QB, false>(tiles + (size_t)t * v.dim4 * 64 + lane, q_lds, v.dim4, acc, qa);
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+        const bool live = (v.alive[t] >> lane) & 1ull;
+#pragma unroll
+        for (int j = 0; j < QB; j++) {
+            const uint64_t key = live ? make_key(finalize<M>(acc[j], qc[j], rn), row) : kDeadKey;
+            if (q0 + j < nq) __builtin_nontemporal_store(key, &keys_all[(size_t)(q0 + j) * n + row]);
+        }
+    }
+}
+
+size_t flat_keys_mq_workspace_bytes(uint32_t nq, uint32_t dim4) { return ((size_t)(nq + 8) * dim4 * 4 * sizeof(double) + 255) / 256 * 256; }
+// keys of nq >= 2 queries in shared corpus passes; d_qws: flat_keys_mq_workspace_bytes
+hipError_t launch_flat_keys_mq(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint64_t* d_keys, void* d_qws, hipStream_t s) {
+    const uint32_t want = (v.n_tiles + kScanWaves - 1) / kScanWaves;
+    const uint32_t grid = std::max(1u, std::min(want, p.grid));
+#define QV_KMQ(MMM, QQ)                                                                                                   \
+    {                                                                                                                     \
+        using QT = typename MT<MMM>::Q;                                                                                   \
+        const uint32_t groups = (nq + QQ - 1) / QQ;                                                                       \
+        const uint32_t per = v.dim4 * 4 * QQ;                                                                             \
+        hipLaunchKernelGGL((k_prep_qblk<MMM, QQ>), dim3((per + 255) / 256, groups), dim3(256), 0, s, d_queries, nq, v.dim, v.dim4, static_cast<QT*>(d_qws)); \
+        hipLaunchKernelGGL((k_flat_keys_mq<MMM, 4, QQ>), dim3(grid, groups), dim3(p.block), 0, s, v, static_cast<const QT*>(d_qws), nq, d_keys); \
+    }
+    if (nq >= 5) { QV_DISPATCH_METRIC(v.metric, { QV_KMQ(MM, 8) }); }
+    else { QV_DISPATCH_METRIC(v.metric, { QV_KMQ(MM, 4) }); }
+#undef QV_KMQ
+    return hipGetLastError();
+}
+
 // One workgroup per query merges n_lists sorted lists of k keys into the final top-k.
 // Bound trick: the smallest k-th entry over all lists, B, is an upper bound of the final
 // k-th key (that list alone holds k keys <= B), so only keys <= B can be in the answer.
