@@ -462,3 +462,24 @@ def test_batched_large_k_ties_tombstones_and_a_clustered_corpus():
         er, ed = O.exact_search(0, rows, qs[i], k, alive=alive)
         assert np.array_equal(got[0][i], er), i
         assert np.array_equal(_bits(got[1][i]), _bits(ed)), i
+
+
+def test_batched_large_k_candidate_overflow_is_redone_exactly():
+    """20 000 copies of one row sit at the same distance from a query: far more candidates than the batch's slots hold (16 k per query
+    at k = 100), so the filter hands that query back (redo flag) and qv_index_search_batched answers it with the exact scan — whose
+    selection then meets 20 000 keys tied on all 32 distance bits and takes the first of them in row order"""
+    import quiver_amd as q
+    dim, nq, k = 96, 40, 100
+    rng = np.random.default_rng(21)
+    rows = rng.standard_normal((120_000, dim)).astype(np.float32)
+    rows[30_000:50_000] = rows[7]
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    qs[3] = rows[7] + 0.01 * rng.standard_normal(dim).astype(np.float32)
+    got = idx.search(qs, k, batched=True)
+    for i in (0, 3, nq - 1):
+        er, ed = O.exact_search(0, rows, qs[i], k)
+        assert np.array_equal(got[0][i], er), i
+        assert np.array_equal(_bits(got[1][i]), _bits(ed)), i
+    assert got[0][3][0] == 7 and list(got[0][3][1:6]) == [30_000, 30_001, 30_002, 30_003, 30_004]
