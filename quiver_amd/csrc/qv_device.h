@@ -156,6 +156,11 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
                           uint32_t* d_rows_out, float* d_dist_out, uint32_t** d_overflow_out, int cus, hipStream_t s,
                           hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
+// the one-term bfloat16 filter with the query operands in registers (qv_qreg.hip): same arguments and candidates as the eight-wave kernels
+bool qreg_filter_applies(const IndexView& v, uint32_t nq_pad, bool bfrows);
+hipError_t launch_qreg_filter(const IndexView& v, const uint4* Qbf, const float* cq, const float* mq, uint32_t nq_pad, uint32_t* cand, float* cscore,
+                              uint32_t* cnt, bool bfrows, int cus, hipStream_t s);
+
 // Device-resident HNSW traversal (hnsw.go:471-713), one wave per query.
 size_t   hnsw_lds_bytes(uint32_t ef);
 uint32_t hnsw_grid(int cus, uint32_t ef, uint32_t nq);

@@ -419,6 +419,32 @@ def test_filter_kernels_at_other_dimensions(metric, dim):
         assert _eq(_exact(idx, qs[:nq], 10), idx.search(qs[:nq], 10, batched=True))
 
 
+@pytest.mark.parametrize("bf16_rows", [False, True])
+@pytest.mark.parametrize("metric,dim,nq", [("cosine", 768, 256), ("dot_product", 512, 600), ("euclidean", 384, 130), ("squared_euclidean", 768, 257),
+                                           ("cosine", 512, 256), ("dot_product", 384, 512)])
+def test_query_resident_filter_against_the_exact_scan(metric, dim, nq, bf16_rows):
+    """k_qreg_filter (qv_qreg.hip; 384, 512 and 768 dimensions, whole workgroups of 256 queries): the queries' operands stay in
+    registers and the rows arrive by LDS-DMA, from the float32 tiles or from the bfloat16 copy.  Ragged last tile, tombstones in
+    the first and the last tile, a revived row, 1-3 workgroups per row walk (600 queries pad to 768), fewer live rows than k in
+    nobody's way: rows, order and float32 bits of the exact scan."""
+    import quiver_amd as q
+    n = 64 * 700 + 37                                                       # 701 tiles: every workgroup of the 256 walks 2-3 of them
+    idx = q.DeviceIndex(dim, metric, bf16_rows=bf16_rows)
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    rows = O.gen_rows(20260424, 0, n, dim)
+    qs[3] = rows[n - 1]                                                     # an exact match in the ragged tile
+    qs[5] = rows[0]
+    assert _eq(_exact(idx, qs, 10), idx.search(qs, 10, batched=True))
+    idx.remove(np.array([0, 1, 63, n - 1, n - 2, 64 * 350 + 7], dtype=np.uint32))
+    idx.update(64 * 350 + 7, qs[7])                                         # revived as an exact match of query 7
+    e = _exact(idx, qs, 10)
+    assert _eq(e, idx.search(qs, 10, batched=True))
+    assert e[0][7][0] == 64 * 350 + 7 and e[0][5][0] != 0
+    assert _eq(_exact(idx, qs, 64), idx.search(qs, 64, batched=True))
+    assert _eq(_exact(idx, qs[:200], 100), idx.search(qs[:200], 100, batched=True))      # the selection path's larger candidate lists
+
+
 # ---------------------------------------------------------------- more than 64 results per query ---
 # HybridIndex.BatchSearch takes any k (hybrid_index.go:677-811); its negative-example branch asks for max(2k, 30) (:516-522).
 # Beyond the 64-key wave lists the filter + re-score path selects by radix selection (k_sample_hist, k_cand_*): the result must

@@ -66,3 +66,30 @@ def test_key_writing_scan_keeps_the_flat_scan_loop(tmp_path):
                         out = min(out, int(w.group(1)))
             need = 8 if metric == 0 else 16
             assert best >= need, "k_flat_keys<%d,16,%d>: at most %d row-chunk loads in flight" % (metric, hist, best)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_query_resident_filter_loop_is_what_was_written(tmp_path):
+    """k_qreg_filter (qv_qreg.hip) keeps 64 queries' operands in registers and streams rows by LDS-DMA issued from inline assembly, which
+    the compiler cannot see.  Three things make or break it, all visible in the compiled tile loop (between a tile's first and last
+    matrix instruction): the A operands are read where they live (no v_accvgpr_read copies), nothing spills into the loop, and
+    the only vector-memory waits are the counted ones written by hand — a compiler-inserted s_waitcnt vmcnt(0) (e.g. for an operand's
+    load at its first use) would drain the whole row ring once per tile (measured: 482 against 391 us)."""
+    asm = str(tmp_path / "qreg.s")
+    src = os.path.join(ROOT, "quiver_amd", "csrc", "qv_qreg.hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", asm, src],
+                   check=True, capture_output=True, text=True, cwd=os.path.dirname(src))
+    text = open(asm).read()
+    kernels = re.findall(r"^(_ZN2qv13k_qreg_filterI\w+):[^\n]*\n(.*?)\n\s+s_endpgm", text, re.S | re.M)
+    assert len(kernels) >= 18, "expected 3 metrics x 3 widths x 2 row formats, found %d" % len(kernels)
+    for name, body in kernels:
+        lines = [l.strip() for l in body.split("\n")]
+        mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma_f32_32x32x16_bf16")]
+        steps = int(re.search(r"k_qreg_filterILi\dELi(\d+)E", name).group(1))
+        assert len(mf) == 4 * steps, "%s: %d matrix instructions for %d steps" % (name, len(mf), steps)
+        loop = lines[mf[0]: mf[-1] + 1]
+        assert not any(l.startswith("v_accvgpr") for l in loop), name + ": operand copies in the tile loop"
+        assert not any(l.startswith("scratch_") for l in loop), name + ": spill traffic in the tile loop"
+        waits = [int(w) for l in loop for w in re.findall(r"vmcnt\((\d+)\)", l)]
+        assert waits and min(waits) >= 8, "%s: a vector-memory wait of %d in the tile loop drains the row ring" % (name, min(waits) if waits else -1)
+        assert sum(1 for l in loop if l.startswith("global_load_lds_dwordx4")) >= 4, name + ": no row requests in the tile loop"
