@@ -72,6 +72,9 @@ constexpr int kQregStageBytes = 16384;
 #ifndef QV_QREG_DMA_GAP
 #define QV_QREG_DMA_GAP 2   // the gap of a step (after its 2nd or 4th matrix instruction) that takes the step's row request
 #endif
+#ifndef QV_QREG_XCD
+#define QV_QREG_XCD 1
+#endif
 #ifndef QV_QREG_NST
 #define QV_QREG_NST 6
 #endif
@@ -108,8 +111,15 @@ k_qreg_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restric
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wgs_per_group = nq_pad >> 8;
-    const uint32_t qb256 = blockIdx.x % wgs_per_group;
     const uint32_t stride = gridDim.x / wgs_per_group;
+    // Which query block and which tiles.  More than 256 queries: the workgroups that walk the SAME tiles (one per query block) go to
+    // the same XCD — workgroup b runs on XCD b mod 8 — so that a tile comes out of HBM once and out of that XCD's L2 for the others.
+    uint32_t qb256 = blockIdx.x % wgs_per_group, first = blockIdx.x / wgs_per_group;
+    if (QV_QREG_XCD == 1 && wgs_per_group > 1 && gridDim.x % (8 * wgs_per_group) == 0) {
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        qb256 = slot % wgs_per_group;
+        first = (slot / wgs_per_group) * 8 + xcd;
+    }
     {
         const uint32_t q = 256 * qb256 + threadIdx.x;
         const float c = cq[q], m = mq[q];
@@ -138,7 +148,6 @@ k_qreg_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restric
     for (int s = 0; s < VSTEPS; s++) { asm volatile("" :: "v"(Av[s][0]), "v"(Av[s][1])); }
     __syncthreads();
     if (stride == 0) return;
-    const uint32_t first = blockIdx.x / wgs_per_group;
     if (first >= v.n_tiles) return;
     const uint32_t n_mine = (v.n_tiles - first + stride - 1) / stride;
     const uint32_t half = lane >> 5, l31 = lane & 31;
@@ -285,7 +294,9 @@ k_qreg_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restric
             for (int j = 0; j < 2; j++) { rnd[j] = *reinterpret_cast<const double*>(rc + 2 * (32 * j + l31)); rho[j] = __uint_as_float(rc[128 + 32 * j + l31]); }
             alv[0] = *reinterpret_cast<const uint64_t*>(rc + 192);
         }
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");             // the last matrix instructions' results, before vector instructions read them
+        // the last matrix instructions' results, before vector instructions read them (18 wait states; the statement names the
+        // accumulators so that nothing that reads them is scheduled ahead of it)
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
 #if QV_QREG_DBG & 1                                                      // (measurement build: no epilogue)
         { float sd = 0.f;
 #pragma unroll
