@@ -475,11 +475,13 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
             "roofline": ({"bound": "mfma", "kernel": "k_mfma_filter", "kernel_ms": mf_ms, "achieved": flop / (mf_ms * 1e-3) / 1e12,
                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flop / (mf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                           "end_to_end_frac": flop / dtm / 1e12 / MFMA_F32_PEAK_TF, "algorithmic_flop_per_launch": flop} if kernel == "fp32" else
-                         {"bound": "hbm", "kernel": "k_bf16rows_filter" if plane else "k_bf16x1_filter_w8x2", "kernel_ms": mf_ms,
+                         {"bound": "hbm", "kernel": "k_qreg_filter (bfloat16 copy)" if plane else "k_qreg_filter (float32 rows)", "kernel_ms": mf_ms,
                           "achieved": rows_n * (dim * (2 if plane else 4) + 8) / (mf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": rows_n * (dim * (2 if plane else 4) + 8) / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "algorithmic_bytes_per_launch": rows_n * (dim * (2 if plane else 4) + 8),
                           "why_hbm": "one term is 0.39 PFLOP of bfloat16 matrix work per launch = 0.16 ms at 2.5 PFLOP/s; reading the float32 rows once is 0.38 ms at 8 TB/s, the bfloat16 copy 0.19 ms",
+                          "matrix_pipe_note": "on this data the chip holds ~1.5 GHz under a bare chain of these matrix instructions: the kernel's own K loop with nothing but its 12M v_mfma_f32_32x32x16_bf16 per SIMD-set takes 0.255 ms (1.54 PFLOP/s, QV_QREG_DBG=15 build) — the practical floor of the bfloat16-copy form; the float32-row form's row stream alone takes 0.44 ms (6.95 TB/s)",
+                          "frac_of_bare_mfma_loop": 0.255 / mf_ms,
                           "matrix_tflops": flop / (mf_ms * 1e-3) / 1e12, "fp32_equivalent_tflops_end_to_end": flop / dtm / 1e12,
                           "times_the_fp32_mfma_peak_end_to_end": flop / dtm / 1e12 / MFMA_F32_PEAK_TF} if kernel == "bf16x1" else
                          {"bound": "mfma", "kernel": "k_bf16x3_filter_shared", "kernel_ms": mf_ms, "achieved": 3.0 * flop / (mf_ms * 1e-3) / 1e12,

@@ -29,7 +29,9 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// one 1-KiB request of a stage: lane l moves bytes [16 l, 16 l + 16); src (wave-uniform) and the LDS byte address both take `off`
+// one 1-KiB request of a stage: lane l moves bytes [16 l, 16 l + 16); src (wave-uniform) and the LDS byte address both take `off`.
+// (The same request through a buffer descriptor — base in the descriptor, the piece's offset in a scalar register — measures the same:
+// 518 / 393 us against 517 / 388; what a request costs the issuing wave, ~55 ns, is not its address arithmetic.)
 template <int OFF>
 __device__ __forceinline__ void dma_piece(const void* src, uint32_t lane16, uint32_t lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %2\n\t"

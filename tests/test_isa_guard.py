@@ -93,3 +93,24 @@ def test_query_resident_filter_loop_is_what_was_written(tmp_path):
         waits = [int(w) for l in loop for w in re.findall(r"vmcnt\((\d+)\)", l)]
         assert waits and min(waits) >= 8, "%s: a vector-memory wait of %d in the tile loop drains the row ring" % (name, min(waits) if waits else -1)
         assert sum(1 for l in loop if l.startswith("global_load_lds_dwordx4")) >= 4, name + ": no row requests in the tile loop"
+        # The matrix instructions are inline assembly: the compiler's hazard recogniser does not look inside.  A vector-ALU write of a
+        # register (a conversion, a copy) needs two wait states before a matrix instruction reads it as A or B.
+        def regs(tok):
+            m2 = re.match(r"([va])\[(\d+):(\d+)\]", tok) or re.match(r"([va])(\d+)$", tok)
+            if not m2:
+                return set()
+            lo = int(m2.group(2)); hi = int(m2.group(3)) if m2.lastindex == 3 else lo
+            return {(m2.group(1), r) for r in range(lo, hi + 1)}
+        recent = []                                             # (registers written, wait states since) of the last vector-ALU writes
+        for l in loop:
+            if not l or l.startswith(";") or l.startswith("."):
+                continue
+            ops = [t.strip() for t in l.split(None, 1)[1].split(",")] if " " in l else []
+            if l.startswith("v_mfma"):
+                src = regs(ops[1]) | regs(ops[2])
+                for written, ws in recent:
+                    assert not (written & src) or ws >= 2, "%s: %s reads a register a vector instruction wrote %d wait states before" % (name, l, ws)
+            gain = int(l.split()[1]) + 1 if l.startswith("s_nop") else 1
+            recent = [(w, ws + gain) for w, ws in recent if ws + gain < 8]
+            if l.startswith("v_") and not l.startswith("v_mfma") and not l.startswith("v_cmp") and ops:
+                recent.append((regs(ops[0]), 0))
