@@ -241,6 +241,8 @@ k_qreg_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restric
 #define QV_MF(ACC, AOP, BOP, NOPP) { if (gs == 0) { if (ag) mfma_bf16<true, true, false>(ACC, AOP, BOP); else mfma_bf16<false, true, false>(ACC, AOP, BOP); } \
                                      else if (ag) mfma_bf16<true, false, NOPP>(ACC, AOP, BOP); else mfma_bf16<false, false, NOPP>(ACC, AOP, BOP); }
                 if constexpr (!BF) {
+                    // (the next step's first reads BEFORE this matrix instruction — two instructions between the conversion that wrote b0
+                    // and its reader instead of the s_nop 1 — measured the same: 520 against 515 us)
                     QV_MF(acc[0][0], a0, b0, true)
                     if (has_next) fetch(np, ns, 0, raw0);            // gap 1: the next step's first operand is requested, this step's second converted
                     b1 = pack(raw1);
@@ -298,7 +300,7 @@ k_qreg_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restric
         }
         // the last matrix instructions' results, before vector instructions read them (18 wait states; the statement names the
         // accumulators so that nothing that reads them is scheduled ahead of it)
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("s_nop 15\n\ts_nop 1" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
 #if QV_QREG_DBG & 1                                                      // (measurement build: no epilogue)
         { float sd = 0.f;
 #pragma unroll
