@@ -314,6 +314,11 @@ k_qreg_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restric
     cand_flush(cqu, cqu_n, cqu_out);
 }
 
+// (Measured and not kept: the same kernel with TWO waves per SIMD on the bfloat16 copy — eight waves of 32 queries, 252-256 registers,
+// so that one wave's row requests and epilogue run under the other's matrix instructions: 403 us against 393.  Together with the
+// schedules above that all land within 2 % of each other this says the kernel is not short of issue slots: the chip is at its power
+// limit — 1.7-1.8 GHz under this kernel, 1.47 under the bare matrix chain — and what costs time is what costs energy.)
+
 // Which shapes run here: whole workgroups of 256 queries; dimensions 384, 512 and 768 (16 STEPS exactly: 64 queries' operands are
 // STEPS x 8 registers per lane, and the row stages divide the K loop); everything else stays on the eight-wave kernels.  QV_QREG=2
 // (read once) turns it off for measurements.
