@@ -419,6 +419,32 @@ def test_filter_kernels_at_other_dimensions(metric, dim):
         assert _eq(_exact(idx, qs[:nq], 10), idx.search(qs[:nq], 10, batched=True))
 
 
+def test_cluster_stored_corpus_at_768_dimensions_keeps_the_filter_path():
+    """The same at the width and batch size where the eight-wave sample kernel runs (the test above is 128 dimensions x 64 queries, which
+    it does not take).  Round 4 briefly selected the bound among per-group MINIMA of the sample: with 30 clusters stored one after the
+    other a query's own cluster has ~8 sample groups, the 10th smallest minimum came from another cluster, and every one of the 256
+    queries overflowed its candidate list.  Selecting among the rows' own bounds hands back a few per cent."""
+    import torch
+    import quiver_amd as q
+    rng = np.random.default_rng(12)
+    dim, n_clusters, per = 768, 30, 4_000
+    centres = rng.standard_normal((n_clusters, dim)).astype(np.float32)
+    rows = np.concatenate([c + 0.3 * rng.standard_normal((per, dim)).astype(np.float32) for c in centres])
+    nq, k = 256, 10
+    qs = (centres[rng.integers(0, n_clusters, nq)] + 0.3 * rng.standard_normal((nq, dim))).astype(np.float32)
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    fl = torch.full((nq,), 7, dtype=torch.int32, device="cuda")
+    idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(fl.abs().sum().item()) <= nq // 4
+    assert _eq(_exact(idx, qs, k), idx.search(qs, k, batched=True))
+    for kk in (64, 100):                                                   # (larger k may overflow here: the results must not care)
+        assert _eq(_exact(idx, qs[:64], kk), idx.search(qs[:64], kk, batched=True))
+
+
 @pytest.mark.parametrize("bf16_rows", [False, True])
 @pytest.mark.parametrize("metric,dim,nq", [("cosine", 768, 256), ("dot_product", 512, 600), ("euclidean", 384, 130), ("squared_euclidean", 768, 257),
                                            ("cosine", 512, 256), ("dot_product", 384, 512)])
