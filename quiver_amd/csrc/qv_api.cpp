@@ -71,7 +71,10 @@ int stream_workspace(qv_index* idx, hipStream_t s, size_t bytes, void** out, std
         if (!w->tickets.p) {
             int rc = w->tickets.ensure(256);
             if (rc != QV_OK) return rc;
-            HIPCHK(hipMemset(w->tickets.p, 0, 256));
+            // on the caller's stream, ahead of the kernel that reads them: hipMemset on device memory returns before the fill has run, and the
+            // null stream it runs on is not ordered against a non-blocking stream — a first search on a fresh stream could start on
+            // tickets that were not zero yet, or be zeroed under (test_concurrent_searches_on_one_handle failed about one run in four)
+            HIPCHK(hipMemsetAsync(w->tickets.p, 0, 256, s));
         }
         *tickets_out = static_cast<uint32_t*>(w->tickets.p);
     }
@@ -86,6 +89,7 @@ template <typename T> hipError_t regrow(T** p, size_t keep_bytes, size_t new_byt
     if (e != hipSuccess) return e;
     if (new_bytes > keep_bytes) e = hipMemset(reinterpret_cast<char*>(n) + keep_bytes, 0, new_bytes - keep_bytes);
     if (e == hipSuccess && keep_bytes) e = hipMemcpy(n, *p, keep_bytes, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // the fill and the copy may return early, and the index's streams are non-blocking: nothing of theirs may overtake these
     if (e != hipSuccess) { (void)hipFree(n); return e; }
     (void)hipFree(*p);
     *p = n;
@@ -464,7 +468,7 @@ static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, u
     // instead of waiting for the stream
     uint32_t* tickets = nullptr; uint32_t* flag = nullptr; bool flag_used = false;
     if (direct && q_direct) {
-        if (!c->tickets.p) { if ((rc = c->tickets.ensure(256))) return rc; HIPCHK(hipMemset(c->tickets.p, 0, 256)); }
+        if (!c->tickets.p) { if ((rc = c->tickets.ensure(256))) return rc; HIPCHK(hipMemsetAsync(c->tickets.p, 0, 256, c->stream)); }   // (on the stream that reads them: see stream_workspace)
         if (!c->h_flag.p) { if ((rc = c->h_flag.ensure(64))) return rc; *static_cast<volatile uint32_t*>(c->h_flag.p) = 0; }
         tickets = static_cast<uint32_t*>(c->tickets.p); flag = static_cast<uint32_t*>(c->h_flag.p);
         c->flag_seq++;

@@ -1531,6 +1531,112 @@ __device__ __forceinline__ void score_interval(double S, double qn_cos, double q
 // The sample bound without an exact scan: the three-term filter kernel's scores of the sample give every sampled row an UPPER
 // bound of its reference distance (written by that kernel: score_upper_f32), and the k-th smallest of those bounds is at least the
 // k-th smallest true distance over the sample, hence over the corpus.  One workgroup per query (and part); a pure selection.
+// The same selection in two stages, all of it in LDS (round 4, late): k_sample_bound's sixteen waves keep sorted lists and insert one
+// key at a time — a chain of dependent steps per row that passes (29 us for 32 768 bounds per query, 85 us at k = 64).  Here thread t
+// reads its chunk of the bounds (rows t, t + 1024, ...) and keeps its minimum; the k-th smallest of the 1024 minima, T1, is at or above the k-th
+// smallest bound U (k different rows are at or below it), and every row at or below U lies in a chunk whose minimum is at or below
+// T1 — k chunks, more only on exact ties.  Their rows are read again (from L2) into LDS, and U is the k-th smallest of them: a
+// radix selection on the ordered bits, 8 bits a pass from the first bit in which the values differ, 256 LDS bins, whole workgroup.
+// Writes what k_mfma_prep reads of k_sample_bound's output: sample_dist[q][k - 1].  Needs k chunks' rows to fit kSelKeys.
+constexpr uint32_t kSelKeys = 16384;                                 // 64 KiB of ordered keys
+__host__ __device__ static inline uint32_t sample_select_chunk(uint32_t srows) { return ((srows + 1023) / 1024 + 3) / 4 * 4; }
+static bool sample_select_applies(uint32_t srows, uint32_t k) { return srows >= 4096 && (uint64_t)k * sample_select_chunk(srows) <= kSelKeys && k <= 1024; }
+template <int M>
+__global__ void __launch_bounds__(1024)
+k_sample_select(const float* __restrict__ bounds, uint32_t srows, uint32_t k, float gref, float* __restrict__ sample_dist) {
+    __shared__ uint32_t s_keys[kSelKeys];
+    __shared__ uint32_t s_min[1024];
+    __shared__ uint32_t s_bins[256];
+    __shared__ uint32_t s_sel[1024];
+    __shared__ uint32_t s_n, s_digit, s_cum, s_lohi[2];
+    const uint32_t t = threadIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t qi = blockIdx.x;
+    const float* sc = bounds + (size_t)qi * srows;
+    const uint32_t chunk = sample_select_chunk(srows);
+    // the k-th smallest (kk >= 1) of keys[0 .. n): every thread returns it; 0xFFFFFFFF when there are fewer than kk keys
+    auto kth_smallest = [&](const uint32_t* keys, uint32_t n, uint32_t kk) -> uint32_t {
+        if (t == 0) { s_lohi[0] = 0xFFFFFFFFu; s_lohi[1] = 0u; }
+        __syncthreads();
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (uint32_t i = t; i < n; i += 1024) { const uint32_t x = keys[i]; lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const uint32_t a = __shfl_xor(lo, m), b = __shfl_xor(hi, m); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+        if (lane == 0) { atomicMin(&s_lohi[0], lo); atomicMax(&s_lohi[1], hi); }
+        __syncthreads();
+        lo = s_lohi[0]; hi = s_lohi[1];
+        if (kk > n) return 0xFFFFFFFFu;
+        if (lo == hi) return lo;
+        const int top = 31 - __builtin_clz(lo ^ hi);
+        uint32_t prefix = top >= 31 ? 0u : (lo >> (top + 1)) << (top + 1);
+        uint32_t pmask = top >= 31 ? 0u : ~((1u << (top + 1)) - 1u);
+        uint32_t krem = kk;
+        for (int shift = top - 7; ; shift -= 8) {
+            const int sh = shift < 0 ? 0 : shift;
+            const uint32_t dmask = shift < 0 ? ((1u << (shift + 8)) - 1u) : 255u;
+            if (t < 256) s_bins[t] = 0;
+            __syncthreads();
+            for (uint32_t i = t; i < n; i += 1024) {
+                const uint32_t x = keys[i];
+                if ((x & pmask) == prefix) atomicAdd(&s_bins[(x >> sh) & dmask], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {                                              // 256 bins over 64 lanes: which bin holds the krem-th
+                uint32_t b4[4], sum = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { b4[u] = s_bins[4 * lane + u]; sum += b4[u]; }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(inc, off); if ((int)lane >= off) inc += y; }
+                const uint32_t excl = inc - sum;
+                if (excl < krem && krem <= inc) {
+                    uint32_t d = 4 * lane, cum = excl;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { if (krem > cum + b4[u] && u < 3) { cum += b4[u]; d++; } else break; }
+                    s_digit = d; s_cum = cum;
+                }
+            }
+            __syncthreads();
+            prefix |= s_digit << sh; pmask |= dmask << sh; krem -= s_cum;
+            if (shift <= 0) break;
+        }
+        return prefix;
+    };
+    // stage 1: this thread's chunk = rows t, t + 1024, t + 2048, ... (consecutive threads read consecutive bounds): its minimum
+    {
+        float m = __builtin_inff();
+        for (uint32_t i0 = 0; i0 < chunk; i0 += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t r = t + 1024u * (i0 + u); x[u] = i0 + u < chunk && r < srows ? sc[r] : __builtin_inff(); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) m = fminf(m, x[u]);
+        }
+        s_min[t] = ord_f32(m);
+    }
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t t1 = kth_smallest(s_min, 1024, k);
+    uint32_t ukey = t1;
+    if (t1 != 0xFFFFFFFFu && t1 < ord_f32(__builtin_inff())) {
+        // stage 2: the chunks at or below T1 (beyond kSelKeys / chunk of them — exact ties only — the bound comes from a subset: still k rows)
+        const uint32_t cap = kSelKeys / chunk;
+        if (s_min[t] <= t1) { const uint32_t slot = atomicAdd(&s_n, 1u); if (slot < 1024) s_sel[slot] = t; }
+        __syncthreads();
+        const uint32_t n_sel = s_n < cap ? s_n : cap;
+        const uint32_t total = n_sel * chunk;
+        for (uint32_t i = t; i < total; i += 1024) {
+            const uint32_t e = i / chunk, r = s_sel[e] + 1024u * (i - e * chunk);
+            s_keys[i] = ord_f32(r < srows ? sc[r] : __builtin_inff());
+        }
+        __syncthreads();
+        ukey = kth_smallest(s_keys, total, k);
+    }
+    if (t == 0) {
+        const float x = ukey == 0xFFFFFFFFu ? __builtin_inff() : unord_f32(ukey);
+        sample_dist[(size_t)qi * k + (k - 1)] = x == x && x < __builtin_inff() ? sample_bound_finish<M>(x, gref) : __builtin_inff();
+    }
+}
+
 template <int M>
 __global__ void __launch_bounds__(1024)
 k_sample_bound(const float* __restrict__ bounds, uint32_t srows, uint32_t k, float gref, float* __restrict__ sample_dist, uint32_t parts) {
@@ -2064,16 +2170,19 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t gmin_mode = gmin_env == 3 ? 1u : (gmin_env == 1 && large_k && k <= 128 ? 4u : 0u);
         const bool group_min = gmin_mode != 0 && sample_groups >= 4 * k && sample_groups <= 16384;
         const uint32_t gmin_vals = sample_groups;
+        static const int sel2_env = env_int("QV_MFMA_SAMPLE_SELECT", 1);                        // 2 = k_sample_bound (wave lists) as in round 3
+        const bool sel2 = sel2_env == 1 && !large_k && !group_min && sample_select_applies(vs.n_rows, k);
 #define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? gmin_mode : 0u); \
                      else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? gmin_mode : 0u); \
                      if (group_min) { /* the bound is selected inside k_mfma_prep from the group minima */ } \
                      else if (large_k) { hipLaunchKernelGGL(k_sample_hist<0>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_hist<1>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_bound_from_state<MMM>, dim3((nq + 255) / 256), dim3(256), 0, s, sst, nq, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); } \
+                     else if (sel2) hipLaunchKernelGGL(k_sample_select<MMM>, dim3(nq), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); \
                      else hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k && !group_min ? sparts : sdist, large_k || group_min ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u, group_min ? (gmin_mode == 4 ? sscore + (size_t)nq_pad * vs.n_rows : sscore) : nullptr, gmin_vals, group_min && gmin_mode == 4 ? sscore : nullptr, vs.n_rows);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k && !group_min && !sel2 ? sparts : sdist, large_k || group_min || sel2 ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u, group_min ? (gmin_mode == 4 ? sscore + (size_t)nq_pad * vs.n_rows : sscore) : nullptr, gmin_vals, group_min && gmin_mode == 4 ? sscore : nullptr, vs.n_rows);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
         e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);

@@ -54,6 +54,7 @@ template <typename T> hipError_t regrow(T** p, size_t keep, size_t new_count) {
     if (e != hipSuccess) return e;
     if (keep) e = hipMemcpy(n, *p, keep * sizeof(T), hipMemcpyDeviceToDevice);
     if (e == hipSuccess && new_count > keep) e = hipMemset(n + keep, 0, (new_count - keep) * sizeof(T));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // (the graph's streams are non-blocking: the fill must have run before they touch the array)
     if (e != hipSuccess) { (void)hipFree(n); return e; }
     (void)hipFree(*p);
     *p = n;
@@ -345,6 +346,7 @@ int qv_graph_make_buildable(qv_graph* g, uint32_t ef_construction) {
     if (e == hipSuccess) e = hipMemset(g->d_l0dist, 0, std::max<size_t>((size_t)g->cap_nodes * m0 * 4, 16));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&g->d_updist), std::max<size_t>((size_t)g->cap_blocks * m * 4, 16));
     if (e == hipSuccess) e = hipMemset(g->d_updist, 0, std::max<size_t>((size_t)g->cap_blocks * m * 4, 16));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) { (void)hipFree(g->d_l0dist); (void)hipFree(g->d_updist); g->d_l0dist = g->d_updist = nullptr;
                            return fail(e == hipErrorOutOfMemory ? QV_ERR_OOM : QV_ERR_DEVICE, "link-distance storage failed: %s", hipGetErrorString(e)); }
     // score every existing link once, a chunk of nodes at a time (their vectors are the queries)
