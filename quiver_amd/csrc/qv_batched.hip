@@ -616,7 +616,8 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nqb64 = nq_pad >> 6;                             // a multiple of 4
     const uint32_t wgs_per_group = nqb64 >> 2;                      // workgroups that share one row group (different query blocks)
-    const uint32_t qb64 = (blockIdx.x % wgs_per_group) * 4 + wave;
+    uint32_t qblk_, walk0_; filter_block_role(wgs_per_group, qblk_, walk0_);
+    const uint32_t qb64 = qblk_ * 4 + wave;
     const uint32_t n_groups = (v.n_tiles + 1) / 2;
     const uint32_t stride = gridDim.x / wgs_per_group;
     {
@@ -652,7 +653,7 @@ k_bf16x3_filter_shared(IndexView v, const uint4* __restrict__ Qbf, const float* 
         return tiles + (size_t)(wave < 2 ? ta : tb) * v.dim4 * 64 + 32 * (wave & 1) + l31;
     };
 
-    for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
+    for (uint32_t g = walk0_; g < n_groups; g += stride) {
         const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
         const f4* bw = rows_of(g);
         const f4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
@@ -847,7 +848,8 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wgs_per_group = nq_pad >> 8;                      // workgroups that share one row group (different query blocks)
-    const uint32_t qb256 = blockIdx.x % wgs_per_group;
+    uint32_t qblk_, walk0_; filter_block_role(wgs_per_group, qblk_, walk0_);
+    const uint32_t qb256 = qblk_;
     const uint32_t n_groups = SAMPLE ? (score_stride + 127) / 128 : (v.n_tiles + 1) / 2;
     const uint32_t stride = gridDim.x / wgs_per_group;
     if (threadIdx.x < 256) {
@@ -926,7 +928,7 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
     // level 1 could be deferred too, does not fit: 256 registers at two waves per SIMD, 16 spilled.)
     constexpr int UNR = RING > AR ? RING : AR;                      // both rings are indexed by the unrolled step number: the loop body covers the longer one
     uint32_t epn = 0;                                               // entries waiting in the dump area (wave-uniform)
-    for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
+    for (uint32_t g = walk0_; g < n_groups; g += stride) {
         const uint32_t ga = SAMPLE ? g * gstep : g;                 // the group's place in the corpus
         const uint32_t t0 = 2 * ga, t1 = (2 * ga + 1 < v.n_tiles) ? 2 * ga + 1 : t0;
         const f4* bwn = rows_of((g + stride < n_groups ? g + stride : g) * (SAMPLE ? gstep : 1u));
@@ -958,7 +960,7 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
         // matrix gaps, which moves their s_waitcnt up to vmcnt(1..3) — the wave then waits for rows it requested a step or two ago.
 #if defined(QV_DBG_STAMP)
 #define QV_STAMP(i) if (stamping && k8 == 2) { stamp[i] = __builtin_amdgcn_s_memtime(); }
-        const bool stamping = blockIdx.x == 7 && g == blockIdx.x / wgs_per_group + 3 * stride;
+        const bool stamping = blockIdx.x == 7 && g == walk0_ + 3 * stride;
         uint64_t stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #else
 #define QV_STAMP(i)
@@ -1130,7 +1132,8 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wgs_per_group = nq_pad >> 8;
-    const uint32_t qb256 = blockIdx.x % wgs_per_group;
+    uint32_t qblk_, walk0_; filter_block_role(wgs_per_group, qblk_, walk0_);
+    const uint32_t qb256 = qblk_;
     const uint32_t n_groups = (v.n_tiles + 3) / 4;                   // groups of four tiles = 256 rows
     const uint32_t stride = gridDim.x / wgs_per_group;
     if (threadIdx.x < 256) {
@@ -1178,7 +1181,7 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
     };
     bool primed = false;
     constexpr int UNR = RING > AR ? RING : AR;
-    for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
+    for (uint32_t g = walk0_; g < n_groups; g += stride) {
         const f4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
         f16v accA[1][4], accB[1][4];                                // tiles 4g, 4g+1 and 4g+2, 4g+3
         const uint32_t tA0 = 4 * g, tA1 = 4 * g + 1 < v.n_tiles ? 4 * g + 1 : tA0;
@@ -1205,7 +1208,7 @@ k_bf16x1_filter_w8x2(IndexView v, const uint4* __restrict__ Qbf, const float* __
         // step s+2+RING); request the query operand of step s+AR-1; read the B operands of step s and multiply.  One memory or LDS
         // instruction per matrix-instruction gap, the LDS write first (see k_bf16x1_filter_w8).
 #if defined(QV_DBG_STAMP)
-        const bool stamping = blockIdx.x == 7 && g == blockIdx.x / wgs_per_group + 3 * stride;
+        const bool stamping = blockIdx.x == 7 && g == walk0_ + 3 * stride;
         uint64_t stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define QV_XSTAMP(i) if (stamping && k8 == 2) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -1318,7 +1321,8 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nqb64 = nq_pad >> 6;                             // a multiple of 4
     const uint32_t wgs_per_group = nqb64 >> 2;
-    const uint32_t qb64 = (blockIdx.x % wgs_per_group) * 4 + wave;
+    uint32_t qblk_, walk0_; filter_block_role(wgs_per_group, qblk_, walk0_);
+    const uint32_t qb64 = qblk_ * 4 + wave;
     const uint32_t n_groups = (v.n_tiles + 1) / 2;
     const uint32_t stride = gridDim.x / wgs_per_group;
     {
@@ -1356,7 +1360,7 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
 #pragma unroll
         for (int j = 0; j < 4; j++) b.h[j] = s_b[stage][j][lane];
     };
-    for (uint32_t g = blockIdx.x / wgs_per_group; g < n_groups; g += stride) {
+    for (uint32_t g = walk0_; g < n_groups; g += stride) {
         const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;
         const uint4* bwn = rows_of(g + stride < n_groups ? g + stride : g);
         f16v acc[2][4];

@@ -74,9 +74,6 @@ constexpr int kQregStageBytes = 16384;
 #ifndef QV_QREG_DMA_GAP
 #define QV_QREG_DMA_GAP 2   // the gap of a step (after its 2nd or 4th matrix instruction) that takes the step's row request
 #endif
-#ifndef QV_QREG_XCD
-#define QV_QREG_XCD 1
-#endif
 #ifndef QV_QREG_NST
 #define QV_QREG_NST 6
 #endif
@@ -114,14 +111,9 @@ k_qreg_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restric
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t wgs_per_group = nq_pad >> 8;
     const uint32_t stride = gridDim.x / wgs_per_group;
-    // Which query block and which tiles.  More than 256 queries: the workgroups that walk the SAME tiles (one per query block) go to
-    // the same XCD — workgroup b runs on XCD b mod 8 — so that a tile comes out of HBM once and out of that XCD's L2 for the others.
-    uint32_t qb256 = blockIdx.x % wgs_per_group, first = blockIdx.x / wgs_per_group;
-    if (QV_QREG_XCD == 1 && wgs_per_group > 1 && gridDim.x % (8 * wgs_per_group) == 0) {
-        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        qb256 = slot % wgs_per_group;
-        first = (slot / wgs_per_group) * 8 + xcd;
-    }
+    // which query block and which tiles: the workgroups that walk the SAME tiles share an XCD's L2 (filter_block_role, qv_filter.h)
+    uint32_t qb256, first;
+    filter_block_role(wgs_per_group, qb256, first);
     {
         const uint32_t q = 256 * qb256 + threadIdx.x;
         const float c = cq[q], m = mq[q];
