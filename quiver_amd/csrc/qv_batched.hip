@@ -1420,7 +1420,10 @@ k_bf16rows_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __res
 // workgroup work for the SAME 64 queries, so their one-term operands (steps x 2 KiB: 96 KiB at 768 dimensions) sit in LDS for the
 // whole kernel, and every wave streams its own row groups from the bfloat16 plane straight into B operands — no barrier, no
 // conversion, no query traffic in the loop: one pass over half the bytes.  Dimensions that are a multiple of 64, up to 1024.
-template <int METRIC, int NB, int R>
+// F32 (round 4): the same kernel on the float32 tiles of an index WITHOUT the copy — a lane's two 16-byte chunk requests are its B operand's
+// eight dimensions, converted right before use (4 v_cvt_pk_bf16_f32); no LDS for rows, no barrier: what 9-64 queries cost on the default
+// index was the per-wave three-term kernel (0.61-0.64 ms at 1M x 768).
+template <int METRIC, int NB, int R, bool F32 = false>
 __global__ void __launch_bounds__(512, 1)
 k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                       uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
@@ -1446,22 +1449,28 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
     __syncthreads();
     const uint32_t half = lane >> 5, l31 = lane & 31;
     const EpiConsts ec = epi_consts<METRIC>(&s_c[0][0], &s_m[0][0], 0u, half);
-    const uint4* plane = reinterpret_cast<const uint4*>(v.bf16);
+    const uint4* plane = reinterpret_cast<const uint4*>(F32 ? reinterpret_cast<const void*>(v.tiles) : reinterpret_cast<const void*>(v.bf16));   // (both are walked in 16-byte units)
     // NB = 4: a row group is two tiles (128 rows), R steps of them in flight; NB = 2: one tile per group and 64 accumulators less, which
     // buys twice the steps in flight (each wave's requests are what feeds the HBM stream: 4.9 TB/s with 16 KB per wave)
     const uint32_t n_groups = NB == 4 ? (v.n_tiles + 1) / 2 : v.n_tiles;
     const uint32_t gw = blockIdx.x * 8 + wave, tw = gridDim.x * 8;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    uint4 rb[R][NB];
+    struct Rb { uint4 x[F32 ? 2 : 1]; };
+    Rb rb[R][NB];
     const uint4* p[NB];
     auto bases = [&](uint32_t g_, const uint4* (&o)[NB]) {           // block j of group g_: rows 32*(j&1) .. +31 of the group's tile j >> 1
         const uint32_t ta = NB == 4 ? 2 * g_ : g_, tb = (NB == 4 && 2 * g_ + 1 < v.n_tiles) ? 2 * g_ + 1 : ta;
 #pragma unroll
-        for (int j = 0; j < NB; j++) o[j] = plane + (size_t)(j < 2 ? ta : tb) * dim8 * 64 + 64 * (j & 1) + 32 * half + l31;
+        for (int j = 0; j < NB; j++) o[j] = F32 ? plane + ((size_t)(j < 2 ? ta : tb) * v.dim4 + 2 * half) * 64 + 32 * (j & 1) + l31     // chunk 2 half (+1) of row 32 (j & 1) + l31
+                                                 : plane + (size_t)(j < 2 ? ta : tb) * dim8 * 64 + 64 * (j & 1) + 32 * half + l31;
     };
-    auto load_step = [&](uint4 (&o)[NB]) {
+    auto load_step = [&](Rb (&o)[NB]) {
 #pragma unroll
-        for (int j = 0; j < NB; j++) { o[j] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p[j]))); p[j] += 128; }
+        for (int j = 0; j < NB; j++) {
+            o[j].x[0] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p[j])));
+            if constexpr (F32) { o[j].x[1] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p[j] + 64))); p[j] += 256; }   // a step is four chunks
+            else p[j] += 128;
+        }
     };
     bool primed = false;
     for (uint32_t g = gw; g < n_groups; g += tw) {
@@ -1490,7 +1499,12 @@ k_bf16rows_filter_q64(IndexView v, const uint4* __restrict__ Qbf, const float* _
                 const bf8 ah0 = __builtin_bit_cast(bf8, a0), ah1 = __builtin_bit_cast(bf8, a1);
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
-                    const bf8 bh = __builtin_bit_cast(bf8, rb[k][j]);
+                    uint4 bu = rb[k][j].x[0];
+                    if constexpr (F32) {
+                        const f4 x0 = __builtin_bit_cast(f4, rb[k][j].x[0]), x1 = __builtin_bit_cast(f4, rb[k][j].x[F32 ? 1 : 0]);
+                        bu.x = pack_bf16(x0.x, x0.y); bu.y = pack_bf16(x0.z, x0.w); bu.z = pack_bf16(x1.x, x1.y); bu.w = pack_bf16(x1.z, x1.w);
+                    }
+                    const bf8 bh = __builtin_bit_cast(bf8, bu);
                     acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0][j], 0, 0, 0);
                     acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1][j], 0, 0, 0);
                 }
@@ -2127,7 +2141,9 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     const bool shared = bf && (nq_pad / 64) % 4 == 0 && share_env == 1;
     static const int q64_env = env_int("QV_MFMA_Q64", 1);                                     // 2 = off
     const uint32_t fsteps0 = (v.dim4 + 3) / 4;
-    const bool q64 = bf && fmode == 3 && nq_pad == 64 && v.bf16 != nullptr && q64_env == 1 && (v.dim4 & 3u) == 0 && fsteps0 % 4 == 0 && fsteps0 >= 8 && fsteps0 <= 64;
+    const bool q64_shape = bf && fmode == 3 && nq_pad == 64 && q64_env == 1 && (v.dim4 & 3u) == 0 && fsteps0 % 4 == 0 && fsteps0 >= 8 && fsteps0 <= 64;
+    const bool q64f = q64_shape && v.bf16 == nullptr;                     // the one-block kernel on float32 rows (round 4)
+    const bool q64 = q64_shape;
     const int gmode = !bf ? 0 : (fmode == 3 && (shared || q64) ? 2 : 1);   // which filter_gamma the main pass obeys (one term: the shared kernels and the one-block kernel)
     // one-term filter on float32 rows at a dimension the eight-wave kernel's loop does not divide: its zero-padded form (round 4);
     // the query operands are then laid out once more, padded, after the sample pass has read them in its own layout
@@ -2206,10 +2222,13 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
                      hipLaunchKernelGGL((k_bf16rows_filter_q64<MMM, NBB, RR>), dim3((uint32_t)cus), dim3(512), lds_a, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         // (one tile per group with sixteen steps in flight, <MMM, 2, 16>, and a plane layout with contiguous KiB per request measure the same
         // 304-315 us at 64 x 1M x 768 as <MMM, 4, 4>: the kernel sits at 4.9-5.0 TB/s whatever each wave keeps in flight)
-#define QV_FQ(MMM) { QV_FQ1(MMM, 4, 4) }
+#define QV_FQ1F(MMM) { e = set_lds(k_bf16rows_filter_q64<MMM, 2, 4, true>, lds_a); if (e != hipSuccess) return e; \
+                     hipLaunchKernelGGL((k_bf16rows_filter_q64<MMM, 2, 4, true>), dim3((uint32_t)cus), dim3(512), lds_a, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
+#define QV_FQ(MMM) { if (q64f) QV_FQ1F(MMM) else QV_FQ1(MMM, 4, 4) }
         if (v.metric == QV_COSINE) QV_FQ(QV_COSINE) else if (v.metric == QV_DOT) QV_FQ(QV_DOT) else QV_FQ(QV_L2)
 #undef QV_FQ
 #undef QV_FQ1
+#undef QV_FQ1F
     } else if (shared) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
         const uint32_t gs = grid_multiple((uint32_t)cus, nqb64 / 4);      // every row group is walked by nqb64/4 workgroups
