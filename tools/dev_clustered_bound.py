@@ -1,3 +1,6 @@
+"""How many queries of a batch the filter + re-score path hands back (candidate overflow -> exact scan) on corpora stored cluster after
+cluster: 30 x 10 000, 300 x 1000, 3000 x 100 rows at 768 dimensions, 30 x 10 000 at 128.  The bound of a query's k-th distance comes from a
+sample; how it is selected (QV_MFMA_SAMPLE_GROUP_MIN) decides whether such corpora fall off the fast path.  python tools/dev_clustered_bound.py"""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch, quiver_amd as q
