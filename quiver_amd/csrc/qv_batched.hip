@@ -30,8 +30,7 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
                             float* __restrict__ Qt, float* __restrict__ cq, float* __restrict__ mq /*[2][nq_pad]: m_q, b_q*/, float* __restrict__ eq /*[nq_pad][2]*/,
                             uint32_t* __restrict__ cand_cnt, uint32_t* __restrict__ overflow, int bf16x3, int what, uint32_t cand_cap,
                             uint32_t steps_pad /* bfloat16 layout: steps of 16 dimensions per query block, zero padded (0 = ceil(dim / 16)) */,
-                            const float* __restrict__ group_min = nullptr, uint32_t n_groups = 0 /* the sample's per-group minima [nq_pad][n_groups]: the bound is selected here */,
-                            const float* __restrict__ row_bounds = nullptr, uint32_t row_stride = 0 /* every sample row's bound [nq_pad][row_stride]: stage 2 */) {
+                            const float* __restrict__ group_min = nullptr, uint32_t n_groups = 0 /* the sample's per-group minima [nq_pad][n_groups]: the bound is selected here */) {
     // what: 1 = operand layout only, 2 = filter constants only (needs sample_dist), 3 = both
     const uint32_t q = blockIdx.x;                     // one block per (padded) query
     if (q == 0 && threadIdx.x == 0) cand_cnt[-1] = cand_cap;           // candidate slots per query, for the filter kernels (CandOut)
@@ -82,17 +81,15 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
     }
     __shared__ float s_U;
     __shared__ uint32_t s_bins[256];
-    constexpr uint32_t kPrepKeys = 16384;                            // 64 KiB: group minima (stage 1), then the rows of up to 128 groups (stage 2)
+    constexpr uint32_t kPrepKeys = 16384;                            // 64 KiB of group minima
     __shared__ uint32_t s_keys[kPrepKeys];
     if ((what & 2) && group_min && q < nq) {
         // The bound from the sample, here instead of in kernels of its own (k_sample_bound / k_sample_hist: launches on the batch's
         // critical path).  One wave; the selection is a radix selection on the ordered bits of the values, 8 bits a pass, 256 bins
         // in LDS, starting at the first bit in which the values differ at all (distances of one query share their exponent and leading
         // mantissa bits: from bit 31 down the first passes threw every value at ONE bin — 4096 serialized LDS atomics, 58 us).
-        //   stage 1: T1 = the k-th smallest of the n_groups group minima;
-        //   stage 2 (row_bounds given): the rows of the groups whose minimum is <= T1 — k groups, more only on exact ties — are
-        //     staged (128 values per group, +inf past the sample's end) and the k-th smallest of THEM is the bound: every row at or
-        //     below the k-th smallest row bound lies in a group whose minimum is at or below it, hence at or below T1.
+        // (The minima-only bound: QV_MFMA_SAMPLE_GROUP_MIN=3, a measurement — see k_bf16x1_filter_w8's sample mode.  The default selects
+        // among every row's bound: k_sample_select.)
         const uint32_t lane = threadIdx.x;
         auto kth_smallest = [&](uint32_t n, uint32_t kk) -> uint32_t {      // over s_keys[0 .. n); kk >= 1; n >= 1
             uint32_t lo = 0xFFFFFFFFu, hi = 0u;
@@ -146,40 +143,7 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
             for (int u = 0; u < 16; u++) { const uint32_t i = base + 64 * u + lane; if (i < ng) s_keys[i] = ord_f32(x[u]); }
         }
         __syncthreads();
-        uint32_t ukey = kth_smallest(ng, k);
-        if (row_bounds && ukey != 0xFFFFFFFFu && ukey < ord_f32(__builtin_inff())) {
-            // which groups: the answer first (s_keys is about to be overwritten), as a list of group numbers in the bins' array's place
-            // (up to kPrepKeys / 128 groups: beyond, the bound comes from a subset of the rows — still k rows or more, still a bound)
-            constexpr uint32_t kMaxSel = kPrepKeys / 128;
-            __shared__ uint32_t s_sel[kMaxSel];
-            uint32_t n_sel = 0;
-            for (uint32_t base = 0; base < ng && n_sel < kMaxSel; base += 64) {
-                const uint32_t i = base + lane;
-                const bool take = i < ng && s_keys[i] <= ukey;
-                const uint64_t m = __ballot(take);
-                const uint32_t pos = n_sel + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                if (take && pos < kMaxSel) s_sel[pos] = i;
-                n_sel += (uint32_t)__builtin_popcountll(m);
-            }
-            if (n_sel > kMaxSel) n_sel = kMaxSel;
-            __syncthreads();
-            const float* rb = row_bounds + (size_t)q * row_stride;
-            for (uint32_t e = 0; e < n_sel; e += 8) {                       // eight groups' rows in flight
-                float x[8][2];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t gsel = e + u < n_sel ? s_sel[e + u] : 0u;
-                    const uint32_t r0 = 128 * gsel + lane, r1 = r0 + 64;
-                    x[u][0] = e + u < n_sel && r0 < row_stride ? rb[r0] : __builtin_inff();
-                    x[u][1] = e + u < n_sel && r1 < row_stride ? rb[r1] : __builtin_inff();
-                }
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < 8; u++) if (e + u < n_sel) { s_keys[128 * (e + u) + lane] = ord_f32(x[u][0]); s_keys[128 * (e + u) + 64 + lane] = ord_f32(x[u][1]); }
-            }
-            __syncthreads();
-            ukey = kth_smallest(128 * n_sel, k);
-        }
+        const uint32_t ukey = kth_smallest(ng, k);
         if (lane == 0) {
             float x = ukey == 0xFFFFFFFFu ? __builtin_inff() : unord_f32(ukey);   // the k-th smallest bound itself (+inf: fewer than k live sample rows)
             const float gref = (float)filter_gamma(dim, 0) * 1.000001f;
@@ -424,7 +388,7 @@ template <int METRIC>
 __global__ void __launch_bounds__(256, 1)
 k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
                 uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt,
-                float* __restrict__ score_out, uint32_t score_stride, uint32_t gstep, uint32_t group_min = 0) {
+                float* __restrict__ score_out, uint32_t score_stride, uint32_t gstep) {
     // score_out != null: no filter — the SAMPLE pass.  Row groups 0, gstep, 2 gstep, ... (score_stride / 128 of them, spread over the
     // corpus so that a corpus stored cluster by cluster still yields a representative bound); what is written to
     // score_out[query * score_stride + 128 * (group's place in the sample) + row of the group] is the UPPER BOUND of the row's
@@ -542,37 +506,6 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
         }
         for (; st < steps; st++) {                   // the steps that do not fill a round of six: one at a time
             load(st, o0); split(o0, h0); mfma(h0);
-        }
-        if (score_out && group_min) {
-            // group_min = 1: the group's minimum only; 4: every row's bound and the minima behind them (see k_bf16x1_filter_w8's sample mode)
-            const float gsm = f32_up((float)filter_gamma(v.dim, 1));
-            float ra[4], rb[4];
-            uint32_t rowj[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                rowj[j] = g * 128 + (j < 2 ? 0u : 64u) + 32 * (j & 1) + l31;
-                const bool gone = (j >= 2 && t1 == t0) || rowj[j] >= score_stride || !((alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull);
-                sample_row_consts<METRIC>(f32_up((float)rnd[j]), gone, filter_tiny_norm(v.dim), ra[j], rb[j]);
-            }
-            float* gmin_out = group_min == 4 ? score_out + (size_t)nq_pad * score_stride : score_out;
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const uint32_t ql = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float qa_ = s_c[wave][ql], qb_ = s_m[wave][ql];
-                    float m = __builtin_inff();
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float u = sample_upper<METRIC>(acc[i][j][r], gsm, qa_, qb_, ra[j], rb[j]);
-                        if (group_min == 4 && rowj[j] < score_stride) score_out[(size_t)(64 * qb64 + ql) * score_stride + rowj[j]] = u;
-                        m = fminf(m, u);
-                    }
-#pragma unroll
-                    for (int off = 1; off < 32; off <<= 1) m = fminf(m, __shfl_xor(m, off));
-                    if (l31 == 0) gmin_out[(size_t)(64 * qb64 + ql) * n_groups + g] = m;
-                }
-            continue;
         }
         if (score_out) {
             const float gsm = f32_up((float)filter_gamma(v.dim, 1));
@@ -1053,35 +986,28 @@ k_bf16x1_filter_w8(IndexView v, const uint4* __restrict__ Qbf, const float* __re
             // times (the k best rows rarely share a group), and k_sample_bound then selects among S / 128 values per query instead
             // of S: 29 -> 5 us at 256 x 32768, and 33 MB of scores are neither written nor read.
             if (group_min) {
-                // group_min = 1: only the group's minimum leaves the kernel (score_out[query][group]) — fast, and fragile: on a corpus
-                // stored cluster by cluster a group's rows are all near or all far, the k best sample rows of a query sit in few groups,
-                // and the k-th smallest MINIMUM hands back 256 of 256 queries on 30 clusters of 10 000 rows where the k-th smallest row
-                // bound hands back 20 (tools/dev_clustered_bound.py).  group_min = 4 (the default): every row's bound AND the minima
-                // (behind the rows' array); k_mfma_prep finds the k groups with the smallest minima and selects among THEIR rows — the
-                // k-th smallest row bound exactly (every row at or below it lies in such a group), from k x 128 values instead of S.
+                // group_min (QV_MFMA_SAMPLE_GROUP_MIN=3, a measurement): only each 128-row group's MINIMUM leaves the kernel
+                // (score_out[query][group]) and k_mfma_prep selects the k-th smallest of those.  Fast (no pass over every row's bound), and
+                // fragile: on a corpus stored cluster by cluster a group's rows are all near or all far, the k best sample rows of a query
+                // sit in few groups, and the k-th smallest minimum hands back 256 of 256 queries on 30 clusters of 10 000 rows where the
+                // k-th smallest ROW bound hands back 20 (tools/dev_clustered_bound.py).  Not the default.
                 float ra[4], rb[4], rc[4];                                 // the four row blocks' constants first (+inf bounds for rows that are not there),
-                uint32_t rowj[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {                              // then one query at a time: min over the blocks, min over the half-wave's 32 rows
-                    rowj[j] = g * 128 + (j < 2 ? 0u : 64u) + 32 * (j & 1) + l31;
-                    const bool gone = (j >= 2 && t1 == t0) || rowj[j] >= score_stride || !((alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull);
+                    const uint32_t row = g * 128 + (j < 2 ? 0u : 64u) + 32 * (j & 1) + l31;
+                    const bool gone = (j >= 2 && t1 == t0) || row >= score_stride || !((alv[j >> 1] >> (32 * (j & 1) + l31)) & 1ull);
                     sample1_row_consts<METRIC>(f32_up((float)rnd[j]), rho[j], gone, filter_tiny_norm(v.dim), ra[j], rb[j], rc[j]);
                 }
-                float* gmin_out = group_min == 4 ? score_out + (size_t)nq_pad * score_stride : score_out;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const uint32_t ql = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * half;
                     const float qa_ = s_c[ql], qb_ = s_m[ql], qc_ = s_m[256 + ql];
                     float m = __builtin_inff();
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float u = sample1_upper<METRIC>(acc[0][j][r], qa_, qb_, qc_, ra[j], rb[j], rc[j]);
-                        if (group_min == 4 && rowj[j] < score_stride) score_out[(size_t)(256 * qb256 + ql) * score_stride + rowj[j]] = u;
-                        m = fminf(m, u);
-                    }
+                    for (int j = 0; j < 4; j++) m = fminf(m, sample1_upper<METRIC>(acc[0][j][r], qa_, qb_, qc_, ra[j], rb[j], rc[j]));
 #pragma unroll
                     for (int off = 1; off < 32; off <<= 1) m = fminf(m, __shfl_xor(m, off));
-                    if (l31 == 0) gmin_out[(size_t)(256 * qb256 + ql) * n_groups + g] = m;
+                    if (l31 == 0) score_out[(size_t)(256 * qb256 + ql) * n_groups + g] = m;
                 }
             } else {
 #pragma unroll
@@ -1556,7 +1482,7 @@ __device__ __forceinline__ void score_interval(double S, double qn_cos, double q
 // T1 — k chunks, more only on exact ties.  Their rows are read again (from L2) into LDS, and U is the k-th smallest of them: a
 // radix selection on the ordered bits, 8 bits a pass from the first bit in which the values differ, 256 LDS bins, whole workgroup.
 // Writes what k_mfma_prep reads of k_sample_bound's output: sample_dist[q][k - 1].  Needs k chunks' rows to fit kSelKeys.
-constexpr uint32_t kSelKeys = 16384;                                 // 64 KiB of ordered keys
+constexpr uint32_t kSelKeys = 24576;                                 // 96 KiB of ordered keys (k = 128 over a sixth of a million rows)
 __host__ __device__ static inline uint32_t sample_select_chunk(uint32_t srows) { return ((srows + 1023) / 1024 + 3) / 4 * 4; }
 static bool sample_select_applies(uint32_t srows, uint32_t k) { return srows >= 4096 && (uint64_t)k * sample_select_chunk(srows) <= kSelKeys && k <= 1024; }
 template <int M>
@@ -2176,33 +2102,27 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         // the eight-wave sample kernel hands out one value per query and 128-row group when the groups outnumber k at least four times
         const uint32_t sample_groups = (vs.n_rows + 127) / 128;
         static const int gmin_env = env_int("QV_MFMA_SAMPLE_GROUP_MIN", 1);                      // 2 = every row's bound (round 3)
-        // How the bound is taken from the sample's per-row upper bounds:
-        //   k <= 64: k_sample_bound (wave lists over every row's bound; 29 us at 256 x 32768) — as in round 3;
-        //   64 < k <= 128: the sample kernel also writes each 128-row group's minimum, and k_mfma_prep selects the bound itself — among
-        //     the rows of the k groups with the smallest minima, which contain every row at or below the k-th smallest row bound:
-        //     the same value as a selection among all rows, from k x 128 values (gmin_mode 4; 1.14 ms per batch at k = 100 against
-        //     1.27 with the histogram kernels below);
-        //   k > 128: k_sample_hist (two radix windows over every row's bound) + k_sample_bound_from_state.
-        // Minima ALONE (gmin_mode 1, QV_MFMA_SAMPLE_GROUP_MIN=3: measurement) were the default for a few hours of round 4: 11 us faster at
-        // k = 10, 85 at k = 64 — and a cliff on a corpus stored cluster by cluster (a group's rows are all near or all far): 256 of 256
-        // queries handed back on 30 clusters x 10 000 rows against 20 with every row's bound (tools/dev_clustered_bound.py).  With the
-        // rows' bounds written as well the minima only steer the selection; they cost it 20 us at k = 10, more than they save there.
-        const uint32_t gmin_mode = gmin_env == 3 ? 1u : (gmin_env == 1 && large_k && k <= 128 ? 4u : 0u);
+        // How the bound is taken from the sample's per-row upper bounds: k_sample_select (per-thread chunk minima, then the rows of the k
+        // best chunks: the exact k-th smallest row bound, in LDS) while k chunks fit its LDS — k <= 128 at a million rows; beyond, the
+        // histogram kernels (k_sample_hist: two radix windows over every row's bound) or, up to 64, k_sample_bound's wave lists.
+        // QV_MFMA_SAMPLE_GROUP_MIN=3 (a measurement): one MINIMUM per query and 128-row group, selected inside k_mfma_prep — 11 us
+        // faster at k = 10, 85 at k = 64, and a cliff on a corpus stored cluster by cluster (tools/dev_clustered_bound.py).
+        const uint32_t gmin_mode = gmin_env == 3 && sample1 ? 1u : 0u;
         const bool group_min = gmin_mode != 0 && sample_groups >= 4 * k && sample_groups <= 16384;
         const uint32_t gmin_vals = sample_groups;
         static const int sel2_env = env_int("QV_MFMA_SAMPLE_SELECT", 1);                        // 2 = k_sample_bound (wave lists) as in round 3
-        const bool sel2 = sel2_env == 1 && !large_k && !group_min && sample_select_applies(vs.n_rows, k);
-#define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? gmin_mode : 0u); \
-                     else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? gmin_mode : 0u); \
+        const bool sel2 = sel2_env == 1 && !group_min && sample_select_applies(vs.n_rows, k);
+#define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? 1u : 0u); \
+                     else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
                      if (group_min) { /* the bound is selected inside k_mfma_prep from the group minima */ } \
+                     else if (sel2) hipLaunchKernelGGL(k_sample_select<MMM>, dim3(nq), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); \
                      else if (large_k) { hipLaunchKernelGGL(k_sample_hist<0>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_hist<1>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_bound_from_state<MMM>, dim3((nq + 255) / 256), dim3(256), 0, s, sst, nq, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); } \
-                     else if (sel2) hipLaunchKernelGGL(k_sample_select<MMM>, dim3(nq), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); \
                      else hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k && !group_min && !sel2 ? sparts : sdist, large_k || group_min || sel2 ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u, group_min ? (gmin_mode == 4 ? sscore + (size_t)nq_pad * vs.n_rows : sscore) : nullptr, gmin_vals, group_min && gmin_mode == 4 ? sscore : nullptr, vs.n_rows);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k && !group_min && !sel2 ? sparts : sdist, large_k || group_min || sel2 ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u, group_min ? sscore : nullptr, gmin_vals);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
         e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
