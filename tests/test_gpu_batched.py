@@ -419,6 +419,38 @@ def test_filter_kernels_at_other_dimensions(metric, dim):
         assert _eq(_exact(idx, qs[:nq], 10), idx.search(qs[:nq], 10, batched=True))
 
 
+def test_concurrent_batches_on_one_index_are_independent():
+    """BatchSearch callers run under the collection's read lock (collection.go:647): several batches at once on ONE index, from
+    different host threads — each on a call context (stream, workspace) of its own, through every batch shape the router has: one
+    query block, whole workgroups of 256, k above 64.  First calls on fresh contexts included (a fill that was not ordered against
+    the context's stream broke exactly those once)."""
+    import threading
+    import quiver_amd as q
+    n, dim = 150_000, 768
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260426, 0, 256, dim)
+    shapes = [(256, 10), (40, 10), (256, 64), (100, 100), (9, 7), (256, 10), (64, 33), (130, 10)]
+    want = [_exact(idx, qs[:m], k) for m, k in shapes]
+    errs = []
+
+    def worker(t):
+        try:
+            m, k = shapes[t]
+            for _ in range(4):
+                if not _eq(want[t], idx.search(qs[:m], k, batched=True)):
+                    errs.append((t, m, k))
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(len(shapes))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert errs == []
+
+
 def test_cluster_stored_corpus_at_768_dimensions_keeps_the_filter_path():
     """The same at the width and batch size where the eight-wave sample kernel runs (the test above is 128 dimensions x 64 queries, which
     it does not take).  Round 4 briefly selected the bound among per-group MINIMA of the sample: with 30 clusters stored one after the
