@@ -158,6 +158,8 @@ def compact_also(also, budget):
                              ("cpu_port_latency_us_1core", "cpu_us"), ("identical_to_exact_scan", "same"), ("identical_to_oracle", "same")):
                 if e.get(src) is not None and not (src == "qps" and "batch_ms" in e):
                     o[dst] = _r(e[src], 4)
+            if isinstance(e.get("plain_c_caller"), dict) and "p50_us" in e["plain_c_caller"]:
+                o["c_us"] = _r(e["plain_c_caller"]["p50_us"], 4)
             rf = e.get("roofline")
             if isinstance(rf, dict):
                 o.update({"bound": rf.get("bound"), "kernel_ms": _r(rf.get("kernel_ms"), 4), "frac": _r(rf.get("frac"), 3)})
@@ -618,6 +620,22 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
             dtc = (time.perf_counter() - t1) / 200
             entry["cpu_port_latency_us_1core"] = dtc * 1e6
             entry["identical_to_oracle"] = bool(np.array_equal(r0[0], O.exact_search(0, rows0, q0[999 % 64], k)[0]))
+        try:
+            # the same calls from plain C (what a cgo caller pays: no interpreter, no per-call allocations): tools/ubench/abi_latency.c,
+            # compiled here and run as a child process; p50 / p99 of 5 000 calls and the aggregate rate of 8 concurrent callers
+            import subprocess, tempfile
+            root_ = os.path.dirname(os.path.abspath(__file__))
+            exe_ = os.path.join(tempfile.gettempdir(), "qv_abi_latency_%d" % os.getpid())
+            libdir_ = os.path.join(root_, "quiver_amd", "lib")
+            subprocess.run(["gcc", "-O2", "-std=c11", "-I", os.path.join(root_, "include"), os.path.join(root_, "tools", "ubench", "abi_latency.c"),
+                            "-L", libdir_, "-lqv", "-lm", "-lpthread", "-Wl,-rpath," + libdir_, "-o", exe_], check=True, capture_output=True, timeout=120)
+            env_ = dict(os.environ); env_["HIP_VISIBLE_DEVICES"] = env_.get("HIP_VISIBLE_DEVICES", str(local_rank))
+            out_ = subprocess.run([exe_, "10000", "128", str(k), "5000", "8"], check=True, capture_output=True, text=True, timeout=120, env=env_).stdout
+            cj_ = json.loads(out_.strip().split("\n")[-1])
+            entry["plain_c_caller"] = {"p50_us": cj_["p50_us"], "p99_us": cj_["p99_us"], "eight_callers_aggregate_qps": cj_["aggregate_qps"]}
+            os.remove(exe_)
+        except Exception as ex:                            # noqa: BLE001  (no compiler on the box, ...: the Python-side number stands)
+            entry["plain_c_caller"] = {"skipped": str(ex)[:120]}
         also["config0_10kx128_single_query"] = entry
         c0.close()
     except Exception as ex:                                # noqa: BLE001
