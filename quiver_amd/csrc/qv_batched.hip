@@ -217,8 +217,8 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
     QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t gw = blockIdx.x * 4 + wave, tw = gridDim.x * 4;
     const uint32_t nqb64 = nq_pad >> 6;
+    const uint32_t gw = filter_logical_block((nqb64 & 3u) == 0 ? nqb64 >> 2 : 1u) * 4 + wave, tw = gridDim.x * 4;
     const uint32_t qb64 = gw % nqb64;
     const uint32_t n_groups = (v.n_tiles + 1) / 2;
     const uint32_t stride = tw / nqb64;
@@ -400,8 +400,8 @@ k_bf16x3_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restr
     QV_EPI_DUMP(du, 4, 64);                                           // 20 KiB
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t gw = blockIdx.x * 4 + wave, tw = gridDim.x * 4;
     const uint32_t nqb64 = nq_pad >> 6;
+    const uint32_t gw = filter_logical_block((nqb64 & 3u) == 0 ? nqb64 >> 2 : 1u) * 4 + wave, tw = gridDim.x * 4;
     const uint32_t qb64 = gw % nqb64;
     const uint32_t n_groups = score_out ? (score_stride + 127) / 128 : (v.n_tiles + 1) / 2;
     const uint32_t stride = tw / nqb64;

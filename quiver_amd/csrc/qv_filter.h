@@ -90,6 +90,15 @@ __device__ __forceinline__ void filter_block_role(uint32_t wgs, uint32_t& qblock
     }
 }
 
+// The per-wave kernels (k_mfma_filter, k_bf16x3_filter): workgroup L's four waves take query blocks 4 L .. 4 L + 3 (mod nqb64), so `share` =
+// nqb64 / 4 consecutive workgroups walk the same row groups.  The same placement rule: those go to one XCD.  Returns the workgroup's
+// logical number L (blockIdx.x itself when the grid does not divide).
+__device__ __forceinline__ uint32_t filter_logical_block(uint32_t share) {
+    if (share <= 1 || gridDim.x % (8 * share) != 0) return blockIdx.x;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    return ((slot / share) * 8 + xcd) * share + slot % share;
+}
+
 // Candidate queue of a wave.  A row that passes the filter test used to be appended to its query's list with a RETURNING global
 // atomic (the slot), inside an epilogue that also spilled around itself.  Vector-memory operations complete in issue order per
 // wave (`s_waitcnt vmcnt` is one counter), so waiting for that slot — or for any vector-memory result: a spill reload is one too
