@@ -81,7 +81,7 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
     }
     __shared__ float s_U;
     __shared__ uint32_t s_bins[256];
-    constexpr uint32_t kPrepKeys = 16384;                            // 64 KiB of group minima
+    constexpr uint32_t kPrepKeys = 4096;                             // 16 KiB of group minima (the measurement mode only: keeps the block's LDS small — 8192 padded queries are 8192 blocks)
     __shared__ uint32_t s_keys[kPrepKeys];
     if ((what & 2) && group_min && q < nq) {
         // The bound from the sample, here instead of in kernels of its own (k_sample_bound / k_sample_hist: launches on the batch's
@@ -1484,11 +1484,12 @@ __device__ __forceinline__ void score_interval(double S, double qn_cos, double q
 // Writes what k_mfma_prep reads of k_sample_bound's output: sample_dist[q][k - 1].  Needs k chunks' rows to fit kSelKeys.
 constexpr uint32_t kSelKeys = 24576;                                 // 96 KiB of ordered keys (k = 128 over a sixth of a million rows)
 __host__ __device__ static inline uint32_t sample_select_chunk(uint32_t srows) { return ((srows + 1023) / 1024 + 3) / 4 * 4; }
+static size_t sample_select_lds_bytes(uint32_t srows, uint32_t k) { return (size_t)std::min<uint64_t>(kSelKeys, (uint64_t)(k + 8) * sample_select_chunk(srows)) * 4; }   // (a few chunks of slack for exact ties)
 static bool sample_select_applies(uint32_t srows, uint32_t k) { return srows >= 4096 && (uint64_t)k * sample_select_chunk(srows) <= kSelKeys && k <= 1024; }
 template <int M>
 __global__ void __launch_bounds__(1024)
 k_sample_select(const float* __restrict__ bounds, uint32_t srows, uint32_t k, float gref, float* __restrict__ sample_dist) {
-    __shared__ uint32_t s_keys[kSelKeys];
+    extern __shared__ uint32_t s_keys[];                              // k chunks' rows (sample_select_lds_bytes): small k leaves room for a second block per CU
     __shared__ uint32_t s_min[1024];
     __shared__ uint32_t s_bins[256];
     __shared__ uint32_t s_sel[1024];
@@ -1563,7 +1564,8 @@ k_sample_select(const float* __restrict__ bounds, uint32_t srows, uint32_t k, fl
     uint32_t ukey = t1;
     if (t1 != 0xFFFFFFFFu && t1 < ord_f32(__builtin_inff())) {
         // stage 2: the chunks at or below T1 (beyond kSelKeys / chunk of them — exact ties only — the bound comes from a subset: still k rows)
-        const uint32_t cap = kSelKeys / chunk;
+        const uint32_t cap_keys = (k + 8) * chunk < kSelKeys ? (k + 8) * chunk : kSelKeys;   // = sample_select_lds_bytes / 4
+        const uint32_t cap = cap_keys / chunk;
         if (s_min[t] <= t1) { const uint32_t slot = atomicAdd(&s_n, 1u); if (slot < 1024) s_sel[slot] = t; }
         __syncthreads();
         const uint32_t n_sel = s_n < cap ? s_n : cap;
@@ -2108,14 +2110,16 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         // QV_MFMA_SAMPLE_GROUP_MIN=3 (a measurement): one MINIMUM per query and 128-row group, selected inside k_mfma_prep — 11 us
         // faster at k = 10, 85 at k = 64, and a cliff on a corpus stored cluster by cluster (tools/dev_clustered_bound.py).
         const uint32_t gmin_mode = gmin_env == 3 && sample1 ? 1u : 0u;
-        const bool group_min = gmin_mode != 0 && sample_groups >= 4 * k && sample_groups <= 16384;
+        const bool group_min = gmin_mode != 0 && sample_groups >= 4 * k && sample_groups <= 4096;
         const uint32_t gmin_vals = sample_groups;
         static const int sel2_env = env_int("QV_MFMA_SAMPLE_SELECT", 1);                        // 2 = k_sample_bound (wave lists) as in round 3
         const bool sel2 = sel2_env == 1 && !group_min && sample_select_applies(vs.n_rows, k);
+        const size_t sel2_lds = sel2 ? sample_select_lds_bytes(vs.n_rows, k) : 0;
 #define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? 1u : 0u); \
                      else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
                      if (group_min) { /* the bound is selected inside k_mfma_prep from the group minima */ } \
-                     else if (sel2) hipLaunchKernelGGL(k_sample_select<MMM>, dim3(nq), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); \
+                     else if (sel2) { e = set_lds(k_sample_select<MMM>, sel2_lds); if (e != hipSuccess) return e; \
+                                      hipLaunchKernelGGL(k_sample_select<MMM>, dim3(nq), dim3(1024), sel2_lds, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); } \
                      else if (large_k) { hipLaunchKernelGGL(k_sample_hist<0>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_hist<1>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_bound_from_state<MMM>, dim3((nq + 255) / 256), dim3(256), 0, s, sst, nq, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); } \
