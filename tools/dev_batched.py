@@ -14,7 +14,8 @@ nq = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 rows = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
 dim = int(sys.argv[4]) if len(sys.argv) > 4 else 768
 k = int(sys.argv[5]) if len(sys.argv) > 5 else 10
-idx = quiver_amd.DeviceIndex(dim, metric, bf16_rows=os.environ.get("DEV_BF16_ROWS") == "1", filter=os.environ.get("DEV_FILTER") or None)   # DEV_FILTER=fp32 | bf16x3 | bf16x1
+idx = quiver_amd.DeviceIndex(dim, metric, bf16_rows=os.environ.get("DEV_BF16_ROWS") == "1", filter=os.environ.get("DEV_FILTER") or None,
+                             rowmajor=os.environ.get("DEV_ROWMAJOR") == "1")   # DEV_FILTER=fp32 | bf16x3 | bf16x1; DEV_ROWMAJOR=1: keep the row-major copy (the exact passes gather from it)
 idx.add_synthetic(20260424, 0, rows)
 qi = quiver_amd.DeviceIndex(dim, metric)
 qi.add_synthetic(20260425, 0, nq)
