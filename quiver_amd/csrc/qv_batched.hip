@@ -1475,6 +1475,59 @@ __device__ __forceinline__ void score_interval(double S, double qn_cos, double q
 // The sample bound without an exact scan: the three-term filter kernel's scores of the sample give every sampled row an UPPER
 // bound of its reference distance (written by that kernel: score_upper_f32), and the k-th smallest of those bounds is at least the
 // k-th smallest true distance over the sample, hence over the corpus.  One workgroup per query (and part); a pure selection.
+// The k-th smallest (kk >= 1) of the ordered keys[0 .. n) in LDS, by the whole workgroup (any multiple of 64 threads): a radix selection, 8 bits a
+// pass from the first bit in which the keys differ at all (distances of one query share their exponent and leading mantissa bits: from bit
+// 31 down the first passes throw every key at ONE bin — serialized LDS atomics), 256 bins.  Every thread returns the key; 0xFFFFFFFF when
+// there are fewer than kk keys.  s_bins: 256 words, s_scal: 4 words of LDS.  Contains barriers: call it from uniform control flow.
+__device__ __forceinline__ uint32_t block_kth_smallest(const uint32_t* keys, uint32_t n, uint32_t kk, uint32_t* s_bins, uint32_t* s_scal) {
+    const uint32_t t = threadIdx.x, nt = blockDim.x, lane = lane_id(), wave = threadIdx.x >> 6;
+    if (t == 0) { s_scal[0] = 0xFFFFFFFFu; s_scal[1] = 0u; }
+    __syncthreads();
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t i = t; i < n; i += nt) { const uint32_t x = keys[i]; lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const uint32_t a = __shfl_xor(lo, m), b = __shfl_xor(hi, m); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if (lane == 0) { atomicMin(&s_scal[0], lo); atomicMax(&s_scal[1], hi); }
+    __syncthreads();
+    lo = s_scal[0]; hi = s_scal[1];
+    if (kk > n) return 0xFFFFFFFFu;
+    if (lo == hi) return lo;
+    const int top = 31 - __builtin_clz(lo ^ hi);
+    uint32_t prefix = top >= 31 ? 0u : (lo >> (top + 1)) << (top + 1);
+    uint32_t pmask = top >= 31 ? 0u : ~((1u << (top + 1)) - 1u);
+    uint32_t krem = kk;
+    for (int shift = top - 7; ; shift -= 8) {
+        const int sh = shift < 0 ? 0 : shift;
+        const uint32_t dmask = shift < 0 ? ((1u << (shift + 8)) - 1u) : 255u;
+        for (uint32_t i = t; i < 256; i += nt) s_bins[i] = 0;
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += nt) {
+            const uint32_t x = keys[i];
+            if ((x & pmask) == prefix) atomicAdd(&s_bins[(x >> sh) & dmask], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {                                              // 256 bins over 64 lanes: which bin holds the krem-th
+            uint32_t b4[4], sum = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { b4[u] = s_bins[4 * lane + u]; sum += b4[u]; }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(inc, off); if ((int)lane >= off) inc += y; }
+            const uint32_t excl = inc - sum;
+            if (excl < krem && krem <= inc) {
+                uint32_t d = 4 * lane, cum = excl;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { if (krem > cum + b4[u] && u < 3) { cum += b4[u]; d++; } else break; }
+                s_scal[2] = d; s_scal[3] = cum;
+            }
+        }
+        __syncthreads();
+        prefix |= s_scal[2] << sh; pmask |= dmask << sh; krem -= s_scal[3];
+        if (shift <= 0) break;
+    }
+    return prefix;
+}
+
 // The same selection in two stages, all of it in LDS (round 4, late): k_sample_bound's sixteen waves keep sorted lists and insert one
 // key at a time — a chain of dependent steps per row that passes (29 us for 32 768 bounds per query, 85 us at k = 64).  Here thread t
 // reads its chunk of the bounds (rows t, t + 1024, ...) and keeps its minimum; the k-th smallest of the 1024 minima, T1, is at or above the k-th
@@ -1493,59 +1546,11 @@ k_sample_select(const float* __restrict__ bounds, uint32_t srows, uint32_t k, fl
     __shared__ uint32_t s_min[1024];
     __shared__ uint32_t s_bins[256];
     __shared__ uint32_t s_sel[1024];
-    __shared__ uint32_t s_n, s_digit, s_cum, s_lohi[2];
-    const uint32_t t = threadIdx.x, lane = lane_id(), wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_n, s_scal[4];
+    const uint32_t t = threadIdx.x;
     const uint32_t qi = blockIdx.x;
     const float* sc = bounds + (size_t)qi * srows;
     const uint32_t chunk = sample_select_chunk(srows);
-    // the k-th smallest (kk >= 1) of keys[0 .. n): every thread returns it; 0xFFFFFFFF when there are fewer than kk keys
-    auto kth_smallest = [&](const uint32_t* keys, uint32_t n, uint32_t kk) -> uint32_t {
-        if (t == 0) { s_lohi[0] = 0xFFFFFFFFu; s_lohi[1] = 0u; }
-        __syncthreads();
-        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-        for (uint32_t i = t; i < n; i += 1024) { const uint32_t x = keys[i]; lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { const uint32_t a = __shfl_xor(lo, m), b = __shfl_xor(hi, m); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
-        if (lane == 0) { atomicMin(&s_lohi[0], lo); atomicMax(&s_lohi[1], hi); }
-        __syncthreads();
-        lo = s_lohi[0]; hi = s_lohi[1];
-        if (kk > n) return 0xFFFFFFFFu;
-        if (lo == hi) return lo;
-        const int top = 31 - __builtin_clz(lo ^ hi);
-        uint32_t prefix = top >= 31 ? 0u : (lo >> (top + 1)) << (top + 1);
-        uint32_t pmask = top >= 31 ? 0u : ~((1u << (top + 1)) - 1u);
-        uint32_t krem = kk;
-        for (int shift = top - 7; ; shift -= 8) {
-            const int sh = shift < 0 ? 0 : shift;
-            const uint32_t dmask = shift < 0 ? ((1u << (shift + 8)) - 1u) : 255u;
-            if (t < 256) s_bins[t] = 0;
-            __syncthreads();
-            for (uint32_t i = t; i < n; i += 1024) {
-                const uint32_t x = keys[i];
-                if ((x & pmask) == prefix) atomicAdd(&s_bins[(x >> sh) & dmask], 1u);
-            }
-            __syncthreads();
-            if (wave == 0) {                                              // 256 bins over 64 lanes: which bin holds the krem-th
-                uint32_t b4[4], sum = 0;
-#pragma unroll
-                for (int u = 0; u < 4; u++) { b4[u] = s_bins[4 * lane + u]; sum += b4[u]; }
-                uint32_t inc = sum;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(inc, off); if ((int)lane >= off) inc += y; }
-                const uint32_t excl = inc - sum;
-                if (excl < krem && krem <= inc) {
-                    uint32_t d = 4 * lane, cum = excl;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { if (krem > cum + b4[u] && u < 3) { cum += b4[u]; d++; } else break; }
-                    s_digit = d; s_cum = cum;
-                }
-            }
-            __syncthreads();
-            prefix |= s_digit << sh; pmask |= dmask << sh; krem -= s_cum;
-            if (shift <= 0) break;
-        }
-        return prefix;
-    };
     // stage 1: this thread's chunk = rows t, t + 1024, t + 2048, ... (consecutive threads read consecutive bounds): its minimum
     {
         float m = __builtin_inff();
@@ -1560,7 +1565,7 @@ k_sample_select(const float* __restrict__ bounds, uint32_t srows, uint32_t k, fl
     }
     if (t == 0) s_n = 0;
     __syncthreads();
-    const uint32_t t1 = kth_smallest(s_min, 1024, k);
+    const uint32_t t1 = block_kth_smallest(s_min, 1024, k, s_bins, s_scal);
     uint32_t ukey = t1;
     if (t1 != 0xFFFFFFFFu && t1 < ord_f32(__builtin_inff())) {
         // stage 2: the chunks at or below T1 (beyond kSelKeys / chunk of them — exact ties only — the bound comes from a subset: still k rows)
@@ -1575,7 +1580,7 @@ k_sample_select(const float* __restrict__ bounds, uint32_t srows, uint32_t k, fl
             s_keys[i] = ord_f32(r < srows ? sc[r] : __builtin_inff());
         }
         __syncthreads();
-        ukey = kth_smallest(s_keys, total, k);
+        ukey = block_kth_smallest(s_keys, total, k, s_bins, s_scal);
     }
     if (t == 0) {
         const float x = ukey == 0xFFFFFFFFu ? __builtin_inff() : unord_f32(ukey);
@@ -1697,12 +1702,15 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
     // gamma: |S~ - S| <= gamma |q||r| for the filter kernel that produced the scores (filter_gamma)
     RSTK();
 
-    // ---- stage 1: H = k-th smallest upper bound
+    // ---- stage 1: H = k-th smallest upper bound.  Every candidate's interval, four candidates per thread at a time: their scores and rows
+    // requested together, then their norms and residuals together (two round trips per 1024 candidates instead of two per 256); lower
+    // bounds and the upper bounds' ordered keys are parked in LDS, and H is a radix selection over the keys by the whole workgroup
+    // (the four waves' sorted lists and their merge were ~30 serial inserts at k = 10, ~190 at k = 64: 12 / 27 us of this kernel).
     const double ea = (double)eq[2 * qi], eb = (double)eq[2 * qi + 1], gref = filter_gamma(v.dim, 0);
     uint64_t list = kDeadKey, thr = kDeadKey;
-    // four candidates per thread at a time: their scores and rows requested together, then their norms and residuals together (two round
-    // trips per 1024 candidates instead of two per 256); the lower bounds are parked in LDS for the survivor pass
     float* lo_l = reinterpret_cast<float*>(surv + kMfmaCandCap);                                              // [kMfmaCandCap]
+    uint32_t* hi_k = reinterpret_cast<uint32_t*>(lo_l + kMfmaCandCap);                                        // [kMfmaCandCap]
+    __shared__ uint32_t s_bins[256], s_scal[4];
     for (uint32_t base0 = wave * 64; base0 < cnt; base0 += 4 * 4 * 64) {
         uint32_t rowv[4]; float scv[4]; double rnv[4]; float rhv[4];
 #pragma unroll
@@ -1711,27 +1719,19 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
         for (int j = 0; j < 4; j++) { const uint32_t i = base0 + (uint32_t)j * 256 + lane; rnv[j] = i < cnt ? v.rnorm[rowv[j]] : 0.0; rhv[j] = i < cnt ? v.rres[rowv[j]] : 0.f; }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t base = base0 + (uint32_t)j * 256, i = base + lane;
-            if (base >= cnt) break;
-            uint64_t key = kDeadKey;
+            const uint32_t i = base0 + (uint32_t)j * 256 + lane;
             if (i < cnt) {
                 float lo, hi;
                 score_interval<M>((double)scv[j], qc.qn, qn_l2, rnv[j], ea * rnv[j] + eb * (double)rhv[j], gref, lo, hi);
                 lo_l[i] = lo;
-                key = make_key(hi, i);
+                hi_k[i] = ord_f32(hi == hi ? hi : __builtin_inff());
             }
-            if (base == wave * 64) list_seed(list, thr, key, kth, lane); else list_insert(list, thr, key, kth, lane);
         }
     }
-    wl[wave * 64 + lane] = list;
     __syncthreads();
-    if (wave == 0) {
-        for (uint32_t w = 1; w < 4; w++) {
-            uint64_t key = lane < k ? wl[w * 64 + lane] : kDeadKey;
-            list_insert(list, thr, key, kth, lane);
-        }
-        const uint64_t kk = readlane64(list, kth);
-        if (lane == 0) s_H = kk == kDeadKey ? __builtin_inff() : unord_f32((uint32_t)(kk >> 32));   // < k candidates: keep all
+    {
+        const uint32_t hk = block_kth_smallest(hi_k, cnt, k, s_bins, s_scal);
+        if (threadIdx.x == 0) s_H = hk == 0xFFFFFFFFu ? __builtin_inff() : unord_f32(hk);          // < k candidates: keep all
     }
     __syncthreads();
     RSTK();
@@ -2203,7 +2203,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     else hipLaunchKernelGGL(k_mfma_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter
     if (ev1) (void)hipEventRecord(ev1, s);
     // 4. exact re-scoring + selection
-    const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * (sizeof(uint32_t) + sizeof(float));   // query, wave lists, survivors, lower bounds
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * (sizeof(uint32_t) + sizeof(float) + sizeof(uint32_t));   // query, wave lists, survivors, lower bounds, upper bounds' keys
     // chunk requests per round of the exact pass, all issued before the round's arithmetic (row_accumulate's BAR): a survivor's row is
     // a gather of dim4 separate lines and the pass is a chain of dim4 / U dependent round trips — 8 / 16 / 32 / 48 / 64 per round:
     // 64.4 / 58.0 / 54.2 / 55.3 / 55.6 us per launch at 256 x 1M x 768 (left to the compiler's own schedule, as the streaming scans
