@@ -512,13 +512,14 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         for kk_ in (10, 64, 100, 1000):
             rb_ = torch.empty((nqb, kk_), dtype=torch.int32, device="cuda"); db_ = torch.empty((nqb, kk_), dtype=torch.float32, device="cuda")
             fl_ = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
-            idx1.search_batched_device(d_q.data_ptr(), nqb, kk_, rb_.data_ptr(), db_.data_ptr(), fl_.data_ptr(), sp)
-            torch.cuda.synchronize()
-            t4 = time.perf_counter()
-            for _ in range(10):
+            for _ in range(3):                             # (first launches of a shape: workspace growth, clocks)
                 idx1.search_batched_device(d_q.data_ptr(), nqb, kk_, rb_.data_ptr(), db_.data_ptr(), fl_.data_ptr(), sp)
             torch.cuda.synchronize()
-            ks_entry["256x1M_k%d_ms" % kk_] = (time.perf_counter() - t4) / 10 * 1e3
+            t4 = time.perf_counter()
+            for _ in range(20):
+                idx1.search_batched_device(d_q.data_ptr(), nqb, kk_, rb_.data_ptr(), db_.data_ptr(), fl_.data_ptr(), sp)
+            torch.cuda.synchronize()
+            ks_entry["256x1M_k%d_ms" % kk_] = (time.perf_counter() - t4) / 20 * 1e3
         also["k_above_64"] = ks_entry
     except Exception as ex:                                # noqa: BLE001
         also["k_above_64"] = {"error": str(ex)}
