@@ -23,6 +23,15 @@
  *     concurrently (the reference runs Index.Search under a read lock,
  *     pkg/core/collection.go:647); add / remove / reserve / destroy need external
  *     exclusion (the reference holds c.Lock there, pkg/core/collection.go:139).
+ *   - concurrent SMALL host-pointer searches on one handle (qv_index_search,
+ *     qv_sharded_search, qv_graph_search) share device passes: one query per call
+ *     from many threads is all the reference's host ever sends (collection.go:647;
+ *     DB.BatchSearch's batch branch type-asserts the reference's own wrapper,
+ *     pkg/core/db.go:726-727, and otherwise fans out single searches, :805-828).
+ *     A call that finds the handle busy joins the calls that arrived during the
+ *     running pass; together they are the next pass — one multi-query launch.  No
+ *     timer: a lone caller runs at once, exactly as if there were no sharing.
+ *     Results are the same bits either way (every path is exact).
  *   - "_device" variants take device pointers and a hipStream_t (passed as
  *     void*), enqueue work and return without synchronising, so a caller can keep
  *     queries and results resident in HBM and time with HIP events.
@@ -37,7 +46,7 @@
 extern "C" {
 #endif
 
-#define QV_ABI_VERSION 3
+#define QV_ABI_VERSION 4
 
 typedef struct qv_index qv_index; /* opaque; owns device memory */
 
@@ -138,9 +147,15 @@ int      qv_index_metric(const qv_index* idx);
  * How k is served (same result whichever applies): up to 64 results the scan keeps a sorted list per wavefront; up to 128 —
  * the negative-example branches fetch max(2k, 30), hybrid_index.go:516-522 — two keys per lane in that list; up to 8192 one
  * key per row and a radix SELECTION of the k smallest; beyond (k = Size() of a filtered search) the full radix ranking.
- * Batches of 9+ queries go through the matrix-core filter + exact re-score up to 4096 results per query. */
+ * Batches of 9+ queries (32+ with the fp32 filter) over a large corpus go through the matrix-core filter + exact re-score up to
+ * 4096 results per query. */
 int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out);
+
+/* How the calls of qv_index_search were served since the index was created (any output may be null): solo = ran at once in
+ * their own context; led / rode = waited for the running pass and then ran a group / had their results written by its leader;
+ * groups, group_queries = passes that carried a group and the queries in them.  For reports and tests. */
+int qv_index_coalesce_stats(qv_index* idx, uint64_t* solo, uint64_t* led, uint64_t* rode, uint64_t* groups, uint64_t* group_queries);
 
 /* Same with device-resident queries/results; enqueues on `stream`, no sync. */
 int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
@@ -254,12 +269,18 @@ int qv_graph_create(qv_graph** out, qv_index* idx, uint32_t n_nodes, const int8_
                     uint32_t n_up_blocks, uint32_t entry, int cur_level);
 int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out);
+/* qv_graph_search is thread-safe: the reference searches under a read lock (hnsw.go:602-606), one goroutine per query
+ * (adapter.go:253-279).  Every call works in a context of its own (stream, visited sets, buffers: a pool); calls of up to 64
+ * queries with the same k and ef_search that find four traversal batches in flight wait and form the next batch together.
+ * qv_graph_insert / qv_graph_make_buildable / qv_graph_destroy need external exclusion against searches (the reference's
+ * write lock).  qv_graph_coalesce_stats: as qv_index_coalesce_stats. */
+int qv_graph_coalesce_stats(qv_graph* g, uint64_t* solo, uint64_t* led, uint64_t* rode, uint64_t* groups, uint64_t* group_queries);
 /* Device-pointer form: queries, results, counts (and optional evals) live on the device; the traversal is
  * enqueued on `stream` (0 = the graph's own stream) with no synchronisation.  One pass only: a query that
  * met two equal distances or a NaN on its way (or visited more nodes than its visited table holds: ~48 x ef)
  * reports count 0xFFFFFFFE and must be redone through qv_graph_search (which runs the exact-heap kernel for
- * those); everything else is final.  Traversals on one graph are ordered one after another whatever their
- * streams (they share the per-wave visited tables). */
+ * those); everything else is final.  DEVICE-FORM traversals on one graph are ordered one after another whatever
+ * their streams (they share the graph's own visited tables; host-pointer calls have a context each). */
 int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef_search,
                            uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_count_out, uint32_t* d_evals_out, void* stream);
 void qv_graph_destroy(qv_graph* g);

@@ -504,12 +504,52 @@ static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, u
     return QV_OK;
 }
 
-int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
-                    uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
-    // many queries over a large cosine/dot corpus: the MFMA filter path returns the identical result faster
-    if (idx && nq >= 32 && k > 0 && idx->n_live >= 4 * (uint64_t)k && qv::batched_supported(idx->view(), nq, std::min(k, idx->n_live)))
+// one call's worth of queries, in a context of the caller's own (what qv_index_search was before callers could share passes)
+static int search_direct(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                         uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
+    // many queries over a large corpus: the matrix-core filter + exact re-score returns the identical result faster (from 9 queries
+    // with the bfloat16 filters, 32 with the fp32 one: batched_supported holds the measured crossovers)
+    if (idx && k > 0 && idx->n_live >= 4 * (uint64_t)k && qv::batched_supported(idx->view(), nq, std::min(k, idx->n_live)))
         return qv_index_search_batched(idx, queries, nq, k, rows_out, dist_out, count_out);
     return exact_search_host(idx, queries, nq, k, rows_out, dist_out, count_out);
+}
+
+// Callers that may share a pass: small requests (the reference's host sends one query per call) with fused-list k over a corpus
+// large enough that a pass costs more than a launch and a wake-up.  Everything else runs on its own as before — so does a
+// request that fails a check, which must report the reference's error in the reference's order (exact.go:96-106).
+constexpr uint64_t kCoalesceMinBytes = (uint64_t)32 << 20;
+constexpr uint32_t kCoalesceMaxNq = 8;
+static bool coalesce_applies(const qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                             const uint32_t* rows_out, const float* dist_out, const uint32_t* count_out) {
+    static const bool off = getenv("QV_COALESCE") && atoi(getenv("QV_COALESCE")) == 0;   // measurement switch, read once per process
+    return !off && idx && queries && rows_out && dist_out && count_out && nq >= 1 && nq <= kCoalesceMaxNq && k >= 1 && k <= (uint32_t)qv::kMaxFusedK &&
+           idx->n_live > 0 && (uint64_t)idx->n_rows * idx->dim4 * 16 >= kCoalesceMinBytes;
+}
+
+int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
+                    uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
+    if (!coalesce_applies(idx, queries, nq, k, rows_out, dist_out, count_out)) return search_direct(idx, queries, nq, k, rows_out, dist_out, count_out);
+    char err[256]; err[0] = 0;
+    const int rc = idx->front.submit(
+        0, queries, nq, idx->dim, k, rows_out, dist_out, count_out, nullptr,
+        [&] { return search_direct(idx, queries, nq, k, rows_out, dist_out, count_out); },
+        [&](qvco::Group& g) {
+            g.size_outputs(false);
+            return search_direct(idx, g.queries.data(), g.nq, g.kmax, g.rows.data(), g.dist.data(), g.count.data());
+        },
+        [] { return qv_last_error(); }, err, sizeof(err));
+    if (rc != QV_OK && err[0]) return fail(rc, "%s", err);                // (a rider's message comes from the thread that ran its group)
+    return rc;
+}
+
+int qv_index_coalesce_stats(qv_index* idx, uint64_t* solo, uint64_t* led, uint64_t* rode, uint64_t* groups, uint64_t* group_queries) {
+    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
+    if (solo) *solo = idx->front.stats.solo.load();
+    if (led) *led = idx->front.stats.led.load();
+    if (rode) *rode = idx->front.stats.rode.load();
+    if (groups) *groups = idx->front.stats.groups.load();
+    if (group_queries) *group_queries = idx->front.stats.group_queries.load();
+    return QV_OK;
 }
 
 // Search with a negative example, device side of hybrid_index.go:517-570 / hnsw/adapter.go:345-437: the reference fetches

@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/qv.h"
 #include "qv_device.h"
+#include "qv_coalesce.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -101,6 +102,10 @@ struct qv_index {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     std::mutex ws_mu;
     std::map<hipStream_t, Workspace*> stream_ws;   // workspaces of the *_device entry points, one per caller stream
+    // concurrent single-query callers (all the reference's host ever produces: collection.go:647, db.go:805-828) ride the next
+    // pass together (qv_coalesce.h): one pass in flight — a flat scan is HBM-bound, a second one beside it only halves both —
+    // and up to 256 queries per group, the size the matrix-core filter walks the corpus once for
+    qvco::Front front{1, 256};
 
     qv::IndexView view() const {
         qv::IndexView v;

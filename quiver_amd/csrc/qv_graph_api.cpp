@@ -5,6 +5,30 @@
 // No CPU compute path: every distance and every selection runs in a HIP kernel (qv_hnsw.hip, qv_build.hip).
 #include "qv_api_internal.h"
 
+#include <atomic>
+
+// Everything ONE host-pointer traversal call owns while it runs: stream, converted-query workspace, result buffers, its redo
+// list and its visited sets.  The reference searches under a read lock (hnsw.go:602-606; a goroutine per query, adapter.go:253-279),
+// so many qv_graph_search calls are in flight at once: each takes a context from the graph's pool and no two share a table.
+// (Until round 5 the graph had ONE set of these and a mutex: concurrent single-query callers ran one after another, ~300 QPS.)
+struct GraphCtx {
+    hipStream_t stream = nullptr;
+    Buf vis_hash; uint32_t vis_hash_cap = 0, vis_hash_slots = 0;      // wave kernel: a hash table per wave slot
+    Buf vis_bits; uint32_t vis_bits_words = 0, vis_bits_slots = 0;    // exact-heap kernel: a bitmap per slot
+    Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev, s_redo, s_counters;
+    PinBuf h_stage[2]; hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    PinBuf h_counters, h_out;
+    void release() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        vis_hash.release(); vis_bits.release();
+        d_q.release(); d_qblk.release(); d_rows.release(); d_dist.release(); d_cnt.release(); d_ev.release(); s_redo.release(); s_counters.release();
+        for (int i = 0; i < 2; i++) { h_stage[i].release(); if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]); ev_stage[i] = nullptr; }
+        h_counters.release(); h_out.release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
 struct qv_graph {
     qv_index* idx = nullptr;
     qv::GraphView g{};
@@ -19,16 +43,17 @@ struct qv_graph {
     Buf vis_hash; uint32_t vis_hash_cap = 0;
     Buf vis_bits; uint32_t vis_bits_words = 0, vis_bits_slots = 0;
     uint32_t grid = 0;                          // wave slots of the wave-resident kernel
-    uint64_t tie_reruns = 0;
-    std::mutex mu;                              // one batch at a time (the visited sets are per wave slot)
+    std::atomic<uint64_t> tie_reruns{0};
+    std::mutex mu;                              // the graph's OWN buffers below (device-form traversals, construction, export): one user at a time
+    // host-pointer searches: a context each (pool), and a front that lets concurrent small calls share a traversal batch
+    // (qv_coalesce.h).  Four batches in flight at most: a traversal is one wavefront per query, so unlike a flat scan a lone
+    // batch does not fill the chip and a second caller should not wait for the first.
+    std::mutex ctx_mu;
+    std::vector<GraphCtx*> free_ctx, all_ctx;
+    qvco::Front front{4, 4096};
     hipStream_t stream = nullptr;
     hipEvent_t ev_last = nullptr;               // end of the most recent traversal: the next one (on any stream) waits for it
-    Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev;
-    PinBuf h_stage[2];                          // pinned bounce buffers for the query upload (pageable callers)
-    hipEvent_t ev_stage[2] = {nullptr, nullptr};
-    hipStream_t stream2 = nullptr;              // exact-heap passes of qv_graph_search beside the next part's wave pass: only QV_HNSW_OVERLAP_REDO=1 creates it
-    hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_heap = nullptr;
-    Buf s_redo, s_counters;                     // qv_graph_search's own redo list and counters (the construction has b_redo / b_counters)
+    Buf d_qblk, d_rows, d_dist, d_cnt, d_ev;
     PinBuf h_counters;                          // counters read back: a pinned member, never the stack (an early return must not leave a copy in flight into a dead frame)
     // build workspace
     Buf b_self, b_keys_a, b_keys_b, b_hist, b_seg, b_redo, b_counters;
@@ -159,19 +184,162 @@ void qv_graph_destroy(qv_graph* g) {
     if (!g) return;
     if (g->idx) (void)hipSetDevice(g->idx->device);
     if (g->ev_last) { (void)hipEventSynchronize(g->ev_last); (void)hipEventDestroy(g->ev_last); }
-    for (int i = 0; i < 2; i++) { if (g->ev_stage[i]) (void)hipEventDestroy(g->ev_stage[i]); g->h_stage[i].release(); }
-    if (g->stream2) { (void)hipStreamSynchronize(g->stream2); (void)hipStreamDestroy(g->stream2); }
-    for (int i = 0; i < 2; i++) if (g->ev_part[i]) (void)hipEventDestroy(g->ev_part[i]);
-    if (g->ev_heap) (void)hipEventDestroy(g->ev_heap);
+    for (GraphCtx* c : g->all_ctx) { c->release(); delete c; }
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
     (void)hipFree(g->d_level); (void)hipFree(g->d_l0deg); (void)hipFree(g->d_l0links); (void)hipFree(g->d_upoff); (void)hipFree(g->d_uplinks);
     (void)hipFree(g->d_l0dist); (void)hipFree(g->d_updist);
     g->vis_hash.release(); g->vis_bits.release();
-    g->d_q.release(); g->d_qblk.release(); g->d_rows.release(); g->d_dist.release(); g->d_cnt.release(); g->d_ev.release();
-    g->s_redo.release(); g->s_counters.release(); g->h_counters.release();
+    g->d_qblk.release(); g->d_rows.release(); g->d_dist.release(); g->d_cnt.release(); g->d_ev.release();
+    g->h_counters.release();
     g->b_self.release(); g->b_keys_a.release(); g->b_keys_b.release(); g->b_hist.release(); g->b_seg.release(); g->b_redo.release(); g->b_counters.release();
     delete g;
 }
+
+}  // extern "C"
+
+namespace {
+
+int acquire_gctx(qv_graph* g, GraphCtx** out) {
+    {
+        std::lock_guard<std::mutex> l(g->ctx_mu);
+        if (!g->free_ctx.empty()) { *out = g->free_ctx.back(); g->free_ctx.pop_back(); return QV_OK; }
+    }
+    GraphCtx* c = new (std::nothrow) GraphCtx();
+    if (!c) return fail(QV_ERR_OOM, "out of host memory");
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(QV_ERR_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    std::lock_guard<std::mutex> l(g->ctx_mu);
+    g->all_ctx.push_back(c);
+    *out = c;
+    return QV_OK;
+}
+struct GCtxGuard {
+    qv_graph* g; GraphCtx* c;
+    ~GCtxGuard() { if (c) { std::lock_guard<std::mutex> l(g->ctx_mu); g->free_ctx.push_back(c); } }
+};
+
+// visited-set storage of one context for a batch of nq queries with list capacity ef: as many slots as the batch can occupy
+int ensure_visited_ctx(qv_graph* g, GraphCtx* c, uint32_t ef, uint32_t nq) {
+    qv_index* idx = g->idx;
+    if (!g->grid) g->grid = qv::hnsw_wave_grid(idx->cus, idx->metric, idx->dim4);
+    const uint32_t cap = qv::hnsw_vis_hash_cap(ef);
+    const uint32_t slots = std::min(g->grid, std::max(nq, 1u));
+    if (cap > c->vis_hash_cap || slots > c->vis_hash_slots) {
+        const uint32_t ncap = std::max(cap, c->vis_hash_cap), nslots = std::max(slots, c->vis_hash_slots);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        int rc = c->vis_hash.ensure((size_t)nslots * ncap * 4);
+        if (rc != QV_OK) return rc;
+        c->vis_hash_cap = ncap; c->vis_hash_slots = nslots;
+    }
+    const uint32_t words = (uint32_t)((((uint64_t)std::max(g->cap_nodes, g->g.n_nodes) + 31) / 32 + 63) / 64 * 64);
+    // the exact-heap kernel has few slots (LDS heaps): at most 8 per CU, and never more than 2 GiB of bitmaps
+    uint32_t hslots = std::min((uint32_t)idx->cus * 8, std::max(nq, 1u));
+    while (hslots > 64 && (size_t)hslots * words * 4 > ((size_t)2 << 30)) hslots /= 2;
+    if (words > c->vis_bits_words || hslots > c->vis_bits_slots) {
+        const uint32_t nwords = std::max(words, c->vis_bits_words), nslots = std::max(hslots, c->vis_bits_slots);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        int rc = c->vis_bits.ensure((size_t)nslots * nwords * 4);
+        if (rc != QV_OK) return rc;
+        c->vis_bits_words = nwords; c->vis_bits_slots = nslots;
+    }
+    return QV_OK;
+}
+
+// One traversal call in a context of its own: upload, wave-resident pass, device-side compaction of the flagged queries, exact-heap
+// pass for those, download.  Nothing of the graph's is written; any number of these run side by side.
+int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+                     uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out) {
+    qv_index* idx = g->idx;
+    const size_t qbytes = (size_t)nq * idx->dim * sizeof(float), obytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
+    const uint32_t efx = std::max(ef_search, k);
+    int rc;
+    if ((rc = c->d_q.ensure(qbytes)) || (rc = c->d_rows.ensure(obytes)) || (rc = c->d_dist.ensure(obytes)) || (rc = c->d_cnt.ensure(cbytes)) ||
+        (rc = c->d_ev.ensure(cbytes)) || (rc = c->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4))) || (rc = ensure_visited_ctx(g, c, efx, nq)) ||
+        (rc = c->s_redo.ensure((size_t)nq * 4)) || (rc = c->s_counters.ensure(64)) || (rc = c->h_counters.ensure(64)))
+        return rc;
+    static const bool trace = getenv("QV_TRACE") && atoi(getenv("QV_TRACE")) > 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    {   // upload through two pinned bounce buffers: the CPU copy of slice i+1 overlaps the DMA of slice i
+        // (a single hipMemcpyAsync from pageable memory ran at 2.5-5 GB/s: a third of a 16k-query batch's time)
+        const size_t slice = (size_t)8 << 20;
+        size_t off = 0; int slot = 0;
+        while (off < qbytes) {
+            const size_t n = std::min(slice, qbytes - off);
+            if ((rc = c->h_stage[slot].ensure(std::min(slice, std::max(qbytes, (size_t)65536))))) return rc;
+            if (!c->ev_stage[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_stage[slot], hipEventDisableTiming));
+            else HIPCHK(hipEventSynchronize(c->ev_stage[slot]));        // the DMA that last read this buffer is done
+            memcpy(c->h_stage[slot].p, reinterpret_cast<const unsigned char*>(queries) + off, n);
+            HIPCHK(hipMemcpyAsync(static_cast<unsigned char*>(c->d_q.p) + off, c->h_stage[slot].p, n, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipEventRecord(c->ev_stage[slot], c->stream));
+            off += n; slot ^= 1;
+        }
+    }
+    if (trace) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "qv: graph search upload %.3f ms (%zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), qbytes); }
+    const auto t_p1 = std::chrono::steady_clock::now();
+    // pass 1: wave-resident traversal (list in registers, rows streamed through LDS); queries that meet equal distances / NaN
+    // or outgrow the visited table report 0xFFFFFFFE.  pass 2: the exact-heap kernel for those (heap pop order under ties depends on
+    // the heap layout), from a work list compacted ON THE DEVICE (as the construction does): no host round trip between the passes.
+    // (Splitting large batches in two so that the first half's pass 2 runs beside the second half's pass 1 was measured in round 3 —
+    // 32.9 / 119.1 ms against 31.5 / 119.4 at 8192 queries, efSearch 128 / 512 — and is gone.)
+    uint32_t* counters = static_cast<uint32_t*>(c->s_counters.p);
+    HIPCHK(hipMemsetAsync(counters, 0, 64, c->stream));
+    const float* dq = static_cast<const float*>(c->d_q.p);
+    uint32_t* d_rows = static_cast<uint32_t*>(c->d_rows.p); float* d_dist = static_cast<float*>(c->d_dist.p);
+    uint32_t* d_cnt = static_cast<uint32_t*>(c->d_cnt.p); uint32_t* d_ev = static_cast<uint32_t*>(c->d_ev.p);
+    qv::HnswOpts wo; wo.vis = static_cast<uint32_t*>(c->vis_hash.p); wo.vis_cap = c->vis_hash_cap;
+    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, c->d_qblk.p, nq, k, ef_search, wo, std::min(c->vis_hash_slots, nq), d_rows, d_dist, d_cnt, d_ev, c->stream);
+    if (e == hipSuccess) e = qv::launch_build_compact_redo(d_cnt, nq, static_cast<uint32_t*>(c->s_redo.p), counters, c->stream);
+    if (e == hipSuccess) {
+        qv::HnswOpts ho; ho.vis = static_cast<uint32_t*>(c->vis_bits.p); ho.vis_cap = c->vis_bits_words;
+        ho.redo_idx = static_cast<const uint32_t*>(c->s_redo.p); ho.redo_n = counters;
+        const uint32_t hgrid = std::min(std::min(qv::hnsw_grid(idx->cus, efx, nq), c->vis_bits_slots), nq);
+        e = qv::launch_hnsw_search(idx->view(), g->g, dq, c->d_qblk.p, nq, k, ef_search, ho, hgrid, false, d_rows, d_dist, d_cnt, d_ev, c->stream);
+    }
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+    uint32_t* hc = static_cast<uint32_t*>(c->h_counters.p);
+    // small result sets come back through one pinned buffer (a copy into pageable memory is staged by the runtime, chunk by chunk)
+    const size_t all = 2 * obytes + 2 * cbytes;
+    const bool pinned_out = all <= ((size_t)4 << 20);
+    if (pinned_out) {
+        if ((rc = c->h_out.ensure(all))) return rc;
+        unsigned char* h = static_cast<unsigned char*>(c->h_out.p);
+        HIPCHK(hipMemcpyAsync(h, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(h + obytes, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(h + 2 * obytes, c->d_cnt.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+        if (evals_out) HIPCHK(hipMemcpyAsync(h + 2 * obytes + cbytes, c->d_ev.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(rows_out, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(dist_out, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(count_out, c->d_cnt.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+        if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, c->d_ev.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(hc, counters, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (pinned_out) {
+        const unsigned char* h = static_cast<const unsigned char*>(c->h_out.p);
+        memcpy(rows_out, h, obytes); memcpy(dist_out, h + obytes, obytes); memcpy(count_out, h + 2 * obytes, cbytes);
+        if (evals_out) memcpy(evals_out, h + 2 * obytes + cbytes, cbytes);
+    }
+    g->tie_reruns.fetch_add(hc[0], std::memory_order_relaxed);
+    if (trace) fprintf(stderr, "qv: graph search passes 1 + 2 + download %.3f ms (%u flagged queries redone on the device)\n",
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p1).count(), hc[0]);
+    for (uint32_t q = 0; q < nq; q++)
+        if (count_out[q] == 0xFFFFFFFEu) return fail(QV_ERR_DEVICE, "hnsw search: a flagged query was not redone");
+    return QV_OK;
+}
+
+int graph_search_direct(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+                        uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out) {
+    GraphCtx* c = nullptr;
+    int rc = acquire_gctx(g, &c);
+    if (rc != QV_OK) return rc;
+    GCtxGuard guard{g, c};
+    return graph_search_ctx(g, c, queries, nq, k, ef_search, rows_out, dist_out, count_out, evals_out);
+}
+
+}  // namespace
+
+extern "C" {
 
 int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out) {
@@ -183,93 +351,32 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     if (g->g.n_nodes == 0) return fail(QV_ERR_INVALID_ARG, "graph is empty");
     qv_index* idx = g->idx;
     HIPCHK(hipSetDevice(idx->device));
-    std::lock_guard<std::mutex> lock(g->mu);
-    HIPCHK(hipEventSynchronize(g->ev_last));                            // a device-form traversal still in flight uses the buffers (re)sized below
-    const size_t qbytes = (size_t)nq * idx->dim * sizeof(float), obytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
-    const uint32_t efx = std::max(ef_search, k);
-    int rc;
-    if ((rc = g->d_q.ensure(qbytes)) || (rc = g->d_rows.ensure(obytes)) || (rc = g->d_dist.ensure(obytes)) || (rc = g->d_cnt.ensure(cbytes)) ||
-        (rc = g->d_ev.ensure(cbytes)) || (rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4))) || (rc = ensure_visited(g, efx)))
-        return rc;
-    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_last, 0));               // after any device-form traversal still running on another stream
-    static const bool trace = getenv("QV_TRACE") && atoi(getenv("QV_TRACE")) > 0;
-    const auto t_begin = std::chrono::steady_clock::now();
-    {   // upload through two pinned bounce buffers: the CPU copy of slice i+1 overlaps the DMA of slice i
-        // (a single hipMemcpyAsync from pageable memory ran at 2.5-5 GB/s: a third of a 16k-query batch's time)
-        const size_t slice = (size_t)8 << 20;
-        size_t off = 0; int slot = 0;
-        while (off < qbytes) {
-            const size_t n = std::min(slice, qbytes - off);
-            if ((rc = g->h_stage[slot].ensure(slice))) return rc;
-            if (!g->ev_stage[slot]) HIPCHK(hipEventCreateWithFlags(&g->ev_stage[slot], hipEventDisableTiming));
-            else HIPCHK(hipEventSynchronize(g->ev_stage[slot]));        // the DMA that last read this buffer is done
-            memcpy(g->h_stage[slot].p, reinterpret_cast<const unsigned char*>(queries) + off, n);
-            HIPCHK(hipMemcpyAsync(static_cast<unsigned char*>(g->d_q.p) + off, g->h_stage[slot].p, n, hipMemcpyHostToDevice, g->stream));
-            HIPCHK(hipEventRecord(g->ev_stage[slot], g->stream));
-            off += n; slot ^= 1;
-        }
-    }
-    if (trace) { (void)hipStreamSynchronize(g->stream); fprintf(stderr, "qv: graph search upload %.3f ms (%zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), qbytes); }
-    const auto t_p1 = std::chrono::steady_clock::now();
-    // pass 1: wave-resident traversal (list in registers, rows streamed through LDS); queries that meet equal distances / NaN
-    // or outgrow the visited table report 0xFFFFFFFE.  pass 2: the exact-heap kernel for those (heap pop order under ties depends on
-    // the heap layout), from a work list compacted ON THE DEVICE (as the construction does): no host round trip between the passes.
-    // QV_HNSW_OVERLAP_REDO=1 (a measurement, not the default): large batches in two halves, each pass 1 at eight wave slots per CU — the
-    // traversal rate is flat from 8 to 16 (profiles/r03_hnsw_heap.txt) and that leaves the LDS an exact-heap workgroup needs — so that the
-    // first half's pass 2 (a handful of queries, ~5 ms of pure latency) can run on a second stream beside the second half's pass 1.
-    // Measured at 8192 queries, efSearch 128 / 512: 32.9 / 119.1 ms against 31.5 / 119.4 in one part: nothing gained.
-    static const int overlap_env = getenv("QV_HNSW_OVERLAP_REDO") ? atoi(getenv("QV_HNSW_OVERLAP_REDO")) : 2;
-    const uint32_t parts = nq >= 4096 && overlap_env == 1 ? 2u : 1u;
-    const uint32_t part_n = (nq + parts - 1) / parts;
-    const size_t part_qblk = (qv::hnsw_qblk_bytes(part_n, idx->dim4) + 255) / 256 * 256;
-    if ((rc = g->d_qblk.ensure(part_qblk * parts)) || (rc = g->s_redo.ensure((size_t)nq * 4)) || (rc = g->s_counters.ensure(64)) || (rc = g->h_counters.ensure(64))) return rc;
-    if (parts > 1) {                                                    // the two-part mode alone needs a second stream and its events
-        if (!g->stream2) HIPCHK(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) if (!g->ev_part[i]) HIPCHK(hipEventCreateWithFlags(&g->ev_part[i], hipEventDisableTiming));
-        if (!g->ev_heap) HIPCHK(hipEventCreateWithFlags(&g->ev_heap, hipEventDisableTiming));
-    }
-    hipStream_t heap_stream = parts > 1 ? g->stream2 : g->stream;
-    uint32_t* counters = static_cast<uint32_t*>(g->s_counters.p);
-    HIPCHK(hipMemsetAsync(counters, 0, 64, g->stream));
-    hipError_t e = hipSuccess;
-    for (uint32_t pi = 0; pi < parts && e == hipSuccess; pi++) {
-        const uint32_t q0 = pi * part_n, n_c = std::min(part_n, nq - q0);
-        if (n_c == 0) break;
-        const float* dq = static_cast<const float*>(g->d_q.p) + (size_t)q0 * idx->dim;
-        void* qblk = static_cast<unsigned char*>(g->d_qblk.p) + part_qblk * pi;
-        uint32_t* d_rows = static_cast<uint32_t*>(g->d_rows.p) + (size_t)q0 * k; float* d_dist = static_cast<float*>(g->d_dist.p) + (size_t)q0 * k;
-        uint32_t* d_cnt = static_cast<uint32_t*>(g->d_cnt.p) + q0; uint32_t* d_ev = static_cast<uint32_t*>(g->d_ev.p) + q0;
-        const uint32_t pgrid = std::min(parts > 1 ? std::min(g->grid, (uint32_t)idx->cus * 8u) : g->grid, n_c);
-        e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, qblk, n_c, k, ef_search, wave_opts(g), pgrid, d_rows, d_dist, d_cnt, d_ev, g->stream);
-        if (e == hipSuccess) e = qv::launch_build_compact_redo(d_cnt, n_c, static_cast<uint32_t*>(g->s_redo.p) + q0, counters + 4 * pi, g->stream);
-        if (e != hipSuccess) break;
-        if (parts > 1) {
-            HIPCHK(hipEventRecord(g->ev_part[pi], g->stream));
-            HIPCHK(hipStreamWaitEvent(g->stream2, g->ev_part[pi], 0));
-        }
-        qv::HnswOpts ho = heap_opts(g);
-        ho.redo_idx = static_cast<const uint32_t*>(g->s_redo.p) + q0; ho.redo_n = counters + 4 * pi;
-        const uint32_t hgrid = std::min(std::min(qv::hnsw_grid(idx->cus, efx, n_c), g->vis_bits_slots), n_c);
-        e = qv::launch_hnsw_search(idx->view(), g->g, dq, qblk, n_c, k, ef_search, ho, hgrid, false, d_rows, d_dist, d_cnt, d_ev, heap_stream);
-    }
-    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
-    if (parts > 1) {
-        HIPCHK(hipEventRecord(g->ev_heap, g->stream2));
-        HIPCHK(hipStreamWaitEvent(g->stream, g->ev_heap, 0));
-    }
-    uint32_t* hc = static_cast<uint32_t*>(g->h_counters.p);
-    HIPCHK(hipMemcpyAsync(rows_out, g->d_rows.p, obytes, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipMemcpyAsync(dist_out, g->d_dist.p, obytes, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipMemcpyAsync(count_out, g->d_cnt.p, cbytes, hipMemcpyDeviceToHost, g->stream));
-    if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, g->d_ev.p, cbytes, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipMemcpyAsync(hc, counters, 32, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
-    HIPCHK(hipEventRecord(g->ev_last, g->stream));
-    g->tie_reruns += (uint64_t)hc[0] + hc[4];
-    if (trace) fprintf(stderr, "qv: graph search passes 1 + 2 + download %.3f ms (%u + %u flagged queries redone on the device, %u part%s)\n",
-                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p1).count(), hc[0], hc[4], parts, parts > 1 ? "s" : "");
-    for (uint32_t q = 0; q < nq; q++)
-        if (count_out[q] == 0xFFFFFFFEu) return fail(QV_ERR_DEVICE, "hnsw search: a flagged query was not redone");
+    // Small calls — the reference's host sends one query per call, concurrently (hnsw.go:602-606) — that find four batches already
+    // in flight ride the next one together (same k and efSearch: those decide a traversal's result).  Larger batches fill the chip
+    // by themselves and run as they are, each in its own context.
+    static const bool off = getenv("QV_COALESCE") && atoi(getenv("QV_COALESCE")) == 0;        // measurement switch, read once per process
+    if (nq > 64 || off) return graph_search_direct(g, queries, nq, k, ef_search, rows_out, dist_out, count_out, evals_out);
+    char err[256]; err[0] = 0;
+    const int rc = g->front.submit(
+        (uint64_t)k | ((uint64_t)ef_search << 16), queries, nq, idx->dim, k, rows_out, dist_out, count_out, evals_out,
+        [&] { return graph_search_direct(g, queries, nq, k, ef_search, rows_out, dist_out, count_out, evals_out); },
+        [&](qvco::Group& grp) {
+            grp.size_outputs(true);
+            (void)hipSetDevice(idx->device);
+            return graph_search_direct(g, grp.queries.data(), grp.nq, grp.kmax, ef_search, grp.rows.data(), grp.dist.data(), grp.count.data(), grp.evals.data());
+        },
+        [] { return qv_last_error(); }, err, sizeof(err));
+    if (rc != QV_OK && err[0]) return fail(rc, "%s", err);
+    return rc;
+}
+
+int qv_graph_coalesce_stats(qv_graph* g, uint64_t* solo, uint64_t* led, uint64_t* rode, uint64_t* groups, uint64_t* group_queries) {
+    if (!g) return fail(QV_ERR_INVALID_ARG, "graph is null");
+    if (solo) *solo = g->front.stats.solo.load();
+    if (led) *led = g->front.stats.led.load();
+    if (rode) *rode = g->front.stats.rode.load();
+    if (groups) *groups = g->front.stats.groups.load();
+    if (group_queries) *group_queries = g->front.stats.group_queries.load();
     return QV_OK;
 }
 
@@ -493,7 +600,7 @@ int qv_graph_stats(const qv_graph* g, double* build_seconds, uint64_t* build_bat
     if (build_seconds) *build_seconds = g->build_seconds;
     if (build_batches) *build_batches = g->build_batches;
     if (build_redo) *build_redo = g->build_redo;
-    if (search_redo) *search_redo = g->tie_reruns;
+    if (search_redo) *search_redo = g->tie_reruns.load();
     return QV_OK;
 }
 

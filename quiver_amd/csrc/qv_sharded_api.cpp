@@ -152,6 +152,7 @@ struct qv_sharded {
     std::atomic<bool> profiling{false};
     std::mutex prof_mu;
     double prof_scan_ms = 0, prof_exchange_ms = 0, prof_merge_ms = 0; uint64_t prof_n = 0;
+    qvco::Front front{1, 256};           // concurrent single-query callers share passes, as on one index (qv_coalesce.h): every shard's scan is HBM-bound
 };
 
 namespace {
@@ -727,7 +728,22 @@ int qv_sharded_get_rows(qv_sharded* s, const uint32_t* global_rows, uint32_t n, 
 int qv_sharded_get_row(qv_sharded* s, uint32_t global_row, float* vec_out) { return qv_sharded_get_rows(s, &global_row, 1, vec_out); }
 
 int qv_sharded_search(qv_sharded* s, const float* queries, uint32_t nq, uint32_t k, uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
-    return search_host(s, queries, nq, k, SearchMode{}, rows_out, dist_out, count_out);   // entries past count: row 0xFFFFFFFF, +inf
+    // small calls over a large corpus ride the next pass together (qv_index_search's rule, qv_coalesce.h); everything else, and
+    // anything that must fail a check in the reference's order, runs as it is
+    const bool share = s && queries && rows_out && dist_out && count_out && nq >= 1 && nq <= 8 && k >= 1 && k <= (uint32_t)qv::kMaxFusedK &&
+                       !s->profiling.load() && qv_sharded_rows(s) * (uint64_t)s->dim * 4 >= ((uint64_t)32 << 20);
+    if (!share) return search_host(s, queries, nq, k, SearchMode{}, rows_out, dist_out, count_out);   // entries past count: row 0xFFFFFFFF, +inf
+    char err[256]; err[0] = 0;
+    const int rc = s->front.submit(
+        0, queries, nq, s->dim, k, rows_out, dist_out, count_out, nullptr,
+        [&] { return search_host(s, queries, nq, k, SearchMode{}, rows_out, dist_out, count_out); },
+        [&](qvco::Group& g) {
+            g.size_outputs(false);
+            return search_host(s, g.queries.data(), g.nq, g.kmax, SearchMode{}, g.rows.data(), g.dist.data(), g.count.data());
+        },
+        [] { return qv_last_error(); }, err, sizeof(err));
+    if (rc != QV_OK && err[0]) return fail(rc, "%s", err);
+    return rc;
 }
 
 int qv_sharded_search_masked(qv_sharded* s, const float* queries, uint32_t nq, uint32_t k, const uint32_t* selected_global_rows, uint32_t n_selected,

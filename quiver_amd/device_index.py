@@ -196,6 +196,10 @@ class DeviceGraph:
         check(lib().qv_graph_create(C.byref(self._g), index.handle, n, levels.ctypes.data, l0_links.shape[1], max(max_m, 1), l0_deg.ctypes.data,
                                     l0_links.ctypes.data, up_off.ctypes.data, up_links.ctypes.data, n_blocks, int(entry), int(cur_level)))
 
+    @property
+    def handle(self):
+        return self._g
+
     def search(self, queries, k: int, ef_search: int, with_evals: bool = False):
         """rows [nq, k] uint32 (0xFFFFFFFF = unfilled), dist [nq, k] float32, count [nq] (< k: the graph search
         under-filled and the caller tops up like hnsw.go:676-710)"""
@@ -334,6 +338,10 @@ class ShardedIndex:
             self.close()
         except Exception:
             pass
+
+    @property
+    def handle(self):
+        return self._h
 
     def shards(self) -> int:
         return int(lib().qv_sharded_shards(self._h))

@@ -36,15 +36,15 @@ def test_library_exports_every_declared_symbol():
 def test_python_prototypes_cover_the_header():
     from quiver_amd import _lib
     assert sorted(_lib.PROTOTYPES) == _declared_symbols()
-    assert _lib.lib().qv_abi_version() == 3
+    assert _lib.lib().qv_abi_version() == 4
 
 
 def test_header_compiles_as_c_and_cpp(tmp_path):
     c = tmp_path / "t.c"
-    c.write_text('#include "qv.h"\nint main(void){return QV_ABI_VERSION - 3;}\n')
+    c.write_text('#include "qv.h"\nint main(void){return QV_ABI_VERSION - 4;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(c), "-o", str(tmp_path / "t.o")])
     cpp = tmp_path / "t.cpp"
-    cpp.write_text('#include "qv.h"\nint main(){return QV_ABI_VERSION - 3;}\n')
+    cpp.write_text('#include "qv.h"\nint main(){return QV_ABI_VERSION - 4;}\n')
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(cpp), "-o", str(tmp_path / "t2.o")])
 
 
