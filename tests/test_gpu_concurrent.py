@@ -184,7 +184,7 @@ def test_concurrent_callers_on_a_sharded_handle_share_passes_and_equal_the_oracl
     qs = O.gen_rows(778, 0, 64, dim)
     res = _callers.run("sharded", sh.handle, qs, k, threads=32, seconds=30.0, max_calls_per_thread=8)
     assert res["rc"] == 0 and res["errors"] == 0 and res["mismatches"] == 0, res["error"]
-    base = [sh.shard_info(g)["base_row"] for g in range(3)]
+    base = [sh.shard_info(g)["base"] for g in range(3)]
     for i in range(qs.shape[0]):
         if res["count"][i] == 0xFFFFFFFD:
             continue
