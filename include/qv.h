@@ -152,10 +152,12 @@ int      qv_index_metric(const qv_index* idx);
 int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out);
 
-/* How the calls of qv_index_search were served since the index was created (any output may be null): solo = ran at once in
- * their own context; led / rode = waited for the running pass and then ran a group / had their results written by its leader;
- * groups, group_queries = passes that carried a group and the queries in them.  For reports and tests. */
-int qv_index_coalesce_stats(qv_index* idx, uint64_t* solo, uint64_t* led, uint64_t* rode, uint64_t* groups, uint64_t* group_queries);
+/* How the calls of qv_index_search were served since the index was created.  out[0] solo = calls that ran at once in their own
+ * context; out[1] led / out[2] rode = calls that ran a group / had their results written by its leader; out[3] groups, out[4]
+ * group_queries = passes that carried a group and the queries in them; out[5] lingers, out[6] linger_ns = groups held open for
+ * callers the previous pass had just released, and the time that took in all; out[7] group_pass_ns = time inside the groups'
+ * device calls.  For reports and tests. */
+int qv_index_coalesce_stats(qv_index* idx, uint64_t out[8]);
 
 /* Same with device-resident queries/results; enqueues on `stream`, no sync. */
 int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
@@ -274,7 +276,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
  * queries with the same k and ef_search that find four traversal batches in flight wait and form the next batch together.
  * qv_graph_insert / qv_graph_make_buildable / qv_graph_destroy need external exclusion against searches (the reference's
  * write lock).  qv_graph_coalesce_stats: as qv_index_coalesce_stats. */
-int qv_graph_coalesce_stats(qv_graph* g, uint64_t* solo, uint64_t* led, uint64_t* rode, uint64_t* groups, uint64_t* group_queries);
+int qv_graph_coalesce_stats(qv_graph* g, uint64_t out[8]);
 /* Device-pointer form: queries, results, counts (and optional evals) live on the device; the traversal is
  * enqueued on `stream` (0 = the graph's own stream) with no synchronisation.  One pass only: a query that
  * met two equal distances or a NaN on its way (or visited more nodes than its visited table holds: ~48 x ef)

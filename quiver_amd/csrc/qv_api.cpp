@@ -533,7 +533,7 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
     const int rc = idx->front.submit(
         0, queries, nq, idx->dim, k, rows_out, dist_out, count_out, nullptr,
         [&] { return search_direct(idx, queries, nq, k, rows_out, dist_out, count_out); },
-        [&](qvco::Group& g) {
+        [&](qvco::Group& g, auto&) {
             g.size_outputs(false);
             return search_direct(idx, g.queries.data(), g.nq, g.kmax, g.rows.data(), g.dist.data(), g.count.data());
         },
@@ -542,13 +542,9 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
     return rc;
 }
 
-int qv_index_coalesce_stats(qv_index* idx, uint64_t* solo, uint64_t* led, uint64_t* rode, uint64_t* groups, uint64_t* group_queries) {
-    if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
-    if (solo) *solo = idx->front.stats.solo.load();
-    if (led) *led = idx->front.stats.led.load();
-    if (rode) *rode = idx->front.stats.rode.load();
-    if (groups) *groups = idx->front.stats.groups.load();
-    if (group_queries) *group_queries = idx->front.stats.group_queries.load();
+int qv_index_coalesce_stats(qv_index* idx, uint64_t out[8]) {
+    if (!idx || !out) return fail(QV_ERR_INVALID_ARG, "index/out is null");
+    idx->front.stats.read(out);
     return QV_OK;
 }
 

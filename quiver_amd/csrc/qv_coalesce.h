@@ -60,7 +60,8 @@ struct Group {
     // results of the group's call: lists of length kmax, padded past count like every host-pointer search
     std::vector<uint32_t> rows, count, evals;
     std::vector<float> dist;
-    std::atomic<uint32_t> go{0}, done{0}, n_members{0};
+    std::atomic<uint32_t> go{0}, phase{0}, n_members{0};   // phase: 0 running, 1 the members marked in delivered[] have their results, 2 all have
+    std::vector<uint8_t> delivered;   // per member (written before phase becomes 1)
     bool has_lane = false;            // (under the front's mutex)
     uint32_t want = 0; int64_t linger_ns = 0;   // hold the group open until it has `want` members, linger_ns at most
     int rc = 0;
@@ -72,8 +73,19 @@ struct Group {
     }
     // every member's share: the first k of each of its queries' kmax results (top-k is a prefix of top-kmax under one total
     // order); a count of 0xFFFFFFFF ("redo on the host", qv_graph_search) passes through
-    void scatter() const {
-        for (const Member& m : members)
+    // pending_only: members whose share went out early (delivered[]) are skipped.  not_final: a count value that marks a query whose
+    // result is not in yet (a member with such a query is not delivered in an early round).
+    void scatter(bool early, uint32_t not_final = 0xFFFFFFFEu) {
+        if (delivered.size() != members.size()) delivered.assign(members.size(), 0);
+        for (size_t mi = 0; mi < members.size(); mi++) {
+            const Member& m = members[mi];
+            if (delivered[mi]) continue;
+            if (early) {
+                bool fin = true;
+                for (uint32_t i = 0; i < m.nq; i++) if (count[m.q0 + i] == not_final) { fin = false; break; }
+                if (!fin) continue;
+            }
+            delivered[mi] = 1;
             for (uint32_t i = 0; i < m.nq; i++) {
                 const size_t src = (size_t)(m.q0 + i) * kmax, dst = (size_t)i * m.k;
                 memcpy(m.rows_out + dst, rows.data() + src, (size_t)m.k * 4);
@@ -82,6 +94,7 @@ struct Group {
                 m.count_out[i] = c == 0xFFFFFFFFu ? c : (c < m.k ? c : m.k);
                 if (m.evals_out && !evals.empty()) m.evals_out[i] = evals[m.q0 + i];
             }
+        }
     }
 };
 
@@ -90,11 +103,18 @@ class Front {
     Front(int lanes, uint32_t max_group_queries) : lanes_(lanes), max_q_(max_group_queries) {}
 
     // What happened to a request (for tests and reports).
-    struct Stats { std::atomic<uint64_t> solo{0}, led{0}, rode{0}, groups{0}, group_queries{0}, lingers{0}, linger_ns{0}; };
+    struct Stats {
+        std::atomic<uint64_t> solo{0}, led{0}, rode{0}, groups{0}, group_queries{0}, lingers{0}, linger_ns{0}, group_pass_ns{0}, early_rounds{0};
+        void read(uint64_t out[8]) const {
+            out[0] = solo.load(); out[1] = led.load(); out[2] = rode.load(); out[3] = groups.load(); out[4] = group_queries.load();
+            out[5] = lingers.load(); out[6] = linger_ns.load(); out[7] = group_pass_ns.load();
+        }
+    };
     Stats stats;
 
     // solo():       run the caller's own request in its own buffers (what the entry point did before there was a front)
-    // run(Group&):  run g.queries (g.nq of them, lists of g.kmax) into g.rows / g.dist / g.count (/ g.evals); returns a status
+    // run(Group&, early): run g.queries (g.nq of them, lists of g.kmax) into g.rows / g.dist / g.count (/ g.evals); returns a status;
+    //               may call early() once (see there)
     // last_error(): the thread-local message of a failed run, copied for the members
     template <class Solo, class Run, class LastErr>
     int submit(uint64_t key, const float* queries, uint32_t nq, uint32_t dim, uint32_t k,
@@ -102,6 +122,7 @@ class Front {
                Solo&& solo, Run&& run, LastErr&& last_error, char* err_out, size_t err_cap) {
         std::shared_ptr<Group> grp;
         bool leader = false, has_lane = false;
+        uint32_t my = 0;                                                       // this caller's place in its group
         uint32_t expect = 0;                                                   // callers the last pass released that have not come back yet
         int64_t linger = 0;
         {
@@ -127,6 +148,7 @@ class Front {
                         grp->queries.reserve((size_t)std::min<uint32_t>(max_q_, 64) * dim);
                         leader = true;
                     }
+                    my = (uint32_t)grp->members.size();
                     grp->members.push_back(Member{grp->nq, nq, k, rows_out, dist_out, count_out, evals_out});
                     grp->queries.insert(grp->queries.end(), queries, queries + (size_t)nq * dim);
                     if (leader) pending_.push_back(grp);                       // (last: a group is visible only once it is whole)
@@ -150,8 +172,15 @@ class Front {
             return rc;
         }
         if (!leader) {                                                         // ride: the leader writes this caller's outputs
-            wait_set(&grp->done);
+            uint32_t ph;
+            for (int spin = 0; (ph = grp->phase.load(std::memory_order_acquire)) == 0; spin++) {
+                if (spin < 64) __builtin_ia32_pause(); else futex_wait(&grp->phase, 0);
+            }
             stats.rode.fetch_add(1, std::memory_order_relaxed);
+            if (ph == 1) {                                                     // an early round: this caller's share may be in it
+                if (grp->delivered[my]) return 0;
+                while (grp->phase.load(std::memory_order_acquire) != 2) futex_wait(&grp->phase, 1);
+            }
             if (grp->rc != 0) snprintf(err_out, err_cap, "%s", grp->err);
             return grp->rc;
         }
@@ -160,21 +189,36 @@ class Front {
         int rc;
         const bool alone = grp->members.size() == 1;
         const int64_t t0 = now_ns();
+        bool lane_released = false;
+        // run() may call this once, when g.count says which queries are final (everything but the entries equal to 0xFFFFFFFE) and
+        // the rest needs a second, slow pass (qv_graph_search's exact-heap redo): the lane goes to the next group and the members
+        // whose queries are all final get their results now instead of waiting for the slowest query of the group.
+        auto early = [&] {
+            if (alone || lane_released) return;
+            lane_released = true;
+            finish_lane((uint32_t)grp->members.size(), now_ns() - t0);
+            grp->scatter(true);
+            grp->phase.store(1, std::memory_order_release);
+            futex_wake(&grp->phase, INT_MAX);
+            stats.early_rounds.fetch_add(1, std::memory_order_relaxed);
+        };
         try {
-            rc = alone ? solo() : run(*grp);
+            rc = alone ? solo() : run(*grp, early);
         } catch (...) { rc = -7; }
         if (rc != 0) snprintf(grp->err, sizeof(grp->err), "%s", rc == -7 && !*last_error() ? "out of host memory" : last_error());
-        finish_lane((uint32_t)grp->members.size(), now_ns() - t0);             // the next group starts before this one's results are handed out
-        if (!alone && rc == 0) grp->scatter();
+        const int64_t pass_ns = now_ns() - t0;
+        if (!lane_released) finish_lane((uint32_t)grp->members.size(), pass_ns);   // the next group starts before this one's results are handed out
+        if (!alone && rc == 0) grp->scatter(false);
         grp->rc = rc;
         if (alone) stats.solo.fetch_add(1, std::memory_order_relaxed);
         else {
             stats.led.fetch_add(1, std::memory_order_relaxed);
             stats.groups.fetch_add(1, std::memory_order_relaxed);
             stats.group_queries.fetch_add(grp->nq, std::memory_order_relaxed);
+            stats.group_pass_ns.fetch_add((uint64_t)pass_ns, std::memory_order_relaxed);
         }
-        grp->done.store(1, std::memory_order_release);
-        if (!alone) futex_wake(&grp->done, INT_MAX);
+        grp->phase.store(2, std::memory_order_release);
+        if (!alone) futex_wake(&grp->phase, INT_MAX);
         if (rc != 0) snprintf(err_out, err_cap, "%s", grp->err);
         return rc;
     }

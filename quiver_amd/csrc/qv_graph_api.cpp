@@ -6,6 +6,7 @@
 #include "qv_api_internal.h"
 
 #include <atomic>
+#include <functional>
 
 // Everything ONE host-pointer traversal call owns while it runs: stream, converted-query workspace, result buffers, its redo
 // list and its visited sets.  The reference searches under a read lock (hnsw.go:602-606; a goroutine per query, adapter.go:253-279),
@@ -248,7 +249,7 @@ int ensure_visited_ctx(qv_graph* g, GraphCtx* c, uint32_t ef, uint32_t nq) {
 // One traversal call in a context of its own: upload, wave-resident pass, device-side compaction of the flagged queries, exact-heap
 // pass for those, download.  Nothing of the graph's is written; any number of these run side by side.
 int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
-                     uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out) {
+                     uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out, const std::function<void()>& early) {
     qv_index* idx = g->idx;
     const size_t qbytes = (size_t)nq * idx->dim * sizeof(float), obytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
     const uint32_t efx = std::max(ef_search, k);
@@ -289,52 +290,78 @@ int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq
     qv::HnswOpts wo; wo.vis = static_cast<uint32_t*>(c->vis_hash.p); wo.vis_cap = c->vis_hash_cap;
     hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, c->d_qblk.p, nq, k, ef_search, wo, std::min(c->vis_hash_slots, nq), d_rows, d_dist, d_cnt, d_ev, c->stream);
     if (e == hipSuccess) e = qv::launch_build_compact_redo(d_cnt, nq, static_cast<uint32_t*>(c->s_redo.p), counters, c->stream);
-    if (e == hipSuccess) {
-        qv::HnswOpts ho; ho.vis = static_cast<uint32_t*>(c->vis_bits.p); ho.vis_cap = c->vis_bits_words;
-        ho.redo_idx = static_cast<const uint32_t*>(c->s_redo.p); ho.redo_n = counters;
-        const uint32_t hgrid = std::min(std::min(qv::hnsw_grid(idx->cus, efx, nq), c->vis_bits_slots), nq);
-        e = qv::launch_hnsw_search(idx->view(), g->g, dq, c->d_qblk.p, nq, k, ef_search, ho, hgrid, false, d_rows, d_dist, d_cnt, d_ev, c->stream);
-    }
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
     uint32_t* hc = static_cast<uint32_t*>(c->h_counters.p);
     // small result sets come back through one pinned buffer (a copy into pageable memory is staged by the runtime, chunk by chunk)
     const size_t all = 2 * obytes + 2 * cbytes;
     const bool pinned_out = all <= ((size_t)4 << 20);
-    if (pinned_out) {
-        if ((rc = c->h_out.ensure(all))) return rc;
-        unsigned char* h = static_cast<unsigned char*>(c->h_out.p);
-        HIPCHK(hipMemcpyAsync(h, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(h + obytes, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(h + 2 * obytes, c->d_cnt.p, cbytes, hipMemcpyDeviceToHost, c->stream));
-        if (evals_out) HIPCHK(hipMemcpyAsync(h + 2 * obytes + cbytes, c->d_ev.p, cbytes, hipMemcpyDeviceToHost, c->stream));
-    } else {
-        HIPCHK(hipMemcpyAsync(rows_out, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(dist_out, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(count_out, c->d_cnt.p, cbytes, hipMemcpyDeviceToHost, c->stream));
-        if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, c->d_ev.p, cbytes, hipMemcpyDeviceToHost, c->stream));
-    }
+    if (pinned_out && (rc = c->h_out.ensure(all))) return rc;
+    unsigned char* h = static_cast<unsigned char*>(c->h_out.p);
+    auto download = [&]() -> int {
+        if (pinned_out) {
+            HIPCHK(hipMemcpyAsync(h, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h + obytes, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h + 2 * obytes, c->d_cnt.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+            if (evals_out) HIPCHK(hipMemcpyAsync(h + 2 * obytes + cbytes, c->d_ev.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+        } else {
+            HIPCHK(hipMemcpyAsync(rows_out, c->d_rows.p, obytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(dist_out, c->d_dist.p, obytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(count_out, c->d_cnt.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+            if (evals_out) HIPCHK(hipMemcpyAsync(evals_out, c->d_ev.p, cbytes, hipMemcpyDeviceToHost, c->stream));
+        }
+        return QV_OK;
+    };
+    if ((rc = download())) return rc;
     HIPCHK(hipMemcpyAsync(hc, counters, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (pinned_out) {
-        const unsigned char* h = static_cast<const unsigned char*>(c->h_out.p);
         memcpy(rows_out, h, obytes); memcpy(dist_out, h + obytes, obytes); memcpy(count_out, h + 2 * obytes, cbytes);
         if (evals_out) memcpy(evals_out, h + 2 * obytes + cbytes, cbytes);
     }
-    g->tie_reruns.fetch_add(hc[0], std::memory_order_relaxed);
-    if (trace) fprintf(stderr, "qv: graph search passes 1 + 2 + download %.3f ms (%u flagged queries redone on the device)\n",
-                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p1).count(), hc[0]);
+    const uint32_t flagged = hc[0];
+    if (trace) fprintf(stderr, "qv: graph search pass 1 + download %.3f ms (%u flagged)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p1).count(), flagged);
+    if (flagged == 0) return QV_OK;                                     // (most batches: the exact-heap kernel is not even launched)
+    // pass 2: the flagged queries (0.06 - 2 % of them by efSearch: count 0xFFFFFFFE) through the exact-heap kernel, one wavefront per
+    // query on a CU of its own — a latency-bound ~4.6 ms at efSearch 128 whether it redoes one query or a hundred.  Everything else is
+    // final NOW: a caller that shares this batch with others (qv_coalesce.h) lets them go before it starts.
+    if (early) early();
+    g->tie_reruns.fetch_add(flagged, std::memory_order_relaxed);
+    const auto t_p2 = std::chrono::steady_clock::now();
+    qv::HnswOpts ho; ho.vis = static_cast<uint32_t*>(c->vis_bits.p); ho.vis_cap = c->vis_bits_words;
+    ho.redo_idx = static_cast<const uint32_t*>(c->s_redo.p); ho.redo_n = counters;
+    const uint32_t hgrid = std::min(std::min(std::min(qv::hnsw_grid(idx->cus, efx, nq), c->vis_bits_slots), nq), flagged);
+    e = qv::launch_hnsw_search(idx->view(), g->g, dq, c->d_qblk.p, nq, k, ef_search, ho, hgrid, false, d_rows, d_dist, d_cnt, d_ev, c->stream);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+    if (pinned_out) {
+        // only the flagged queries' entries change: the others' (already handed out, perhaps) are left alone
+        if ((rc = download())) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const uint32_t* hcnt = reinterpret_cast<const uint32_t*>(h + 2 * obytes);
+        for (uint32_t q = 0; q < nq; q++) {
+            if (count_out[q] != 0xFFFFFFFEu) continue;
+            memcpy(rows_out + (size_t)q * k, h + (size_t)q * k * 4, (size_t)k * 4);
+            memcpy(dist_out + (size_t)q * k, h + obytes + (size_t)q * k * 4, (size_t)k * 4);
+            if (evals_out) evals_out[q] = reinterpret_cast<const uint32_t*>(h + 2 * obytes + cbytes)[q];
+            count_out[q] = hcnt[q];
+        }
+    } else {
+        if ((rc = download())) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (trace) fprintf(stderr, "qv: graph search pass 2 (%u flagged queries redone by the exact-heap kernel) + download %.3f ms\n", flagged,
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p2).count());
     for (uint32_t q = 0; q < nq; q++)
         if (count_out[q] == 0xFFFFFFFEu) return fail(QV_ERR_DEVICE, "hnsw search: a flagged query was not redone");
     return QV_OK;
 }
 
 int graph_search_direct(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
-                        uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out) {
+                        uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out, const std::function<void()>& early = nullptr) {
     GraphCtx* c = nullptr;
     int rc = acquire_gctx(g, &c);
     if (rc != QV_OK) return rc;
     GCtxGuard guard{g, c};
-    return graph_search_ctx(g, c, queries, nq, k, ef_search, rows_out, dist_out, count_out, evals_out);
+    return graph_search_ctx(g, c, queries, nq, k, ef_search, rows_out, dist_out, count_out, evals_out, early);
 }
 
 }  // namespace
@@ -360,23 +387,20 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     const int rc = g->front.submit(
         (uint64_t)k | ((uint64_t)ef_search << 16), queries, nq, idx->dim, k, rows_out, dist_out, count_out, evals_out,
         [&] { return graph_search_direct(g, queries, nq, k, ef_search, rows_out, dist_out, count_out, evals_out); },
-        [&](qvco::Group& grp) {
+        [&](qvco::Group& grp, auto& early) {
             grp.size_outputs(true);
             (void)hipSetDevice(idx->device);
-            return graph_search_direct(g, grp.queries.data(), grp.nq, grp.kmax, ef_search, grp.rows.data(), grp.dist.data(), grp.count.data(), grp.evals.data());
+            return graph_search_direct(g, grp.queries.data(), grp.nq, grp.kmax, ef_search, grp.rows.data(), grp.dist.data(), grp.count.data(), grp.evals.data(),
+                                       [&early] { early(); });
         },
         [] { return qv_last_error(); }, err, sizeof(err));
     if (rc != QV_OK && err[0]) return fail(rc, "%s", err);
     return rc;
 }
 
-int qv_graph_coalesce_stats(qv_graph* g, uint64_t* solo, uint64_t* led, uint64_t* rode, uint64_t* groups, uint64_t* group_queries) {
-    if (!g) return fail(QV_ERR_INVALID_ARG, "graph is null");
-    if (solo) *solo = g->front.stats.solo.load();
-    if (led) *led = g->front.stats.led.load();
-    if (rode) *rode = g->front.stats.rode.load();
-    if (groups) *groups = g->front.stats.groups.load();
-    if (group_queries) *group_queries = g->front.stats.group_queries.load();
+int qv_graph_coalesce_stats(qv_graph* g, uint64_t out[8]) {
+    if (!g || !out) return fail(QV_ERR_INVALID_ARG, "graph/out is null");
+    g->front.stats.read(out);
     return QV_OK;
 }
 

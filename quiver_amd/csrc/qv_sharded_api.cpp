@@ -737,7 +737,7 @@ int qv_sharded_search(qv_sharded* s, const float* queries, uint32_t nq, uint32_t
     const int rc = s->front.submit(
         0, queries, nq, s->dim, k, rows_out, dist_out, count_out, nullptr,
         [&] { return search_host(s, queries, nq, k, SearchMode{}, rows_out, dist_out, count_out); },
-        [&](qvco::Group& g) {
+        [&](qvco::Group& g, auto&) {
             g.size_outputs(false);
             return search_host(s, g.queries.data(), g.nq, g.kmax, SearchMode{}, g.rows.data(), g.dist.data(), g.count.data());
         },

@@ -43,7 +43,7 @@ def run(kind, handle, queries, k, threads, seconds=1.0, max_calls_per_thread=0, 
 
 def coalesce_stats(kind, handle):
     import quiver_amd
-    v = [C.c_uint64() for _ in range(5)]
+    v = (C.c_uint64 * 8)()
     fn = quiver_amd.lib().qv_index_coalesce_stats if kind == "index" else quiver_amd.lib().qv_graph_coalesce_stats
-    fn(handle, *[C.byref(x) for x in v])
-    return dict(zip(("solo", "led", "rode", "groups", "group_queries"), [x.value for x in v]))
+    fn(handle, v)
+    return dict(zip(("solo", "led", "rode", "groups", "group_queries", "lingers", "linger_ns", "group_pass_ns"), [int(x) for x in v]))

@@ -6,7 +6,7 @@
 #include <chrono>
 #include <thread>
 
-extern "C" int coalesce_harness(int lanes, unsigned max_group, unsigned n_threads, unsigned calls_per_thread, unsigned pass_us, unsigned think_us, int two_keys,
+extern "C" int coalesce_harness(int lanes, unsigned max_group, unsigned n_threads, unsigned calls_per_thread, unsigned pass_us, unsigned think_us, int two_keys, unsigned slow_every,
                                 unsigned long long* out /* solo, led, rode, groups, group_queries, lingers, wrong, max_concurrent_passes */) {
     qvco::Front front(lanes, max_group);
     std::atomic<unsigned long long> wrong{0};
@@ -36,10 +36,24 @@ extern "C" int coalesce_harness(int lanes, unsigned max_group, unsigned n_thread
                         for (unsigned i = 0; i < nq; i++) { count[i] = k; for (unsigned j = 0; j < k; j++) { rows[(size_t)i * k + j] = answer(q[(size_t)i * dim], j); dist[(size_t)i * k + j] = (float)j; } }
                         return 0;
                     },
-                    [&](qvco::Group& g) {
+                    [&](qvco::Group& g, auto& early) {
                         g.size_outputs(false);
                         pass(g.nq);
-                        for (unsigned i = 0; i < g.nq; i++) { g.count[i] = g.kmax; for (unsigned j = 0; j < g.kmax; j++) { g.rows[(size_t)i * g.kmax + j] = answer(g.queries[(size_t)i * dim], j); g.dist[(size_t)i * g.kmax + j] = (float)j; } }
+                        // a "slow" query now and then (qv_graph_search's exact-heap redo): everything else is final after the first
+                        // pass and goes out early; the slow ones follow after a second pass
+                        bool slow = false;
+                        for (unsigned i = 0; i < g.nq; i++) {
+                            const bool s = slow_every && ((unsigned)g.queries[(size_t)i * dim]) % slow_every == 0;
+                            slow |= s;
+                            g.count[i] = s ? 0xFFFFFFFEu : g.kmax;
+                            if (!s) for (unsigned j = 0; j < g.kmax; j++) { g.rows[(size_t)i * g.kmax + j] = answer(g.queries[(size_t)i * dim], j); g.dist[(size_t)i * g.kmax + j] = (float)j; }
+                        }
+                        if (slow) {
+                            early();
+                            std::this_thread::sleep_for(std::chrono::microseconds(pass_us));   // (second passes run beside the next groups' first passes: not counted against the lanes)
+                            for (unsigned i = 0; i < g.nq; i++)
+                                if (g.count[i] == 0xFFFFFFFEu) { g.count[i] = g.kmax; for (unsigned j = 0; j < g.kmax; j++) { g.rows[(size_t)i * g.kmax + j] = answer(g.queries[(size_t)i * dim], j); g.dist[(size_t)i * g.kmax + j] = (float)j; } }
+                        }
                         return 0;
                     },
                     [] { return ""; }, err, sizeof(err));

@@ -173,11 +173,11 @@ KATS = [
                     "127-52 = 75 = 0x4B -> 0x25800000, not 0.  sqrt(|a|^2 * |b|^2) = sqrt(4) = 2 would give exactly 0 = 0x00000000.",
          fn=lambda a, b: cosine(a, b), wrong={"sqrt_of_the_product": lambda a, b: cosine(a, b, sqrt_of_product=True)}),
     dict(name="euclidean_subtracts_in_float32_before_widening", metric=1, cites="pkg/vectortypes/distances.go:49-52",
-         a=[16777218.0] * 3, b=[0.75] * 3, want_bits=0x4BDDB3D8,
+         a=[16777218.0] * 3, b=[0.75] * 3, want_bits=0x4BDDB3D9,
          derivation="a[i] - b[i] = 16777217.25 lies between the float32 neighbours 16777216 and 16777218 (spacing 2 above 2^24) and rounds "
-                    "to 16777218; sum = 3 * 16777218^2 = 844425131458572 (exact in float64: < 2^53); sqrt = 29059007.25...; spacing 2 -> "
-                    "float32 29059008 = 0x4BDDB3D8.  Widening first keeps 16777217.25: sqrt(3) * 16777217.25 = 29059005.95... -> 29059006 = "
-                    "0x4BDDB3D7.",
+                    "to 16777218; sum = 3 * 16777218^2 = 844425131458572 (exact in float64: < 2^53); sqrt = sqrt(3) * 16777218 = 29058993.98...; spacing 2 -> "
+                    "float32 29058994 = 0x4BDDB3D9.  Widening first keeps 16777217.25: sqrt(3) * 16777217.25 = 29058992.68... -> 29058992 = "
+                    "0x4BDDB3D8.",
          fn=lambda a, b: euclidean(a, b), wrong={"widen_then_subtract": lambda a, b: euclidean(a, b, widen_first=True)}),
     dict(name="manhattan_subtracts_in_float32_before_widening", metric=4, cites="pkg/vectortypes/distances.go:99-101",
          a=[16777218.0] * 3, b=[0.75] * 3, want_bits=0x4C400002,
@@ -203,8 +203,8 @@ KATS = [
          a=[4096.0, 1.0, 1.0, 1.0, 1.0], b=[4096.0, 0.0, 0.0, 0.0, 0.0], want_bits=0x00000000,
          derivation="float32 sums: dot = 2^24, normB = 2^24, normA = 2^24 + 1 + 1 + 1 + 1 with every + 1 lost to ties-to-even = 2^24; "
                     "sqrt = 4096 each, 4096 * 4096 = 2^24, similarity = 1, distance 1 - 1 = 0 -> 0x00000000 although the vectors differ.  "
-                    "With float64 sums normA = 2^24 + 4, similarity = 1/sqrt(1 + 2^-22) = 1 - 2^-23 + ..., distance float32(2^-23 - ...) "
-                    "= 0x34000000 (vectortypes.CosineDistance on the same pair).",
+                    "With float64 sums normA = 2^24 + 4, similarity = 1/sqrt(1 + 2^-22) = 1 - 2^-23 + 3 * 2^-47 - ..., distance "
+                    "float32(2^-23 - 3 * 2^-47) = 0x33FFFFFD, three float32 steps below 2^-23 (vectortypes.CosineDistance on the same pair).",
          fn=lambda a, b: cosine_f32(a, b), wrong={"float64_accumulators": lambda a, b: cosine_f32(a, b, f64acc=True)}),
     dict(name="hnsw_euclidean_accumulates_in_float32", metric=6, cites="pkg/hnsw/adapter.go:144-150",
          a=[4096.0, 1.0, 1.0, 1.0, 1.0], b=[0.0] * 5, want_bits=0x45800000,

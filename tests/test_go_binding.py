@@ -78,3 +78,66 @@ def test_core_index_and_batch_index_are_implemented():
         t = re.sub(r"`[^`]*`", "``", t)
         for a, b in ("()", "{}", "[]"):
             assert t.count(a) == t.count(b), (os.path.basename(path), a)
+
+
+# ---- prototype-level check (tests/_gocgo.py): argument TYPES against the header, pointer rules -------------------------------
+
+def test_every_cgo_argument_has_the_type_the_header_declares_and_every_pointer_is_safe():
+    from tests._gocgo import Checker
+    c = Checker().run()
+    assert not c.problems, "\n".join(c.problems)
+    assert c.n_calls >= 40 and c.n_args >= 180 and c.n_pointers >= 80
+
+
+def _problems(edit):
+    from tests._gocgo import Checker
+    return Checker(edit).run().problems
+
+
+def _sub(fname, old, new, count=1):
+    def edit(name, text):
+        if name != fname:
+            return text
+        assert old in text, (fname, old)
+        return text.replace(old, new, count)
+    return edit
+
+
+def test_the_checker_catches_each_class_of_mistake():
+    """the same files with one mistake planted each: a checker that passes everything proves nothing"""
+    # a []float32 handed over as uint32_t*
+    p = _problems(_sub("index.go", "C.qv_index_add(d.h, f32p(flat)", "C.qv_index_add(d.h, u32p(flat)"))
+    assert any("u32p" in x and "[]float32" in x for x in p) and any("wants *C.float" in x for x in p), p
+    # an integer of the wrong C type
+    p = _problems(_sub("index.go", "C.qv_index_update(d.h, C.uint32_t(row)", "C.qv_index_update(d.h, C.int(row)"))
+    assert any("has type C.int, the header wants C.uint32_t" in x for x in p), p
+    # a missing argument
+    p = _problems(_sub("sharded.go", "C.qv_sharded_remove(d.h, u32p(rows), C.uint32_t(len(rows)))", "C.qv_sharded_remove(d.h, u32p(rows))"))
+    assert any("called with 2 arguments, declared with 3" in x for x in p), p
+    # &slice[0] without the emptiness guard
+    p = _problems(_sub("metric.go", "\tif n == 0 {\n\t\treturn out, nil\n\t}\n", ""))
+    assert sum("empty slice" in x for x in p) == 3, p
+    # the helpers' own guard
+    p = _problems(_sub("index.go", "func u32p(s []uint32) *C.uint32_t {\n\tif len(s) == 0 {\n\t\treturn nil\n\t}\n", "func u32p(s []uint32) *C.uint32_t {\n"))
+    assert any("helper u32p lacks" in x for x in p), p
+    # the address of a Go-typed variable as an out parameter
+    p = _problems(_sub("index.go", "\tvar n C.uint32_t\n", "\tvar n uint32\n"))
+    assert any("non-C variable &n" in x for x in p), p
+    # a handle of the wrong kind
+    p = _problems(_sub("graph.go", "C.qv_graph_destroy(h.g)", "C.qv_graph_destroy(h.idx)"))
+    assert any("has type *C.qv_index, the header wants *C.qv_graph" in x for x in p), p
+    # reinterpreting a slice as a pointer to a different element type
+    p = _problems(_sub("graph.go", "(*C.int8_t)(unsafe.Pointer(&levels[0]))", "(*C.uint32_t)(unsafe.Pointer(&levels[0]))"))
+    assert any("reinterprets []int8 as *C.uint32_t" in x for x in p), p
+
+
+def test_nothing_in_the_binding_lets_c_keep_a_go_pointer():
+    """cgo's rule: C may not keep a Go pointer after the call returns.  include/qv.h promises that no caller pointer is retained;
+    on the Go side that leaves only indirect ways to break the rule, and none of them is used: no Go memory reachable from a
+    C-allocated struct, no handle or callback, and every slice whose address crosses holds C scalars only (checked above)."""
+    for path in GO:
+        t = re.sub(r"//[^\n]*", "", open(path).read())
+        for banned in ("C.malloc", "C.calloc", "C.CBytes", "C.CString", "cgo.Handle", "cgo.NewHandle", "//export", "uintptr(unsafe.Pointer"):
+            assert banned not in t, (os.path.basename(path), banned)
+    header = open(os.path.join(ROOT, "include", "qv.h")).read()
+    assert "no\n *     caller pointer is retained after a call returns" in header

@@ -44,7 +44,9 @@ def main():
             groups = s1["groups"] - s0["groups"]
             e = dict(callers=t, qps=round(r["qps"], 1), p50_us=round(r["p50_us"], 1), p99_us=round(r["p99_us"], 1), max_us=round(r["max_us"], 1),
                      calls=r["calls"], errors=r["errors"], mismatches=r["mismatches"], same_as_batch_call=same,
-                     solo=s1["solo"] - s0["solo"], groups=groups, mean_group=round((s1["group_queries"] - s0["group_queries"]) / max(groups, 1), 1))
+                     solo=s1["solo"] - s0["solo"], groups=groups, mean_group=round((s1["group_queries"] - s0["group_queries"]) / max(groups, 1), 1),
+                     mean_group_pass_us=round((s1["group_pass_ns"] - s0["group_pass_ns"]) / max(groups, 1) / 1e3, 1),
+                     lingers=s1["lingers"] - s0["lingers"], mean_linger_us=round((s1["linger_ns"] - s0["linger_ns"]) / max(s1["lingers"] - s0["lingers"], 1) / 1e3, 1))
             rec["flat"].append(e)
             print("flat ", json.dumps(e), flush=True)
         rec["flat_shape"] = [a.rows, a.dim]
@@ -57,6 +59,24 @@ def main():
         g = DeviceGraph.build(gi, np.zeros(a.graph_rows, np.int8), m=16, max_m0=32, ef_construction=200)
         rec["graph_build_s"] = round(time.time() - t0, 2)
         ref_r, ref_d, ref_c = g.search(qs, a.k, a.ef)
+        # one batch call of nq queries, alone on the device: what a group of that size costs without any caller traffic
+        rec["graph_batch_ms"] = {}
+        for nq in (1, 8, 64, 160, 256, 1024):
+            ts = []
+            for _ in range(7):
+                t1 = time.perf_counter(); g.search(qs[:nq], a.k, a.ef); ts.append((time.perf_counter() - t1) * 1e3)
+            rec["graph_batch_ms"][nq] = round(sorted(ts)[3], 3)
+        print("graph batch ms", rec["graph_batch_ms"], flush=True)
+        # the same with 4 threads at once (the front's four lanes), 160 queries each
+        import threading
+        lat = []
+        def worker():
+            for _ in range(6):
+                t1 = time.perf_counter(); g.search(qs[:160], a.k, a.ef); lat.append((time.perf_counter() - t1) * 1e3)
+        th = [threading.Thread(target=worker) for _ in range(4)]
+        [x.start() for x in th]; [x.join() for x in th]
+        rec["graph_batch160_x4_threads_ms"] = round(sorted(lat)[len(lat) // 2], 3)
+        print("graph 4 x 160 concurrently, ms per call", rec["graph_batch160_x4_threads_ms"], flush=True)
         for t in [int(x) for x in a.graph_callers.split(",")]:
             s0 = _callers.coalesce_stats("graph", g.handle)
             r = _callers.run("graph", g.handle, qs, a.k, threads=t, seconds=a.seconds, ef=a.ef)
@@ -67,7 +87,9 @@ def main():
             groups = s1["groups"] - s0["groups"]
             e = dict(callers=t, qps=round(r["qps"], 1), p50_us=round(r["p50_us"], 1), p99_us=round(r["p99_us"], 1), max_us=round(r["max_us"], 1),
                      calls=r["calls"], errors=r["errors"], mismatches=r["mismatches"], same_as_batch_call=same,
-                     solo=s1["solo"] - s0["solo"], groups=groups, mean_group=round((s1["group_queries"] - s0["group_queries"]) / max(groups, 1), 1))
+                     solo=s1["solo"] - s0["solo"], groups=groups, mean_group=round((s1["group_queries"] - s0["group_queries"]) / max(groups, 1), 1),
+                     mean_group_pass_us=round((s1["group_pass_ns"] - s0["group_pass_ns"]) / max(groups, 1) / 1e3, 1),
+                     lingers=s1["lingers"] - s0["lingers"], mean_linger_us=round((s1["linger_ns"] - s0["linger_ns"]) / max(s1["lingers"] - s0["lingers"], 1) / 1e3, 1))
             rec["graph"].append(e)
             print("graph", json.dumps(e), flush=True)
         rec["graph_shape"] = [a.graph_rows, a.dim, a.ef]
