@@ -33,6 +33,8 @@
 #include <linux/futex.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <sched.h>
+#include <time.h>
 
 namespace qvco {
 
@@ -42,10 +44,31 @@ inline void futex_wait(std::atomic<uint32_t>* w, uint32_t expect) {
 inline void futex_wake(std::atomic<uint32_t>* w, int n) {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
 }
+inline void futex_wait_for(std::atomic<uint32_t>* w, uint32_t expect, int64_t ns) {
+    struct timespec ts; ts.tv_sec = ns / 1000000000; ts.tv_nsec = ns % 1000000000;
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, expect, &ts, nullptr, 0);
+}
 inline void wait_set(std::atomic<uint32_t>* w) {
     for (int spin = 0; spin < 64; spin++) { if (w->load(std::memory_order_acquire)) return; __builtin_ia32_pause(); }
     while (!w->load(std::memory_order_acquire)) futex_wait(w, 0);
 }
+
+// The front's own lock.  Its critical sections are a few hundred nanoseconds (a 3 KB copy, two vector pushes) and a thousand callers
+// come through it within a millisecond of every pass's end: a sleeping mutex turns that burst into a convoy (every hand-over a
+// futex wake and a context switch, ~7 us each: measured, 1024 callers needed longer to queue up again than the pass they were
+// queueing for took).  Test-and-test-and-set with a yield after a short spin.
+class SpinLock {
+  public:
+    void lock() {
+        for (int spin = 0;; spin++) {
+            if (!f_.load(std::memory_order_relaxed) && !f_.exchange(1, std::memory_order_acquire)) return;
+            if (spin < 200) __builtin_ia32_pause(); else { sched_yield(); spin = 100; }
+        }
+    }
+    void unlock() { f_.store(0, std::memory_order_release); }
+  private:
+    std::atomic<uint32_t> f_{0};
+};
 
 struct Member {                       // one caller's request inside a group
     uint32_t q0, nq, k;               // its queries are rows q0 .. q0+nq-1 of the group's block
@@ -60,7 +83,7 @@ struct Group {
     // results of the group's call: lists of length kmax, padded past count like every host-pointer search
     std::vector<uint32_t> rows, count, evals;
     std::vector<float> dist;
-    std::atomic<uint32_t> go{0}, phase{0}, n_members{0};   // phase: 0 running, 1 the members marked in delivered[] have their results, 2 all have
+    std::atomic<uint32_t> go{0}, phase{0}, n_members{0}, full{0};   // phase: 0 running, 1 the members marked in delivered[] have their results, 2 all have
     std::vector<uint8_t> delivered;   // per member (written before phase becomes 1)
     bool has_lane = false;            // (under the front's mutex)
     uint32_t want = 0; int64_t linger_ns = 0;   // hold the group open until it has `want` members, linger_ns at most
@@ -123,10 +146,11 @@ class Front {
         std::shared_ptr<Group> grp;
         bool leader = false, has_lane = false;
         uint32_t my = 0;                                                       // this caller's place in its group
+        bool wake_leader = false;
         uint32_t expect = 0;                                                   // callers the last pass released that have not come back yet
         int64_t linger = 0;
         {
-            std::lock_guard<std::mutex> l(mu_);
+            std::lock_guard<SpinLock> l(mu_);
             const int64_t now = now_ns();
             if (released_ > 0) { if (now - released_at_ < kReturnWindowNs) released_--; else released_ = 0; }   // this caller is (as good as) one of them
             // an open group of this key — one that waits for a lane, or one its leader holds open for returning callers: join it
@@ -161,9 +185,12 @@ class Front {
                 grp->nq += nq;
                 if (k > grp->kmax) grp->kmax = k;
                 grp->n_members.store((uint32_t)grp->members.size(), std::memory_order_release);
+                if (grp->nq + kMinRequest > max_q_) grp->full.store(1, std::memory_order_relaxed);
+                wake_leader = !leader && grp->has_lane && (grp->members.size() >= grp->want || grp->full.load(std::memory_order_relaxed));
                 if (leader && has_lane) { grp->has_lane = true; grp->want = 1 + expect; grp->linger_ns = linger; grp->go.store(1, std::memory_order_relaxed); }
             }
         }
+        if (wake_leader) futex_wake(&grp->n_members, 1);                       // the leader holds the group open for exactly this
         if (!grp) {                                                            // solo: nobody to wait for
             const int64_t t0 = now_ns();
             const int rc = solo();
@@ -225,28 +252,33 @@ class Front {
 
   private:
     static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    static constexpr int64_t kReturnWindowNs = 200000;     // a released caller that has not come back after this long is not coming
-    static constexpr int64_t kLingerMaxNs = 150000;
+    static constexpr int64_t kReturnWindowNs = 2000000;    // a released caller that has not come back after this long is not coming
+    static constexpr int64_t kLingerMaxNs = 1000000;
+    static constexpr uint32_t kMinRequest = 1;
     bool waiting_for_lane() const { for (auto& g : pending_) if (!g->has_lane) return true; return false; }   // (under mu_)
-    // how long a group may be held open for the callers the last pass released: an eighth of a pass, 150 us at most (under mu_)
+    // how long a group may be held open for the callers the last pass released: an eighth of a pass, 1 ms at most (under mu_)
     int64_t linger_ns() const { return std::min<int64_t>(pass_ns_ / 8, kLingerMaxNs); }
 
     // Closed-loop callers come back TOGETHER, a few microseconds after the pass that served them ends — just after the next group
     // has started without them, so that N callers alternate in two groups of N/2 and each waits two passes per answer (measured:
     // 8 callers on 1M x 768, 7.9 k QPS in groups of 4).  The leader therefore holds its group open until the callers which that
-    // last pass released are back — it knows how many — or for an eighth of a pass (150 us at most), whichever comes first.
+    // last pass released are back — it knows how many — or for an eighth of a pass (1 ms at most), whichever comes first.
     // No caller waits for company that is not known to be on its way: expect is 0 for a lone caller, always.
     void linger_then_close(const std::shared_ptr<Group>& grp) {
         if (grp->linger_ns > 0 && grp->n_members.load(std::memory_order_acquire) < grp->want) {
             const int64_t t0 = now_ns(), deadline = t0 + grp->linger_ns;
-            while (grp->n_members.load(std::memory_order_acquire) < grp->want && grp->n_members.load(std::memory_order_relaxed) < max_q_) {
-                for (int i = 0; i < 32; i++) __builtin_ia32_pause();
-                if (now_ns() >= deadline) break;
+            for (;;) {
+                const uint32_t have = grp->n_members.load(std::memory_order_acquire);
+                if (have >= grp->want || grp->full.load(std::memory_order_relaxed)) break;
+                const int64_t now = now_ns();
+                if (now >= deadline) break;
+                if (now - t0 < 20000) { for (int i = 0; i < 32; i++) __builtin_ia32_pause(); }   // the first ones are back within microseconds
+                else futex_wait_for(&grp->n_members, have, deadline - now);                        // (the join that completes the group wakes)
             }
             stats.lingers.fetch_add(1, std::memory_order_relaxed);
             stats.linger_ns.fetch_add((uint64_t)(now_ns() - t0), std::memory_order_relaxed);
         }
-        std::lock_guard<std::mutex> l(mu_);
+        std::lock_guard<SpinLock> l(mu_);
         for (auto it = pending_.begin(); it != pending_.end(); ++it)
             if (*it == grp) { pending_.erase(it); break; }
     }
@@ -255,7 +287,7 @@ class Front {
     void finish_lane(uint32_t callers, int64_t pass_ns) {
         std::shared_ptr<Group> next;
         {
-            std::lock_guard<std::mutex> l(mu_);
+            std::lock_guard<SpinLock> l(mu_);
             const int64_t now = now_ns();
             released_ = (now - released_at_ < kReturnWindowNs ? released_ : 0) + callers;
             released_at_ = now;
@@ -267,7 +299,7 @@ class Front {
         if (next) { next->go.store(1, std::memory_order_release); futex_wake(&next->go, 1); }
     }
 
-    std::mutex mu_;
+    SpinLock mu_;
     std::deque<std::shared_ptr<Group>> pending_;   // groups that can still be joined: waiting for a lane, or held open by their leader
     int inflight_ = 0;
     uint32_t released_ = 0;                        // callers that recent passes released and that have not called again yet
