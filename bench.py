@@ -43,6 +43,10 @@ import time
 
 import numpy as np
 
+# more hardware queues than the runtime's default four (streams that share one run their kernels one after another): libqv asks for the
+# same when it is loaded, but torch initialises HIP first in this process, and the runtime reads the variable once, at that moment
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -19,12 +19,15 @@ struct GraphCtx {
     Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev, s_redo, s_counters;
     PinBuf h_stage[2]; hipEvent_t ev_stage[2] = {nullptr, nullptr};
     PinBuf h_counters, h_out;
+    hipEvent_t ev_block = nullptr;       // blocking-sync event: a thread that runs a shared batch sleeps until the device is done instead of spinning
     void release() {
         if (stream) (void)hipStreamSynchronize(stream);
         vis_hash.release(); vis_bits.release();
         d_q.release(); d_qblk.release(); d_rows.release(); d_dist.release(); d_cnt.release(); d_ev.release(); s_redo.release(); s_counters.release();
         for (int i = 0; i < 2; i++) { h_stage[i].release(); if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]); ev_stage[i] = nullptr; }
         h_counters.release(); h_out.release();
+        if (ev_block) (void)hipEventDestroy(ev_block);
+        ev_block = nullptr;
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -251,6 +254,16 @@ int ensure_visited_ctx(qv_graph* g, GraphCtx* c, uint32_t ef, uint32_t nq) {
 int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
                      uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out, const std::function<void()>& early) {
     qv_index* idx = g->idx;
+    // A caller on its own waits for the device the way every other entry point does (the runtime spins: lowest latency).  A thread that
+    // runs a batch for OTHER callers too does so while hundreds of them want the cores to come back with their next query: it sleeps on a
+    // blocking event instead (measured with 1024 callers on 8 usable cores: the spinning leaders of four lanes took half of them).
+    const bool blocking = (bool)early;
+    if (blocking && !c->ev_block) HIPCHK(hipEventCreateWithFlags(&c->ev_block, hipEventBlockingSync | hipEventDisableTiming));
+    auto wait_device = [&]() -> hipError_t {
+        if (!blocking) return hipStreamSynchronize(c->stream);
+        hipError_t e0 = hipEventRecord(c->ev_block, c->stream);
+        return e0 == hipSuccess ? hipEventSynchronize(c->ev_block) : e0;
+    };
     const size_t qbytes = (size_t)nq * idx->dim * sizeof(float), obytes = (size_t)nq * k * 4, cbytes = (size_t)nq * 4;
     const uint32_t efx = std::max(ef_search, k);
     int rc;
@@ -266,7 +279,7 @@ int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq
         size_t off = 0; int slot = 0;
         while (off < qbytes) {
             const size_t n = std::min(slice, qbytes - off);
-            if ((rc = c->h_stage[slot].ensure(std::min(slice, std::max(qbytes, (size_t)65536))))) return rc;
+            if ((rc = c->h_stage[slot].ensure(std::min(slice, std::max(2 * qbytes, (size_t)65536))))) return rc;   // (twice the need: groups grow)
             if (!c->ev_stage[slot]) HIPCHK(hipEventCreateWithFlags(&c->ev_stage[slot], hipEventDisableTiming));
             else HIPCHK(hipEventSynchronize(c->ev_stage[slot]));        // the DMA that last read this buffer is done
             memcpy(c->h_stage[slot].p, reinterpret_cast<const unsigned char*>(queries) + off, n);
@@ -313,7 +326,7 @@ int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq
     };
     if ((rc = download())) return rc;
     HIPCHK(hipMemcpyAsync(hc, counters, 32, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(wait_device());
     if (pinned_out) {
         memcpy(rows_out, h, obytes); memcpy(dist_out, h + obytes, obytes); memcpy(count_out, h + 2 * obytes, cbytes);
         if (evals_out) memcpy(evals_out, h + 2 * obytes + cbytes, cbytes);
@@ -335,7 +348,7 @@ int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq
     if (pinned_out) {
         // only the flagged queries' entries change: the others' (already handed out, perhaps) are left alone
         if ((rc = download())) return rc;
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(wait_device());
         const uint32_t* hcnt = reinterpret_cast<const uint32_t*>(h + 2 * obytes);
         for (uint32_t q = 0; q < nq; q++) {
             if (count_out[q] != 0xFFFFFFFEu) continue;
@@ -346,7 +359,7 @@ int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq
         }
     } else {
         if ((rc = download())) return rc;
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(wait_device());
     }
     if (trace) fprintf(stderr, "qv: graph search pass 2 (%u flagged queries redone by the exact-heap kernel) + download %.3f ms\n", flagged,
                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p2).count());
