@@ -542,7 +542,7 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
         [&] { return search_direct(idx, queries, nq, k, rows_out, dist_out, count_out); },
         [&](qvco::Group& g, auto&) {
             g.size_outputs(false);
-            return search_direct(idx, g.queries.data(), g.nq, g.kmax, g.rows.data(), g.dist.data(), g.count.data());
+            return search_direct(idx, g.queries(), g.nq, g.kmax, g.rows.data(), g.dist.data(), g.count.data());
         },
         [] { return qv_last_error(); }, err, sizeof(err));
     if (rc != QV_OK && err[0]) return fail(rc, "%s", err);                // (a rider's message comes from the thread that ran its group)

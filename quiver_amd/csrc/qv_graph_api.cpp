@@ -403,7 +403,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
         [&](qvco::Group& grp, auto& early) {
             grp.size_outputs(true);
             (void)hipSetDevice(idx->device);
-            return graph_search_direct(g, grp.queries.data(), grp.nq, grp.kmax, ef_search, grp.rows.data(), grp.dist.data(), grp.count.data(), grp.evals.data(),
+            return graph_search_direct(g, grp.queries(), grp.nq, grp.kmax, ef_search, grp.rows.data(), grp.dist.data(), grp.count.data(), grp.evals.data(),
                                        [&early] { early(); });
         },
         [] { return qv_last_error(); }, err, sizeof(err));

@@ -739,7 +739,7 @@ int qv_sharded_search(qv_sharded* s, const float* queries, uint32_t nq, uint32_t
         [&] { return search_host(s, queries, nq, k, SearchMode{}, rows_out, dist_out, count_out); },
         [&](qvco::Group& g, auto&) {
             g.size_outputs(false);
-            return search_host(s, g.queries.data(), g.nq, g.kmax, SearchMode{}, g.rows.data(), g.dist.data(), g.count.data());
+            return search_host(s, g.queries(), g.nq, g.kmax, SearchMode{}, g.rows.data(), g.dist.data(), g.count.data());
         },
         [] { return qv_last_error(); }, err, sizeof(err));
     if (rc != QV_OK && err[0]) return fail(rc, "%s", err);

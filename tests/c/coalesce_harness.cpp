@@ -43,16 +43,16 @@ extern "C" int coalesce_harness(int lanes, unsigned max_group, unsigned n_thread
                         // pass and goes out early; the slow ones follow after a second pass
                         bool slow = false;
                         for (unsigned i = 0; i < g.nq; i++) {
-                            const bool s = slow_every && ((unsigned)g.queries[(size_t)i * dim]) % slow_every == 0;
+                            const bool s = slow_every && ((unsigned)g.queries()[(size_t)i * dim]) % slow_every == 0;
                             slow |= s;
                             g.count[i] = s ? 0xFFFFFFFEu : g.kmax;
-                            if (!s) for (unsigned j = 0; j < g.kmax; j++) { g.rows[(size_t)i * g.kmax + j] = answer(g.queries[(size_t)i * dim], j); g.dist[(size_t)i * g.kmax + j] = (float)j; }
+                            if (!s) for (unsigned j = 0; j < g.kmax; j++) { g.rows[(size_t)i * g.kmax + j] = answer(g.queries()[(size_t)i * dim], j); g.dist[(size_t)i * g.kmax + j] = (float)j; }
                         }
                         if (slow) {
                             early();
                             std::this_thread::sleep_for(std::chrono::microseconds(pass_us));   // (second passes run beside the next groups' first passes: not counted against the lanes)
                             for (unsigned i = 0; i < g.nq; i++)
-                                if (g.count[i] == 0xFFFFFFFEu) { g.count[i] = g.kmax; for (unsigned j = 0; j < g.kmax; j++) { g.rows[(size_t)i * g.kmax + j] = answer(g.queries[(size_t)i * dim], j); g.dist[(size_t)i * g.kmax + j] = (float)j; } }
+                                if (g.count[i] == 0xFFFFFFFEu) { g.count[i] = g.kmax; for (unsigned j = 0; j < g.kmax; j++) { g.rows[(size_t)i * g.kmax + j] = answer(g.queries()[(size_t)i * dim], j); g.dist[(size_t)i * g.kmax + j] = (float)j; } }
                         }
                         return 0;
                     },

@@ -27,7 +27,7 @@ def harness(tmp_path_factory):
     return run
 
 
-@pytest.mark.parametrize("lanes,threads", [(1, 1), (1, 2), (1, 8), (1, 64), (4, 3), (4, 64), (2, 200)])
+@pytest.mark.parametrize("lanes,threads", [(1, 1), (1, 2), (1, 8), (1, 64), (4, 3), (4, 64), (2, 200), (4, 600)])
 def test_every_caller_gets_its_own_results(harness, lanes, threads):
     r = harness(lanes, 64, threads, 40, 300)
     assert r["wrong"] == 0
