@@ -50,11 +50,14 @@ struct qv_graph {
     std::atomic<uint64_t> tie_reruns{0};
     std::mutex mu;                              // the graph's OWN buffers below (device-form traversals, construction, export): one user at a time
     // host-pointer searches: a context each (pool), and a front that lets concurrent small calls share a traversal batch
-    // (qv_coalesce.h).  Four batches in flight at most: a traversal is one wavefront per query, so unlike a flat scan a lone
+    // (qv_coalesce.h).  Two batches in flight at most (measured with 8 / 256 / 1024 callers on 1M x 768, efSearch 128: 1 lane is what
+    // a second lone caller waits behind, 2 lanes 2.1 k / 48 k / 109 k QPS, 4 lanes 2.2 k / 40 k / 93 k, 8 lanes 1.7 k / 24 k / 66 k — more lanes
+    // mean smaller batches, and every batch pays the same ~4.5 ms): a traversal is one wavefront per query, so unlike a flat scan a lone
     // batch does not fill the chip and a second caller should not wait for the first.
     std::mutex ctx_mu;
     std::vector<GraphCtx*> free_ctx, all_ctx;
-    qvco::Front front{4, 4096};
+    static int lanes() { static const int n = getenv("QV_GRAPH_LANES") ? std::max(1, atoi(getenv("QV_GRAPH_LANES"))) : 4; return n; }   // (measurement switch, read once)
+    qvco::Front front{lanes(), 4096};
     hipStream_t stream = nullptr;
     hipEvent_t ev_last = nullptr;               // end of the most recent traversal: the next one (on any stream) waits for it
     Buf d_qblk, d_rows, d_dist, d_cnt, d_ev;
@@ -256,7 +259,7 @@ int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq
     qv_index* idx = g->idx;
     // A caller on its own waits for the device the way every other entry point does (the runtime spins: lowest latency).  A thread that
     // runs a batch for OTHER callers too does so while hundreds of them want the cores to come back with their next query: it sleeps on a
-    // blocking event instead (measured with 1024 callers on 8 usable cores: the spinning leaders of four lanes took half of them).
+    // blocking event instead (measured with 1024 callers on 8 usable cores: the spinning leaders of four lanes — the setting then — took half of them).
     const bool blocking = (bool)early;
     if (blocking && !c->ev_block) HIPCHK(hipEventCreateWithFlags(&c->ev_block, hipEventBlockingSync | hipEventDisableTiming));
     auto wait_device = [&]() -> hipError_t {
@@ -391,7 +394,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
     if (g->g.n_nodes == 0) return fail(QV_ERR_INVALID_ARG, "graph is empty");
     qv_index* idx = g->idx;
     HIPCHK(hipSetDevice(idx->device));
-    // Small calls — the reference's host sends one query per call, concurrently (hnsw.go:602-606) — that find four batches already
+    // Small calls — the reference's host sends one query per call, concurrently (hnsw.go:602-606) — that find two batches already
     // in flight ride the next one together (same k and efSearch: those decide a traversal's result).  Larger batches fill the chip
     // by themselves and run as they are, each in its own context.
     static const bool off = getenv("QV_COALESCE") && atoi(getenv("QV_COALESCE")) == 0;        // measurement switch, read once per process
