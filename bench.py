@@ -148,6 +148,9 @@ def compact_also(also, budget):
             cpick = next((x for x in cpu if pick and x.get("ef_search") == pick.get("ef_search")), None)
             if cpick:
                 o.update({"cpu_qps": _r(cpick.get("qps"), 4), "same": cpick.get("identical_to_device")})
+            cc = (e.get("concurrent_single_query_callers") or {}).get("by_callers")
+            if cc:
+                o["callers_qps"] = {str(x["callers"]): _r(x["qps"], 4) for x in cc}
             c[short] = o
         elif key == "batched_small_1Mx768":
             c["b_small_1Mx768_ms"] = {k2.replace("_queries_", "q_").replace("float32", "f32"): _r(v2.get("batch_ms"), 3) for k2, v2 in e.items() if isinstance(v2, dict)}
@@ -156,6 +159,9 @@ def compact_also(also, budget):
             c["k_gt_64_ms"]["same"] = all(v2 for k2, v2 in e.items() if k2.endswith("_same"))
         elif key == "pcie_inclusive_single_query":
             c["pcie_inclusive_qps"] = _r(e.get("qps"), 4)
+        elif key == "concurrent_single_query_callers":
+            c["callers_1M_qps"] = {str(x["callers"]): _r(x["qps"], 4) for x in e.get("by_callers", [])}
+            c["callers_1M_qps"]["same"] = all(x.get("same_as_batch_call") and not x.get("errors") and not x.get("mismatches") for x in e.get("by_callers", []))
         else:
             o = {}
             for src, dst in (("batch_ms", "ms"), ("qps", "qps"), ("hbm_frac", "frac"), ("frac_of_f64_matrix_peak", "frac"), ("latency_us", "us"),
@@ -429,6 +435,27 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         "workload": "flat cosine 1Mx768 fp32, k=10, single query (BASELINE configs[1])",
         "qps": steps1 / dt1, "ms_per_query": dt1 / steps1 * 1e3, "scan_kernel_ms": ms1 / max(n1, 1),
         "hbm_gbs": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9, "hbm_frac": b1 / (ms1 / max(n1, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # The traffic the reference's unchanged host produces on that corpus: Collection.Search holds a read lock and calls Index.Search(q, k)
+    # once per request (collection.go:647); DB.BatchSearch reaches a batch entry only through a type assertion on the reference's own
+    # wrapper (db.go:726-727) and otherwise fans out one goroutine per query (:805-828).  T native threads, qv_index_search with nq = 1,
+    # closed loop (tools/native/qv_callers.cpp); libqv lets such callers share passes (qv_coalesce.h).  Every result is compared with the
+    # first one seen for the same query, and those with one batch call.
+    try:
+        from tests import _callers
+        ref_r, ref_d, _ = idx1.search(qs_host[:256], k, batched=True)
+        by = []
+        for t in (1, 8, 64, 256):
+            cr = _callers.run("index", idx1.handle, qs_host[:256], k, threads=t, seconds=1.0)
+            seen = cr["count"] != 0xFFFFFFFD
+            same = bool(np.array_equal(cr["rows"][seen], ref_r[seen]) and np.array_equal(cr["dist"][seen].view(np.uint32), ref_d[seen].view(np.uint32)))
+            by.append({"callers": t, "qps": cr["qps"], "p50_us": cr["p50_us"], "p99_us": cr["p99_us"], "errors": cr["errors"], "mismatches": cr["mismatches"],
+                       "same_as_batch_call": same})
+        st = _callers.coalesce_stats("index", idx1.handle)
+        also["concurrent_single_query_callers"] = {
+            "workload": "T threads x qv_index_search(nq = 1, k = %d) on 1Mx768 cosine, host pointers, closed loop" % k, "by_callers": by,
+            "passes_shared": {"groups": st["groups"], "mean_queries_per_group": st["group_queries"] / max(st["groups"], 1), "solo_calls": st["solo"]}}
+    except Exception as ex:                                # noqa: BLE001
+        also["concurrent_single_query_callers"] = {"error": str(ex)}
     # configs[2]: 256 queries x 1M x 768
     nqb = 256
     d_rb = torch.empty((nqb, k), dtype=torch.int32, device="cuda")
@@ -665,7 +692,8 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
                  "regime embeddings live in): same bytes per row, same kernels — this is the 'QPS @ recall' curve of the graph search")):
             try:
                 e = hnsw_run(rows=a.hnsw_rows, dim=dim, metric=a.metric, m=16, efc=200, max_level=max_level, efs=efs, nq=8192, k=k,
-                             cpu_queries=cpuq, device=local_rank, corpus_seed=CORPUS_SEED, query_seed=QUERY_SEED, intrinsic_dim=idim)
+                             cpu_queries=cpuq, device=local_rank, corpus_seed=CORPUS_SEED, query_seed=QUERY_SEED, intrinsic_dim=idim,
+                             callers=(1, 64, 1024) if key == "hnsw_1Mx768_maxlevel1" else ())
                 e["note"] = note
                 also[key] = e
             except Exception as ex:                        # noqa: BLE001  (a measurement beside the headline; never fail the bench line over it)

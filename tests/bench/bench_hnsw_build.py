@@ -21,7 +21,8 @@ import numpy as np
 
 
 def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, batch_max=16384, ramp_div=16, efs=(64, 128, 256, 512),
-        nq=8192, k=10, cpu_queries=100, device=0, level_seed=1, corpus_seed=20260424, query_seed=20260425, cpu_build_rows=0, intrinsic_dim=0):
+        nq=8192, k=10, cpu_queries=100, device=0, level_seed=1, corpus_seed=20260424, query_seed=20260425, cpu_build_rows=0, intrinsic_dim=0,
+        callers=()):
     import torch                      # before libqv: both must share one HIP runtime (torch bundles its own)
     import quiver_amd
     from quiver_amd.device_index import DeviceGraph, random_levels
@@ -112,6 +113,22 @@ def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, b
                       "search_complete": {"qps": nq / (t_host + t_top), "recall_at_%d_vs_exact" % k: hit_full / (nq * k),
                                           "what": "HNSW.Search as the reference defines it: graph traversal, then the exact top-k for queries the graph under-filled (hnsw.go:676-710)"}})
     out["search"] = sweep
+    if callers:
+        # The traffic the reference's host produces: HNSW.Search under a read lock, one query per call, a goroutine per request
+        # (hnsw.go:602-606, adapter.go:253-279).  Native threads through qv_graph_search with nq = 1 (tools/native/qv_callers.cpp); every
+        # result is compared with the batch call's above.
+        from tests import _callers
+        ef = 128 if 128 in efs else efs[0]
+        r0, d0, c0, _ = host[ef]
+        rows_c = []
+        for t in callers:
+            cr = _callers.run("graph", g.handle, hq[:1024], k, threads=t, seconds=1.5, ef=ef)
+            seen = cr["count"] != 0xFFFFFFFD
+            same = bool(np.array_equal(cr["count"][seen], c0[:1024][seen]) and np.array_equal(cr["rows"][seen], r0[:1024][seen]) and
+                        np.array_equal(cr["dist"][seen].view(np.uint32), d0[:1024][seen].view(np.uint32)))
+            rows_c.append({"callers": t, "qps": cr["qps"], "p50_us": cr["p50_us"], "p99_us": cr["p99_us"], "errors": cr["errors"],
+                           "mismatches": cr["mismatches"], "same_as_batch_call": same})
+        out["concurrent_single_query_callers"] = {"ef_search": ef, "what": "T native threads, qv_graph_search with one query per call, closed loop", "by_callers": rows_c}
 
     if cpu_queries:
         from tests import _oracle as O                    # checker / CPU baseline only
