@@ -475,6 +475,15 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         "batch_ms": dtb * 1e3, "qps": nqb / dtb, "f64_tflops_equiv": flop / dtb / 1e12,
         "frac_of_f64_matrix_peak": flop / dtb / 1e12 / MFMA_F64_PEAK_TF, "peak_tflops_measured": MFMA_F64_PEAK_TF}
 
+    # which one-term kernel the library dispatches for this shape (qv_batched.hip qreg_filter_applies: 384 / 512 / 768 dimensions, whole
+    # workgroups of 256 queries, QV_QREG != 2); QV_TRACE=1 prints the same decision from inside the library
+    qreg_applies = dim in (384, 512, 768) and nqb % 256 == 0 and os.environ.get("QV_QREG", "") != "2"
+
+    def filter_kernel_name(plane):
+        if qreg_applies:
+            return "k_qreg_filter (bfloat16 copy)" if plane else "k_qreg_filter (float32 rows)"
+        return "k_bf16rows_filter (bfloat16 copy)" if plane and dim % 128 == 0 else "k_bf16x1_filter_w8x2 (float32 rows)"
+
     def mfma_entry(index, label, want_rows, want_dist, rows_n=1_000_000, kernel="bf16x3", plane=False):
         index.set_filter(kernel)                                # qv_index_set_filter: the index's own choice of filter kernel
         d_flags = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
@@ -508,13 +517,14 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
             "roofline": ({"bound": "mfma", "kernel": "k_mfma_filter", "kernel_ms": mf_ms, "achieved": flop / (mf_ms * 1e-3) / 1e12,
                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flop / (mf_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                           "end_to_end_frac": flop / dtm / 1e12 / MFMA_F32_PEAK_TF, "algorithmic_flop_per_launch": flop} if kernel == "fp32" else
-                         {"bound": "hbm", "kernel": "k_qreg_filter (bfloat16 copy)" if plane else "k_qreg_filter (float32 rows)", "kernel_ms": mf_ms,
+                         {"bound": "hbm", "kernel": filter_kernel_name(plane), "kernel_ms": mf_ms,
                           "achieved": rows_n * (dim * (2 if plane else 4) + 8) / (mf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": rows_n * (dim * (2 if plane else 4) + 8) / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "algorithmic_bytes_per_launch": rows_n * (dim * (2 if plane else 4) + 8),
                           "why_hbm": "one term is 0.39 PFLOP of bfloat16 matrix work per launch = 0.16 ms at 2.5 PFLOP/s; reading the float32 rows once is 0.38 ms at 8 TB/s, the bfloat16 copy 0.19 ms",
                           "matrix_pipe_note": "on this data the chip holds ~1.5 GHz under a bare chain of these matrix instructions: the kernel's own K loop with nothing but its 12M v_mfma_f32_32x32x16_bf16 per SIMD-set takes 0.255 ms (1.54 PFLOP/s, QV_QREG_DBG=15 build) — the practical floor of the bfloat16-copy form; the float32-row form's row stream alone takes 0.44 ms (6.95 TB/s)",
-                          "frac_of_bare_mfma_loop": 0.255 / mf_ms,
+                          # (that constant was measured at 256 x 1M x 768 on the query-resident kernel: only there does the ratio mean anything)
+                          "frac_of_bare_mfma_loop": (0.255 / mf_ms) if (qreg_applies and rows_n == 1_000_000 and dim == 768) else None,
                           "matrix_tflops": flop / (mf_ms * 1e-3) / 1e12, "fp32_equivalent_tflops_end_to_end": flop / dtm / 1e12,
                           "times_the_fp32_mfma_peak_end_to_end": flop / dtm / 1e12 / MFMA_F32_PEAK_TF} if kernel == "bf16x1" else
                          {"bound": "mfma", "kernel": "k_bf16x3_filter_shared", "kernel_ms": mf_ms, "achieved": 3.0 * flop / (mf_ms * 1e-3) / 1e12,
@@ -551,6 +561,17 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
                 idx1.search_batched_device(d_q.data_ptr(), nqb, kk_, rb_.data_ptr(), db_.data_ptr(), fl_.data_ptr(), sp)
             torch.cuda.synchronize()
             ks_entry["256x1M_k%d_ms" % kk_] = (time.perf_counter() - t4) / 20 * 1e3
+            # checked against the exact scans of the same index (filter off: multi-query scan / key per row + selection); a query the filter
+            # handed back (flag set) is the caller's to redo and is left out
+            xr_ = torch.empty((nqb, kk_), dtype=torch.int32, device="cuda"); xd_ = torch.empty((nqb, kk_), dtype=torch.float32, device="cuda")
+            idx1.set_filter("off")
+            idx1.search_device(d_q.data_ptr(), nqb, kk_, xr_.data_ptr(), xd_.data_ptr(), sp)
+            torch.cuda.synchronize()
+            idx1.set_filter("auto")
+            ok_ = fl_ == 0
+            ks_entry["256x1M_k%d_same" % kk_] = bool(torch.equal(rb_[ok_], xr_[ok_]) and torch.equal(db_[ok_].view(torch.int32), xd_[ok_].view(torch.int32)))
+            ks_entry["256x1M_k%d_handed_back" % kk_] = int((~ok_).sum().item())
+            del xr_, xd_
         also["k_above_64"] = ks_entry
     except Exception as ex:                                # noqa: BLE001
         also["k_above_64"] = {"error": str(ex)}

@@ -142,11 +142,14 @@ k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
         for (uint32_t u = 0; u < 4; u++) { const uint32_t b = threadIdx.x * 4 + u; sum += b < nb ? hh[b] : 0u; }
         const uint32_t inc = wave_incl_scan(sum, lane_);
         if (lane_ == 63) wcnt[wave_] = inc;
+        // (fewer than krem keys in the histogram — a query with fewer live candidates than results asked for — leaves no thread to
+        // write the answer: the last bin then, everything below it counted, an empty bucket)
+        if (threadIdx.x == 0) { r_d = nb - 1; r_cum = 0; r_bucket = 0; }
         __syncthreads();
         uint32_t before = 0;
         for (uint32_t x = 0; x < wave_; x++) before += wcnt[x];
         const uint32_t excl = before + inc - sum;
-        if (excl < krem && krem <= excl + sum) {                       // exactly one thread
+        if (excl < krem && krem <= excl + sum) {                       // exactly one thread (or none: see above)
             uint32_t cum = excl, d = threadIdx.x * 4;
             for (uint32_t u = 0; u < 4; u++, d++) { if (krem <= cum + hh[d]) break; cum += hh[d]; }
             r_d = d; r_cum = cum; r_bucket = hh[d];
@@ -161,6 +164,9 @@ k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
         const uint32_t want = s->k_rem;
         const uint64_t* all = keys + (size_t)q * stride;
         if (threadIdx.x == 0) s_run = 0;
+        // the slots the ties go to start out dead: when fewer than k_rem live ties exist (the k-th key fell among dead keys: a
+        // handed-back query, a query with fewer live candidates than k) the rest is padding, not whatever LDS held
+        for (uint32_t i = threadIdx.x; i < want; i += kSelSortBlock) a[nc + i] = kDeadKey;
         __syncthreads();
         if (ordered) {
         // the keys array is in row order — walk it front to back, a block of 4096 keys per round, and keep the first k_rem ties

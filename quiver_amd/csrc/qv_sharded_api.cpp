@@ -122,9 +122,13 @@ struct ShardPool {
                 item = q.front(); q.pop_front();
             }
             ShardJob* j = item.first;
-            const int rc = j->fn(item.second);
+            int rc;
+            try {                                                              // (nothing may leave a pool thread: an escaping exception ends the process)
+                rc = j->fn(item.second);
+                if (rc != QV_OK) j->msg[item.second] = qv_last_error();        // the message is thread-local: carry it to the caller
+            } catch (const std::bad_alloc&) { rc = QV_ERR_OOM; }
+            catch (...) { rc = QV_ERR_DEVICE; }
             j->rc[item.second] = rc;
-            if (rc != QV_OK) j->msg[item.second] = qv_last_error();            // the message is thread-local: carry it to the caller
             j->remaining.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
@@ -146,7 +150,7 @@ struct qv_sharded {
     bool rccl = true;
     std::shared_mutex mu;                // searches shared, mutations exclusive (collection.go:647 RLock / :139 Lock)
     std::mutex ctx_mu;
-    std::vector<CallCtx*> free_ctx, all_ctx;
+    std::vector<CallCtx*> free_ctx, all_ctx, retired;   // retired: surplus contexts waiting to be freed (release_ctx)
     std::mutex exch_mu;                  // RCCL: one group of collectives is enqueued at a time on the communicators
     Buf d_bases;
     std::atomic<bool> profiling{false};
@@ -194,8 +198,14 @@ int for_shards(qv_sharded* s, const std::function<int(uint32_t)>& fn) {
     s->pool.cv.notify_all();
     job.rc[0] = fn(0);
     if (job.rc[0] != QV_OK) job.msg[0] = qv_last_error();
-    while (job.remaining.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
-    for (uint32_t g = 0; g < G; g++) if (job.rc[g] != QV_OK) return fail(job.rc[g], "%s", job.msg[g].c_str());
+    // the workers' shares are a handful of enqueues each: spin briefly, then give the core away between looks (a wedged device call in a
+    // worker must not pin this thread at 100 %)
+    for (uint32_t spin = 0; job.remaining.load(std::memory_order_acquire) != 0; spin++) {
+        if (spin < 4096) __builtin_ia32_pause();
+        else std::this_thread::sleep_for(std::chrono::microseconds(spin < 100000 ? 20 : 1000));
+    }
+    for (uint32_t g = 0; g < G; g++)
+        if (job.rc[g] != QV_OK) return fail(job.rc[g], "%s", job.msg[g].empty() ? (job.rc[g] == QV_ERR_OOM ? "out of host memory" : "shard task failed") : job.msg[g].c_str());
     return QV_OK;
 }
 
@@ -235,12 +245,23 @@ void destroy_ctx(qv_sharded* s, CallCtx* c);
 // shard's index — a workspace per stream: beyond kKeepCtx idle contexts the extra ones are destroyed instead of pooled.
 constexpr size_t kKeepCtx = 8;
 void release_ctx(qv_sharded* s, CallCtx* c) {
+    // Surplus contexts are PARKED, not destroyed here: destroying one synchronises its streams and frees device and pinned memory
+    // (an implicit device-wide synchronisation on every shard's device) — on the thread of a search, under the handle's shared
+    // lock, at the tail of a burst, that stalled every other search in flight.  reap_retired frees them from the next exclusive
+    // operation (add / remove / update / reserve hold the handle alone) or with the handle.
+    std::lock_guard<std::mutex> g(s->ctx_mu);
+    if (s->free_ctx.size() < kKeepCtx) s->free_ctx.push_back(c);
+    else s->retired.push_back(c);
+}
+// (the caller holds the handle exclusively: no search is running)
+void reap_retired(qv_sharded* s) {
+    std::vector<CallCtx*> dead;
     {
         std::lock_guard<std::mutex> g(s->ctx_mu);
-        if (s->free_ctx.size() < kKeepCtx) { s->free_ctx.push_back(c); return; }
-        s->all_ctx.erase(std::find(s->all_ctx.begin(), s->all_ctx.end(), c));
+        dead.swap(s->retired);
+        for (CallCtx* c : dead) s->all_ctx.erase(std::find(s->all_ctx.begin(), s->all_ctx.end(), c));
     }
-    destroy_ctx(s, c);
+    for (CallCtx* c : dead) destroy_ctx(s, c);
 }
 struct CtxGuard { qv_sharded* s; CallCtx* c; ~CtxGuard() { if (c) release_ctx(s, c); } };
 
@@ -606,6 +627,7 @@ int qv_sharded_shard_info(const qv_sharded* s, int shard, int* device, uint32_t*
 int qv_sharded_reserve(qv_sharded* s, uint64_t rows_total) {
     if (!s) return fail(QV_ERR_INVALID_ARG, "handle is null");
     std::unique_lock<std::shared_mutex> l(s->mu);
+    reap_retired(s);
     const uint64_t G = s->sh.size();
     for (auto& x : s->sh) { int rc = qv_index_reserve(x.idx, (rows_total + G - 1) / G); if (rc != QV_OK) return rc; }
     return QV_OK;
@@ -618,6 +640,7 @@ int qv_sharded_add(qv_sharded* s, const float* rows, uint32_t n, uint32_t* globa
     if (n == 0) return QV_OK;
     if (!rows) return fail(QV_ERR_INVALID_ARG, "rows is null");
     std::unique_lock<std::shared_mutex> l(s->mu);
+    reap_retired(s);
     const uint32_t G = (uint32_t)s->sh.size();
     // target fill after the add: everyone at the same level where possible
     std::vector<uint64_t> have(G), give(G, 0);
@@ -652,6 +675,7 @@ int qv_sharded_add(qv_sharded* s, const float* rows, uint32_t n, uint32_t* globa
 int qv_sharded_add_synthetic(qv_sharded* s, uint64_t seed, uint64_t gen_row0, uint64_t n) {
     if (!s) return fail(QV_ERR_INVALID_ARG, "handle is null");
     std::unique_lock<std::shared_mutex> l(s->mu);
+    reap_retired(s);
     const uint64_t G = s->sh.size();
     for (uint64_t g = 0; g < G; g++) {
         const uint64_t b = g * n / G, e = (g + 1) * n / G;
@@ -688,6 +712,7 @@ int qv_sharded_remove(qv_sharded* s, const uint32_t* global_rows, uint32_t n) {
     if (n == 0) return QV_OK;
     if (!global_rows) return fail(QV_ERR_INVALID_ARG, "rows is null");
     std::unique_lock<std::shared_mutex> l(s->mu);
+    reap_retired(s);
     std::vector<std::vector<uint32_t>> per;
     int rc = split_rows(s, global_rows, n, &per, nullptr);
     if (rc != QV_OK) return rc;
@@ -700,6 +725,7 @@ int qv_sharded_update(qv_sharded* s, uint32_t global_row, const float* vec) {
     if (!s) return fail(QV_ERR_INVALID_ARG, "handle is null");
     if (!vec) return fail(QV_ERR_INVALID_ARG, "vector is null");
     std::unique_lock<std::shared_mutex> l(s->mu);
+    reap_retired(s);
     const uint32_t g = shard_of(s, global_row), local = global_row - s->sh[g].base;
     if (local >= qv_index_rows(s->sh[g].idx)) return fail(QV_ERR_OUT_OF_RANGE, "global row %u is not in shard %u", global_row, g);
     return qv_index_update(s->sh[g].idx, local, vec);
@@ -844,6 +870,7 @@ int qv_runtime_info(char* out, size_t cap) {
 int qv_sharded_set_filter(qv_sharded* s, int filter) {
     if (!s) return fail(QV_ERR_INVALID_ARG, "handle is null");
     std::unique_lock<std::shared_mutex> l(s->mu);
+    reap_retired(s);
     for (auto& x : s->sh) { const int rc = qv_index_set_filter(x.idx, filter); if (rc != QV_OK) return rc; }
     return QV_OK;
 }
@@ -851,6 +878,7 @@ int qv_sharded_set_filter(qv_sharded* s, int filter) {
 int qv_sharded_profile(qv_sharded* s, int enable) {
     if (!s) return fail(QV_ERR_INVALID_ARG, "handle is null");
     std::unique_lock<std::shared_mutex> l(s->mu);
+    reap_retired(s);
     s->profiling.store(enable != 0);
     for (auto& x : s->sh) { (void)qv_index_profile(x.idx, enable); double ms; uint64_t n; (void)qv_index_profile_read(x.idx, &ms, &n); }
     std::lock_guard<std::mutex> g(s->prof_mu);
