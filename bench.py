@@ -794,6 +794,9 @@ def preflight_ranks(torch, dist, rank, world, device_id, backend, full):
 
 # ---------------------------------------------------------------------------------------------- one process, C-ABI sharding
 def run_abi_sharded(a):
+    # torch first, here as in the one-process-per-GPU mode: librccl / libamdhip64 resolve by soname to whatever the process loaded first, so
+    # both launch modes of this file run on the SAME pair (PyTorch's bundled one) and their N > 1 lines compare like with like
+    # (config.runtime names it; qv_sharded_create refuses a mixed pair)
     import torch
     import quiver_amd
     from quiver_amd.device_index import device_info, runtime_info
@@ -876,7 +879,9 @@ def run_abi_sharded(a):
                    "rows_total": a.rows, "rows_per_gpu": [sh.shard_info(g)["rows"] for g in range(G)], "dim": dim, "k": k,
                    "sharding": "C ABI qv_sharded_*: ONE process, a shard per device, %s of the per-shard top-k inside libqv, merge on the first device"
                                % ("hipMemcpyPeerAsync (point-to-point)" if a.peer_copy else "ncclAllGather (RCCL)"),
-                   "devices": devices, "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3), "runtime": short_runtime(runtime_info())},
+                   "devices": devices, "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3), "runtime": short_runtime(runtime_info()),
+                   # how many RCCL ranks took part in the exchange that was timed (0: point-to-point copies / one shard has nobody to talk to)
+                   "rccl_ranks_seen": 0 if a.peer_copy else G},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_flat_scan", "kernel_ms": kern_ms0, "algorithmic_bytes_per_launch": alg_bytes, "per_gpu": per_gpu,
                      "scan_phase_ms": prof["scan_ms"], "allgather_plus_merge_us": (prof["exchange_ms"] + prof["merge_ms"]) * 1e3,
@@ -1086,7 +1091,10 @@ def main():
                                     "exchange of step i overlaps scan of step i+1") if use_pg else "single shard",
                        "exchange": None if not use_pg else ("RCCL (torch.distributed nccl backend)" if backend == "nccl" else "gloo (ranks share a device: RCCL needs one device per rank)"),
                        "device": info["name"], "cus": info["cus"], "corpus_gen_s": round(t_gen, 3),
-                       "runtime": short_runtime(runtime_info())},
+                       "runtime": short_runtime(runtime_info()),
+                       # how many RCCL ranks took part in the all-gather that was timed: the process group's size when its backend is nccl
+                       # (= RCCL); 0 when the exchange ran over gloo or there was no exchange
+                       "rccl_ranks_seen": (dist.get_world_size() if (use_pg and backend == "nccl") else 0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_flat_scan", "kernel_ms": kern_ms, "launches_timed": launches,

@@ -389,7 +389,7 @@ static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, ui
             if (flag_used) *flag_used = nq == 1 && done_flag != nullptr;
             return QV_OK;
         }
-        hipError_t e = qv::launch_flat_topk(v, plan, d_queries, nq, kk, ws, d_rows_out, d_dist_out, s, ev0, ev1);
+        hipError_t e = qv::launch_flat_topk(v, plan, d_queries, nq, kk, ws, d_rows_out, d_dist_out, s, ev0, ev1, d_tickets);
         if (e != hipSuccess) return fail(QV_ERR_DEVICE, "flat scan launch failed: %s", hipGetErrorString(e));
         return QV_OK;
     }
@@ -474,10 +474,11 @@ static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, u
     // small collections: one launch for scan + merge, and the host polls a sequence number the kernel writes behind its results
     // instead of waiting for the stream
     uint32_t* tickets = nullptr; uint32_t* flag = nullptr; bool flag_used = false;
+    if (!c->tickets.p) { if ((rc = c->tickets.ensure(256))) return rc; HIPCHK(hipMemsetAsync(c->tickets.p, 0, 256, c->stream)); }   // (on the stream that reads them: see stream_workspace)
+    tickets = static_cast<uint32_t*>(c->tickets.p);                    // single-launch scans: the small collection's, and one query over a large one
     if (direct && q_direct) {
-        if (!c->tickets.p) { if ((rc = c->tickets.ensure(256))) return rc; HIPCHK(hipMemsetAsync(c->tickets.p, 0, 256, c->stream)); }   // (on the stream that reads them: see stream_workspace)
         if (!c->h_flag.p) { if ((rc = c->h_flag.ensure(64))) return rc; *static_cast<volatile uint32_t*>(c->h_flag.p) = 0; }
-        tickets = static_cast<uint32_t*>(c->tickets.p); flag = static_cast<uint32_t*>(c->h_flag.p);
+        flag = static_cast<uint32_t*>(c->h_flag.p);
         c->flag_seq++;
     }
     rc = enqueue_search(idx, static_cast<const float*>(q_direct ? c->h_q.p : c->d_q.p), nq, kk, kk, c->ws.p, c->ws.cap,

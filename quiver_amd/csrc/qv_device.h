@@ -116,9 +116,11 @@ hipError_t launch_fetch_rows(const IndexView& v, const uint32_t* d_rows, uint32_
 // d_ws: workspace of scan_workspace_bytes().  Writes d_rows_out/d_dist_out [nq][k]
 // (padded with 0xFFFFFFFF / +inf).
 // ev0/ev1 (optional): recorded immediately before/after the scan kernel on `s`.
+// d_tickets (optional): 64 zeroed words that belong to the caller's stream alone — with them a single query is ONE launch (the last
+// workgroup of the scan merges the lists); without, scan + k_merge_lists.
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
-                            hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                            hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, uint32_t* d_tickets = nullptr);
 // Small collections (<= 256 tiles, <= 4 queries, k <= 16): scan + merge in ONE launch (the last workgroup to finish merges).
 // d_ws: flat_small_workspace_bytes (partial lists); d_tickets: 64 zeroed words that belong to the caller's stream alone (the kernel
 // leaves them zero).  done_flag (optional, device-visible host memory): receives done_seq after the results have been written.

@@ -8,9 +8,16 @@ namespace qv {
 // grid = (workgroups, nq); each wave walks tiles gw, gw+tw, ... ; lane == row.
 // Output: partial[(q*gridDim.x + blockIdx.x)*k + i] = workgroup's i-th best key.
 
-template <int M, int U>
+__device__ void merge_lists_last_workgroup(const uint64_t* src, uint32_t n_lists, uint32_t k, uint32_t* rows_out, float* dist_out);
+
+// FUSE: the workgroups publish their lists with returning atomic exchanges and take a ticket; the LAST one to finish merges all of
+// them (k_merge_lists' own code) and writes the final rows / distances — one launch per query instead of two (round 5: a single
+// query over 1M x 768 is 0.44 ms of scan; the second launch and the gap in front of it were 2 % of it).  tickets[qi]: zero before
+// the first launch, left zero.  Nothing crosses workgroups through a fence (see k_flat_scan_small).
+template <int M, int U, bool FUSE = false>
 __global__ void __launch_bounds__(kScanBlock)
-k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t* __restrict__ partial) {
+k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t* __restrict__ partial,
+            uint32_t* __restrict__ tickets = nullptr, uint32_t* __restrict__ rows_out = nullptr, float* __restrict__ dist_out = nullptr) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
@@ -60,7 +67,24 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
             uint64_t key = lane < k ? wl[w * 64 + lane] : kDeadKey;
             list_insert(list, thr, key, kth, lane);
         }
-        if (lane < k) partial[((size_t)qi * gridDim.x + blockIdx.x) * k + lane] = list;
+        if constexpr (!FUSE) {
+            if (lane < k) partial[((size_t)qi * gridDim.x + blockIdx.x) * k + lane] = list;
+        } else {
+            uint64_t* mine = partial + ((size_t)qi * gridDim.x + blockIdx.x) * k;
+            if (lane < k) (void)atomicExch(reinterpret_cast<unsigned long long*>(&mine[lane]), (unsigned long long)list);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every lane's exchange has returned: the list is at the memory side
+            uint32_t last = 0;
+            if (lane == 0) last = atomicAdd(&tickets[qi], 1u) == gridDim.x - 1 ? 1u : 0u;
+            last = __builtin_amdgcn_readfirstlane(last);
+            if (last && lane == 0) tickets[qi] = 0;                    // for the next launch on this workspace (stream order)
+            if (lane == 0) wl[0] = last;
+        }
+    }
+    if constexpr (FUSE) {
+        __syncthreads();
+        if (!(uint32_t)wl[0]) return;
+        __syncthreads();                                               // (wl is the merge's scratch next)
+        merge_lists_last_workgroup(partial + (size_t)qi * gridDim.x * k, gridDim.x, k, rows_out + (size_t)qi * k, dist_out + (size_t)qi * k);
     }
 }
 
@@ -472,9 +496,16 @@ constexpr int kMergeCap = 2048;                       // survivors kept in LDS; 
 constexpr int kMergeHeads = 128;                      // sampled list heads ranked in LDS
 
 
-__global__ void __launch_bounds__(kMergeBlock)
-k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k,
-              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+// The merge itself, for one query: src = its n_lists lists of k keys, rows_out / dist_out = its k results.  AT: the lists were
+// published by other workgroups of the SAME launch (returning atomic exchanges, then a ticket: k_flat_scan<., ., true>) and are read
+// with agent-scope atomic loads; otherwise by an earlier launch, and plain loads do.
+template <bool AT>
+__device__ void merge_lists_body(const uint64_t* __restrict__ src, uint32_t n_lists, uint32_t k, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+    auto ld = [](const uint64_t* p) -> uint64_t {
+        if constexpr (AT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *p;
+    };
+
     __shared__ uint64_t wl[kMergeBlock / 64][64];
     __shared__ uint64_t surv[kMergeCap];
     __shared__ uint32_t hd[kMergeHeads], hlt[kMergeHeads], hle[kMergeHeads];
@@ -483,8 +514,6 @@ k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nw = blockDim.x >> 6;
-    const uint32_t qi = blockIdx.x;
-    const uint64_t* src = partial + (size_t)qi * n_lists * k;
     const uint32_t total = n_lists * k;
     const uint32_t kth = k - 1;
 
@@ -493,7 +522,7 @@ k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k
     const bool small = total <= blockDim.x * 8;
     uint64_t mine[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { uint32_t i = u * blockDim.x + threadIdx.x; mine[u] = (small && i < total) ? src[i] : kDeadKey; }
+    for (int u = 0; u < 8; u++) { uint32_t i = u * blockDim.x + threadIdx.x; mine[u] = (small && i < total) ? ld(src + i) : kDeadKey; }
     // sampled heads: m = min(n_lists, kMergeHeads) lists at a fixed stride.  Any k different
     // lists each hold a key <= the k-th smallest of their heads, so a subset still gives a
     // valid (slightly looser) bound, and the O(m^2) rank count stays ~0.5 us on one CU.
@@ -501,9 +530,9 @@ k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k
     const uint32_t hstride = n_lists / m;
     const bool use_heads = m >= k;
     uint64_t b = kDeadKey;
-    for (uint32_t w = threadIdx.x; w < n_lists; w += blockDim.x) { uint64_t x = src[(size_t)w * k + kth]; b = x < b ? x : b; }
+    for (uint32_t w = threadIdx.x; w < n_lists; w += blockDim.x) { uint64_t x = ld(src + (size_t)w * k + kth); b = x < b ? x : b; }
     if (use_heads)
-        for (uint32_t w = threadIdx.x; w < m; w += blockDim.x) { hd[w] = (uint32_t)(src[(size_t)w * hstride * k] >> 32); hlt[w] = 0; hle[w] = 0; }
+        for (uint32_t w = threadIdx.x; w < m; w += blockDim.x) { hd[w] = (uint32_t)(ld(src + (size_t)w * hstride * k) >> 32); hlt[w] = 0; hle[w] = 0; }
 
     // phase A: two upper bounds of the final k-th key.
     //   B0 = min over lists of their k-th key (that list alone has k keys <= B0);
@@ -562,7 +591,7 @@ k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k
         for (uint32_t base = 0; base < total; base += blockDim.x * 8) {
             uint64_t key[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { uint32_t i = base + u * blockDim.x + threadIdx.x; key[u] = i < total ? src[i] : kDeadKey; }
+            for (int u = 0; u < 8; u++) { uint32_t i = base + u * blockDim.x + threadIdx.x; key[u] = i < total ? ld(src + i) : kDeadKey; }
 #pragma unroll
             for (int u = 0; u < 8; u++) keep(key[u]);
         }
@@ -588,7 +617,7 @@ k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k
         // reduces a slice, wave 0 merges the waves
         for (uint32_t base = wave * 64; base < total; base += nw * 64) {
             uint32_t i = base + lane;
-            uint64_t key = i < total ? src[i] : kDeadKey;
+            uint64_t key = i < total ? ld(src + i) : kDeadKey;
             list_insert(list, thr, key, kth, lane);
         }
         wl[wave][lane] = list;
@@ -601,9 +630,21 @@ k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k
     }
     if (lane < k) {
         bool dead = list == kDeadKey;
-        rows_out[(size_t)qi * k + lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
-        dist_out[(size_t)qi * k + lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+        rows_out[lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
+        dist_out[lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
     }
+}
+
+
+__global__ void __launch_bounds__(kMergeBlock)
+k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k,
+              uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+    const uint32_t qi = blockIdx.x;
+    merge_lists_body<false>(partial + (size_t)qi * n_lists * k, n_lists, k, rows_out + (size_t)qi * k, dist_out + (size_t)qi * k);
+}
+// (out of line: the scan's loop keeps its own register allocation and schedule — tests/test_isa_guard.py counts its loads in flight)
+__device__ __noinline__ void merge_lists_last_workgroup(const uint64_t* src, uint32_t n_lists, uint32_t k, uint32_t* rows_out, float* dist_out) {
+    merge_lists_body<true>(src, n_lists, k, rows_out, dist_out);
 }
 
 // merge of (distance, row) pair lists, e.g. the all-gathered per-shard top-k of a sharded scan
@@ -778,7 +819,7 @@ hipError_t launch_flat_wide(const IndexView& v, const ScanPlan& p, const float* 
 
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
-                            hipEvent_t ev0, hipEvent_t ev1) {
+                            hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_tickets) {
     if (k == 0 || k > (uint32_t)kMaxFusedK || nq == 0) return hipErrorInvalidValue;
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
     uint64_t* partial = static_cast<uint64_t*>(d_ws);
@@ -804,10 +845,10 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
             // HBM-bound pass of k_flat_scan_mq (0.45-0.65 ms): split it off.  Same stream, so the workspace is reused in order.
             const uint32_t rem = nq & 31u;
             if (nq > 32 && rem >= 1 && rem <= 8) {
-                e = launch_flat_topk(v, p, d_queries, nq - rem, k, d_ws, d_rows_out, d_dist_out, s, ev0, ev1);
+                e = launch_flat_topk(v, p, d_queries, nq - rem, k, d_ws, d_rows_out, d_dist_out, s, ev0, ev1, nullptr);
                 if (e != hipSuccess) return e;
                 return launch_flat_topk(v, p, d_queries + (size_t)(nq - rem) * v.dim, rem, k, d_ws, d_rows_out + (size_t)(nq - rem) * k,
-                                        d_dist_out + (size_t)(nq - rem) * k, s, nullptr, nullptr);
+                                        d_dist_out + (size_t)(nq - rem) * k, s, nullptr, nullptr, nullptr);
             }
             uint32_t g64 = 0;
             if (trace) fprintf(stderr, "qv: scan kernel = k_flat_scan_mq64 (nq=%u, tiles=%u)\n", nq, v.n_tiles);
@@ -848,16 +889,31 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
 #define QV_SCAN_U(UU)                                                                                             \
         case UU: e = set_lds(k_flat_scan<QV_COSINE, UU>, lds); if (e != hipSuccess) return e;                    \
             if (ev0) (void)hipEventRecord(ev0, s);                                                                \
-            hipLaunchKernelGGL((k_flat_scan<QV_COSINE, UU>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial); \
+            hipLaunchKernelGGL((k_flat_scan<QV_COSINE, UU>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial, (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr); \
             if (ev1) (void)hipEventRecord(ev1, s); break;
         switch (unroll) { QV_SCAN_U(4) QV_SCAN_U(8) QV_SCAN_U(12) QV_SCAN_U(24) QV_SCAN_U(32) default: return hipErrorInvalidValue; }
 #undef QV_SCAN_U
     } else
+    {
+        // one query, the caller's tickets at hand: scan + merge in ONE launch (the last workgroup merges).  QV_SCAN_FUSE=0 (read once)
+        // keeps the two launches, for measurements.
+        static const int fuse = env_int("QV_SCAN_FUSE", 1);
+        if (d_tickets && nq == 1 && fuse && p.grid > 1) {
+            QV_DISPATCH_METRIC(v.metric, {
+                e = set_lds((k_flat_scan<MM, kUnroll, true>), lds);
+                if (e != hipSuccess) return e;
+                if (ev0) (void)hipEventRecord(ev0, s);
+                hipLaunchKernelGGL((k_flat_scan<MM, kUnroll, true>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial, d_tickets, d_rows_out, d_dist_out);
+                if (ev1) (void)hipEventRecord(ev1, s);
+            });
+            return hipGetLastError();
+        }
+    }
     QV_DISPATCH_METRIC(v.metric, {
         e = set_lds(k_flat_scan<MM, kUnroll>, lds);
         if (e != hipSuccess) return e;
         if (ev0) (void)hipEventRecord(ev0, s);
-        hipLaunchKernelGGL((k_flat_scan<MM, kUnroll>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial);
+        hipLaunchKernelGGL((k_flat_scan<MM, kUnroll>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial, (uint32_t*)nullptr, (uint32_t*)nullptr, (float*)nullptr);
         if (ev1) (void)hipEventRecord(ev1, s);
     });
     e = hipGetLastError();

@@ -23,9 +23,9 @@ def test_every_metric_keeps_16_loads_in_flight(tmp_path):
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", asm, src],
                    check=True, capture_output=True, text=True, cwd=os.path.dirname(src))
     text = open(asm).read()
-    for metric in range(9):
-        m = re.search(r"^_ZN2qv11k_flat_scanILi%dELi16EEEv\w*:[^\n]*\n(.*?)\n\s+s_endpgm" % metric, text, re.S | re.M)
-        assert m, "k_flat_scan<%d,16> not found" % metric
+    for metric, fused in [(m_, f_) for m_ in range(9) for f_ in (0, 1)]:      # fused: the single-launch form (the last workgroup merges), round 5
+        m = re.search(r"^_ZN2qv11k_flat_scanILi%dELi16ELb%dEEEv\w*:[^\n]*\n(.*?)\n\s+s_endpgm" % (metric, fused), text, re.S | re.M)
+        assert m, "k_flat_scan<%d,16,%d> not found" % (metric, fused)
         # outstanding vector loads along the instruction stream: +1 per row-chunk load, clipped by every s_waitcnt vmcnt(N)
         best = out = 0
         for line in m.group(1).split("\n"):
