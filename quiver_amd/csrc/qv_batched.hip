@@ -1652,67 +1652,12 @@ k_sample_bound(const float* __restrict__ bounds, uint32_t srows, uint32_t k, flo
 // e_r its error bound, d_r is in [d~ - e_r, d~ + e_r]; let H be the k-th smallest upper bound
 // over the candidates (which contain the true top-k).  Then the true k-th distance is <= H, so
 // only candidates with lower bound <= H can be in the answer — typically k..k+2 of hundreds.
-// ---- a group of rows out of the tile layout, all of their lines in flight at once ------------------------------------------------
-// A row in the tile layout is dim4 pieces of 16 bytes, one memory line each (chunk c of row r sits between the same chunk of the 63 other
-// rows of its tile).  A lane that walks its own row asks for them U at a time and waits U / dim4 times for a whole round trip, with
-// nothing of the next round in flight: 6 dependent rounds per survivor at U = 32, ~35 us of k_rescore_select's 51.  Here the workgroup's
-// 256 threads request EVERY piece of a group of R rows together (24 requests each for 32 rows x 768 dimensions), park them in LDS as a
-// miniature tile [chunk][R slots] — the request of thread t lands at slot t of its round, a contiguous write — and after one barrier
-// lane j of one wave walks row j from LDS: the same values in the same order through the same acc1, one round trip instead of six.
-// (The bytes do not change: a piece still comes with the 112 bytes of its line's other rows.  What changes is how long they take.)
-static inline uint32_t gather_group_rows(uint32_t dim4, size_t budget_bytes) {
-    uint32_t r = 64;
-    while (r >= 8 && (size_t)dim4 * r * 16 > budget_bytes) r >>= 1;
-    return r >= 8 ? r : 0;
-}
-constexpr size_t kGatherLdsBudget = 96 * 1024;
-
-// all 256 threads: rows_lds[0 .. n) (n <= R; R a power of two, 8 <= R <= 64) -> buf[c * R + j] = chunk c of row j
-__device__ __forceinline__ void gather_group_load(const IndexView& v, const uint32_t* rows_lds, uint32_t n, uint32_t R, f4* buf) {
-    const uint32_t t = threadIdx.x, j = t & (R - 1), c_first = t / R, c_step = 256 / R;
-    if (j >= n) return;
-    const uint32_t row = rows_lds[j];
-    const f4* src = reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63);
-    constexpr int B = 24;                                              // requests per thread and round: 32 rows x 768 dimensions in one round
-    for (uint32_t c0 = c_first; c0 < v.dim4; c0 += B * c_step) {
-        f4 x[B];
-#pragma unroll
-        for (int u = 0; u < B; u++) { const uint32_t c = c0 + (uint32_t)u * c_step; if (c < v.dim4) x[u] = __builtin_nontemporal_load(&src[(size_t)c * 64]); }
-        __builtin_amdgcn_sched_barrier(0);                             // every request of the round before the first wait
-#pragma unroll
-        for (int u = 0; u < B; u++) { const uint32_t c = c0 + (uint32_t)u * c_step; if (c < v.dim4) buf[(size_t)c * R + j] = x[u]; }
-    }
-}
-// lane j of ONE wave: row j of the group from LDS, the scan's arithmetic in the scan's order
-template <int M>
-__device__ __forceinline__ typename MT<M>::A gather_group_walk(const f4* buf, uint32_t R, uint32_t j, const typename MT<M>::Q* q_lds, uint32_t dim4) {
-    typename MT<M>::A acc = 0;
-    uint32_t c = 0;
-    for (; c + 8 <= dim4; c += 8) {
-        f4 x[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = buf[(size_t)(c + u) * R + j];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const typename MT<M>::Q* qq = q_lds + (size_t)(c + u) * 4;
-            acc1<M>(acc, qq[0], x[u].x); acc1<M>(acc, qq[1], x[u].y); acc1<M>(acc, qq[2], x[u].z); acc1<M>(acc, qq[3], x[u].w);
-        }
-    }
-    for (; c < dim4; c++) {
-        const f4 x = buf[(size_t)c * R + j];
-        const typename MT<M>::Q* qq = q_lds + (size_t)c * 4;
-        acc1<M>(acc, qq[0], x.x); acc1<M>(acc, qq[1], x.y); acc1<M>(acc, qq[2], x.z); acc1<M>(acc, qq[3], x.w);
-    }
-    return acc;
-}
-
 // Stage 2 re-scores those exactly (same arithmetic as k_flat_scan) and sorts them.
 template <int M, int U>
 __global__ void __launch_bounds__(256)
 k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_score,
                  const uint32_t* __restrict__ cand_cnt, uint32_t k, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out,
-                 uint32_t* __restrict__ overflow, const float* __restrict__ eq /*[nq][2]: |S~ - S| <= eq[0] |r| + eq[1] |r - rh| (k_mfma_prep)*/,
-                 uint32_t grp_rows /* stage 2: survivors per cooperative gather (gather_group_rows; 0 = a lane per row, rounds of U requests) */) {
+                 uint32_t* __restrict__ overflow, const float* __restrict__ eq /*[nq][2]: |S~ - S| <= eq[0] |r| + eq[1] |r - rh| (k_mfma_prep)*/) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
@@ -1800,29 +1745,6 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 
     // ---- stage 2: exact distances of the survivors, top-k by (distance, row)
     list = kDeadKey; thr = kDeadKey;
-    if (grp_rows != 0 && v.rowmaj == nullptr) {
-        // groups of grp_rows survivors, every piece of their rows requested at once by the whole workgroup (gather_group_load); the
-        // buffer takes the place of the lower bounds and the upper bounds' keys, which are done with
-        f4* gbuf = reinterpret_cast<f4*>(lo_l);
-        bool seeded = false;
-        for (uint32_t base = 0, g = 0; base < ns; base += grp_rows, g++) {
-            const uint32_t n = ns - base < grp_rows ? ns - base : grp_rows;
-            gather_group_load(v, surv + base, n, grp_rows, gbuf);
-            __syncthreads();
-            if (wave == (g & 3u)) {                                    // the waves take turns: each keeps a list of its own, merged below
-                uint64_t key = kDeadKey;
-                if (lane < n) {
-                    const uint32_t row = surv[base + lane];
-                    const typename MT<M>::A acc = gather_group_walk<M>(gbuf, grp_rows, lane, q_lds, v.dim4);
-                    double rn = 0.0;
-                    if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
-                    key = make_key(finalize<M>(acc, qc, rn), row);
-                }
-                if (!seeded) { list_seed(list, thr, key, kth, lane); seeded = true; } else list_insert(list, thr, key, kth, lane);
-            }
-            __syncthreads();
-        }
-    } else
     for (uint32_t base = wave * 64; base < ns; base += 4 * 64) {
         const uint32_t i = base + lane;
         uint64_t key = kDeadKey;
@@ -1979,7 +1901,7 @@ k_cand_survive(const uint32_t* __restrict__ cand_rows, const uint32_t* __restric
 template <int M, int U>
 __global__ void __launch_bounds__(256)
 k_cand_exact(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ surv, const uint32_t* __restrict__ n_surv, uint32_t cap,
-             const double* __restrict__ qnorms, uint64_t* __restrict__ keys_ex, uint32_t grp_rows /* gather_group_rows; 0 = a lane per row */) {
+             const double* __restrict__ qnorms, uint64_t* __restrict__ keys_ex) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
@@ -1992,37 +1914,12 @@ k_cand_exact(IndexView v, const float* __restrict__ queries, const uint32_t* __r
 #endif
     if (blockIdx.y * blockDim.x >= ns) { if (i < cap) keys_ex[(size_t)q * cap + i] = kDeadKey; return; }
     stage_query<M>(q_lds, queries + (size_t)q * v.dim, v.dim, v.dim4);
-    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
-    if constexpr (M == QV_COSINE) qc.qn = qnorms[2 * q + 1];
-    if (grp_rows != 0 && v.rowmaj == nullptr) {
-        // this workgroup's 256 survivors in groups whose rows' pieces are requested all at once (gather_group_load): one round trip per
-        // group instead of dim4 / U dependent ones per row — k = 100: 230 us of the batch were this kernel
-        __shared__ uint32_t rows_l[256];
-        f4* gbuf = reinterpret_cast<f4*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);
-        const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const uint32_t base0 = blockIdx.y * blockDim.x, mine = ns - base0 < 256u ? ns - base0 : 256u;
-        rows_l[threadIdx.x] = threadIdx.x < mine ? surv[(size_t)q * cap + base0 + threadIdx.x] : 0u;
-        if (i < cap && threadIdx.x >= mine) keys_ex[(size_t)q * cap + i] = kDeadKey;
-        __syncthreads();
-        for (uint32_t b = 0, g = 0; b < mine; b += grp_rows, g++) {
-            const uint32_t n = mine - b < grp_rows ? mine - b : grp_rows;
-            gather_group_load(v, rows_l + b, n, grp_rows, gbuf);
-            __syncthreads();
-            if (wave == (g & 3u) && lane < n) {
-                const uint32_t row = rows_l[b + lane];
-                const typename MT<M>::A acc = gather_group_walk<M>(gbuf, grp_rows, lane, q_lds, v.dim4);
-                double rn = 0.0;
-                if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
-                keys_ex[(size_t)q * cap + base0 + b + lane] = make_key(finalize<M>(acc, qc, rn), row);
-            }
-            __syncthreads();
-        }
-        return;
-    }
     __syncthreads();
     uint64_t key = kDeadKey;
     if (i < ns) {
         const uint32_t row = surv[(size_t)q * cap + i];
+        QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+        if constexpr (M == QV_COSINE) qc.qn = qnorms[2 * q + 1];
         typename MT<M>::A acc;
         if (v.rowmaj != nullptr && (v.dim & 3) == 0) acc = row_accumulate<M, U, false, true>(reinterpret_cast<const f4*>(v.rowmaj + (size_t)row * v.dim), 1, q_lds, v.dim4);
         else acc = row_accumulate<M, U, false, true>(reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63), 64, q_lds, v.dim4);
@@ -2306,19 +2203,14 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     else hipLaunchKernelGGL(k_mfma_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter
     if (ev1) (void)hipEventRecord(ev1, s);
     // 4. exact re-scoring + selection
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * (sizeof(uint32_t) + sizeof(float) + sizeof(uint32_t));   // query, wave lists, survivors, lower bounds, upper bounds' keys
     // chunk requests per round of the exact pass, all issued before the round's arithmetic (row_accumulate's BAR): a survivor's row is
     // a gather of dim4 separate lines and the pass is a chain of dim4 / U dependent round trips — 8 / 16 / 32 / 48 / 64 per round:
     // 64.4 / 58.0 / 54.2 / 55.3 / 55.6 us per launch at 256 x 1M x 768 (left to the compiler's own schedule, as the streaming scans
     // are for cosine, deeper rounds were slower: 90 us at 16)
     static const int rs_u = env_int("QV_MFMA_RESCORE_U", 32);
-    // stage 2 by cooperative gathers (round 5): groups of grp survivors whose rows fit 96 KiB of LDS, in place of the lower / upper bound arrays
-    // (QV_MFMA_RESCORE_GATHER=2, read once: a lane per row in rounds of U requests, as before)
-    static const int rs_gather = env_int("QV_MFMA_RESCORE_GATHER", 1);
-    const uint32_t grp = rs_gather == 1 && v.rowmaj == nullptr ? gather_group_rows(v.dim4, kGatherLdsBudget) : 0u;
-    const size_t lds_rs = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * sizeof(uint32_t) +
-                          std::max((size_t)kMfmaCandCap * (sizeof(float) + sizeof(uint32_t)), (size_t)grp * v.dim4 * 16);
-#define QV_RS1(MMM, UU) { e = set_lds(k_rescore_select<MMM, UU>, lds_rs); if (e != hipSuccess) return e;                                   \
-        hipLaunchKernelGGL((k_rescore_select<MMM, UU>), dim3(nq), dim3(256), lds_rs, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, eq, grp); }
+#define QV_RS1(MMM, UU) { e = set_lds(k_rescore_select<MMM, UU>, lds); if (e != hipSuccess) return e;                                   \
+        hipLaunchKernelGGL((k_rescore_select<MMM, UU>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, eq); }
 #define QV_RS(MMM) { if (rs_u == 8) QV_RS1(MMM, 8) else QV_RS1(MMM, 32) }
     if (large_k) {
         // intervals -> H (k-th smallest upper bound) -> survivors -> exact distances -> the k best; srows / sdist take the first
@@ -2330,8 +2222,8 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         hipLaunchKernelGGL(k_cand_bounds<MMM>, cgrid, dim3(256), 0, s, v, cand, cscore, cnt, ccap, eq, qnorms, keys_hi, lo_b, ovf, nsurv);                 \
         e = launch_select_topk(keys_hi, ccap, ccap, nq, k, k, sel_ws, srows, sdist, s, false, false); if (e != hipSuccess) return e;                       \
         hipLaunchKernelGGL(k_cand_survive, cgrid, dim3(256), 0, s, cand, cnt, ccap, lo_b, sdist, k, surv, nsurv);                                          \
-        e = set_lds(k_cand_exact<MMM, 32>, lds_x + (size_t)grp * v.dim4 * 16); if (e != hipSuccess) return e;                                              \
-        hipLaunchKernelGGL((k_cand_exact<MMM, 32>), dim3(nq, (ccap + 255) / 256), dim3(256), lds_x + (size_t)grp * v.dim4 * 16, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex, grp); \
+        e = set_lds(k_cand_exact<MMM, 32>, lds_x); if (e != hipSuccess) return e;                                                                           \
+        hipLaunchKernelGGL((k_cand_exact<MMM, 32>), dim3(nq, (ccap + 255) / 256), dim3(256), lds_x, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex);                         \
         e = launch_select_topk(keys_ex, ccap, ccap, nq, k, k, sel_ws, d_rows_out, d_dist_out, s, false, false); if (e != hipSuccess) return e; }
         if (v.metric == QV_COSINE) QV_LK(QV_COSINE) else if (v.metric == QV_DOT) QV_LK(QV_DOT) else if (v.metric == QV_L2) QV_LK(QV_L2) else QV_LK(QV_L2SQ)
 #undef QV_LK
