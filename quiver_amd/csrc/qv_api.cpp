@@ -699,6 +699,25 @@ int qv_internal_search_candidates_device(qv_index* idx, const float* d_queries, 
     return enqueue_search(idx, d_queries, nq, kk, k_stride, ws, 0, d_rows_out, d_dist_out, s, d_candidates);
 }
 
+// Internal, for the sharded handle: the exact scan for the queries of a batch whose d_flags word is set (handed back by
+// qv_index_search_batched_device), enqueued on `stream` behind the batch — listed and scanned on the device, nothing read back.
+int qv_internal_redo_flagged_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_flags,
+                                    uint32_t* d_rows_out, float* d_dist_out, void* stream) {
+    if (!idx || !d_queries || !d_flags || !d_rows_out || !d_dist_out || k == 0 || k > (uint32_t)qv::kMaxFusedK) return fail(QV_ERR_INVALID_ARG, "bad argument");
+    if (nq == 0) return QV_OK;
+    HIPCHK(hipSetDevice(idx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const qv::IndexView v = idx->view();
+    const qv::ScanPlan plan = qv::plan_scan(v.n_tiles, idx->cus);
+    void* ws = nullptr;
+    std::unique_lock<std::mutex> ws_hold;
+    int rc = stream_workspace(idx, s, qv::redo_workspace_bytes(plan, nq, k), &ws, &ws_hold);
+    if (rc != QV_OK) return rc;
+    hipError_t e = qv::launch_flat_redo_flagged(v, plan, d_queries, nq, k, k, d_flags, ws, d_rows_out, d_dist_out, s);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "redo launch failed: %s", hipGetErrorString(e));
+    return QV_OK;
+}
+
 void qv_internal_drop_stream_workspace(qv_index* idx, void* stream) {
     if (!idx) return;
     Workspace* w = nullptr;

@@ -56,6 +56,10 @@ struct Workspace { Buf ws; Buf tickets; std::mutex mu; };      // tickets: 64 ze
 int qv_internal_search_candidates_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k_stride, const uint64_t* d_candidates,
                                          uint64_t matching, uint32_t* d_rows_out, float* d_dist_out, void* stream);
 
+// qv_api.cpp, for qv_sharded_api.cpp: the exact scan for the flagged queries of a batch, decided on the device (see the definition)
+int qv_internal_redo_flagged_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_flags,
+                                    uint32_t* d_rows_out, float* d_dist_out, void* stream);
+
 // qv_api.cpp, for qv_sharded_api.cpp: forget (and free) the workspace the *_device entry points keep for `stream` — called when a
 // call context of the sharded handle, and with it the stream, goes away
 void qv_internal_drop_stream_workspace(qv_index* idx, void* stream);

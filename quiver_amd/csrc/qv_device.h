@@ -121,6 +121,11 @@ hipError_t launch_fetch_rows(const IndexView& v, const uint32_t* d_rows, uint32_
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
                             hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, uint32_t* d_tickets = nullptr);
+// The exact scan (k <= kMaxFusedK) for exactly the queries whose d_flags word is non-zero — the ones a filter handed back —, listed and
+// scanned on the device: nothing is read back.  Results replace rows / distances [q][k_stride] of those queries.  d_ws: redo_workspace_bytes.
+size_t redo_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k);
+hipError_t launch_flat_redo_flagged(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k, uint32_t k_stride, const uint32_t* d_flags,
+                                    void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 // Small collections (<= 256 tiles, <= 4 queries, k <= 16): scan + merge in ONE launch (the last workgroup to finish merges).
 // d_ws: flat_small_workspace_bytes (partial lists); d_tickets: 64 zeroed words that belong to the caller's stream alone (the kernel
 // leaves them zero).  done_flag (optional, device-visible host memory): receives done_seq after the results have been written.

@@ -88,6 +88,100 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
     }
 }
 
+// ---------------------------------------------------------------- queries a filter handed back, redone WITHOUT the host --
+// The matrix-core filter hands a query back when its candidate buffer overflows (flags[q] != 0: a loose sample bound, e.g. a corpus
+// stored cluster by cluster); such a query needs the exact scan.  Until round 5 the callers read the flags on the host — one round trip
+// per batch (and per shard: qv_sharded_search_device was synchronous for 9+ queries because of it).  Here: k_redo_compact lists the
+// flagged queries and zeroes their tickets; k_flat_scan_redo — a FIXED launch of grid workgroups, each of which leaves at once when the
+// list is empty — walks the listed queries one after another: per query the flat scan's own loop over the workgroup's tiles, the
+// lists published with returning atomic exchanges, a ticket, and the LAST workgroup merges and writes the query's k results in place
+// of what the filter left there (k_flat_scan<., ., true>'s protocol, once per listed query).  A launch serves kRedoSlots list entries
+// from `first` on (its lists live in [slot][grid][k] of the workspace); the launcher issues ceil(nq / kRedoSlots) of them, all but the
+// needed ones empty: nothing is decided on the host.
+constexpr uint32_t kRedoSlots = 64;
+__global__ void k_redo_compact(const uint32_t* __restrict__ flags, uint32_t nq, uint32_t* __restrict__ list, uint32_t* __restrict__ count /* [0] count, [1 ..] tickets [nq] */) {
+    // one workgroup, in query order (a wave at a time: ballot + prefix popcount)
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nq; base += blockDim.x) {
+        const uint32_t q = base + threadIdx.x;
+        const bool f = q < nq && flags[q] != 0;
+        const uint64_t m = __ballot(f);
+        const uint32_t lane = lane_id();
+        __shared__ uint32_t w_off[16];
+        const uint32_t wave = threadIdx.x >> 6;
+        if (lane == 0) w_off[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        uint32_t before = s_n;
+        for (uint32_t w = 0; w < wave; w++) before += w_off[w];
+        if (f) list[before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = q;
+        if (q < nq) count[1 + q] = 0;                                  // tickets
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < (blockDim.x >> 6); w++) t += w_off[w]; s_n += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = s_n;
+}
+
+template <int M, int U>
+__global__ void __launch_bounds__(kScanBlock)
+k_flat_scan_redo(IndexView v, const float* __restrict__ queries, uint32_t k, uint32_t k_stride, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                 uint32_t first, uint64_t* __restrict__ partial /* [kRedoSlots][grid][k] */, uint32_t* __restrict__ tickets /* [nq] by list position */,
+                 uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+    using Q = typename MT<M>::Q;
+    const uint32_t n = count[0];
+    if (first >= n) return;                                           // (the usual case: nothing was handed back)
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16);  // [kScanWaves][64]
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tw = gridDim.x * kScanWaves, kth = k - 1;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t last_j = n < first + kRedoSlots ? n : first + kRedoSlots;
+    for (uint32_t j = first; j < last_j; j++) {
+        const uint32_t qi = list[j];
+        __syncthreads();                                               // (q_lds and wl are reused from the previous entry)
+        stage_query<M>(q_lds, queries + (size_t)qi * v.dim, v.dim, v.dim4);
+        __syncthreads();
+        uint64_t lst = kDeadKey, thr = kDeadKey;
+        QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+        bool first_tile = true;
+        for (uint32_t t = blockIdx.x * kScanWaves + wave; t < v.n_tiles; t += tw) {
+            typename MT<M>::A qn2 = 0, acc;
+            if (first_tile) { acc = row_accumulate<M, U, true>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4, &qn2); qc = qconst_from_norm2<M>(qn2); }
+            else acc = row_accumulate<M, U, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4);
+            const uint32_t row = t * 64 + lane;
+            double rn = 0.0;
+            if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[row];
+            const float dist = finalize<M>(acc, qc, rn);
+            const uint64_t am = v.alive[t];
+            const uint64_t key = ((am >> lane) & 1ull) ? make_key(dist, row) : kDeadKey;
+            if (first_tile) { lst = wave_sort64(key, lane); thr = readlane64(lst, kth); first_tile = false; }
+            else list_insert(lst, thr, key, kth, lane);
+        }
+        wl[wave * 64 + lane] = lst;
+        __syncthreads();
+        uint64_t* slot = partial + (size_t)(j - first) * gridDim.x * k;
+        if (wave == 0) {
+            for (uint32_t w = 1; w < kScanWaves; w++) list_insert(lst, thr, lane < k ? wl[w * 64 + lane] : kDeadKey, kth, lane);
+            uint64_t* mine = slot + (size_t)blockIdx.x * k;
+            if (lane < k) (void)atomicExch(reinterpret_cast<unsigned long long*>(&mine[lane]), (unsigned long long)lst);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every lane's exchange has returned: the list is at the memory side
+            uint32_t last = 0;
+            if (lane == 0) last = atomicAdd(&tickets[j], 1u) == gridDim.x - 1 ? 1u : 0u;
+            last = __builtin_amdgcn_readfirstlane(last);
+            if (lane == 0) wl[0] = last;
+        }
+        __syncthreads();
+        if ((uint32_t)wl[0]) {
+            __syncthreads();
+            merge_lists_last_workgroup(slot, gridDim.x, k, rows_out + (size_t)qi * k_stride, dist_out + (size_t)qi * k_stride);
+        }
+    }
+}
+
 __device__ __forceinline__ uint64_t wave_min64(uint64_t x) {
 #pragma unroll
     for (int off = 32; off; off >>= 1) {
@@ -924,5 +1018,30 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
     return hipGetLastError();
 }
 
+
+
+// the exact scan for the queries whose flags are set, decided and listed on the device (see k_flat_scan_redo)
+size_t redo_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k) {
+    return ((size_t)kRedoSlots * p.grid * k * sizeof(uint64_t) + 255) / 256 * 256 + ((size_t)nq * 4 + 255) / 256 * 256 + ((size_t)(nq + 1) * 4 + 255) / 256 * 256;
+}
+hipError_t launch_flat_redo_flagged(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k, uint32_t k_stride, const uint32_t* d_flags,
+                                    void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    if (k == 0 || k > (uint32_t)kMaxFusedK || nq == 0) return hipErrorInvalidValue;
+    char* w = static_cast<char*>(d_ws);
+    uint64_t* partial = reinterpret_cast<uint64_t*>(w); w += ((size_t)kRedoSlots * p.grid * k * sizeof(uint64_t) + 255) / 256 * 256;
+    uint32_t* list = reinterpret_cast<uint32_t*>(w); w += ((size_t)nq * 4 + 255) / 256 * 256;
+    uint32_t* count = reinterpret_cast<uint32_t*>(w);
+    hipLaunchKernelGGL(k_redo_compact, dim3(1), dim3(1024), 0, s, d_flags, nq, list, count);
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
+    hipError_t e = hipSuccess;
+    for (uint32_t first = 0; first < nq; first += kRedoSlots) {
+        QV_DISPATCH_METRIC(v.metric, {
+            e = set_lds((k_flat_scan_redo<MM, kUnroll>), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_flat_scan_redo<MM, kUnroll>), dim3(p.grid), dim3(p.block), lds, s, v, d_queries, k, k_stride, list, count, first, partial, count + 1, d_rows_out, d_dist_out);
+        });
+    }
+    return hipGetLastError();
+}
 
 }  // namespace qv

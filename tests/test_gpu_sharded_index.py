@@ -195,3 +195,44 @@ def test_concurrent_searches_on_one_handle(n_shards):
         t.join()
     assert errs == []
     sh.close()
+
+
+def test_batch_with_queries_the_filter_hands_back_is_redone_on_the_device_without_a_host_round_trip():
+    """A corpus stored cluster by cluster makes the matrix-core filter hand some queries back (candidate overflow); on a sharded handle
+    those are listed and re-scanned exactly ON THE DEVICE (k_redo_compact + k_flat_scan_redo) behind the batch — the device-pointer call
+    stays asynchronous.  Results must equal the exact scan of one index over the same rows, handed-back queries included."""
+    import torch
+    rng = np.random.default_rng(12)
+    dim, n_clusters, per = 768, 30, 4_000
+    centres = rng.standard_normal((n_clusters, dim)).astype(np.float32)
+    rows = np.concatenate([c + 0.3 * rng.standard_normal((per, dim)).astype(np.float32) for c in centres])
+    nq, k = 256, 10
+    qs = (centres[rng.integers(0, n_clusters, nq)] + 0.3 * rng.standard_normal((nq, dim))).astype(np.float32)
+    n = rows.shape[0]
+    one = quiver_amd.DeviceIndex(dim, "cosine", filter="off")
+    one.add(rows)
+    er, ed, _ = one.search(qs, k)
+    # the shards' own filter runs do hand queries back: shard 0's rows in an index of their own, through the batched device entry point
+    G = 3
+    sh = quiver_amd.ShardedIndex(dim, "cosine", devices=[0] * G, peer_copy=True)
+    gids = sh.add(rows)
+    info = [sh.shard_info(g) for g in range(G)]
+    first = quiver_amd.DeviceIndex(dim, "cosine")
+    first.add(rows[:info[0]["rows"]])
+    dq = torch.from_numpy(qs).cuda()
+    fr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); fd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    fl = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+    first.search_batched_device(dq.data_ptr(), nq, k, fr.data_ptr(), fd.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int((fl != 0).sum().item()) >= 1, "this corpus no longer makes the filter hand anything back: the test exercises nothing"
+    # the sharded batch, device pointers in and out
+    dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    sh.search_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    sh.sync(); torch.cuda.synchronize()
+    got = dr.cpu().numpy().view(np.uint32)
+    want = gids[er]                                        # global ids of the single index's rows
+    assert np.array_equal(got, want)
+    assert np.array_equal(dd.cpu().numpy().view(np.uint32), ed.view(np.uint32))
+    # and through host pointers
+    hr, hd, hc = sh.search(qs, k)
+    assert np.array_equal(hr, want) and np.array_equal(hd.view(np.uint32), ed.view(np.uint32))
