@@ -65,8 +65,6 @@ struct HnswOpts {
     const uint32_t* redo_n    = nullptr;  // heap kernel: how many of them (device word)
     uint32_t*       vis       = nullptr;  // visited storage: [slots][vis_cap] hash entries / [slots][vis_cap] bitmap words
     uint32_t        vis_cap   = 0;        // per slot: hash entries (power of two) / bitmap words
-    int             cus       = 0;        // compute units of the device (0 = unknown: the one-query-per-wave kernel); the visited storage
-                                          // then holds min(nq, 16 * cus) slots at least
 };
 
 // the mutable arrays of a graph under construction (qv_build.hip); every link carries its distance

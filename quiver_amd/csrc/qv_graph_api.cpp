@@ -142,7 +142,7 @@ int ensure_visited(qv_graph* g, uint32_t ef) {
     return QV_OK;
 }
 
-qv::HnswOpts wave_opts(qv_graph* g) { qv::HnswOpts o; o.vis = static_cast<uint32_t*>(g->vis_hash.p); o.vis_cap = g->vis_hash_cap; o.cus = g->idx->cus; return o; }
+qv::HnswOpts wave_opts(qv_graph* g) { qv::HnswOpts o; o.vis = static_cast<uint32_t*>(g->vis_hash.p); o.vis_cap = g->vis_hash_cap; return o; }
 qv::HnswOpts heap_opts(qv_graph* g) { qv::HnswOpts o; o.vis = static_cast<uint32_t*>(g->vis_bits.p); o.vis_cap = g->vis_bits_words; return o; }
 
 int graph_common_init(qv_graph* g) {
@@ -303,7 +303,7 @@ int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq
     const float* dq = static_cast<const float*>(c->d_q.p);
     uint32_t* d_rows = static_cast<uint32_t*>(c->d_rows.p); float* d_dist = static_cast<float*>(c->d_dist.p);
     uint32_t* d_cnt = static_cast<uint32_t*>(c->d_cnt.p); uint32_t* d_ev = static_cast<uint32_t*>(c->d_ev.p);
-    qv::HnswOpts wo; wo.vis = static_cast<uint32_t*>(c->vis_hash.p); wo.vis_cap = c->vis_hash_cap; wo.cus = idx->cus;
+    qv::HnswOpts wo; wo.vis = static_cast<uint32_t*>(c->vis_hash.p); wo.vis_cap = c->vis_hash_cap;
     hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, c->d_qblk.p, nq, k, ef_search, wo, std::min(c->vis_hash_slots, nq), d_rows, d_dist, d_cnt, d_ev, c->stream);
     if (e == hipSuccess) e = qv::launch_build_compact_redo(d_cnt, nq, static_cast<uint32_t*>(c->s_redo.p), counters, c->stream);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));

@@ -922,324 +922,6 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     }
 }
 
-// ---- two queries per wavefront (round 5) -------------------------------------------------------------------------------------------
-// A hop's rows sit on as many lanes as it has unvisited neighbours: ~15 of 64 at efSearch 128 on a MaxM0 = 32 graph, and the 768-step
-// convert + fma chain costs the SIMD the same 22 k cycles of vector issue whether 15 lanes run it or 64 — with four waves per SIMD the
-// evaluation IS the kernel (79 k of a hop's 110 k cycles, the vector ALU ~80 % busy: profiles/r02_hnsw_build_sweeps.txt).  Here a wave
-// walks TWO queries: each keeps the state of k_hnsw_search_wave (list registers, expanded bits, visited table, level, phase) and does
-// its own bookkeeping — pop, links, visited test, admissions — one after the other; but the rows of both hops are evaluated TOGETHER,
-// query A's on lanes 0..31, query B's on lanes 32..63 (one 64-row slab image, each half reading its own query's values from LDS): half
-// the vector instructions per row.  Same arithmetic per lane, same admission order per query: the results are k_hnsw_search_wave's.
-// A half that finishes its query takes the wave's next one; the halves never wait for each other beyond the shared evaluation.
-// Row-major indexes whose dimension is a multiple of 32 (the LDS query form), list widths up to 256 entries (S <= 4).
-struct DmaRole2 {
-    const float* src[8];    // groups 0..3: rows of half A (lanes 0..31 of the batch), 4..7: half B
-    uint32_t ng_a, ng_b;
-};
-__device__ __forceinline__ void dma_role2(DmaRole2& r, const float* rowmaj, uint32_t dim, const lds_u32* batch, uint32_t n_a, uint32_t n_b, uint32_t lane) {
-    const uint32_t drow = lane >> 3, dslot = lane & 7;
-    const uint32_t sw0 = dslot ^ drow, sw1 = dslot ^ drow ^ 1u;
-    r.ng_a = (n_a + 7) >> 3; r.ng_b = (n_b + 7) >> 3;
-    const uint32_t fa = 0u, fb = 32u;                                  // a lane past its half's count re-reads that half's first row (valid memory, slots nobody reads)
-#pragma unroll
-    for (int gi = 0; gi < 4; gi++) {
-        const uint32_t ra = (uint32_t)gi * 8 + drow;
-        r.src[gi] = rowmaj + (size_t)batch[ra < n_a ? ra : fa] * dim + ((gi & 1) ? sw1 : sw0) * 4;
-        r.src[4 + gi] = rowmaj + (size_t)batch[32 + (ra < n_b ? ra : 0u)] * dim + ((gi & 1) ? sw1 : sw0) * 4;
-    }
-    (void)fb;
-}
-__device__ __forceinline__ void dma_issue_slab2(const DmaRole2& r, uint32_t sl, lds_u8* buf) {
-    const uint32_t chunk0 = sl * 8;
-#pragma unroll
-    for (int gi = 0; gi < 4; gi++) {
-        if ((uint32_t)gi < r.ng_a) glds16(r.src[gi] + (size_t)chunk0 * 4, buf + gi * 1024);
-        if ((uint32_t)gi < r.ng_b) glds16(r.src[4 + gi] + (size_t)chunk0 * 4, buf + (4 + gi) * 1024);
-    }
-}
-constexpr int kHnswSlab2Bytes = 64 * kHnswSlab * 16;                  // 8 KiB: 64 rows x 128 bytes
-constexpr int kHnswQBuf2Bytes = 1024;                                // half A's 32 query values at 0, half B's at 512 (LDS-DMA lands lane-linear)
-
-template <int M, int S, int NB>
-__global__ void __launch_bounds__(64)
-k_hnsw_search_wave2(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t nq, uint32_t k, uint32_t ef_search,
-                    HnswOpts o,
-                    uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
-    using Q = typename MT<M>::Q;
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* batch = reinterpret_cast<uint32_t*>(smem);                   // [64]: half A's rows at 0.., half B's at 32..
-    lds_u32* batch_l = (lds_u32*)smem;
-    lds_u8* slabs_l = (lds_u8*)(batch_l + 64);                             // NB x kHnswSlab2Bytes
-    lds_u8* qbufs_l = slabs_l + NB * kHnswSlab2Bytes;                      // NB x kHnswQBuf2Bytes
-    const uint32_t lane = threadIdx.x;
-    const bool build = o.qlevel != nullptr;
-    auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && (!g.has_dead || g.level[n] >= 0); };
-    constexpr uint32_t kCap = (uint32_t)S * 64;
-
-    struct St {
-        uint64_t key[S]; uint64_t expd[S];
-        uint32_t n_list, n_eval, qi, entry, ef, n_vis, hmask, hshift, hlimit;
-        int level, stop, phase;                                            // phase 0: traversing, 1: the build's d(node, node) is being evaluated
-        bool tie, first, active;
-        const Q* q_g; double qn; float qn32; uint32_t* tab;
-    };
-    St A, B;
-    uint32_t next_q = blockIdx.x;                                          // the wave's query stream: next_q, next_q + gridDim.x, ...
-
-    auto entry_at = [&](St& st, uint32_t e) -> uint64_t {
-        uint64_t r = kDeadKey;
-#pragma unroll
-        for (int s2 = 0; s2 < S; s2++) if ((int)(e >> 6) == s2) r = readlane64(st.key[s2], e & 63);
-        return r;
-    };
-    // k_hnsw_search_wave's insert, on a state
-    auto insert = [&](St& st, uint64_t x) {
-        const uint32_t ef = st.ef;
-        const uint32_t xd = (uint32_t)(x >> 32);
-        if (xd == 0xFFFFFFFEu) st.tie = true;
-        if (st.n_list >= ef && xd >= (uint32_t)(entry_at(st, ef - 1) >> 32)) return;
-        const uint64_t lost = st.n_list == kCap ? entry_at(st, kCap - 1) : kDeadKey;
-        uint32_t p = 0;
-#pragma unroll
-        for (int s2 = 0; s2 < S; s2++) p += (uint32_t)__builtin_popcountll(__ballot(st.key[s2] < x));
-        const uint32_t s0 = p >> 6, l0 = p & 63;
-        uint64_t carry = 0; uint64_t cbit = 0;
-#pragma unroll
-        for (int s2 = 0; s2 < S; s2++) {
-            if ((uint32_t)s2 < s0) continue;
-            const uint64_t last = readlane64(st.key[s2], 63);
-            const uint64_t lastbit = (st.expd[s2] >> 63) & 1ull;
-            const uint64_t up = wave_shr1(st.key[s2]);
-            if ((uint32_t)s2 == s0) {
-                st.key[s2] = lane < l0 ? st.key[s2] : (lane == l0 ? x : up);
-                const uint64_t low = (1ull << l0) - 1;
-                st.expd[s2] = (st.expd[s2] & low) | ((st.expd[s2] & ~low) << 1);
-            } else {
-                st.key[s2] = lane == 0 ? carry : up;
-                st.expd[s2] = (st.expd[s2] << 1) | cbit;
-            }
-            carry = last; cbit = lastbit;
-        }
-        if (st.n_list < kCap) st.n_list++;
-        if (st.n_list > ef || lost != kDeadKey) {
-            const uint32_t w = (uint32_t)(entry_at(st, ef - 1) >> 32);
-            uint32_t dropped = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) {
-                const uint32_t e = (uint32_t)s2 * 64 + lane;
-                const bool drop = e >= ef && st.key[s2] != kDeadKey && (uint32_t)(st.key[s2] >> 32) > w;
-                const uint64_t dm = __ballot(drop);
-                if (drop) st.key[s2] = kDeadKey;
-                st.expd[s2] &= ~dm;
-                dropped += (uint32_t)__builtin_popcountll(dm);
-            }
-            st.n_list -= dropped;
-            if (lost != kDeadKey && (uint32_t)(lost >> 32) == w) st.tie = true;
-        }
-    };
-    auto begin_level = [&](St& st) {
-        st.ef = st.level > st.stop ? 1u : (build ? ef_search : (ef_search > k ? ef_search : k));
-        const uint32_t hcap = st.level > st.stop && o.vis_cap > kVisGreedyCap ? kVisGreedyCap : o.vis_cap;
-        st.hmask = hcap - 1; st.hshift = (uint32_t)__builtin_clz(hcap) + 1; st.hlimit = hcap - (hcap >> 2);
-        st.n_vis = 1;
-        vis_hash_clear(st.tab, hcap, lane);
-#pragma unroll
-        for (int s2 = 0; s2 < S; s2++) { st.key[s2] = kDeadKey; st.expd[s2] = 0; }
-        st.n_list = 0; st.first = true;
-    };
-    auto begin_query = [&](St& st) {
-        st.phase = 0;
-        if (next_q >= nq) { st.active = false; return; }
-        st.active = true; st.qi = next_q; next_q += gridDim.x;
-        st.q_g = qblk + (size_t)st.qi * v.dim4 * 4;
-        st.qn = qconst[(size_t)st.qi * 2]; st.qn32 = (float)qconst[(size_t)st.qi * 2 + 1];
-        st.n_eval = 0; st.tie = false; st.entry = g.entry;
-        st.stop = 0;
-        if (build) { st.stop = (int)o.qlevel[st.qi]; if (st.stop > g.cur_level) st.stop = g.cur_level; }
-        st.level = g.cur_level;
-        if (st.level < st.stop) st.level = st.stop;                        // (cannot happen: stop <= cur_level)
-        begin_level(st);
-    };
-    // the query's results (k_hnsw_search_wave's tail); returns true when the build's d(node, node) has to be evaluated next
-    auto finish_query = [&](St& st) -> bool {
-        const uint32_t kq = build ? (st.stop == 0 ? g.max_m0 : g.max_m) : k;
-        const uint32_t ef_last = build ? ef_search : (ef_search > k ? ef_search : k);
-        const uint32_t n_res = st.n_list < ef_last ? st.n_list : ef_last;
-        uint32_t cnt = n_res < kq ? n_res : kq;
-        bool tie = st.tie;
-        if (!tie && st.n_list > ef_last) {
-            const uint32_t w = (uint32_t)(entry_at(st, ef_last - 1) >> 32);
-            uint32_t below = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) below += (uint32_t)__builtin_popcountll(__ballot((uint32_t)(st.key[s2] >> 32) < w));
-            if (cnt > below) tie = true;
-        }
-        if (!build && !tie) {
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) {
-                const uint32_t e = (uint32_t)s2 * 64 + lane;
-                uint64_t nxt = __shfl_down(st.key[s2], 1);
-                if (lane == 63) nxt = s2 + 1 < S ? readlane64(st.key[s2 + 1 < S ? s2 + 1 : s2], 0) : kDeadKey;
-                if (__ballot(e < cnt && e + 1 < st.n_list && (uint32_t)(st.key[s2] >> 32) == (uint32_t)(nxt >> 32))) tie = true;
-            }
-        }
-        bool self = false;
-        if (tie) cnt = kHnswTieFlag;
-        else {
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) {
-                const uint32_t e = (uint32_t)s2 * 64 + lane;
-                if (e < k) {
-                    const bool has = e < cnt;
-                    rows_out[(size_t)st.qi * k + e] = has ? (uint32_t)st.key[s2] : 0xFFFFFFFFu;
-                    dist_out[(size_t)st.qi * k + e] = has ? unord_f32((uint32_t)(st.key[s2] >> 32)) : __uint_as_float(0x7F800000u);
-                }
-            }
-            self = build && st.stop >= 1 && o.self_dist != nullptr;
-        }
-        if (lane == 0) { count_out[st.qi] = cnt; if (evals_out) evals_out[st.qi] = st.n_eval; }
-        return self;
-    };
-    // One step of a query up to its next evaluation: returns the number of rows it put into its half of the batch (0: the wave's
-    // stream has no more queries for this half).  h = 0 / 1.
-    auto prepare = [&](St& st, uint32_t h) -> uint32_t {
-        const uint32_t b0 = 32 * h;
-        for (;;) {
-            if (!st.active) return 0;
-            if (st.phase == 1) {                                           // build: d(node, node) (:463-467)
-                if (lane == 0) batch[b0] = o.qnode0 + st.qi;
-                return 1;
-            }
-            if (st.tie) { (void)finish_query(st); begin_query(st); continue; }   // flagged: the exact-heap kernel redoes it from scratch
-            if (st.first) {                                                // :492-506: the entry point itself
-                st.first = false;
-                if (lane == 0) { (void)vis_hash_insert(st.tab, st.hmask, st.hshift, st.entry); batch[b0] = st.entry; }
-                return 1;
-            }
-            // pop: first unexpanded entry
-            uint32_t cur = 0xFFFFFFFFu, cur_d = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) {
-                if (cur != 0xFFFFFFFFu) continue;
-                const uint64_t m = __ballot(st.key[s2] != kDeadKey) & ~st.expd[s2];
-                if (m) { const uint32_t l = (uint32_t)__builtin_ctzll(m); const uint64_t kc = readlane64(st.key[s2], l); cur = (uint32_t)kc; cur_d = (uint32_t)(kc >> 32); st.expd[s2] |= 1ull << l; }
-            }
-            if (cur == 0xFFFFFFFFu) {                                      // the level is done
-                if (st.level > st.stop && st.n_list > 0) st.entry = (uint32_t)readlane64(st.key[0], 0);   // :649-657
-                if (st.level > st.stop) { st.level--; begin_level(st); continue; }
-                if (finish_query(st)) { st.phase = 1; continue; }
-                begin_query(st);
-                continue;
-            }
-            {   // candidates.pop() among equal minima is the heap's choice
-                uint64_t same = 0;
-#pragma unroll
-                for (int s2 = 0; s2 < S; s2++) same |= __ballot((uint32_t)(st.key[s2] >> 32) == cur_d && st.key[s2] != kDeadKey) & ~st.expd[s2];
-                if (same) { st.tie = true; continue; }
-            }
-            uint32_t deg = 0; const uint32_t* links = nullptr;
-            uint32_t c = 0xFFFFFFFFu; bool fresh = false;
-            if (st.level == 0 && !g.has_dead && cur < g.n_nodes) {
-                deg = g.l0_deg[cur];
-                const uint32_t cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu;
-                if (lane < deg) { c = cl; fresh = c < g.n_nodes; }
-            } else {
-                if (alive(cur) && (st.level == 0 ? (!g.has_dead || g.level[cur] >= 0) : st.level <= (int)g.level[cur])) {
-                    if (st.level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
-                    else { const uint32_t* blk = g.up_links + (size_t)(g.up_off[cur] + (uint32_t)(st.level - 1)) * (1 + g.max_m); deg = blk[0]; links = blk + 1; }
-                }
-                if (lane < deg) { c = links[lane]; fresh = alive(c); }
-            }
-            for (uint32_t j = 0; j + 1 < deg; j++) {                       // a node repeated inside one list is new at its FIRST occurrence
-                const uint32_t cj = __builtin_amdgcn_readlane(c, j);
-                if (lane > j && c == cj) fresh = false;
-            }
-            if (fresh) fresh = vis_hash_insert(st.tab, st.hmask, st.hshift, c);
-            const uint64_t fm = __ballot(fresh);
-            const uint32_t nb = (uint32_t)__builtin_popcountll(fm);
-            st.n_vis += nb;
-            if (st.n_vis > st.hlimit) { st.tie = true; continue; }          // table 3/4 full: hand the query to the exact-heap kernel
-            if (nb == 0) continue;
-            if (fresh) batch[b0 + __builtin_popcountll(fm & ((1ull << lane) - 1))] = c;
-            return nb;
-        }
-    };
-    // admissions of an evaluated hop, in adjacency order (:553-560); kx = this wave's keys, the hop's on lanes b0 .. b0 + nb - 1
-    auto finish = [&](St& st, uint32_t h, uint32_t nb, uint64_t kx, float dd) {
-        const uint32_t b0 = 32 * h;
-        st.n_eval += nb;
-        if (st.phase == 1) {
-            const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dd), (int)b0));
-            if (lane == 0) o.self_dist[st.qi] = d0;
-            begin_query(st);
-            return;
-        }
-        const bool mine = lane >= b0 && lane < b0 + nb;
-        uint64_t pend = __ballot(mine);
-        if (st.n_list >= st.ef) {
-            const uint32_t w = (uint32_t)(entry_at(st, st.ef - 1) >> 32);
-            pend = __ballot(mine && (uint32_t)(kx >> 32) < w);
-        }
-        while (pend) {
-            const uint32_t i = (uint32_t)__builtin_ctzll(pend);
-            pend &= pend - 1;
-            insert(st, readlane64(kx, i));
-        }
-    };
-
-    // this wave's two visited tables: the slots of the FIRST queries the halves take (both below nq, hence inside the storage)
-    A.tab = o.vis + (size_t)blockIdx.x * o.vis_cap;
-    B.tab = o.vis + (size_t)(blockIdx.x + gridDim.x) * o.vis_cap;
-    begin_query(A);
-    begin_query(B);
-    const uint32_t nslab = v.dim4 >> 3;
-    for (;;) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the previous evaluation's batch reads are done before the halves refill it
-        __builtin_amdgcn_s_barrier();
-        const uint32_t na = prepare(A, 0);
-        const uint32_t nb = prepare(B, 1);
-        if (na + nb == 0) break;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- the shared evaluation: A's rows on lanes 0 .. na - 1, B's on lanes 32 .. 32 + nb - 1
-        const bool hb = lane >= 32;
-        const bool me = hb ? (lane - 32 < nb) : (lane < na);
-        const uint32_t myrow = me ? batch_l[lane] : 0u;
-        double rn = 0.0;
-        if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[myrow]; }
-        DmaRole2 role;
-        dma_role2(role, v.rowmaj, v.dim, batch_l, na, nb, lane);
-        typename MT<M>::A acc = 0;
-        // the two queries' values of a slab: lanes 0..15 (float64; 0..7 float32) fetch A's, lanes 32.. B's, into their halves of the buffer
-        constexpr uint32_t qlanes = kHnswSlab * 4 * sizeof(Q) / 16;
-        const Q* q_mine = hb ? B.q_g : A.q_g;
-        const bool q_active = (lane & 31u) < qlanes && (hb ? nb != 0 : na != 0);
-        auto issue_query = [&](uint32_t sl, lds_u8* qb) {
-            if (q_active) glds16(reinterpret_cast<const float*>(q_mine + (size_t)sl * (kHnswSlab * 4)) + (lane & 31u) * 4, qb);
-        };
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        dma_issue_slab2(role, 0, slabs_l); issue_query(0, qbufs_l);
-        for (uint32_t sl = 0; sl < nslab; sl++) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // slab sl and its query values have landed
-            if (NB == 2 && sl + 1 < nslab) {                                  // the next slab lands while this one is consumed
-                dma_issue_slab2(role, sl + 1, slabs_l + ((sl + 1) & 1) * kHnswSlab2Bytes);
-                issue_query(sl + 1, qbufs_l + ((sl + 1) & 1) * kHnswQBuf2Bytes);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t bi = NB == 2 ? (sl & 1) : 0u;
-            if (me) slab_accumulate_qlds<M>(acc, slabs_l + bi * kHnswSlab2Bytes, lane, qbufs_l + bi * kHnswQBuf2Bytes + (hb ? 512 : 0));
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this slab's buffers are read before they are refilled
-            if (NB == 1 && sl + 1 < nslab) { dma_issue_slab2(role, sl + 1, slabs_l); issue_query(sl + 1, qbufs_l); }
-        }
-        QConst qc; qc.qn = hb ? B.qn : A.qn; qc.qn32 = hb ? B.qn32 : A.qn32;
-        const float dd = me ? finalize<M>(acc, qc, rn) : 0.0f;
-        const uint64_t kx = me ? make_key(dd, myrow) : kDeadKey;
-        if (na) finish(A, 0, na, kx, dd);
-        if (nb) finish(B, 1, nb, kx, dd);
-    }
-}
-
 // ---- link distances of an uploaded graph ---------------------------------------------------
 // A graph that was built on the host arrives without the per-link distances the device-side construction works on
 // (qv_build.hip).  One wavefront per adjacency list of nodes [n0, n0 + nq): the node's own vector is the query (converted by
@@ -1363,25 +1045,6 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     // the query through LDS for row-major indexes whose dimension is a multiple of 32 (QV_HNSW_QLDS=2: never)
     static const int qlds_env = env_int("QV_HNSW_QLDS", 1);
     const bool deep = qlds_env == 1 && hnsw_qlds_ok(v);
-    // two queries per wavefront (k_hnsw_search_wave2) where it applies: the LDS query form, list widths up to 256 entries, a known CU
-    // count.  QV_HNSW_PAIR (read once): 2 = never (one query per wave, as before round 5), 3 = single-buffered slabs, sixteen waves per CU
-    // instead of double-buffered slabs and eight.  A batch that fits the wave slots still gets a wave per query.
-    static const int pair_env = env_int("QV_HNSW_PAIR", 1);
-    if (deep && pair_env != 2 && efx < 256 && o.cus > 0) {
-        const bool nb1 = pair_env == 3;
-        const size_t lds2 = 64 * sizeof(uint32_t) + (nb1 ? 1 : 2) * ((size_t)kHnswSlab2Bytes + kHnswQBuf2Bytes) + 64;
-        const uint32_t waves = std::min<uint32_t>((uint32_t)o.cus * (nb1 ? 16u : 8u), std::min(grid, nq));
-#define QV_HW2(SS, NBB) QV_DISPATCH_METRIC(v.metric, {                                                                 \
-            e = set_lds((k_hnsw_search_wave2<MM, SS, NBB>), lds2);                                                     \
-            if (e != hipSuccess) return e;                                                                             \
-            hipLaunchKernelGGL((k_hnsw_search_wave2<MM, SS, NBB>), dim3(waves), dim3(64), lds2, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
-                               static_cast<const double*>(d_qconst), nq, k, ef, o, d_rows_out, d_dist_out, d_count_out, d_evals_out); \
-        })
-        if (efx < 128) { if (nb1) { QV_HW2(2, 1); } else { QV_HW2(2, 2); } }
-        else { if (nb1) { QV_HW2(4, 1); } else { QV_HW2(4, 2); } }
-#undef QV_HW2
-        return hipGetLastError();
-    }
 #define QV_HW(SS) if (deep) { QV_HWD(SS, true); } else { QV_HWD(SS, false); }
     // list registers: S x 64 entries.  One notch more than efx needs where that is free (<= 128 VGPRs either way), so that a tie
     // group at the end of the result heap has room (ef <= 127 -> S = 2, ef = 128..256 -> S = 4; S = 8 would cost a wave per SIMD)
