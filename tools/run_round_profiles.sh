@@ -17,3 +17,14 @@ done
 (cd /tmp && rm -rf /tmp/rp_b && DEV_REPS=60 DEV_BF16_ROWS=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_b -o b -- python3 $root/tools/dev_batched.py cosine 256 1000000 768 10 > /dev/null 2>&1)
 cp $(find /tmp/rp_b -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_batched_bf16rows_256x1Mx768_kernel_stats.csv 2>/dev/null
 wc -c gpurun_out/${tag}_bench_n1.jsonl; head -c 3500 gpurun_out/${tag}_bench_n1.jsonl; echo; head -5 gpurun_out/${tag}_10Mx768_kernel_stats.csv; head -4 gpurun_out/${tag}_batched_default_256x1Mx768_kernel_stats.csv; head -3 gpurun_out/${tag}_batched_fp32_256x1Mx768_kernel_stats.csv
+# round 5: configs[1] (one query over 1M x 768, single launch per query) under rocprofv3, the concurrent-caller bench, the fp32-MFMA filter's
+# matrix-instruction counters, the sharded handle's batch path (8 co-located shards: device-side redo, no host round trip per shard)
+(cd /tmp && rm -rf /tmp/rp_1m && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_1m -o s -- python3 $root/tools/dev_scan_1m.py > $root/gpurun_out/${tag}_1Mx768_under_rocprof.txt 2>/dev/null)
+cp $(find /tmp/rp_1m -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_1Mx768_kernel_stats.csv 2>/dev/null
+python3 tools/dev_scan_1m.py > gpurun_out/${tag}_1Mx768_scan.txt 2>/dev/null
+QV_SCAN_FUSE=0 python3 tools/dev_scan_1m.py >> gpurun_out/${tag}_1Mx768_scan.txt 2>/dev/null
+python3 tools/bench_callers.py --out gpurun_out/${tag}_callers.json > gpurun_out/${tag}_callers.log 2>&1
+QV_COALESCE=0 python3 tools/bench_callers.py --flat-callers 1,8,64 --graph-callers 1,64 --out gpurun_out/${tag}_callers_off.json > gpurun_out/${tag}_callers_off.log 2>&1
+DEV_FILTER=fp32 DEV_REPS=30 bash tools/pmc_kernel.sh k_mfma_filter gpurun_out/${tag}_mfma_pmc.txt "SQ_INSTS_VALU_MFMA_MOPS_F32/SQ_INSTS_VALU_MFMA_F32/SQ_VALU_MFMA_BUSY_CYCLES/SQ_BUSY_CYCLES/SQ_INSTS_MFMA/SQ_INSTS_VALU/GRBM_GUI_ACTIVE/SQ_WAVES/SQ_BUSY_CU_CYCLES" -- python3 $root/tools/dev_batched.py cosine 256 1000000 768 10 > /dev/null 2>&1
+python3 tools/dev_sharded_batch.py 8 256 8000000 > gpurun_out/${tag}_sharded_batch.txt 2>&1
+head -3 gpurun_out/${tag}_1Mx768_kernel_stats.csv; cat gpurun_out/${tag}_1Mx768_scan.txt; cat gpurun_out/${tag}_mfma_pmc.txt; tail -5 gpurun_out/${tag}_sharded_batch.txt; cut -c1-260 gpurun_out/${tag}_callers.log
