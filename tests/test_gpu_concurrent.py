@@ -176,6 +176,39 @@ def test_concurrent_graph_callers_with_duplicate_rows_take_the_exact_heap_pass_e
         assert res["rows"][i, :n].tolist() == ro[:n].tolist() and res["dist"][i, :n].tobytes() == do[:n].tobytes()
 
 
+def test_shared_traversal_batches_in_which_only_some_queries_need_the_exact_heap_pass():
+    """one row in eight appears twice: some queries meet equal distances (flagged by the wave kernel, redone by the exact-heap kernel)
+    and most do not — in a shared batch the latter get their results after the first pass, the former after the second; all equal
+    the oracle's walk"""
+    from quiver_amd.device_index import DeviceGraph
+    import torch
+    qs = O.gen_rows(910, 0, 192, 64)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((192, 10), dtype=torch.int32, device="cuda"); dd = torch.empty((192, 10), dtype=torch.float32, device="cuda")
+    dc = torch.empty(192, dtype=torch.int32, device="cuda")
+    for n_dup in (8, 32, 2, 128):                                               # enough duplicated vectors that SOME queries meet a tie, not all
+        rows = O.gen_rows(909, 0, 4000, 64)
+        rows[4000 - n_dup:] = rows[:n_dup]
+        idx, deg, links = _knn_graph(rows, "l2", 16)
+        g = DeviceGraph(idx, np.zeros(4000, np.int8), deg, links, entry=11)
+        # the device form says which queries are flagged on the way (count 0xFFFFFFFE)
+        g.search_device(dq.data_ptr(), 192, 10, 48, dr.data_ptr(), dd.data_ptr(), dc.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        flagged = int((dc.cpu().numpy().view(np.uint32) == 0xFFFFFFFE).sum())
+        if 0 < flagged < 192:
+            break
+    assert 0 < flagged < 192, flagged
+    o = O.HNSW(quiver_amd.metric_id("l2"), 64, M=8, maxM0=16, efSearch=48, maxLevel=1, seed=1)
+    o.load_flat(rows, deg, links, 11)
+    res = _callers.run("graph", g.handle, qs, 10, threads=48, seconds=60.0, max_calls_per_thread=16, ef=48)
+    assert res["rc"] == 0 and res["errors"] == 0 and res["mismatches"] == 0, res["error"]
+    for i in range(192):
+        ro, do = o.search(qs[i], 10)
+        n = min(int(res["count"][i]), 10)
+        assert n == min(len(ro), 10)
+        assert res["rows"][i, :n].tolist() == ro[:n].tolist() and res["dist"][i, :n].tobytes() == do[:n].tobytes(), i
+
+
 def test_concurrent_callers_on_a_sharded_handle_share_passes_and_equal_the_oracle():
     n, dim, k = 240_000, 128, 10
     sh = quiver_amd.ShardedIndex(dim, "cosine", devices=[0, 0, 0], peer_copy=True)

@@ -236,3 +236,19 @@ def test_batch_with_queries_the_filter_hands_back_is_redone_on_the_device_withou
     # and through host pointers
     hr, hd, hc = sh.search(qs, k)
     assert np.array_equal(hr, want) and np.array_equal(hd.view(np.uint32), ed.view(np.uint32))
+    # a batch large enough that one shard hands back MORE than 64 queries: the redo kernel serves 64 list entries per launch, so this
+    # one goes through several of them
+    nq2 = 2048
+    qs2 = (centres[rng.integers(0, n_clusters, nq2)] + 0.3 * rng.standard_normal((nq2, dim))).astype(np.float32)
+    dq2 = torch.from_numpy(qs2).cuda()
+    fr2 = torch.empty((nq2, k), dtype=torch.int32, device="cuda"); fd2 = torch.empty((nq2, k), dtype=torch.float32, device="cuda")
+    fl2 = torch.zeros((nq2,), dtype=torch.int32, device="cuda")
+    first.search_batched_device(dq2.data_ptr(), nq2, k, fr2.data_ptr(), fd2.data_ptr(), fl2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    handed_back = int((fl2 != 0).sum().item())
+    er2, ed2, _ = one.search(qs2, k)
+    dr2 = torch.empty((nq2, k), dtype=torch.int32, device="cuda"); dd2 = torch.empty((nq2, k), dtype=torch.float32, device="cuda")
+    sh.search_device(dq2.data_ptr(), nq2, k, dr2.data_ptr(), dd2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    sh.sync(); torch.cuda.synchronize()
+    assert np.array_equal(dr2.cpu().numpy().view(np.uint32), gids[er2]) and np.array_equal(dd2.cpu().numpy().view(np.uint32), ed2.view(np.uint32))
+    assert handed_back > 64, "only %d of %d queries were handed back by shard 0's filter: the multi-launch redo was not exercised" % (handed_back, nq2)
