@@ -93,6 +93,18 @@ func (h *Graph) InsertBatch(flat []float32, levels []int8, batchMax int) (uint32
 	return uint32(first), nil
 }
 
+// Search is hnsw.HNSW.Search (hnsw.go:602-713) for ONE query — what the reference's callers send, one goroutine per request under a
+// read lock (hnsw.go:602-606; adapter.go:253-279).  It is a batch of one: libqv lets concurrent calls on one graph share traversal
+// batches (include/qv.h, qv_graph_search), so a thousand goroutines calling this cost a few batches, not a thousand walks one after
+// another; a lone caller is served at once.
+func (h *Graph) Search(q []float32, k int) ([]GraphResult, error) {
+	res, err := h.SearchBatch(q, k)
+	if err != nil || len(res) == 0 {
+		return nil, err
+	}
+	return res[0], nil
+}
+
 // GraphResult is hnsw.Result (hnsw.go:87-95) without the string id: the caller maps VectorIndex to its ids.
 type GraphResult struct {
 	VectorIndex uint32

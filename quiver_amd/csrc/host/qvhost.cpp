@@ -592,8 +592,22 @@ Error HNSW::Delete(const std::string& id) {                            // hnsw.g
 }
 
 Error HNSW::Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>* out) {   // hnsw.go:602-713
-    std::shared_lock<std::shared_mutex> l(mu_);                        // :603-604
-    return searchLocked(q, len, k, out);
+    // A graph whose device copy is current (built or extended on the device, or uploaded by an earlier batch) is walked ON the device:
+    // the search is a batch of one, and concurrent callers — the reference searches under a read lock, one goroutine per query
+    // (hnsw.go:602-606, adapter.go:253-279) — share traversal batches inside libqv (qv_graph_search).  While the copy is stale (the host
+    // graph has moved on since) the host drives the walk hop by hop, as before: re-uploading the graph per search would cost more.
+    bool device_current;
+    {
+        std::shared_lock<std::shared_mutex> l(mu_);                    // :603-604
+        device_current = dg_ != nullptr && !dg_dirty_.load() && !nodes_.empty() && size_ > 0 && k > 0 && k <= 512 && efS_ <= 512 && M_ <= 64 && maxM0_ <= 64 &&
+                         (int)len == dim_;
+        if (!device_current) return searchLocked(q, len, k, out);
+    }
+    std::vector<std::vector<HNSWResult>> one;
+    Error e = SearchBatch(q, len, 1, k, &one, nullptr);                // (takes the lock itself; a mutation in between only means a fresh upload)
+    out->clear();
+    if (e.empty() && !one.empty()) *out = std::move(one[0]);
+    return e;
 }
 
 Error HNSW::searchLocked(const float* q, uint32_t len, int k, std::vector<HNSWResult>* out) {

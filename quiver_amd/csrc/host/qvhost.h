@@ -182,7 +182,7 @@ private:
     uint32_t entry_ = 0; int cur_level_ = -1; std::atomic<uint32_t> size_{0};
     uint64_t rng_;
     std::atomic<uint64_t> n_calls_{0}, n_evals_{0};
-    qv_graph* dg_ = nullptr; bool dg_dirty_ = true; std::atomic<uint32_t> device_fallbacks_{0}, topups_{0};
+    qv_graph* dg_ = nullptr; std::atomic<bool> dg_dirty_{true}; std::atomic<uint32_t> device_fallbacks_{0}, topups_{0};
     qv_graph* bg_ = nullptr; bool bg_synced_ = true;   // graph under device-side construction (== dg_ while in sync with nodes_)
     Error syncDeviceGraph();
 };
