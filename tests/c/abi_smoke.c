@@ -50,6 +50,8 @@ int main(void) {
     uint32_t gr[3], gc = 0; float gd[3];
     if (qv_graph_search(g, gq, 1, 3, 32, gr, gd, &gc, NULL) != QV_OK || gc != 3) { fprintf(stderr, "graph search: %s\n", qv_last_error()); return 14; }
     if (gr[0] != 50 || gd[0] != 0.0f || !((gr[1] == 49 && gr[2] == 51) || (gr[1] == 51 && gr[2] == 49))) { fprintf(stderr, "graph result [%u %u %u]\n", gr[0], gr[1], gr[2]); return 15; }
+    { uint64_t st[8];                                      /* how the calls were served: a lone caller runs at once, in its own context */
+      if (qv_graph_coalesce_stats(g, st) != QV_OK || st[0] != 1 || st[1] + st[2] + st[3] != 0) { fprintf(stderr, "graph coalesce stats\n"); return 26; } }
     qv_graph_destroy(g); qv_index_destroy(gi);
 
     /* one corpus behind one handle: a single shard here, a real RCCL communicator all the same */
