@@ -109,7 +109,7 @@ struct qv_index {
     // concurrent single-query callers (all the reference's host ever produces: collection.go:647, db.go:805-828) ride the next
     // pass together (qv_coalesce.h): one pass in flight — a flat scan is HBM-bound, a second one beside it only halves both —
     // and up to 256 queries per group, the size the matrix-core filter walks the corpus once for
-    qvco::Front front{1, 256};
+    qvco::Front front{1, 256, 4};
 
     qv::IndexView view() const {
         qv::IndexView v;

@@ -14,7 +14,7 @@
 // joins the open GROUP of its key (or opens one); when a lane frees up, the thread that finished hands the lane to the oldest
 // group's first member, which runs the whole group as ONE multi-query call and distributes the results.  Groups therefore hold
 // the queries that arrived while the previous pass was running — plus, see Front::linger_then_close, the callers that pass
-// itself released, for whom the leader waits a bounded moment (an eighth of a pass) because it knows they are coming back.
+// itself released, for whom the leader waits a bounded moment (a quarter of a pass at most) because it knows they are coming back.
 //
 // Waiting is on futex words of the group (`go` for its leader, `phase` for everybody else: one system call wakes the lot).
 // What a caller does under the front's lock is a slot claim (a few integer operations); its query is copied outside it.
@@ -24,6 +24,7 @@
 #include <chrono>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -132,7 +133,8 @@ struct Group {
 
 class Front {
   public:
-    Front(int lanes, uint32_t max_group_queries) : lanes_(lanes), max_q_(max_group_queries) {}
+    // linger_div: a leader holds its group open for returning callers for 1 / linger_div of a pass at most
+    Front(int lanes, uint32_t max_group_queries, int linger_div = 8) : lanes_(lanes), max_q_(max_group_queries), linger_div_(env_linger_div() ? env_linger_div() : linger_div) {}
 
     // What happened to a request (for tests and reports).
     struct Stats {
@@ -286,14 +288,15 @@ class Front {
     static constexpr int64_t kReturnWindowNs = 2000000;    // a released caller that has not come back after this long is not coming
     static constexpr int64_t kLingerMaxNs = 1000000;
     bool waiting_for_lane() const { for (auto& g : pending_) if (!g->has_lane) return true; return false; }   // (under mu_)
-    // how long a group may be held open for the callers the last pass released: an eighth of a pass, 1 ms at most (under mu_)
-    int64_t linger_ns() const { return std::min<int64_t>(pass_ns_ / 8, kLingerMaxNs); }
+    // how long a group may be held open for the callers the last pass released: 1 / linger_div of a pass, 1 ms at most (under mu_)
+    static int env_linger_div() { static const int d = getenv("QV_COALESCE_LINGER_DIV") && atoi(getenv("QV_COALESCE_LINGER_DIV")) > 0 ? atoi(getenv("QV_COALESCE_LINGER_DIV")) : 0; return d; }   // (measurement switch, read once)
+    int64_t linger_ns() const { return std::min<int64_t>(pass_ns_ / linger_div_, kLingerMaxNs); }
 
     // Closed-loop callers come back TOGETHER, a few microseconds after the pass that served them ends — just after the next group
     // has started without them, so that N callers alternate in two groups of N/2 and each waits two passes per answer (measured:
     // 8 callers on 1M x 768, 7.9 k QPS in groups of 4; 13.9 k in groups of 8 with this).  The leader therefore holds its group open
-    // until the callers which that last pass released are back — it knows how many — or for an eighth of a pass (1 ms at most),
-    // whichever comes first.  No caller waits for company that is not known to be on its way: a lone caller never does.
+    // until the callers which that last pass released are back — it knows how many — or for a fraction of a pass (a quarter on the flat
+    // indexes, an eighth on a graph — measured, profiles/r05_notes.md; 1 ms at most), whichever comes first.  No caller waits for company that is not known to be on its way: a lone caller never does.
     void linger_then_close(const std::shared_ptr<Group>& grp) {
         if (grp->linger_ns > 0 && grp->n_members.load(std::memory_order_acquire) < grp->want) {
             const int64_t t0 = now_ns(), deadline = t0 + grp->linger_ns;
@@ -350,6 +353,7 @@ class Front {
     uint32_t last_group_q_ = 0;
     const int lanes_;
     const uint32_t max_q_;
+    const int linger_div_;
 };
 
 }  // namespace qvco

@@ -156,7 +156,7 @@ struct qv_sharded {
     std::atomic<bool> profiling{false};
     std::mutex prof_mu;
     double prof_scan_ms = 0, prof_exchange_ms = 0, prof_merge_ms = 0; uint64_t prof_n = 0;
-    qvco::Front front{1, 256};           // concurrent single-query callers share passes, as on one index (qv_coalesce.h): every shard's scan is HBM-bound
+    qvco::Front front{1, 256, 4};           // concurrent single-query callers share passes, as on one index (qv_coalesce.h): every shard's scan is HBM-bound
 };
 
 namespace {
