@@ -31,6 +31,8 @@
  *     A call that finds the handle busy joins the calls that arrived during the
  *     running pass; together they are the next pass — one multi-query launch.  No
  *     timer: a lone caller runs at once, exactly as if there were no sharing.
+ *     A scan of 256 MiB or more runs one pass at a time; a smaller index (where a
+ *     single-query pass leaves most of the device idle) up to four side by side.
  *     Results are the same bits either way (every path is exact).
  *   - "_device" variants take device pointers and a hipStream_t (passed as
  *     void*), enqueue work and return without synchronising, so a caller can keep

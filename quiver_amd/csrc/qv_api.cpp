@@ -525,18 +525,31 @@ static int search_direct(qv_index* idx, const float* queries, uint32_t nq, uint3
 // Callers that may share a pass: small requests (the reference's host sends one query per call) with fused-list k over a corpus
 // large enough that a pass costs more than a launch and a wake-up.  Everything else runs on its own as before — so does a
 // request that fails a check, which must report the reference's error in the reference's order (exact.go:96-106).
-constexpr uint64_t kCoalesceMinBytes = (uint64_t)32 << 20;
 constexpr uint32_t kCoalesceMaxNq = 8;
 static bool coalesce_applies(const qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                              const uint32_t* rows_out, const float* dist_out, const uint32_t* count_out) {
     static const bool off = getenv("QV_COALESCE") && atoi(getenv("QV_COALESCE")) == 0;   // measurement switch, read once per process
     return !off && idx && queries && rows_out && dist_out && count_out && nq >= 1 && nq <= kCoalesceMaxNq && k >= 1 && k <= (uint32_t)qv::kMaxFusedK &&
-           idx->n_live > 0 && (uint64_t)idx->n_rows * idx->dim4 * 16 >= kCoalesceMinBytes;
+           idx->n_live > 0;
+}
+// Passes in flight by what a pass costs: a scan of hundreds of megabytes is HBM-bound and a second one beside it only halves both (one
+// lane); a small collection's pass is launch and wait latency, which concurrent passes on their own streams hide — until there are so
+// many callers that the launches themselves queue up, and then the callers share passes there too.  Measured with 8 / 64 callers
+// (profiles/r05_notes.md): 12k x 768 with ONE lane 42 k / 155 k QPS against 102 k / 44 k for every call on its own.
+static int coalesce_lanes(const qv_index* idx) {
+    static const int forced = getenv("QV_FLAT_LANES") ? atoi(getenv("QV_FLAT_LANES")) : 0;              // measurement switch, read once
+    if (forced > 0) return forced;
+    // a scan of 256 MiB or more fills the memory system by itself: one pass at a time, and its leader holds the group open for the
+    // callers the previous pass released.  Below that a single-query pass leaves most of the device idle and a multi-query pass costs
+    // more than it: four passes side by side, nobody held (profiles/r05_notes.md, the lane sweep at 5 MiB - 300 MiB).
+    const uint64_t bytes = (uint64_t)idx->n_rows * idx->dim4 * 16;
+    return bytes >= ((uint64_t)256 << 20) ? 1 : 4;
 }
 
 int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
     if (!coalesce_applies(idx, queries, nq, k, rows_out, dist_out, count_out)) return search_direct(idx, queries, nq, k, rows_out, dist_out, count_out);
+    { const int lanes = coalesce_lanes(idx); idx->front.set_lanes(lanes, lanes == 1); }
     char err[256]; err[0] = 0;
     const int rc = idx->front.submit(
         0, queries, nq, idx->dim, k, rows_out, dist_out, count_out, nullptr,

@@ -146,6 +146,11 @@ class Front {
     };
     Stats stats;
 
+    // passes in flight at most, from now on (a handle whose pass cost changes with its size adjusts it; passes already running finish)
+    // hold_open: whether a leader holds its group open for returning callers at all — worth it where a multi-query pass costs what a
+    // single-query pass costs (a large scan, a traversal batch), not where grouping has a price and free lanes are the better answer
+    void set_lanes(int n, bool hold_open = true) { lanes_.store(n < 1 ? 1 : n, std::memory_order_relaxed); hold_open_.store(hold_open, std::memory_order_relaxed); }
+
     // solo():       run the caller's own request in its own buffers (what the entry point did before there was a front)
     // run(Group&, early): run g.queries() (g.nq of them, lists of g.kmax) into g.rows / g.dist / g.count (/ g.evals); returns a
     //               status; may call early() once (see there)
@@ -170,7 +175,7 @@ class Front {
                 // an open group of this key — one that waits for a lane, or one its leader holds open for returning callers: join it
                 for (auto it = pending_.rbegin(); it != pending_.rend(); ++it)
                     if ((*it)->key == key && (*it)->dim == dim && (*it)->nq + nq <= (*it)->cap_q) { grp = *it; break; }
-                if (!grp && !has_lane && inflight_ < lanes_ && !waiting_for_lane()) {   // a free lane and nobody queueing for one
+                if (!grp && !has_lane && inflight_ < lanes_.load(std::memory_order_relaxed) && !waiting_for_lane()) {   // a free lane and nobody queueing for one
                     inflight_++; has_lane = true;
                 }
                 uint32_t expect = 0; int64_t linger = 0;
@@ -290,7 +295,7 @@ class Front {
     bool waiting_for_lane() const { for (auto& g : pending_) if (!g->has_lane) return true; return false; }   // (under mu_)
     // how long a group may be held open for the callers the last pass released: 1 / linger_div of a pass, 1 ms at most (under mu_)
     static int env_linger_div() { static const int d = getenv("QV_COALESCE_LINGER_DIV") && atoi(getenv("QV_COALESCE_LINGER_DIV")) > 0 ? atoi(getenv("QV_COALESCE_LINGER_DIV")) : 0; return d; }   // (measurement switch, read once)
-    int64_t linger_ns() const { return std::min<int64_t>(pass_ns_ / linger_div_, kLingerMaxNs); }
+    int64_t linger_ns() const { return hold_open_.load(std::memory_order_relaxed) ? std::min<int64_t>(pass_ns_ / linger_div_, kLingerMaxNs) : 0; }
 
     // Closed-loop callers come back TOGETHER, a few microseconds after the pass that served them ends — just after the next group
     // has started without them, so that N callers alternate in two groups of N/2 and each waits two passes per answer (measured:
@@ -351,7 +356,8 @@ class Front {
     uint32_t released_ = 0;                        // callers that recent passes released and that have not called again yet
     int64_t released_at_ = 0, pass_ns_ = 0;
     uint32_t last_group_q_ = 0;
-    const int lanes_;
+    std::atomic<int> lanes_;
+    std::atomic<bool> hold_open_{true};
     const uint32_t max_q_;
     const int linger_div_;
 };

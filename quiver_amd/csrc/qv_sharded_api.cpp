@@ -758,10 +758,10 @@ int qv_sharded_get_rows(qv_sharded* s, const uint32_t* global_rows, uint32_t n, 
 int qv_sharded_get_row(qv_sharded* s, uint32_t global_row, float* vec_out) { return qv_sharded_get_rows(s, &global_row, 1, vec_out); }
 
 int qv_sharded_search(qv_sharded* s, const float* queries, uint32_t nq, uint32_t k, uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
-    // small calls over a large corpus ride the next pass together (qv_index_search's rule, qv_coalesce.h); everything else, and
-    // anything that must fail a check in the reference's order, runs as it is
+    // small calls ride the next pass together (qv_index_search's rule, qv_coalesce.h; one pass at a time here, the shards' contexts
+    // being the handle's); everything else, and anything that must fail a check in the reference's order, runs as it is
     const bool share = s && queries && rows_out && dist_out && count_out && nq >= 1 && nq <= 8 && k >= 1 && k <= (uint32_t)qv::kMaxFusedK &&
-                       !s->profiling.load() && qv_sharded_rows(s) * (uint64_t)s->dim * 4 >= ((uint64_t)32 << 20);
+                       !s->profiling.load() && qv_sharded_rows(s) > 0;
     if (!share) return search_host(s, queries, nq, k, SearchMode{}, rows_out, dist_out, count_out);   // entries past count: row 0xFFFFFFFF, +inf
     char err[256]; err[0] = 0;
     const int rc = s->front.submit(

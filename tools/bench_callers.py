@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--flat-callers", default="1,2,4,8,16,64,256")
     ap.add_argument("--graph-callers", default="1,8,64,256,1024")
+    ap.add_argument("--sharded", type=int, default=0, help="also: a sharded handle of this many shards on device 0, the flat caller counts")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     rec = {"coalesce": os.environ.get("QV_COALESCE", "1"), "k": a.k, "flat": [], "graph": []}
@@ -51,6 +52,21 @@ def main():
             print("flat ", json.dumps(e), flush=True)
         rec["flat_shape"] = [a.rows, a.dim]
         idx.close()
+    if a.rows and a.sharded:
+        from quiver_amd.device_index import ShardedIndex
+        sh = ShardedIndex(a.dim, "cosine", devices=[0] * a.sharded, peer_copy=a.sharded > 1)
+        sh.add_synthetic(20260424, 0, a.rows)
+        ref_r, ref_d, _ = sh.search(qs[:256], a.k)
+        rec["sharded"] = []
+        for t in [int(x) for x in a.flat_callers.split(",")]:
+            r = _callers.run("sharded", sh.handle, qs[:256], a.k, threads=t, seconds=a.seconds)
+            seen = r["count"] != 0xFFFFFFFD
+            same = bool(np.array_equal(r["rows"][seen], ref_r[seen]) and np.array_equal(r["dist"][seen].view(np.uint32), ref_d[seen].view(np.uint32)))
+            e = dict(callers=t, qps=round(r["qps"], 1), p50_us=round(r["p50_us"], 1), p99_us=round(r["p99_us"], 1), calls=r["calls"], errors=r["errors"],
+                     mismatches=r["mismatches"], same_as_batch_call=same)
+            rec["sharded"].append(e)
+            print("sharded", json.dumps(e), flush=True)
+        sh.close()
     if a.graph_rows:
         from quiver_amd.device_index import DeviceGraph
         gi = quiver_amd.DeviceIndex(a.dim, "cosine", rowmajor=True)
