@@ -65,6 +65,7 @@ struct HnswOpts {
     const uint32_t* redo_n    = nullptr;  // heap kernel: how many of them (device word)
     uint32_t*       vis       = nullptr;  // visited storage: [slots][vis_cap] hash entries / [slots][vis_cap] bitmap words
     uint32_t        vis_cap   = 0;        // per slot: hash entries (power of two) / bitmap words
+    uint32_t        vis_lds   = 0;        // set by launch_hnsw_search_wave for its latency form: the hash table is in LDS
 };
 
 // the mutable arrays of a graph under construction (qv_build.hip); every link carries its distance

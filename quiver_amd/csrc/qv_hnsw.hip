@@ -421,40 +421,236 @@ __device__ __forceinline__ void slab_accumulate_qlds(typename MT<M>::A& acc, con
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+// ---- a row's sum over several lanes, certified -----------------------------------------------------------------------
+// The reference's value is ONE chain: 768 dependent rounded additions per row (distances.go:18-22), 21 cycles each on one wave
+// (convert + fma, tools/ubench/f64chain.hip) — 9 us per hop however few rows the hop has, and a hop has ~15 of 64 lanes' worth.
+// A different summation order gives a different float64, but the distance is that float64 pushed through a MONOTONE function
+// (finalize: divide by a positive constant, clamp, subtract from one / square root, round to float32 — every step monotone, so
+// their composition is), and both orders lie within a computable distance of the exact sum of the (exactly representable)
+// products: |computed - exact| <= g(h) * sum|p_i| with g(h) = h u / (1 - h u), u = 2^-53, h = the longest chain of additions
+// (Higham, Accuracy and Stability of Numerical Algorithms, 4.2).  So with S = the sum over P lanes' partial chains and
+// B >= (g(dim) + g(dim / P + 3)) * sum|p_i|, the reference's float64 lies in [S - B, S + B]; when finalize(S - B) and
+// finalize(S + B) are the same float32 — all but a few in a million evaluations: B is ~2e-13 of the operands' size, a float32
+// step is 6e-8 — that float32 IS the reference's, bit for bit.  Otherwise the round is evaluated again as one chain.
+// sum|p_i| <= |q| |r| (Cauchy-Schwarz; the cached norms) for cosine; for the metrics whose terms are >= 0 it is the sum itself.
+// The slack in kSplitSlack covers the norms' own rounding, the rounding of S -+ B and of B, and the second-order terms.
+template <int M> struct SplitOK { static constexpr bool value = M == QV_COSINE || M == QV_L2 || M == QV_L1 || M == QV_L2SQ_F64; };
+constexpr double kSplitSlack = 128.0;
+template <int M> __device__ __forceinline__ double split_bound(double s, double k_u, const QConst& qc, double rn) {
+    if constexpr (M == QV_COSINE) return k_u * qc.qn * rn;
+    else return k_u * s;
+}
+// lane walks NCH consecutive chunks (from chunk c0) of its row's 8 in the slab; otherwise slab_accumulate_qlds
+template <int M, int NCH>
+__device__ __forceinline__ void slab_accumulate_qlds_part(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, const lds_u8* qbuf, uint32_t c0) {
+    typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    typedef typename MT<M>::Q Q;
+    typedef const __attribute__((address_space(3))) Q* lds_qp;
+    const uint32_t mg = r >> 3, mr = r & 7, msw = mr ^ (mg & 1);
+    const lds_u8* mine = buf + mg * 1024 + mr * 128;
+    lds_qp q = (lds_qp)qbuf + 4 * c0;
+    f4 x[2]; Q qq[2][4];
+    x[0] = *(lds_f4p)(mine + ((c0 ^ msw) << 4));
+#pragma unroll
+    for (int e = 0; e < 4; e++) qq[0][e] = q[e];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        if (c + 1 < NCH) {
+            x[nxt] = *(lds_f4p)(mine + (((c0 + (uint32_t)(c + 1)) ^ msw) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; e++) qq[nxt][e] = q[4 * (c + 1) + e];
+        }
+        acc1<M>(acc, qq[cur][0], x[cur].x); acc1<M>(acc, qq[cur][1], x[cur].y); acc1<M>(acc, qq[cur][2], x[cur].z); acc1<M>(acc, qq[cur][3], x[cur].w);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // slabs_l: 2 x kHnswSlabBytes of row buffers followed by 2 x kHnswQBufBytes of query buffers.  Requires hnsw_qlds_ok(v).
+// One round of <= 32 rows (row r of the round on lane base + r).  P = 1: every row one chain on its lane (the reference's order).
+// P = 2 / 4 / 8 (cnt <= 32 / 16 / 8): row r on the P lanes r + j * 64 / P, lane j taking chunks j * 8 / P ... of every slab; the
+// lanes' sums are added pairwise and certified as above; `ok` comes back false on the lanes whose row needs the single chain.
+template <int M, int P>
+__device__ __forceinline__ float hnsw_eval_round_qlds(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l, const typename MT<M>::Q* __restrict__ q_g,
+                                                      const QConst& qc, uint32_t base, uint32_t cnt, uint32_t lane, bool& ok) {
+    lds_u8* qbufs = slabs_l + 2 * kHnswSlabBytes;
+    const uint32_t nslab = v.dim4 >> 3;
+    constexpr uint32_t kRows = 64 / (P == 1 ? 2 : P);                 // rows a round of this form can hold
+    const bool me = lane >= base && lane < base + cnt;                 // the lane that reports row lane - base
+    const uint32_t r = P == 1 ? (lane - base) & 31u : lane & (kRows - 1);
+    const uint32_t part = P == 1 ? 0u : lane / kRows;
+    const bool work = P == 1 ? me : r < cnt;
+    double rn = 0.0;
+    if constexpr (MT<M>::needs_rnorm) { if (work) rn = v.rnorm[batch_l[base + r]]; }
+    DmaRole role;
+    dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
+    typename MT<M>::A acc = 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    dma_issue_slab<kHnswSlab>(role, 0, v.dim4, slabs_l); dma_issue_query(q_g, 0, qbufs, lane);
+    for (uint32_t sl = 0; sl < nslab; sl++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl and its query values have landed
+        if (sl + 1 < nslab) {                                  // the next slab lands while this one is consumed
+            dma_issue_slab<kHnswSlab>(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);
+            dma_issue_query(q_g, sl + 1, qbufs + ((sl + 1) & 1) * kHnswQBufBytes, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 1) { if (work) slab_accumulate_qlds<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, r, qbufs + (sl & 1) * kHnswQBufBytes); }
+        else { if (work) slab_accumulate_qlds_part<M, 8 / P>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, r, qbufs + (sl & 1) * kHnswQBufBytes, part * (8 / P)); }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this slab's buffers are read before they are refilled
+    }
+    ok = true;
+    if constexpr (P == 1) return me ? finalize<M>(acc, qc, rn) : 0.0f;
+    else {
+        double s = (double)acc;
+#pragma unroll
+        for (uint32_t off = kRows; off < 64; off <<= 1) s = s + __shfl_xor(s, (int)off);       // every lane of a row ends with the same sum
+        const double k_u = ((double)(2u * v.dim) + kSplitSlack) * 0x1p-53;
+        const double b = split_bound<M>(s, k_u, qc, rn);
+        const float d_lo = finalize<M>((typename MT<M>::A)(s - b), qc, rn), d_hi = finalize<M>((typename MT<M>::A)(s + b), qc, rn);
+        ok = !me || (__float_as_uint(d_lo) == __float_as_uint(d_hi) && d_lo == d_lo);
+        return me ? d_lo : 0.0f;
+    }
+}
 template <int M, int U>
 __device__ __forceinline__ float hnsw_eval_rows_qlds(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l,
                                                      const typename MT<M>::Q* __restrict__ q_g, const QConst& qc, uint32_t n, uint32_t lane) {
     static_assert(kHnswSlab == 8, "one 128-byte piece per row and slab");
-    lds_u8* qbufs = slabs_l + 2 * kHnswSlabBytes;
     float out = 0.0f;
-    const uint32_t nslab = v.dim4 >> 3;
     for (uint32_t base = 0; base < n; base += kHnswRound) {
         const uint32_t cnt = n - base < (uint32_t)kHnswRound ? n - base : (uint32_t)kHnswRound;
-        const bool me = lane >= base && lane < base + cnt;       // row r of this round sits on lane base + r
-        const uint32_t myrow = me ? batch_l[lane] : 0u;
-        double rn = 0.0;
-        if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[myrow]; }
-        DmaRole role;
-        dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
-        const uint32_t r = (lane - base) & 31u;
-        typename MT<M>::A acc = 0;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        dma_issue_slab<kHnswSlab>(role, 0, v.dim4, slabs_l); dma_issue_query(q_g, 0, qbufs, lane);
-        for (uint32_t sl = 0; sl < nslab; sl++) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl and its query values have landed
-            if (sl + 1 < nslab) {                                  // the next slab lands while this one is consumed
-                dma_issue_slab<kHnswSlab>(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);
-                dma_issue_query(q_g, sl + 1, qbufs + ((sl + 1) & 1) * kHnswQBufBytes, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (me) slab_accumulate_qlds<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, r, qbufs + (sl & 1) * kHnswQBufBytes);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this slab's buffers are read before they are refilled
+        const bool me = lane >= base && lane < base + cnt;
+        bool ok = false; float d = 0.0f;
+        if constexpr (SplitOK<M>::value) {
+            if (cnt <= 8) d = hnsw_eval_round_qlds<M, 8>(v, batch_l, slabs_l, q_g, qc, base, cnt, lane, ok);
+            else if (cnt <= 16) d = hnsw_eval_round_qlds<M, 4>(v, batch_l, slabs_l, q_g, qc, base, cnt, lane, ok);
+            else d = hnsw_eval_round_qlds<M, 2>(v, batch_l, slabs_l, q_g, qc, base, cnt, lane, ok);
+            ok = __ballot(!ok) == 0;                               // (wave-uniform from here)
         }
-        if (me) out = finalize<M>(acc, qc, rn);
+        if (!ok) d = hnsw_eval_round_qlds<M, 1>(v, batch_l, slabs_l, q_g, qc, base, cnt, lane, ok);
+        if (me) out = d;
     }
     return out;
+}
+
+
+// ---- the latency form: one workgroup of W waves per query ----------------------------------------------------------------
+// A batch that leaves most of the device idle (a lone caller; a shared batch of a few dozen callers) is bound by ONE query's chain
+// of hops, and a hop by its parts in sequence.  Measured at 1M x 768, efSearch 128, four queries in flight (QV_HNSW_PROF):
+// 150 hops of 16.5 us = 2.5 ms — evaluation 9.2 us (24 slabs, each a DMA round trip nothing else covers, ~0.4 us), adjacency list
+// + visited table 4.2 us (two dependent round trips to L2), list inserts 2.8 us.  With a CU to itself a query takes the whole
+// LDS instead: every row of the hop is requested at once (32 x 3 KiB in flight, one round trip), the query stays resident,
+// the visited table is in LDS — and W waves evaluate the hop: wave w requests and walks columns [w, w + 1) * dim / W of every
+// row, its 64 lanes split those columns 2 / 4 / 8 ways per row (cnt <= 32 / 16 / 8), so a row's 768-step chain becomes chains of
+// 96 / 48 / 24 steps whose sum is certified as in hnsw_eval_round_qlds (rows that fail are walked again from LDS as ONE chain:
+// the reference's order).  Wave 0 keeps the list and drives; the others wait at a barrier between hops.
+struct LatLds {
+    lds_u32* batch;     // [64] the hop's rows
+    lds_u32* ctrl;      // [0] rows of the round (0xFFFFFFFF: leave), [1] first row of the round in batch[]
+    lds_u8*  part;      // [W][32] float64 partial sums
+    lds_u8*  q;         // the query in the metric's Q type, dim4 * 4 elements
+    lds_u8*  rows;      // [4 groups of 8 rows][dim4 / 8 pieces][8 rows][8 slots] x 16 bytes (slot j of row r: chunk j ^ sw(r))
+};
+constexpr uint32_t kLatQOff = 2048;                                     // batch, ctrl, partial sums below it
+__host__ __device__ inline uint32_t lat_q_bytes(uint32_t dim4, uint32_t qsize) { return (dim4 * 4 * qsize + 1023u) & ~1023u; }
+__host__ __device__ inline uint32_t lat_rows_bytes(uint32_t dim4) { return 4u * (dim4 >> 3) * 1024u; }
+
+// chunks [c_lo, c_hi) of row r of the round, in order (c_lo = 0, c_hi = dim4: the reference's chain)
+template <int M>
+__device__ __forceinline__ typename MT<M>::A lat_row_chain(const lds_u8* rows, const lds_u8* qb, uint32_t nP, uint32_t r, uint32_t c_lo, uint32_t c_hi) {
+    typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    typedef typename MT<M>::Q Q;
+    typedef const __attribute__((address_space(3))) Q* lds_qp;
+    const uint32_t mg = r >> 3, mr = r & 7, msw = mr ^ (mg & 1);
+    const lds_u8* mine = rows + mg * nP * 1024 + mr * 128;
+    lds_qp q = (lds_qp)qb;
+    typename MT<M>::A acc = 0;
+    if (c_lo >= c_hi) return acc;
+    f4 x = *(lds_f4p)(mine + (c_lo >> 3) * 1024 + (((c_lo & 7) ^ msw) << 4));
+    Q q0 = q[4 * c_lo], q1 = q[4 * c_lo + 1], q2 = q[4 * c_lo + 2], q3 = q[4 * c_lo + 3];
+    for (uint32_t c = c_lo; c < c_hi; c++) {
+        f4 xn = x; Q n0 = q0, n1 = q1, n2 = q2, n3 = q3;
+        if (c + 1 < c_hi) {
+            const uint32_t cn = c + 1;
+            xn = *(lds_f4p)(mine + (cn >> 3) * 1024 + (((cn & 7) ^ msw) << 4));
+            n0 = q[4 * cn]; n1 = q[4 * cn + 1]; n2 = q[4 * cn + 2]; n3 = q[4 * cn + 3];
+        }
+        acc1<M>(acc, q0, x.x); acc1<M>(acc, q1, x.y); acc1<M>(acc, q2, x.z); acc1<M>(acc, q3, x.w);
+        x = xn; q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+    }
+    return acc;
+}
+// one wave's share of a round (every wave of the workgroup calls it between the two barriers of the round)
+template <int M, int W>
+__device__ __forceinline__ void lat_round_part(const IndexView& v, const LatLds& L, uint32_t base, uint32_t cnt, uint32_t wave, uint32_t lane) {
+    const uint32_t nP = v.dim4 >> 3;
+    const uint32_t p_lo = wave * nP / W, p_hi = (wave + 1) * nP / W;     // this wave's pieces of every row
+    const uint32_t drow = lane >> 3, dslot = lane & 7, ng = (cnt + 7) >> 3;
+    for (uint32_t gi = 0; gi < ng; gi++) {
+        const uint32_t rr = gi * 8 + drow;
+        const uint32_t row = L.batch[base + (rr < cnt ? rr : 0u)];       // lanes past the round's rows fetch its first row into slots nobody reads
+        const float* src = v.rowmaj + (size_t)row * v.dim + ((dslot ^ drow ^ (gi & 1u)) << 2);
+        lds_u8* dst = L.rows + gi * nP * 1024;
+        for (uint32_t p = p_lo; p < p_hi; p++) glds16(src + p * 32, dst + p * 1024);
+    }
+    const uint32_t rows_cap = cnt <= 8 ? 8u : (cnt <= 16 ? 16u : 32u), lpr = 64u / rows_cap;
+    const uint32_t r = lane & (rows_cap - 1), sub = lane / rows_cap;
+    const uint32_t c0 = p_lo * 8, n = (p_hi - p_lo) * 8;
+    const uint32_t my_lo = c0 + sub * n / lpr, my_hi = c0 + (sub + 1) * n / lpr;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's columns have landed (it reads no others)
+    double s = 0.0;
+    if (r < cnt) s = (double)lat_row_chain<M>(L.rows, L.q, nP, r, my_lo, my_hi);
+    for (uint32_t off = rows_cap; off < 64; off <<= 1) s = s + __shfl_xor(s, (int)off);
+    if (lane < rows_cap && r < cnt) *(__attribute__((address_space(3))) double*)(L.part + (wave * 32 + r) * 8) = s;
+}
+// the driver's side of a hop: distance(query, batch[i]) on lane i for i < n
+template <int M, int W>
+__device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds& L, const QConst& qc, uint32_t n, uint32_t lane) {
+    float out = 0.0f;
+    const uint32_t nP = v.dim4 >> 3;
+    for (uint32_t base = 0; base < n; base += 32) {
+        const uint32_t cnt = n - base < 32u ? n - base : 32u;
+        const bool me = lane >= base && lane < base + cnt;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[L.batch[lane]]; }
+        if (lane == 0) { L.ctrl[0] = cnt; L.ctrl[1] = base; }
+        __syncthreads();                                                // the round is posted (and batch[] is visible to every wave)
+        lat_round_part<M, W>(v, L, base, cnt, 0, lane);
+        __syncthreads();                                                // every wave's columns are in LDS, every partial sum written
+        float d = 0.0f; bool ok = true;
+        if (me) {
+            typedef const __attribute__((address_space(3))) double* lds_dp;
+            lds_dp pp = (lds_dp)L.part + (lane - base);
+            double s = pp[0];
+#pragma unroll
+            for (int w = 1; w < W; w++) s = s + pp[w * 32];
+            const double k_u = ((double)(2u * v.dim) + kSplitSlack) * 0x1p-53;
+            const double b = split_bound<M>(s, k_u, qc, rn);
+            const float d_lo = finalize<M>((typename MT<M>::A)(s - b), qc, rn), d_hi = finalize<M>((typename MT<M>::A)(s + b), qc, rn);
+            ok = __float_as_uint(d_lo) == __float_as_uint(d_hi) && d_lo == d_lo;
+            d = d_lo;
+        }
+        if (__ballot(!ok)) { if (me && !ok) d = finalize<M>(lat_row_chain<M>(L.rows, L.q, nP, lane - base, 0, v.dim4), qc, rn); }   // the rows are all here: one chain
+        if (me) out = d;
+    }
+    return out;
+}
+// visited table in LDS (the latency form, when it fits): the same open-addressed table
+typedef __attribute__((address_space(3))) uint32_t* lds_u32w;
+__device__ __forceinline__ void vis_hash_clear_lds(lds_u32w tab, uint32_t cap, uint32_t lane) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 e = {kVisEmpty, kVisEmpty, kVisEmpty, kVisEmpty};
+    for (uint32_t i = lane * 4; i < cap; i += 256) *reinterpret_cast<__attribute__((address_space(3))) u4*>(tab + i) = e;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ bool vis_hash_insert_lds(lds_u32w tab, uint32_t mask, uint32_t shift, uint32_t node) {
+    uint32_t h = (node * 0x9E3779B1u) >> shift;
+    for (;;) {
+        uint32_t expected = kVisEmpty;
+        if (__hip_atomic_compare_exchange_strong(tab + h, &expected, node, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return true;
+        if (expected == node) return false;
+        h = (h + 1) & mask;
+    }
 }
 
 #ifdef QV_HNSW_PROF
@@ -663,8 +859,8 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
 }
 
 
-template <int M, int U, int S, bool QLDS>
-__global__ void __launch_bounds__(64)
+template <int M, int U, int S, bool QLDS, int W = 1>
+__global__ void __launch_bounds__(64 * W)
 k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t nq, uint32_t k, uint32_t ef_search,
                    HnswOpts o,
                    uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
@@ -675,8 +871,28 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     lds_u32* batch_l = (lds_u32*)smem;
     lds_u8* slabs_l = (lds_u8*)(batch_l + 64);                             // 2 x kHnswSlabBytes (row-major index only)
     const Q* q_g = qblk;                                                   // this wave's query, zero-padded to dim4*4, in the metric's Q type
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t* tab = o.vis + (size_t)blockIdx.x * o.vis_cap;               // this wave slot's visited hash table
+    // W > 1, the latency form (see LatLds): wave 0 runs everything below, the other waves only take their share of each hop's rows
+    LatLds L;
+    L.batch = (lds_u32*)batch_l; L.ctrl = (lds_u32*)batch_l + 64; L.part = (lds_u8*)smem + 512; L.q = (lds_u8*)smem + kLatQOff;
+    L.rows = L.q + lat_q_bytes(v.dim4, (uint32_t)sizeof(Q));
+    lds_u32w tab_l = (lds_u32w)(L.rows + lat_rows_bytes(v.dim4));          // (used when o.vis_lds)
+    const bool vis_lds = W > 1 && o.vis_lds;
+    if constexpr (W > 1) {
+        const uint32_t wave = threadIdx.x >> 6;
+        if (wave != 0) {
+            for (;;) {
+                __syncthreads();
+                const uint32_t cnt = L.ctrl[0], base = L.ctrl[1];
+                if (cnt == 0xFFFFFFFFu) return;
+                lat_round_part<M, W>(v, L, base, cnt, wave, lane);
+                __syncthreads();
+            }
+        }
+    }
+    // wave 0's own LDS traffic (batch[] written by some lanes, read by others): LDS operations of one wave execute in order
+    auto wsync = [&]() { if constexpr (W > 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); };
     const bool build = o.qlevel != nullptr;
     // a graph without tombstones (every graph built on the device) needs no level[] lookup to know a node is there
     auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && (!g.has_dead || g.level[n] >= 0); };
@@ -694,7 +910,9 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
 
     // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n)
     auto eval_keys = [&](uint32_t n) -> uint64_t {
-        const float dd = QLDS ? hnsw_eval_rows_qlds<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane) : hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
+        float dd;
+        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane);
+        else dd = QLDS ? hnsw_eval_rows_qlds<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane) : hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
         return lane < n ? make_key(dd, batch_l[lane]) : kDeadKey;
     };
     // sorted insert of x (distance part xd) into the list; ef = size of the reference's result heap
@@ -768,6 +986,12 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         q_g = qblk + (size_t)qi * v.dim4 * 4;
         qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
         n_eval = 0; tie = false;
+        if constexpr (W > 1) {                                          // the query into LDS (the other waves are at their barrier)
+            const uint32_t qbytes = v.dim4 * 4 * (uint32_t)sizeof(Q);
+            for (uint32_t off = 0; off < qbytes; off += 1024)
+                if (off + lane * 16 < qbytes) glds16(reinterpret_cast<const float*>(q_g) + (off >> 2) + lane * 4, L.q + off);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         uint32_t entry = g.entry;
         int stop = 0;                                                   // build: connectNode stops at min(level, graphLevel), hnsw.go:383
         if (build) { stop = (int)o.qlevel[qi]; if (stop > g.cur_level) stop = g.cur_level; }
@@ -781,7 +1005,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             const uint32_t hmask = hcap - 1, hshift = (uint32_t)__builtin_clz(hcap) + 1;   // 32 - log2(hcap)
             const uint32_t hlimit = hcap - (hcap >> 2);
             uint32_t n_vis = 1;
-            vis_hash_clear(tab, hcap, lane);                               // :483-488
+            if (vis_lds) vis_hash_clear_lds(tab_l, hcap, lane); else vis_hash_clear(tab, hcap, lane);   // :483-488
 #pragma unroll
             for (int s2 = 0; s2 < S; s2++) { key[s2] = kDeadKey; expd[s2] = 0; }
             n_list = 0;
@@ -790,9 +1014,9 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                 uint32_t nb;
                 if (first) {                                                 // :492-506: the entry point itself
                     first = false;
-                    __syncthreads();
-                    if (lane == 0) { (void)vis_hash_insert(tab, hmask, hshift, entry); batch[0] = entry; }
-                    __syncthreads();
+                    wsync();
+                    if (lane == 0) { if (vis_lds) (void)vis_hash_insert_lds(tab_l, hmask, hshift, entry); else (void)vis_hash_insert(tab, hmask, hshift, entry); batch[0] = entry; }
+                    wsync();
                     nb = 1;
                 } else {
                     // pop: first unexpanded entry
@@ -833,14 +1057,14 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                         const uint32_t cj = __builtin_amdgcn_readlane(c, j);
                         if (lane > j && c == cj) fresh = false;
                     }
-                    if (fresh) fresh = vis_hash_insert(tab, hmask, hshift, c);
+                    if (fresh) fresh = vis_lds ? vis_hash_insert_lds(tab_l, hmask, hshift, c) : vis_hash_insert(tab, hmask, hshift, c);
                     const uint64_t fm = __ballot(fresh);
                     nb = (uint32_t)__builtin_popcountll(fm);
                     n_vis += nb;
                     if (n_vis > hlimit) { tie = true; break; }               // table 3/4 full: hand the query to the exact-heap kernel
-                    __syncthreads();                                         // previous hop's batch[] reads are done
+                    wsync();                                         // previous hop's batch[] reads are done
                     if (fresh) batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c;
-                    __syncthreads();
+                    wsync();
                     HTICK(1);
                     if (nb == 0) continue;
                 }
@@ -906,9 +1130,9 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                 }
             }
             if (build && stop >= 1 && o.self_dist) {                    // lower levels link the node to itself (:463-467): d(node, node)
-                __syncthreads();
+                wsync();
                 if (lane == 0) batch[0] = o.qnode0 + qi;
-                __syncthreads();
+                wsync();
                 const uint64_t ks = eval_keys(1);
                 if (lane == 0) o.self_dist[qi] = unord_f32((uint32_t)(ks >> 32));
             }
@@ -920,6 +1144,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                    (unsigned long long)(wall_clock64() - wc0), (unsigned long long)(T[0]+T[1]+T[2]+T[3]+T[4]+T[5]+T[6]+T[7]), full_hops, full_rows, surv_hops, surv_rows);
 #endif
     }
+    if constexpr (W > 1) { if (lane == 0) L.ctrl[0] = 0xFFFFFFFFu; __syncthreads(); }      // the other waves leave
 }
 
 // ---- link distances of an uploaded graph ---------------------------------------------------
@@ -1045,6 +1270,30 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     // the query through LDS for row-major indexes whose dimension is a multiple of 32 (QV_HNSW_QLDS=2: never)
     static const int qlds_env = env_int("QV_HNSW_QLDS", 1);
     const bool deep = qlds_env == 1 && hnsw_qlds_ok(v);
+    // The latency form (a workgroup of four waves and a CU's LDS per query) for batches that would leave most CUs idle anyway:
+    // at most one query per CU, a metric whose chain can be split and certified, rows of a hop + query within the LDS.
+    static const int lat_env = env_int("QV_HNSW_LAT", 1);
+    static const int lat_cus = [] { int d = 0, c = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c; }();
+    const uint32_t qsize = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
+    const size_t lat_fixed = (size_t)kLatQOff + lat_q_bytes(v.dim4, qsize) + lat_rows_bytes(v.dim4);
+    const bool lat_metric = v.metric == QV_COSINE || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
+    if (lat_env == 1 && lat_metric && hnsw_qlds_ok(v) && nq <= (uint32_t)lat_cus && nq <= grid && lat_fixed <= (size_t)160 * 1024) {
+        HnswOpts ol = o;
+        ol.vis_lds = lat_fixed + (size_t)o.vis_cap * 4 <= (size_t)160 * 1024 ? 1u : 0u;
+        const size_t lds_lat = lat_fixed + (ol.vis_lds ? (size_t)o.vis_cap * 4 : 0);
+#define QV_HWL(SS) QV_DISPATCH_METRIC(v.metric, {                                                                     \
+        if constexpr (SplitOK<MM>::value) {                                                                           \
+            e = set_lds(k_hnsw_search_wave<MM, 4, SS, true, 4>, lds_lat);                                             \
+            if (e != hipSuccess) return e;                                                                            \
+            hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS, true, 4>), dim3(nq), dim3(256), lds_lat, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
+                               static_cast<const double*>(d_qconst), nq, k, ef, ol,                                  \
+                               d_rows_out, d_dist_out, d_count_out, d_evals_out);                                     \
+        }                                                                                                             \
+    })
+        if (efx < 128) { QV_HWL(2); } else if (efx < 256) { QV_HWL(4); } else if (efx < 320) { QV_HWL(5); } else if (efx < 512) { QV_HWL(8); } else { QV_HWL(9); }
+#undef QV_HWL
+        return e != hipSuccess ? e : hipGetLastError();
+    }
 #define QV_HW(SS) if (deep) { QV_HWD(SS, true); } else { QV_HWD(SS, false); }
     // list registers: S x 64 entries.  One notch more than efx needs where that is free (<= 128 VGPRs either way), so that a tie
     // group at the end of the result heap has room (ef <= 127 -> S = 2, ef = 128..256 -> S = 4; S = 8 would cost a wave per SIMD)

@@ -167,3 +167,40 @@ def test_graph_replicas_round_robin_equals_one_graph():
     r2, d2, c2 = reps.search(qs[:2], k, ef)                           # fewer queries than replicas
     assert np.array_equal(r2[:, :k], r[:2, :k])
     reps.close(); one.close(); one_idx.close()
+
+
+@pytest.mark.parametrize("metric,dim,n,m,ef", [
+    ("cosine", 768, 3000, 32, 128),
+    ("cosine", 96, 2500, 24, 64),            # 3 pieces for 4 waves: one wave of the latency form has no columns
+    ("l2", 160, 2000, 32, 200),
+    ("l1", 32, 1500, 16, 64),
+    ("l2sq_f64", 224, 1200, 16, 300),
+])
+def test_split_chains_both_kernel_forms_identical_to_oracle(metric, dim, n, m, ef):
+    """The metrics whose float64 chain is evaluated as several lanes' partial chains and certified (SplitOK, qv_hnsw.hip):
+    a batch of 320 queries takes the throughput form (a wave per query, hnsw_eval_round_qlds), batches of <= 64 the latency
+    form (a workgroup per query, lat_eval_rows).  Both must give the oracle's rows, float32 bits and evaluation counts.
+    Half of the queries ARE corpus rows: their distance to themselves is ~0, where the certification cannot hold and the
+    row is walked again as one chain (the fallback)."""
+    mid = quiver_amd.metric_id(metric)
+    k = 10
+    rows = O.gen_rows(5151, 0, n, dim)
+    idx, deg, links = _knn_graph(rows, metric, m)
+    g = quiver_amd.DeviceGraph(idx, np.zeros(n, np.int8), deg, links, entry=3)
+    o = O.HNSW(mid, dim, M=max(m // 2, 1), maxM0=m, efSearch=ef, maxLevel=1, seed=1)
+    o.load_flat(rows, deg, links, 3)
+    qs = np.concatenate([O.gen_rows(5152, 0, 160, dim), rows[np.arange(160) * 7 % n]])
+    r, d, c, ev = g.search(qs, k, ef, with_evals=True)                       # 320 > CUs: throughput form
+    for lo in range(0, 320, 64):                                             # latency form
+        r2, d2, c2, ev2 = g.search(qs[lo:lo + 64], k, ef, with_evals=True)
+        assert np.array_equal(c2, c[lo:lo + 64]) and np.array_equal(ev2, ev[lo:lo + 64]), lo
+        for i in range(64):
+            assert r2[i, :c2[i]].tolist() == r[lo + i, :c2[i]].tolist(), (lo, i)
+            assert d2[i, :c2[i]].tobytes() == d[lo + i, :c2[i]].tobytes(), (lo, i)
+    for i in list(range(0, 320, 9)):
+        ro, do, eo = o.search(qs[i], k, with_evals=True)
+        assert c[i] <= k
+        assert r[i, :c[i]].tolist() == ro[:c[i]].tolist(), i
+        assert d[i, :c[i]].tobytes() == do[:c[i]].tobytes(), i
+        if c[i] == k:
+            assert int(ev[i]) == eo - 1, i
