@@ -193,6 +193,9 @@ constexpr uint32_t kHnswTieFlag = 0xFFFFFFFEu;
 #ifndef QV_HNSW_SLAB
 #define QV_HNSW_SLAB 8
 #endif
+#ifndef QV_HNSW_LAT_WAVES
+#define QV_HNSW_LAT_WAVES 8
+#endif
 constexpr int kHnswSlab = QV_HNSW_SLAB;   // chunks per slab (128 B of each row): 2 x 4 KiB of slab buffers per wave -> 16 waves per CU
                                           // (measured 5k x 768, efSearch 128: slab 8 -> 554k QPS, 16 -> 430k, 32 -> 209k: occupancy wins)
 constexpr int kHnswRound = 32;            // rows per round (MaxM0 = 32 by default: one round per hop)
@@ -551,7 +554,9 @@ struct LatLds {
     lds_u8*  q;         // the query in the metric's Q type, dim4 * 4 elements
     lds_u8*  rows;      // [4 groups of 8 rows][dim4 / 8 pieces][8 rows][8 slots] x 16 bytes (slot j of row r: chunk j ^ sw(r))
 };
-constexpr uint32_t kLatQOff = 2048;                                     // batch, ctrl, partial sums below it
+constexpr int kLatWaves = QV_HNSW_LAT_WAVES;                            // waves per query in the latency form
+constexpr uint32_t kLatQOff = 512 + kLatWaves * 256 + 512;              // batch, ctrl, partial sums below it (a multiple of 1 KiB)
+static_assert(kLatQOff % 1024 == 0, "LDS-DMA blocks are 1 KiB");
 __host__ __device__ inline uint32_t lat_q_bytes(uint32_t dim4, uint32_t qsize) { return (dim4 * 4 * qsize + 1023u) & ~1023u; }
 __host__ __device__ inline uint32_t lat_rows_bytes(uint32_t dim4) { return 4u * (dim4 >> 3) * 1024u; }
 
@@ -566,23 +571,31 @@ __device__ __forceinline__ typename MT<M>::A lat_row_chain(const lds_u8* rows, c
     lds_qp q = (lds_qp)qb;
     typename MT<M>::A acc = 0;
     if (c_lo >= c_hi) return acc;
-    f4 x = *(lds_f4p)(mine + (c_lo >> 3) * 1024 + (((c_lo & 7) ^ msw) << 4));
-    Q q0 = q[4 * c_lo], q1 = q[4 * c_lo + 1], q2 = q[4 * c_lo + 2], q3 = q[4 * c_lo + 3];
-    for (uint32_t c = c_lo; c < c_hi; c++) {
-        f4 xn = x; Q n0 = q0, n1 = q1, n2 = q2, n3 = q3;
-        if (c + 1 < c_hi) {
-            const uint32_t cn = c + 1;
-            xn = *(lds_f4p)(mine + (cn >> 3) * 1024 + (((cn & 7) ^ msw) << 4));
-            n0 = q[4 * cn]; n1 = q[4 * cn + 1]; n2 = q[4 * cn + 2]; n3 = q[4 * cn + 3];
-        }
-        acc1<M>(acc, q0, x.x); acc1<M>(acc, q1, x.y); acc1<M>(acc, q2, x.z); acc1<M>(acc, q3, x.w);
-        x = xn; q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+    // two register sets, each loaded a chunk ahead of its use (an index past the range is clamped: a load nobody uses)
+    auto row_at = [&](uint32_t c) -> f4 { return *(lds_f4p)(mine + (c >> 3) * 1024 + (((c & 7) ^ msw) << 4)); };
+    const uint32_t c_last = c_hi - 1;
+    uint32_t c = c_lo;
+    f4 xa = row_at(c), xb;
+    Q a0 = q[4 * c], a1 = q[4 * c + 1], a2 = q[4 * c + 2], a3 = q[4 * c + 3], b0, b1, b2, b3;
+    for (; c + 1 < c_hi; c += 2) {
+        const uint32_t cb = c + 1, ca = c + 2 < c_hi ? c + 2 : c_last;
+        xb = row_at(cb); b0 = q[4 * cb]; b1 = q[4 * cb + 1]; b2 = q[4 * cb + 2]; b3 = q[4 * cb + 3];
+        acc1<M>(acc, a0, xa.x); acc1<M>(acc, a1, xa.y); acc1<M>(acc, a2, xa.z); acc1<M>(acc, a3, xa.w);
+        xa = row_at(ca); a0 = q[4 * ca]; a1 = q[4 * ca + 1]; a2 = q[4 * ca + 2]; a3 = q[4 * ca + 3];
+        acc1<M>(acc, b0, xb.x); acc1<M>(acc, b1, xb.y); acc1<M>(acc, b2, xb.z); acc1<M>(acc, b3, xb.w);
     }
+    if (c < c_hi) { acc1<M>(acc, a0, xa.x); acc1<M>(acc, a1, xa.y); acc1<M>(acc, a2, xa.z); acc1<M>(acc, a3, xa.w); }
     return acc;
 }
 // one wave's share of a round (every wave of the workgroup calls it between the two barriers of the round)
 template <int M, int W>
-__device__ __forceinline__ void lat_round_part(const IndexView& v, const LatLds& L, uint32_t base, uint32_t cnt, uint32_t wave, uint32_t lane) {
+__device__ __forceinline__ void lat_round_part(const IndexView& v, const LatLds& L, uint32_t base, uint32_t cnt, uint32_t wave, uint32_t lane, uint64_t* st = nullptr) {
+#ifdef QV_HNSW_PROF
+    uint64_t t_l = __builtin_readcyclecounter();
+#define LTICK(i) if (st) { const uint64_t t_n = __builtin_readcyclecounter(); st[i] += t_n - t_l; t_l = t_n; }
+#else
+#define LTICK(i)
+#endif
     const uint32_t nP = v.dim4 >> 3;
     const uint32_t p_lo = wave * nP / W, p_hi = (wave + 1) * nP / W;     // this wave's pieces of every row
     const uint32_t drow = lane >> 3, dslot = lane & 7, ng = (cnt + 7) >> 3;
@@ -597,15 +610,26 @@ __device__ __forceinline__ void lat_round_part(const IndexView& v, const LatLds&
     const uint32_t r = lane & (rows_cap - 1), sub = lane / rows_cap;
     const uint32_t c0 = p_lo * 8, n = (p_hi - p_lo) * 8;
     const uint32_t my_lo = c0 + sub * n / lpr, my_hi = c0 + (sub + 1) * n / lpr;
+    LTICK(8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's columns have landed (it reads no others)
+    LTICK(9);
     double s = 0.0;
     if (r < cnt) s = (double)lat_row_chain<M>(L.rows, L.q, nP, r, my_lo, my_hi);
+    LTICK(10);
     for (uint32_t off = rows_cap; off < 64; off <<= 1) s = s + __shfl_xor(s, (int)off);
     if (lane < rows_cap && r < cnt) *(__attribute__((address_space(3))) double*)(L.part + (wave * 32 + r) * 8) = s;
+    LTICK(11);
+#undef LTICK
 }
 // the driver's side of a hop: distance(query, batch[i]) on lane i for i < n
 template <int M, int W>
-__device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds& L, const QConst& qc, uint32_t n, uint32_t lane) {
+__device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds& L, const QConst& qc, uint32_t n, uint32_t lane, uint64_t* st = nullptr) {
+#ifdef QV_HNSW_PROF
+    uint64_t t_l = __builtin_readcyclecounter();
+#define LTICK(i) if (st) { const uint64_t t_n = __builtin_readcyclecounter(); st[i] += t_n - t_l; t_l = t_n; }
+#else
+#define LTICK(i)
+#endif
     float out = 0.0f;
     const uint32_t nP = v.dim4 >> 3;
     for (uint32_t base = 0; base < n; base += 32) {
@@ -615,8 +639,13 @@ __device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds&
         if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[L.batch[lane]]; }
         if (lane == 0) { L.ctrl[0] = cnt; L.ctrl[1] = base; }
         __syncthreads();                                                // the round is posted (and batch[] is visible to every wave)
-        lat_round_part<M, W>(v, L, base, cnt, 0, lane);
+        LTICK(12);
+        lat_round_part<M, W>(v, L, base, cnt, 0, lane, st);
+#ifdef QV_HNSW_PROF
+        t_l = __builtin_readcyclecounter();
+#endif
         __syncthreads();                                                // every wave's columns are in LDS, every partial sum written
+        LTICK(13);
         float d = 0.0f; bool ok = true;
         if (me) {
             typedef const __attribute__((address_space(3))) double* lds_dp;
@@ -632,7 +661,9 @@ __device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds&
         }
         if (__ballot(!ok)) { if (me && !ok) d = finalize<M>(lat_row_chain<M>(L.rows, L.q, nP, lane - base, 0, v.dim4), qc, rn); }   // the rows are all here: one chain
         if (me) out = d;
+        LTICK(14);
     }
+#undef LTICK
     return out;
 }
 // visited table in LDS (the latency form, when it fits): the same open-addressed table
@@ -651,6 +682,20 @@ __device__ __forceinline__ bool vis_hash_insert_lds(lds_u32w tab, uint32_t mask,
         if (expected == node) return false;
         h = (h + 1) & mask;
     }
+}
+
+// lanes whose node already stands on a LOWER lane of the same adjacency list (the self-link quirk: rare).  c = the list, one node
+// per lane, 0xFFFFFFFF past its end; every lane index is a constant, so a step is v_readlane + v_cmp + two scalar operations
+// and no branch (the loop over a register lane index took 3.7 k cycles per hop: 1.5 us of a lone traversal's 10).
+__device__ __forceinline__ uint64_t repeats_in_list(uint32_t c, uint32_t deg) {
+    uint64_t rep = 0;
+#pragma unroll
+    for (int j = 0; j < kHnswMaxDeg - 1; j++) {
+        if ((j & 7) == 0 && (uint32_t)j + 1 >= deg) break;             // (wave-uniform)
+        const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+        rep |= __ballot(c == cj) & ~((2ull << j) - 1ull);
+    }
+    return rep;
 }
 
 #ifdef QV_HNSW_PROF
@@ -743,10 +788,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                 if (lane < deg) { c = links[lane]; fresh = alive(c); }     // :539-541
             }
             // a list may hold the same node twice (the self-link quirk): only its first occurrence is new
-            for (uint32_t j = 0; j + 1 < deg; j++) {
-                uint32_t cj = __builtin_amdgcn_readlane(c, j);
-                if (lane > j && c == cj) fresh = false;
-            }
+            if ((repeats_in_list(c, deg) >> lane) & 1ull) fresh = false;
             if (fresh) fresh = vis_bits_insert(bm, c);                 // :543-544
             const uint64_t fm = __ballot(fresh);
             const uint32_t n = (uint32_t)__builtin_popcountll(fm);
@@ -897,7 +939,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     // a graph without tombstones (every graph built on the device) needs no level[] lookup to know a node is there
     auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && (!g.has_dead || g.level[n] >= 0); };
 #ifdef QV_HNSW_PROF
-    uint64_t T[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_last = __builtin_readcyclecounter(); const uint64_t wc0 = wall_clock64(); uint64_t hops = 0;
+    uint64_t T[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_last = __builtin_readcyclecounter(); const uint64_t wc0 = wall_clock64(); uint64_t hops = 0;
     uint64_t full_hops = 0, full_rows = 0, surv_hops = 0, surv_rows = 0;
     auto tick = [&](int ph) { uint64_t t = __builtin_readcyclecounter(); T[ph] += t - t_last; t_last = t; };
 #endif
@@ -911,7 +953,11 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     // distance of the query to batch[lane] for lane < n  ->  64-bit key (all lanes return; dead beyond n)
     auto eval_keys = [&](uint32_t n) -> uint64_t {
         float dd;
+#ifdef QV_HNSW_PROF
+        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane, T);
+#else
         if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane);
+#endif
         else dd = QLDS ? hnsw_eval_rows_qlds<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane) : hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
         return lane < n ? make_key(dd, batch_l[lane]) : kDeadKey;
     };
@@ -982,6 +1028,80 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         }
     };
 
+    // A hop's admissions at once (latency form).  One by one, each admission shifts the S registers (~1.6 k cycles: 4 per hop were
+    // the largest single part of a lone traversal's hop).  Write T(Z) = the entries of Z at or below its ef-th smallest distance
+    // (Z itself while it has fewer than ef): an admission is L -> T(L + x) unless L is full and d(x) >= w(L), the ef-th smallest —
+    // for d(x) > w(L) that IS T(L + x), and T(T(Z) + Y) = T(Z + Y), so the hop leaves T(L + X) unless some x met d(x) == w(L) and
+    // was turned away (hnsw.go:553 is a strict <) where T would keep it.  Such an x has d(x) >= the final w'; above w' it is dropped
+    // either way; so only a survivor AT the final w' (with more than ef entries in all) can make the two differ — then, as for a
+    // NaN or a list that would outgrow its registers, the hop is admitted one by one as before (false; nothing has been touched).
+    // Positions: an old entry moves up by the survivors below it, a survivor goes to (old entries below it) + (survivors below it) —
+    // one compare per (survivor, register) serves both; the scatter goes through LDS (the row buffer is idle between hops).
+    auto insert_batch = [&](uint64_t kx, uint64_t pend, uint32_t ef) -> bool {
+        constexpr uint32_t kCap = (uint32_t)S * 64;
+        const uint32_t ns = (uint32_t)__builtin_popcountll(pend);
+        if (n_list + ns > kCap) return false;
+        const bool mine = (pend >> lane) & 1ull;
+        if (__ballot(mine && (uint32_t)(kx >> 32) == 0xFFFFFFFEu)) return false;
+        uint32_t up[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) up[s2] = 0;
+        uint32_t pos = 0;
+        const uint32_t n_dead = kCap - n_list;                          // dead registers compare above every key
+        for (uint64_t m = pend; m; m &= m - 1) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(m);
+            const uint64_t xi = readlane64(kx, i);
+            uint32_t above = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) {
+                const bool gt = key[s2] > xi;
+                up[s2] += gt ? 1u : 0u;
+                above += (uint32_t)__builtin_popcountll(__ballot(gt));
+            }
+            if (mine && kx > xi) pos++;
+            if (lane == i) pos += n_list - (above - n_dead);
+        }
+        const uint32_t merged = n_list + ns;
+        uint32_t w = 0;
+        if (merged > ef) {
+            uint64_t wk = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) {
+                const uint32_t e = (uint32_t)s2 * 64 + lane;
+                const uint64_t bal = __ballot(e < n_list && e + up[s2] == ef - 1);
+                if (bal) wk = readlane64(key[s2], (uint32_t)__builtin_ctzll(bal));
+            }
+            const uint64_t bal = __ballot(mine && pos == ef - 1);
+            if (bal) wk = readlane64(kx, (uint32_t)__builtin_ctzll(bal));
+            w = (uint32_t)(wk >> 32);
+            if (__ballot(mine && (uint32_t)(kx >> 32) == w)) return false;
+        }
+        typedef __attribute__((address_space(3))) uint64_t* lds_u64w;
+        typedef __attribute__((address_space(3))) uint32_t* lds_f;
+        lds_u64w kb = (lds_u64w)L.rows; lds_f fb = (lds_f)(L.rows + kCap * 8);
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) {
+            const uint32_t e = (uint32_t)s2 * 64 + lane;
+            if (e < n_list) { kb[e + up[s2]] = key[s2]; fb[e + up[s2]] = (uint32_t)((expd[s2] >> lane) & 1ull); }
+        }
+        if (mine) { kb[pos] = kx; fb[pos] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        uint32_t dropped = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) {
+            const uint32_t e = (uint32_t)s2 * 64 + lane;
+            uint64_t kk = kDeadKey; uint32_t f = 0;
+            if (e < merged) { kk = kb[e]; f = fb[e]; }
+            const bool drop = merged > ef && e >= ef && e < merged && (uint32_t)(kk >> 32) > w;   // above the ef-th smallest: out (the entries AT it stay)
+            if (drop) kk = kDeadKey;
+            key[s2] = kk;
+            expd[s2] = __ballot(f != 0 && !drop);
+            dropped += (uint32_t)__builtin_popcountll(__ballot(drop));
+        }
+        n_list = merged - dropped;
+        return true;
+    };
+
     for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
         q_g = qblk + (size_t)qi * v.dim4 * 4;
         qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
@@ -1010,6 +1130,8 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             for (int s2 = 0; s2 < S; s2++) { key[s2] = kDeadKey; expd[s2] = 0; }
             n_list = 0;
             bool first = true;
+            // latency form: the adjacency list of the entry most likely to be popped next, requested a hop ahead (see below)
+            uint32_t spec = 0xFFFFFFFFu, spec_deg = 0, spec_cl = 0xFFFFFFFFu;
             for (;;) {
                 uint32_t nb;
                 if (first) {                                                 // :492-506: the entry point itself
@@ -1040,9 +1162,14 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     if (level == 0 && !g.has_dead && cur < g.n_nodes) {
                         // level 0 of a graph without tombstones (every graph built on the device): the degree and the fixed-width list
                         // are requested together — one round trip instead of two dependent ones per hop
-                        deg = g.l0_deg[cur];
-                        const uint32_t cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu;
+                        uint32_t cl;
+                        if (W > 1 && cur == spec) { deg = spec_deg; cl = spec_cl; }
+                        else { deg = g.l0_deg[cur]; cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu; }
                         if (lane < deg) { c = cl; fresh = c < g.n_nodes; }
+#ifdef QV_HNSW_PROF
+                        asm volatile("" : "+v"(c));
+                        HTICK(2);
+#endif
                     } else {
                         if (alive(cur) && (level == 0 ? (!g.has_dead || g.level[cur] >= 0) : level <= (int)g.level[cur])) {
                             if (level == 0) { deg = g.l0_deg[cur]; links = g.l0_links + (size_t)cur * g.max_m0; }
@@ -1053,11 +1180,10 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     // a node repeated inside one list (the self-link quirk) is new at its FIRST occurrence: admissions of a hop go
                     // in adjacency order (:537-560), and between two nodes of equal distance that order decides which one a full
                     // result set keeps — so the hash's test-and-set must not pick the winner among a node's repeats
-                    for (uint32_t j = 0; j + 1 < deg; j++) {
-                        const uint32_t cj = __builtin_amdgcn_readlane(c, j);
-                        if (lane > j && c == cj) fresh = false;
-                    }
+                    if ((repeats_in_list(c, deg) >> lane) & 1ull) fresh = false;
+                    HTICK(6);
                     if (fresh) fresh = vis_lds ? vis_hash_insert_lds(tab_l, hmask, hshift, c) : vis_hash_insert(tab, hmask, hshift, c);
+                    HTICK(3);
                     const uint64_t fm = __ballot(fresh);
                     nb = (uint32_t)__builtin_popcountll(fm);
                     n_vis += nb;
@@ -1067,6 +1193,22 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     wsync();
                     HTICK(1);
                     if (nb == 0) continue;
+                }
+                if constexpr (W > 1) {
+                    // The next pop is the first unexpanded entry — the one the list shows NOW unless this hop admits something
+                    // closer.  Its adjacency list is requested before the hop's rows are evaluated and has arrived long before
+                    // the pop: a hop's two dependent round trips (list, then rows) become one on most hops.
+                    spec = 0xFFFFFFFFu;
+                    if (level == 0 && !g.has_dead) {
+#pragma unroll
+                        for (int s2 = 0; s2 < S; s2++) {
+                            if (spec != 0xFFFFFFFFu) continue;
+                            const uint64_t m = __ballot(key[s2] != kDeadKey) & ~expd[s2];
+                            if (m) spec = (uint32_t)readlane64(key[s2], (uint32_t)__builtin_ctzll(m));
+                        }
+                        if (spec < g.n_nodes) { spec_deg = g.l0_deg[spec]; spec_cl = lane < g.max_m0 ? g.l0_links[(size_t)spec * g.max_m0 + lane] : 0xFFFFFFFFu; }
+                        else spec = 0xFFFFFFFFu;
+                    }
                 }
                 const uint64_t kx = eval_keys(nb); n_eval += nb;
                 HTICK(7);
@@ -1080,7 +1222,9 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                         full_hops++; full_rows += nb; surv_hops += pend != 0; surv_rows += (uint64_t)__builtin_popcountll(pend);
 #endif
                     }
-                    while (pend) {
+                    bool done = false;
+                    if constexpr (W > 1) { if (pend) done = insert_batch(kx, pend, ef); }
+                    while (!done && pend) {
                         const uint32_t i = (uint32_t)__builtin_ctzll(pend);
                         pend &= pend - 1;
                         insert(readlane64(kx, i), ef);
@@ -1140,8 +1284,11 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
 #ifdef QV_HNSW_PROF
         if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 777) && qi >= nq - gridDim.x)
+        {
+            if (W > 1) printf("lat eval: issue %llu dma-wait %llu chain %llu shuffle+write %llu | post+barrier %llu barrier B %llu certify %llu\n", T[8], T[9], T[10], T[11], T[12], T[13], T[14]);
             printf("blk %u: pop %llu links+vis %llu dma-wait %llu issue %llu compute %llu insert %llu other %llu/%llu hops %llu evals(last q) %u wall(10ns) %llu cyc %llu | list-full hops %llu rows %llu, with a row below the worst: hops %llu rows %llu\n", blockIdx.x, T[0], T[1], T[2], T[6], T[3], T[4], T[5], T[7], hops, n_eval,
                    (unsigned long long)(wall_clock64() - wc0), (unsigned long long)(T[0]+T[1]+T[2]+T[3]+T[4]+T[5]+T[6]+T[7]), full_hops, full_rows, surv_hops, surv_rows);
+        }
 #endif
     }
     if constexpr (W > 1) { if (lane == 0) L.ctrl[0] = 0xFFFFFFFFu; __syncthreads(); }      // the other waves leave
@@ -1283,9 +1430,9 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
         const size_t lds_lat = lat_fixed + (ol.vis_lds ? (size_t)o.vis_cap * 4 : 0);
 #define QV_HWL(SS) QV_DISPATCH_METRIC(v.metric, {                                                                     \
         if constexpr (SplitOK<MM>::value) {                                                                           \
-            e = set_lds(k_hnsw_search_wave<MM, 4, SS, true, 4>, lds_lat);                                             \
+            e = set_lds(k_hnsw_search_wave<MM, 4, SS, true, kLatWaves>, lds_lat);                                             \
             if (e != hipSuccess) return e;                                                                            \
-            hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS, true, 4>), dim3(nq), dim3(256), lds_lat, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
+            hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS, true, kLatWaves>), dim3(nq), dim3(64 * kLatWaves), lds_lat, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
                                static_cast<const double*>(d_qconst), nq, k, ef, ol,                                  \
                                d_rows_out, d_dist_out, d_count_out, d_evals_out);                                     \
         }                                                                                                             \
