@@ -547,6 +547,9 @@ __device__ __forceinline__ float hnsw_eval_rows_qlds(const IndexView& v, const l
 // row, its 64 lanes split those columns 2 / 4 / 8 ways per row (cnt <= 32 / 16 / 8), so a row's 768-step chain becomes chains of
 // 96 / 48 / 24 steps whose sum is certified as in hnsw_eval_round_qlds (rows that fail are walked again from LDS as ONE chain:
 // the reference's order).  Wave 0 keeps the list and drives; the others wait at a barrier between hops.
+// workgroup barrier of the latency form: LDS traffic only (a __syncthreads would also wait for the vector-memory queue — the row
+// norms and the adjacency prefetch the driver has in flight — ~1.5 k cycles per hop)
+__device__ __forceinline__ void lat_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct LatLds {
     lds_u32* batch;     // [64] the hop's rows
     lds_u32* ctrl;      // [0] rows of the round (0xFFFFFFFF: leave), [1] first row of the round in batch[]
@@ -599,12 +602,18 @@ __device__ __forceinline__ void lat_round_part(const IndexView& v, const LatLds&
     const uint32_t nP = v.dim4 >> 3;
     const uint32_t p_lo = wave * nP / W, p_hi = (wave + 1) * nP / W;     // this wave's pieces of every row
     const uint32_t drow = lane >> 3, dslot = lane & 7, ng = (cnt + 7) >> 3;
-    for (uint32_t gi = 0; gi < ng; gi++) {
+    uint32_t rowid[4];
+#pragma unroll
+    for (uint32_t gi = 0; gi < 4; gi++) {                                // (one LDS round trip for the four groups' row numbers)
         const uint32_t rr = gi * 8 + drow;
-        const uint32_t row = L.batch[base + (rr < cnt ? rr : 0u)];       // lanes past the round's rows fetch its first row into slots nobody reads
-        const float* src = v.rowmaj + (size_t)row * v.dim + ((dslot ^ drow ^ (gi & 1u)) << 2);
-        lds_u8* dst = L.rows + gi * nP * 1024;
-        for (uint32_t p = p_lo; p < p_hi; p++) glds16(src + p * 32, dst + p * 1024);
+        rowid[gi] = L.batch[base + (rr < cnt ? rr : 0u)];               // lanes past the round's rows fetch its first row into slots nobody reads
+    }
+#pragma unroll
+    for (uint32_t gi = 0; gi < 4; gi++) {
+        if (gi >= ng) break;
+        const float* src = v.rowmaj + (size_t)rowid[gi] * v.dim + ((dslot ^ drow ^ (gi & 1u)) << 2) + p_lo * 32;
+        lds_u8* dst = L.rows + (gi * nP + p_lo) * 1024;
+        for (uint32_t p = p_lo; p < p_hi; p++, src += 32, dst += 1024) glds16(src, dst);
     }
     const uint32_t rows_cap = cnt <= 8 ? 8u : (cnt <= 16 ? 16u : 32u), lpr = 64u / rows_cap;
     const uint32_t r = lane & (rows_cap - 1), sub = lane / rows_cap;
@@ -638,26 +647,36 @@ __device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds&
         double rn = 0.0;
         if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[L.batch[lane]]; }
         if (lane == 0) { L.ctrl[0] = cnt; L.ctrl[1] = base; }
-        __syncthreads();                                                // the round is posted (and batch[] is visible to every wave)
+        lat_barrier();                                                  // the round is posted (and batch[] is visible to every wave)
         LTICK(12);
         lat_round_part<M, W>(v, L, base, cnt, 0, lane, st);
 #ifdef QV_HNSW_PROF
         t_l = __builtin_readcyclecounter();
 #endif
-        __syncthreads();                                                // every wave's columns are in LDS, every partial sum written
+        lat_barrier();                                                  // every wave's columns are in LDS, every partial sum written
         LTICK(13);
+        // the two ends of the interval on the two halves of the wave: lane base + r takes S - B, lane (base + r) ^ 32 takes S + B
         float d = 0.0f; bool ok = true;
-        if (me) {
+        {
             typedef const __attribute__((address_space(3))) double* lds_dp;
-            lds_dp pp = (lds_dp)L.part + (lane - base);
-            double s = pp[0];
+            const uint32_t r = lane & 31u;
+            const bool has = r < cnt;
+            const bool low = (lane & 32u) == (base & 32u);
+            double rn2 = __shfl_xor(rn, 32);
+            if (low) rn2 = rn;
+            double s = 0.0;
+            if (has) {
+                lds_dp pp = (lds_dp)L.part + r;
+                s = pp[0];
 #pragma unroll
-            for (int w = 1; w < W; w++) s = s + pp[w * 32];
+                for (int w = 1; w < W; w++) s = s + pp[w * 32];
+            }
             const double k_u = ((double)(2u * v.dim) + kSplitSlack) * 0x1p-53;
-            const double b = split_bound<M>(s, k_u, qc, rn);
-            const float d_lo = finalize<M>((typename MT<M>::A)(s - b), qc, rn), d_hi = finalize<M>((typename MT<M>::A)(s + b), qc, rn);
-            ok = __float_as_uint(d_lo) == __float_as_uint(d_hi) && d_lo == d_lo;
-            d = d_lo;
+            const double b = split_bound<M>(s, k_u, qc, rn2);
+            const float de = finalize<M>((typename MT<M>::A)(low ? s - b : s + b), qc, rn2);
+            const float other = __shfl_xor(de, 32);
+            ok = !me || (__float_as_uint(de) == __float_as_uint(other) && de == de);
+            d = de;
         }
         if (__ballot(!ok)) { if (me && !ok) d = finalize<M>(lat_row_chain<M>(L.rows, L.q, nP, lane - base, 0, v.dim4), qc, rn); }   // the rows are all here: one chain
         if (me) out = d;
@@ -925,11 +944,11 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         const uint32_t wave = threadIdx.x >> 6;
         if (wave != 0) {
             for (;;) {
-                __syncthreads();
+                lat_barrier();
                 const uint32_t cnt = L.ctrl[0], base = L.ctrl[1];
                 if (cnt == 0xFFFFFFFFu) return;
                 lat_round_part<M, W>(v, L, base, cnt, wave, lane);
-                __syncthreads();
+                lat_barrier();
             }
         }
     }
@@ -1291,7 +1310,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         }
 #endif
     }
-    if constexpr (W > 1) { if (lane == 0) L.ctrl[0] = 0xFFFFFFFFu; __syncthreads(); }      // the other waves leave
+    if constexpr (W > 1) { if (lane == 0) L.ctrl[0] = 0xFFFFFFFFu; lat_barrier(); }      // the other waves leave
 }
 
 // ---- link distances of an uploaded graph ---------------------------------------------------
