@@ -50,14 +50,17 @@ struct qv_graph {
     std::atomic<uint64_t> tie_reruns{0};
     std::mutex mu;                              // the graph's OWN buffers below (device-form traversals, construction, export): one user at a time
     // host-pointer searches: a context each (pool), and a front that lets concurrent small calls share a traversal batch
-    // (qv_coalesce.h).  Two batches in flight at most (measured with 8 / 256 / 1024 callers on 1M x 768, efSearch 128: 1 lane is what
-    // a second lone caller waits behind, 2 lanes 2.1 k / 48 k / 109 k QPS, 4 lanes 2.2 k / 40 k / 93 k, 8 lanes 1.7 k / 24 k / 66 k — more lanes
-    // mean smaller batches, and every batch pays the same ~4.5 ms): a traversal is one wavefront per query, so unlike a flat scan a lone
-    // batch does not fill the chip and a second caller should not wait for the first.
+    // (qv_coalesce.h).  A traversal is a chain of hops, so a lone batch does not fill the chip and a second caller should not wait for the
+    // first: two batches in flight, of at most 256 queries each — one query per CU, the batches the latency form of the wave kernel
+    // serves (qv_hnsw.hip: 1.1 - 1.7 ms per batch against 4.5 - 6 for the wave-per-query form).  Measured on 1M x 768, efSearch 128,
+    // QPS at 8 / 64 / 256 / 1024 callers (tools/dev_graph_lanes.sh): 1 lane x 4096 5.2 k / 36 k / 95 k / 87 k; 2 x 4096 5.6 k / 36 k /
+    // 124 k / 92 k; 2 x 256 5.6 k / 34 k / 119 k / 158 k; 2 x 128 5.6 k / 35 k / 128 k / 145 k; 4 x 256 5.6 k / 34 k / 80 k / 152 k;
+    // 4 x 128 5.7 k / 35 k / 96 k / 190 k (p99 at 256 callers 31 ms against 3 ms with two lanes); 8 x 128 4.3 k / 21 k / 64 k / 174 k.
     std::mutex ctx_mu;
     std::vector<GraphCtx*> free_ctx, all_ctx;
-    static int lanes() { static const int n = getenv("QV_GRAPH_LANES") ? std::max(1, atoi(getenv("QV_GRAPH_LANES"))) : 4; return n; }   // (measurement switch, read once)
-    qvco::Front front{lanes(), 4096};
+    static int lanes() { static const int n = getenv("QV_GRAPH_LANES") ? std::max(1, atoi(getenv("QV_GRAPH_LANES"))) : 2; return n; }   // (measurement switch, read once)
+    static uint32_t max_group() { static const uint32_t n = getenv("QV_GRAPH_MAX_GROUP") ? (uint32_t)std::max(1, atoi(getenv("QV_GRAPH_MAX_GROUP"))) : 256u; return n; }
+    qvco::Front front{lanes(), max_group()};
     hipStream_t stream = nullptr;
     hipEvent_t ev_last = nullptr;               // end of the most recent traversal: the next one (on any stream) waits for it
     Buf d_qblk, d_rows, d_dist, d_cnt, d_ev;

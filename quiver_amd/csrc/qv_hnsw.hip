@@ -727,35 +727,56 @@ __device__ __forceinline__ uint64_t repeats_in_list(uint32_t c, uint32_t deg) {
 // Build mode (o.qlevel != null, connectNode's searches hnsw.go:367-385): query i stands for node o.qnode0 + i, descends
 // greedily to min(level, cur_level) and searches THAT level with ef exactly; the ascending result is re-ordered inside
 // equal-distance runs by node index (selectNeighbors' order, hnsw.go:589-594) and cut to the level's degree bound.
-template <int M, int U>
-__global__ void __launch_bounds__(64)
+template <int M, int U, int W = 1>
+__global__ void __launch_bounds__(64 * W)
 k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qblk, const double* __restrict__ qconst, uint32_t nq, uint32_t k, uint32_t ef_search,
               HnswOpts o, uint32_t cand_cap,
               uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* __restrict__ count_out, uint32_t* __restrict__ evals_out) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
-    // LDS: two row slabs (hnsw_eval_rows) | candidate heap | result heap | the hop's batch | its distances
+    // LDS, W == 1: two row slabs (hnsw_eval_rows) | candidate heap | result heap | the hop's batch | its distances
+    //      W  > 1 (the latency form, as in k_hnsw_search_wave: the other waves only take their share of each hop's rows):
+    //             batch, round, partial sums | query | the hop's rows | candidate heap | result heap | distances
+    LatLds L;
+    L.batch = (lds_u32*)smem; L.ctrl = (lds_u32*)smem + 64; L.part = (lds_u8*)smem + 512; L.q = (lds_u8*)smem + kLatQOff;
+    L.rows = L.q + lat_q_bytes(v.dim4, (uint32_t)sizeof(Q));
     lds_u8* slabs_l = (lds_u8*)smem;
-    unsigned char* base = smem + 2 * slab_bytes<kHnswHeapSlab>();
+    unsigned char* base = W > 1 ? smem + kLatQOff + lat_q_bytes(v.dim4, (uint32_t)sizeof(Q)) + lat_rows_bytes(v.dim4) : smem + 2 * slab_bytes<kHnswHeapSlab>();
     HRes* cand = reinterpret_cast<HRes*>(base);                       // [cand_cap]
     HRes* res = cand + cand_cap;                                      // [kHnswEfMax + 1]
-    uint32_t* batch = reinterpret_cast<uint32_t*>(res + kHnswEfMax + 1);   // [kHnswMaxDeg]
-    float* bd = reinterpret_cast<float*>(batch + kHnswMaxDeg);        // [kHnswMaxDeg]
-    const lds_u32* batch_l = (const lds_u32*)((lds_u8*)smem + 2 * slab_bytes<kHnswHeapSlab>() + (size_t)(cand_cap + kHnswEfMax + 1) * sizeof(HRes));
+    uint32_t* batch = W > 1 ? reinterpret_cast<uint32_t*>(smem) : reinterpret_cast<uint32_t*>(res + kHnswEfMax + 1);   // [kHnswMaxDeg]
+    float* bd = W > 1 ? reinterpret_cast<float*>(res + kHnswEfMax + 1) : reinterpret_cast<float*>(batch + kHnswMaxDeg);   // [kHnswMaxDeg]
+    const lds_u32* batch_l = W > 1 ? (const lds_u32*)smem
+                                   : (const lds_u32*)((lds_u8*)smem + 2 * slab_bytes<kHnswHeapSlab>() + (size_t)(cand_cap + kHnswEfMax + 1) * sizeof(HRes));
     const Q* q_g = qblk;
     __shared__ int s_ncand, s_nres;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t* bm = o.vis + (size_t)blockIdx.x * o.vis_cap;            // one bit per node
     const uint32_t bm_words = (g.n_nodes + 31) >> 5;
     const bool build = o.qlevel != nullptr;
+    if constexpr (W > 1) {
+        const uint32_t wave = threadIdx.x >> 6;
+        if (wave != 0) {
+            for (;;) {
+                lat_barrier();
+                const uint32_t cnt = L.ctrl[0], rbase = L.ctrl[1];
+                if (cnt == 0xFFFFFFFFu) return;
+                lat_round_part<M, W>(v, L, rbase, cnt, wave, lane);
+                lat_barrier();
+            }
+        }
+    }
+    auto wsync = [&]() { if constexpr (W > 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); };
 
     auto alive = [&](uint32_t n) -> bool { return n < g.n_nodes && g.level[n] >= 0; };
     // distances of batch[0..n) -> bd[0..n); lane i scores batch[i]
     QConst qc;
     auto eval = [&](uint32_t n) {
-        const float dd = hnsw_eval_rows<M, U, kHnswHeapSlab>(v, batch_l, slabs_l, q_g, qc, n, lane);
+        float dd;
+        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane);
+        else dd = hnsw_eval_rows<M, U, kHnswHeapSlab>(v, batch_l, slabs_l, q_g, qc, n, lane);
         if (lane < n) bd[lane] = dd;
-        __syncthreads();
+        wsync();
     };
     // searchLayer (hnsw.go:471-580); result: res[0..s_nres) ascending; returns false on overflow
     uint32_t n_eval = 0;
@@ -769,13 +790,13 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
     auto search_layer = [&](uint32_t entry, int ef, int level) -> bool {
         vis_bits_clear(bm, bm_words, lane);                            // :483-488
         if (lane == 0) { (void)vis_bits_insert(bm, entry); batch[0] = entry; }
-        __syncthreads();
+        wsync();
         eval(1); n_eval += 1;                                          // :492
         if (lane == 0) {
             cand[0] = {bd[0], entry}; res[0] = {bd[0], entry};        // :498-506
             s_ncand = 1; s_nres = 1;
         }
-        __syncthreads();
+        wsync();
         for (;;) {
             HTK(5);
             // every lane carries the heap sizes and walks the same branches (the sifts are wave operations)
@@ -783,9 +804,9 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
             if (nc == 0) break;                                        // :509
             nc--;
             const HRes top = cand[0], lastc = cand[nc];                // :511 pop: the last element sinks from the root
-            __syncthreads();
+            wsync();
             if (nc > 0) wave_heap_down<false>(cand, nc, lastc, lane);
-            __syncthreads();
+            wsync();
             if (lane == 0) s_ncand = nc;
             if (nr >= ef && top.dist > res[0].dist) break;             // :514-516
             HTK(0);
@@ -812,7 +833,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
             const uint64_t fm = __ballot(fresh);
             const uint32_t n = (uint32_t)__builtin_popcountll(fm);
             if (fresh) batch[__builtin_popcountll(fm & ((1ull << lane) - 1))] = c;   // adjacency order kept
-            __syncthreads();
+            wsync();
             HTK(1);
             if (n == 0) continue;
             eval(n); n_eval += n;                                      // :548 (batched)
@@ -835,19 +856,19 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                         const HRes x = {cd, batch[i]};
                         wave_heap_up<false>(cand, nc, x, lane); nc++;                 // :554
                         wave_heap_up<true>(res, nr, x, lane); nr++;                   // :555
-                        __syncthreads();
+                        wsync();
                         if (nr > ef) {                                                // :558-560: the last element sinks from the root
                             nr--;
                             const HRes lastr = res[nr];
-                            __syncthreads();
+                            wsync();
                             wave_heap_down<true>(res, nr, lastr, lane);
-                            __syncthreads();
+                            wsync();
                         }
                     }
                 }
-                __syncthreads();
+                wsync();
                 if (lane == 0) { s_ncand = nc; s_nres = nr; }
-                __syncthreads();
+                wsync();
                 if (overflow) return false;
             }
             HTK(3);
@@ -856,13 +877,13 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
             const int nr = s_nres;
             for (int m = nr; m > 1; m--) {
                 const HRes t = res[0], lastr = res[m - 1];
-                __syncthreads();
+                wsync();
                 if (lane == 0) res[m - 1] = t;
                 if (m - 1 > 0) wave_heap_down<true>(res, m - 1, lastr, lane);
-                __syncthreads();
+                wsync();
             }
         }
-        __syncthreads();
+        wsync();
         return true;
     };
 
@@ -872,6 +893,12 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
         q_g = qblk + (size_t)qi * v.dim4 * 4;
         qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
         n_eval = 0;
+        if constexpr (W > 1) {                                          // the query into LDS (the other waves are at their barrier)
+            const uint32_t qbytes = v.dim4 * 4 * (uint32_t)sizeof(Q);
+            for (uint32_t off = 0; off < qbytes; off += 1024)
+                if (off + lane * 16 < qbytes) glds16(reinterpret_cast<const float*>(q_g) + (off >> 2) + lane * 4, L.q + off);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         uint32_t entry = g.entry;
         bool ok = true;
         int stop = 0;
@@ -879,7 +906,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
         for (int level = g.cur_level; level > stop && ok; level--) {    // :649-657 / :367-380
             ok = search_layer(entry, 1, level);
             if (ok && s_nres > 0) entry = res[0].idx;
-            __syncthreads();
+            wsync();
         }
         const int ef = build ? (int)ef_search : ((int)ef_search > (int)k ? (int)ef_search : (int)k);   // :660-663 / :385
         if (ok) ok = search_layer(entry, ef, stop);                     // :664
@@ -896,7 +923,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                         res[j] = x;
                     }
                 }
-                __syncthreads();
+                wsync();
             }
             cnt = (uint32_t)s_nres < kq ? (uint32_t)s_nres : kq;        // :670-672 (under-filled: the caller tops up, :676-710)
             for (uint32_t i = lane; i < k; i += 64) {
@@ -904,19 +931,20 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                 dist_out[(size_t)qi * k + i] = i < cnt ? res[i].dist : __uint_as_float(0x7F800000u);
             }
             if (build && stop >= 1 && o.self_dist) {                    // the node's lower levels link to itself (:463-467): d(node, node)
-                __syncthreads();
+                wsync();
                 if (lane == 0) batch[0] = o.qnode0 + qi;
-                __syncthreads();
+                wsync();
                 eval(1);
                 if (lane == 0) o.self_dist[qi] = bd[0];
             }
         }
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
-        __syncthreads();
+        wsync();
 #ifdef QV_HNSW_PROF
         if (lane == 0 && blockIdx.x == 1) printf("heap kernel q%u: pop %llu links+vis %llu eval %llu insert %llu other %llu (x10 ns) hops %llu evals %u\n", qi, T[0], T[1], T[2], T[3], T[5], hops, n_eval);
 #endif
     }
+    if constexpr (W > 1) { if (lane == 0) L.ctrl[0] = 0xFFFFFFFFu; lat_barrier(); }      // the other waves leave
 }
 
 
@@ -1396,10 +1424,27 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
     double* d_qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qblk) + (size_t)nq * v.dim4 * 4 * sizeof(double));
     QV_DISPATCH_METRIC(v.metric, {
         if (prep) hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
-        e = set_lds(k_hnsw_search<MM, 16>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_hnsw_search<MM, 16>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk),
-                           static_cast<const double*>(d_qconst), nq, k, ef, o, cand_cap, d_rows_out, d_dist_out, d_count_out, d_evals_out);
+        bool lat = false;
+        if constexpr (SplitOK<MM>::value) {
+            // the latency form (eight waves per query, the hop's rows requested at once and evaluated as certified partial chains):
+            // this kernel only ever runs a handful of queries, each a chain of ~200 hops (QV_HNSW_LAT=2: never)
+            static const int lat_env = env_int("QV_HNSW_LAT", 1);
+            const size_t heaps = (size_t)(cand_cap + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 4 + 64;
+            const size_t lds_lat = (size_t)kLatQOff + lat_q_bytes(v.dim4, (uint32_t)sizeof(typename MT<MM>::Q)) + lat_rows_bytes(v.dim4) + heaps;
+            if (lat_env == 1 && hnsw_qlds_ok(v) && lds_lat <= (size_t)160 * 1024) {
+                lat = true;
+                e = set_lds(k_hnsw_search<MM, 16, kLatWaves>, lds_lat);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((k_hnsw_search<MM, 16, kLatWaves>), dim3(grid), dim3(64 * kLatWaves), lds_lat, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk),
+                                   static_cast<const double*>(d_qconst), nq, k, ef, o, cand_cap, d_rows_out, d_dist_out, d_count_out, d_evals_out);
+            }
+        }
+        if (!lat) {
+            e = set_lds(k_hnsw_search<MM, 16>, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_hnsw_search<MM, 16>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk),
+                               static_cast<const double*>(d_qconst), nq, k, ef, o, cand_cap, d_rows_out, d_dist_out, d_count_out, d_evals_out);
+        }
     });
     return hipGetLastError();
 }
@@ -1438,7 +1483,7 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     const bool deep = qlds_env == 1 && hnsw_qlds_ok(v);
     // The latency form (a workgroup of four waves and a CU's LDS per query) for batches that would leave most CUs idle anyway:
     // at most one query per CU, a metric whose chain can be split and certified, rows of a hop + query within the LDS.
-    static const int lat_env = env_int("QV_HNSW_LAT", 1);
+    static const int lat_env = env_int("QV_HNSW_LAT", 1);                    // (QV_HNSW_LAT=2: never)
     static const int lat_cus = [] { int d = 0, c = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c; }();
     const uint32_t qsize = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
     const size_t lat_fixed = (size_t)kLatQOff + lat_q_bytes(v.dim4, qsize) + lat_rows_bytes(v.dim4);

@@ -8,7 +8,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 NQ = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 D = 768
 idx = quiver_amd.DeviceIndex(D, "cosine", rowmajor=True); idx.reserve(N); idx.add_synthetic(20260424, 0, N)
+t0 = time.perf_counter()
 g = DeviceGraph.build(idx, random_levels(N, 1, 1), m=16, max_m0=32, ef_construction=200)
+print("build %.2f s" % (time.perf_counter() - t0), g.stats() if hasattr(g, "stats") else "", flush=True)
 qg = quiver_amd.DeviceIndex(D, "cosine"); qg.add_synthetic(20260425, 0, 64)
 hq = np.stack([qg.get_row(i) for i in range(64)])
 print("---- search ----", flush=True)
