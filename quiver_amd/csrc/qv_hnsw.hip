@@ -424,118 +424,64 @@ __device__ __forceinline__ void slab_accumulate_qlds(typename MT<M>::A& acc, con
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+// slabs_l: 2 x kHnswSlabBytes of row buffers followed by 2 x kHnswQBufBytes of query buffers.  Requires hnsw_qlds_ok(v).
+template <int M, int U>
+__device__ __forceinline__ float hnsw_eval_rows_qlds(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l,
+                                                     const typename MT<M>::Q* __restrict__ q_g, const QConst& qc, uint32_t n, uint32_t lane) {
+    static_assert(kHnswSlab == 8, "one 128-byte piece per row and slab");
+    lds_u8* qbufs = slabs_l + 2 * kHnswSlabBytes;
+    float out = 0.0f;
+    const uint32_t nslab = v.dim4 >> 3;
+    for (uint32_t base = 0; base < n; base += kHnswRound) {
+        const uint32_t cnt = n - base < (uint32_t)kHnswRound ? n - base : (uint32_t)kHnswRound;
+        const bool me = lane >= base && lane < base + cnt;       // row r of this round sits on lane base + r
+        const uint32_t myrow = me ? batch_l[lane] : 0u;
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[myrow]; }
+        DmaRole role;
+        dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
+        const uint32_t r = (lane - base) & 31u;
+        typename MT<M>::A acc = 0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        dma_issue_slab<kHnswSlab>(role, 0, v.dim4, slabs_l); dma_issue_query(q_g, 0, qbufs, lane);
+        for (uint32_t sl = 0; sl < nslab; sl++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl and its query values have landed
+            if (sl + 1 < nslab) {                                  // the next slab lands while this one is consumed
+                dma_issue_slab<kHnswSlab>(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);
+                dma_issue_query(q_g, sl + 1, qbufs + ((sl + 1) & 1) * kHnswQBufBytes, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (me) slab_accumulate_qlds<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, r, qbufs + (sl & 1) * kHnswQBufBytes);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this slab's buffers are read before they are refilled
+        }
+        if (me) out = finalize<M>(acc, qc, rn);
+    }
+    return out;
+}
+
 // ---- a row's sum over several lanes, certified -----------------------------------------------------------------------
 // The reference's value is ONE chain: 768 dependent rounded additions per row (distances.go:18-22), 21 cycles each on one wave
-// (convert + fma, tools/ubench/f64chain.hip) — 9 us per hop however few rows the hop has, and a hop has ~15 of 64 lanes' worth.
+// (convert + fma, tools/ubench/f64chain.hip) — 9 us per hop however few rows the hop has.
 // A different summation order gives a different float64, but the distance is that float64 pushed through a MONOTONE function
 // (finalize: divide by a positive constant, clamp, subtract from one / square root, round to float32 — every step monotone, so
 // their composition is), and both orders lie within a computable distance of the exact sum of the (exactly representable)
 // products: |computed - exact| <= g(h) * sum|p_i| with g(h) = h u / (1 - h u), u = 2^-53, h = the longest chain of additions
-// (Higham, Accuracy and Stability of Numerical Algorithms, 4.2).  So with S = the sum over P lanes' partial chains and
-// B >= (g(dim) + g(dim / P + 3)) * sum|p_i|, the reference's float64 lies in [S - B, S + B]; when finalize(S - B) and
+// (Higham, Accuracy and Stability of Numerical Algorithms, 4.2).  So with S = the sum of P partial chains and
+// B >= (g(dim) + g(dim / P + log2 P)) * sum|p_i|, the reference's float64 lies in [S - B, S + B]; when finalize(S - B) and
 // finalize(S + B) are the same float32 — all but a few in a million evaluations: B is ~2e-13 of the operands' size, a float32
-// step is 6e-8 — that float32 IS the reference's, bit for bit.  Otherwise the round is evaluated again as one chain.
+// step is 6e-8 — that float32 IS the reference's, bit for bit.  Otherwise the row is walked again as one chain.
 // sum|p_i| <= |q| |r| (Cauchy-Schwarz; the cached norms) for cosine; for the metrics whose terms are >= 0 it is the sum itself.
-// The slack in kSplitSlack covers the norms' own rounding, the rounding of S -+ B and of B, and the second-order terms.
+// kSplitSlack covers the norms' own rounding, the rounding of S -+ B and of B, and the second-order terms.
+// Used where a traversal has lanes and waves to spare — the latency form below.  (In the wave-per-query form, two / four / eight
+// lanes per row measured 3.1 -> 2.8 ms for a lone query and -5 % at full occupancy, where the 19 extra registers cost the fourth
+// wave per SIMD at efSearch 128: not kept there.)
 template <int M> struct SplitOK { static constexpr bool value = M == QV_COSINE || M == QV_L2 || M == QV_L1 || M == QV_L2SQ_F64; };
 constexpr double kSplitSlack = 128.0;
 template <int M> __device__ __forceinline__ double split_bound(double s, double k_u, const QConst& qc, double rn) {
     if constexpr (M == QV_COSINE) return k_u * qc.qn * rn;
     else return k_u * s;
 }
-// lane walks NCH consecutive chunks (from chunk c0) of its row's 8 in the slab; otherwise slab_accumulate_qlds
-template <int M, int NCH>
-__device__ __forceinline__ void slab_accumulate_qlds_part(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, const lds_u8* qbuf, uint32_t c0) {
-    typedef const __attribute__((address_space(3))) f4* lds_f4p;
-    typedef typename MT<M>::Q Q;
-    typedef const __attribute__((address_space(3))) Q* lds_qp;
-    const uint32_t mg = r >> 3, mr = r & 7, msw = mr ^ (mg & 1);
-    const lds_u8* mine = buf + mg * 1024 + mr * 128;
-    lds_qp q = (lds_qp)qbuf + 4 * c0;
-    f4 x[2]; Q qq[2][4];
-    x[0] = *(lds_f4p)(mine + ((c0 ^ msw) << 4));
-#pragma unroll
-    for (int e = 0; e < 4; e++) qq[0][e] = q[e];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const int cur = c & 1, nxt = cur ^ 1;
-        if (c + 1 < NCH) {
-            x[nxt] = *(lds_f4p)(mine + (((c0 + (uint32_t)(c + 1)) ^ msw) << 4));
-#pragma unroll
-            for (int e = 0; e < 4; e++) qq[nxt][e] = q[4 * (c + 1) + e];
-        }
-        acc1<M>(acc, qq[cur][0], x[cur].x); acc1<M>(acc, qq[cur][1], x[cur].y); acc1<M>(acc, qq[cur][2], x[cur].z); acc1<M>(acc, qq[cur][3], x[cur].w);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// slabs_l: 2 x kHnswSlabBytes of row buffers followed by 2 x kHnswQBufBytes of query buffers.  Requires hnsw_qlds_ok(v).
-// One round of <= 32 rows (row r of the round on lane base + r).  P = 1: every row one chain on its lane (the reference's order).
-// P = 2 / 4 / 8 (cnt <= 32 / 16 / 8): row r on the P lanes r + j * 64 / P, lane j taking chunks j * 8 / P ... of every slab; the
-// lanes' sums are added pairwise and certified as above; `ok` comes back false on the lanes whose row needs the single chain.
-template <int M, int P>
-__device__ __forceinline__ float hnsw_eval_round_qlds(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l, const typename MT<M>::Q* __restrict__ q_g,
-                                                      const QConst& qc, uint32_t base, uint32_t cnt, uint32_t lane, bool& ok) {
-    lds_u8* qbufs = slabs_l + 2 * kHnswSlabBytes;
-    const uint32_t nslab = v.dim4 >> 3;
-    constexpr uint32_t kRows = 64 / (P == 1 ? 2 : P);                 // rows a round of this form can hold
-    const bool me = lane >= base && lane < base + cnt;                 // the lane that reports row lane - base
-    const uint32_t r = P == 1 ? (lane - base) & 31u : lane & (kRows - 1);
-    const uint32_t part = P == 1 ? 0u : lane / kRows;
-    const bool work = P == 1 ? me : r < cnt;
-    double rn = 0.0;
-    if constexpr (MT<M>::needs_rnorm) { if (work) rn = v.rnorm[batch_l[base + r]]; }
-    DmaRole role;
-    dma_role(role, v.rowmaj, v.dim, batch_l + base, cnt, lane);
-    typename MT<M>::A acc = 0;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    dma_issue_slab<kHnswSlab>(role, 0, v.dim4, slabs_l); dma_issue_query(q_g, 0, qbufs, lane);
-    for (uint32_t sl = 0; sl < nslab; sl++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl and its query values have landed
-        if (sl + 1 < nslab) {                                  // the next slab lands while this one is consumed
-            dma_issue_slab<kHnswSlab>(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);
-            dma_issue_query(q_g, sl + 1, qbufs + ((sl + 1) & 1) * kHnswQBufBytes, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (P == 1) { if (work) slab_accumulate_qlds<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, r, qbufs + (sl & 1) * kHnswQBufBytes); }
-        else { if (work) slab_accumulate_qlds_part<M, 8 / P>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, r, qbufs + (sl & 1) * kHnswQBufBytes, part * (8 / P)); }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this slab's buffers are read before they are refilled
-    }
-    ok = true;
-    if constexpr (P == 1) return me ? finalize<M>(acc, qc, rn) : 0.0f;
-    else {
-        double s = (double)acc;
-#pragma unroll
-        for (uint32_t off = kRows; off < 64; off <<= 1) s = s + __shfl_xor(s, (int)off);       // every lane of a row ends with the same sum
-        const double k_u = ((double)(2u * v.dim) + kSplitSlack) * 0x1p-53;
-        const double b = split_bound<M>(s, k_u, qc, rn);
-        const float d_lo = finalize<M>((typename MT<M>::A)(s - b), qc, rn), d_hi = finalize<M>((typename MT<M>::A)(s + b), qc, rn);
-        ok = !me || (__float_as_uint(d_lo) == __float_as_uint(d_hi) && d_lo == d_lo);
-        return me ? d_lo : 0.0f;
-    }
-}
-template <int M, int U>
-__device__ __forceinline__ float hnsw_eval_rows_qlds(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l,
-                                                     const typename MT<M>::Q* __restrict__ q_g, const QConst& qc, uint32_t n, uint32_t lane) {
-    static_assert(kHnswSlab == 8, "one 128-byte piece per row and slab");
-    float out = 0.0f;
-    for (uint32_t base = 0; base < n; base += kHnswRound) {
-        const uint32_t cnt = n - base < (uint32_t)kHnswRound ? n - base : (uint32_t)kHnswRound;
-        const bool me = lane >= base && lane < base + cnt;
-        bool ok = false; float d = 0.0f;
-        if constexpr (SplitOK<M>::value) {
-            if (cnt <= 8) d = hnsw_eval_round_qlds<M, 8>(v, batch_l, slabs_l, q_g, qc, base, cnt, lane, ok);
-            else if (cnt <= 16) d = hnsw_eval_round_qlds<M, 4>(v, batch_l, slabs_l, q_g, qc, base, cnt, lane, ok);
-            else d = hnsw_eval_round_qlds<M, 2>(v, batch_l, slabs_l, q_g, qc, base, cnt, lane, ok);
-            ok = __ballot(!ok) == 0;                               // (wave-uniform from here)
-        }
-        if (!ok) d = hnsw_eval_round_qlds<M, 1>(v, batch_l, slabs_l, q_g, qc, base, cnt, lane, ok);
-        if (me) out = d;
-    }
-    return out;
-}
-
 
 // ---- the latency form: one workgroup of W waves per query ----------------------------------------------------------------
 // A batch that leaves most of the device idle (a lone caller; a shared batch of a few dozen callers) is bound by ONE query's chain
@@ -545,7 +491,7 @@ __device__ __forceinline__ float hnsw_eval_rows_qlds(const IndexView& v, const l
 // LDS instead: every row of the hop is requested at once (32 x 3 KiB in flight, one round trip), the query stays resident,
 // the visited table is in LDS — and W waves evaluate the hop: wave w requests and walks columns [w, w + 1) * dim / W of every
 // row, its 64 lanes split those columns 2 / 4 / 8 ways per row (cnt <= 32 / 16 / 8), so a row's 768-step chain becomes chains of
-// 96 / 48 / 24 steps whose sum is certified as in hnsw_eval_round_qlds (rows that fail are walked again from LDS as ONE chain:
+// 48 / 24 / 12 steps (eight waves) whose sum is certified as above (rows that fail are walked again from LDS as ONE chain:
 // the reference's order).  Wave 0 keeps the list and drives; the others wait at a barrier between hops.
 // workgroup barrier of the latency form: LDS traffic only (a __syncthreads would also wait for the vector-memory queue — the row
 // norms and the adjacency prefetch the driver has in flight — ~1.5 k cycles per hop)

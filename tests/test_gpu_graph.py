@@ -177,9 +177,10 @@ def test_graph_replicas_round_robin_equals_one_graph():
     ("l2sq_f64", 224, 1200, 16, 300),
 ])
 def test_split_chains_both_kernel_forms_identical_to_oracle(metric, dim, n, m, ef):
-    """The metrics whose float64 chain is evaluated as several lanes' partial chains and certified (SplitOK, qv_hnsw.hip):
-    a batch of 320 queries takes the throughput form (a wave per query, hnsw_eval_round_qlds), batches of <= 64 the latency
-    form (a workgroup per query, lat_eval_rows).  Both must give the oracle's rows, float32 bits and evaluation counts.
+    """The metrics whose float64 chain the latency form evaluates as several lanes' and waves' partial chains and certifies
+    (SplitOK, qv_hnsw.hip): a batch of 320 queries takes the throughput form (a wave per query, every row one chain), batches
+    of <= 64 the latency form (a workgroup per query, lat_eval_rows).  Both must give the oracle's rows, float32 bits and
+    evaluation counts.
     Half of the queries ARE corpus rows: their distance to themselves is ~0, where the certification cannot hold and the
     row is walked again as one chain (the fallback)."""
     mid = quiver_amd.metric_id(metric)
