@@ -715,7 +715,7 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
             try:
                 e = hnsw_run(rows=a.hnsw_rows, dim=dim, metric=a.metric, m=16, efc=200, max_level=max_level, efs=efs, nq=8192, k=k,
                              cpu_queries=cpuq, device=local_rank, corpus_seed=CORPUS_SEED, query_seed=QUERY_SEED, intrinsic_dim=idim,
-                             callers=(1, 64, 1024) if key == "hnsw_1Mx768_maxlevel1" else ())
+                             callers=(1, 8, 64, 256, 1024) if key == "hnsw_1Mx768_maxlevel1" else ())
                 e["note"] = note
                 also[key] = e
             except Exception as ex:                        # noqa: BLE001  (a measurement beside the headline; never fail the bench line over it)

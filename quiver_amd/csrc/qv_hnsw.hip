@@ -471,15 +471,15 @@ __device__ __forceinline__ float hnsw_eval_rows_qlds(const IndexView& v, const l
 // B >= (g(dim) + g(dim / P + log2 P)) * sum|p_i|, the reference's float64 lies in [S - B, S + B]; when finalize(S - B) and
 // finalize(S + B) are the same float32 — all but a few in a million evaluations: B is ~2e-13 of the operands' size, a float32
 // step is 6e-8 — that float32 IS the reference's, bit for bit.  Otherwise the row is walked again as one chain.
-// sum|p_i| <= |q| |r| (Cauchy-Schwarz; the cached norms) for cosine; for the metrics whose terms are >= 0 it is the sum itself.
+// sum|p_i| <= |q| |r| (Cauchy-Schwarz; the cached norms) for cosine and dot; for the metrics whose terms are >= 0 it is the sum itself.
 // kSplitSlack covers the norms' own rounding, the rounding of S -+ B and of B, and the second-order terms.
 // Used where a traversal has lanes and waves to spare — the latency form below.  (In the wave-per-query form, two / four / eight
 // lanes per row measured 3.1 -> 2.8 ms for a lone query and -5 % at full occupancy, where the 19 extra registers cost the fourth
 // wave per SIMD at efSearch 128: not kept there.)
-template <int M> struct SplitOK { static constexpr bool value = M == QV_COSINE || M == QV_L2 || M == QV_L1 || M == QV_L2SQ_F64; };
+template <int M> struct SplitOK { static constexpr bool value = M == QV_COSINE || M == QV_DOT || M == QV_L2 || M == QV_L1 || M == QV_L2SQ_F64; };
 constexpr double kSplitSlack = 128.0;
 template <int M> __device__ __forceinline__ double split_bound(double s, double k_u, const QConst& qc, double rn) {
-    if constexpr (M == QV_COSINE) return k_u * qc.qn * rn;
+    if constexpr (M == QV_COSINE || M == QV_DOT) return k_u * qc.qn * rn;    // (dot: the query's norm comes from k_hnsw_prep_queries, the row's is cached for every float64 metric)
     else return k_u * s;
 }
 
@@ -507,7 +507,9 @@ constexpr int kLatWaves = QV_HNSW_LAT_WAVES;                            // waves
 constexpr uint32_t kLatQOff = 512 + kLatWaves * 256 + 512;              // batch, ctrl, partial sums below it (a multiple of 1 KiB)
 static_assert(kLatQOff % 1024 == 0, "LDS-DMA blocks are 1 KiB");
 __host__ __device__ inline uint32_t lat_q_bytes(uint32_t dim4, uint32_t qsize) { return (dim4 * 4 * qsize + 1023u) & ~1023u; }
-__host__ __device__ inline uint32_t lat_rows_bytes(uint32_t dim4) { return 4u * (dim4 >> 3) * 1024u; }
+// rows of a round (32, or 16 / 8 where 32 rows of this dimension do not fit the LDS) x dim4 chunks; never below 8 KiB: between hops the
+// buffer is the scratch the list's batched admissions scatter through (576 entries x 12 bytes at most)
+__host__ __device__ inline uint32_t lat_rows_bytes(uint32_t dim4, uint32_t round_rows) { const uint32_t b = (round_rows >> 3) * (dim4 >> 3) * 1024u; return b < 8192u ? 8192u : b; }
 
 // chunks [c_lo, c_hi) of row r of the round, in order (c_lo = 0, c_hi = dim4: the reference's chain)
 template <int M>
@@ -578,7 +580,7 @@ __device__ __forceinline__ void lat_round_part(const IndexView& v, const LatLds&
 }
 // the driver's side of a hop: distance(query, batch[i]) on lane i for i < n
 template <int M, int W>
-__device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds& L, const QConst& qc, uint32_t n, uint32_t lane, uint64_t* st = nullptr) {
+__device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds& L, const QConst& qc, uint32_t n, uint32_t lane, uint32_t round_rows, uint64_t* st = nullptr) {
 #ifdef QV_HNSW_PROF
     uint64_t t_l = __builtin_readcyclecounter();
 #define LTICK(i) if (st) { const uint64_t t_n = __builtin_readcyclecounter(); st[i] += t_n - t_l; t_l = t_n; }
@@ -587,11 +589,11 @@ __device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds&
 #endif
     float out = 0.0f;
     const uint32_t nP = v.dim4 >> 3;
-    for (uint32_t base = 0; base < n; base += 32) {
-        const uint32_t cnt = n - base < 32u ? n - base : 32u;
+    for (uint32_t base = 0; base < n; base += round_rows) {
+        const uint32_t cnt = n - base < round_rows ? n - base : round_rows;
         const bool me = lane >= base && lane < base + cnt;
         double rn = 0.0;
-        if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[L.batch[lane]]; }
+        if constexpr (MT<M>::needs_rnorm || M == QV_DOT) { if (me) rn = v.rnorm[L.batch[lane]]; }
         if (lane == 0) { L.ctrl[0] = cnt; L.ctrl[1] = base; }
         lat_barrier();                                                  // the round is posted (and batch[] is visible to every wave)
         LTICK(12);
@@ -605,9 +607,9 @@ __device__ __forceinline__ float lat_eval_rows(const IndexView& v, const LatLds&
         float d = 0.0f; bool ok = true;
         {
             typedef const __attribute__((address_space(3))) double* lds_dp;
-            const uint32_t r = lane & 31u;
+            const uint32_t r = (lane - base) & 31u;                       // (the same row on lane and lane ^ 32)
             const bool has = r < cnt;
-            const bool low = (lane & 32u) == (base & 32u);
+            const bool low = ((lane - base) & 63u) < 32u;
             double rn2 = __shfl_xor(rn, 32);
             if (low) rn2 = rn;
             double s = 0.0;
@@ -687,7 +689,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
     L.batch = (lds_u32*)smem; L.ctrl = (lds_u32*)smem + 64; L.part = (lds_u8*)smem + 512; L.q = (lds_u8*)smem + kLatQOff;
     L.rows = L.q + lat_q_bytes(v.dim4, (uint32_t)sizeof(Q));
     lds_u8* slabs_l = (lds_u8*)smem;
-    unsigned char* base = W > 1 ? smem + kLatQOff + lat_q_bytes(v.dim4, (uint32_t)sizeof(Q)) + lat_rows_bytes(v.dim4) : smem + 2 * slab_bytes<kHnswHeapSlab>();
+    unsigned char* base = W > 1 ? smem + kLatQOff + lat_q_bytes(v.dim4, (uint32_t)sizeof(Q)) + lat_rows_bytes(v.dim4, o.lat_rows) : smem + 2 * slab_bytes<kHnswHeapSlab>();
     HRes* cand = reinterpret_cast<HRes*>(base);                       // [cand_cap]
     HRes* res = cand + cand_cap;                                      // [kHnswEfMax + 1]
     uint32_t* batch = W > 1 ? reinterpret_cast<uint32_t*>(smem) : reinterpret_cast<uint32_t*>(res + kHnswEfMax + 1);   // [kHnswMaxDeg]
@@ -719,7 +721,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
     QConst qc;
     auto eval = [&](uint32_t n) {
         float dd;
-        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane);
+        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane, o.lat_rows);
         else dd = hnsw_eval_rows<M, U, kHnswHeapSlab>(v, batch_l, slabs_l, q_g, qc, n, lane);
         if (lane < n) bd[lane] = dd;
         wsync();
@@ -912,7 +914,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     LatLds L;
     L.batch = (lds_u32*)batch_l; L.ctrl = (lds_u32*)batch_l + 64; L.part = (lds_u8*)smem + 512; L.q = (lds_u8*)smem + kLatQOff;
     L.rows = L.q + lat_q_bytes(v.dim4, (uint32_t)sizeof(Q));
-    lds_u32w tab_l = (lds_u32w)(L.rows + lat_rows_bytes(v.dim4));          // (used when o.vis_lds)
+    lds_u32w tab_l = (lds_u32w)(L.rows + lat_rows_bytes(v.dim4, o.lat_rows));          // (used when o.vis_lds)
     const bool vis_lds = W > 1 && o.vis_lds;
     if constexpr (W > 1) {
         const uint32_t wave = threadIdx.x >> 6;
@@ -947,9 +949,9 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     auto eval_keys = [&](uint32_t n) -> uint64_t {
         float dd;
 #ifdef QV_HNSW_PROF
-        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane, T);
+        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane, o.lat_rows, T);
 #else
-        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane);
+        if constexpr (W > 1) dd = lat_eval_rows<M, W>(v, L, qc, n, lane, o.lat_rows);
 #endif
         else dd = QLDS ? hnsw_eval_rows_qlds<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane) : hnsw_eval_rows<M, U>(v, batch_l, slabs_l, q_g, qc, n, lane);
         return lane < n ? make_key(dd, batch_l[lane]) : kDeadKey;
@@ -1335,7 +1337,12 @@ __global__ void k_hnsw_prep_queries(const float* __restrict__ queries, uint32_t 
     Q* out = qblk + (size_t)blockIdx.x * dim4 * 4;
     for (uint32_t i = threadIdx.x; i < dim4 * 4; i += blockDim.x) out[i] = i < dim ? (Q)q[i] : (Q)0;
     if (threadIdx.x == 0) {
-        const QConst c = query_const<M>(q, dim);          // same element order as everywhere else (distances.go:20)
+        QConst c = query_const<M>(q, dim);                // same element order as everywhere else (distances.go:20)
+        if constexpr (M == QV_DOT) {                      // not part of the distance: the bound of the latency form's certificate (split_bound)
+            double ma = 0.0;
+            for (uint32_t i = 0; i < dim; i++) { const double a = (double)q[i]; ma = __builtin_fma(a, a, ma); }
+            c.qn = __builtin_sqrt(ma);
+        }
         qconst[(size_t)blockIdx.x * 2] = c.qn; qconst[(size_t)blockIdx.x * 2 + 1] = (double)c.qn32;
     }
 }
@@ -1376,13 +1383,18 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
             // this kernel only ever runs a handful of queries, each a chain of ~200 hops (QV_HNSW_LAT=2: never)
             static const int lat_env = env_int("QV_HNSW_LAT", 1);
             const size_t heaps = (size_t)(cand_cap + kHnswEfMax + 1) * sizeof(HRes) + (size_t)kHnswMaxDeg * 4 + 64;
-            const size_t lds_lat = (size_t)kLatQOff + lat_q_bytes(v.dim4, (uint32_t)sizeof(typename MT<MM>::Q)) + lat_rows_bytes(v.dim4) + heaps;
-            if (lat_env == 1 && hnsw_qlds_ok(v) && lds_lat <= (size_t)160 * 1024) {
+            HnswOpts ol = o;
+            size_t lds_lat = 0;
+            for (ol.lat_rows = 32; ol.lat_rows >= 8; ol.lat_rows >>= 1) {      // the hop's rows at once; half / a quarter of them where the dimension asks for it
+                lds_lat = (size_t)kLatQOff + lat_q_bytes(v.dim4, (uint32_t)sizeof(typename MT<MM>::Q)) + lat_rows_bytes(v.dim4, ol.lat_rows) + heaps;
+                if (lds_lat <= (size_t)160 * 1024) break;
+            }
+            if (lat_env == 1 && hnsw_qlds_ok(v) && ol.lat_rows >= 8) {
                 lat = true;
                 e = set_lds(k_hnsw_search<MM, 16, kLatWaves>, lds_lat);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL((k_hnsw_search<MM, 16, kLatWaves>), dim3(grid), dim3(64 * kLatWaves), lds_lat, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk),
-                                   static_cast<const double*>(d_qconst), nq, k, ef, o, cand_cap, d_rows_out, d_dist_out, d_count_out, d_evals_out);
+                                   static_cast<const double*>(d_qconst), nq, k, ef, ol, cand_cap, d_rows_out, d_dist_out, d_count_out, d_evals_out);
             }
         }
         if (!lat) {
@@ -1432,10 +1444,14 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     static const int lat_env = env_int("QV_HNSW_LAT", 1);                    // (QV_HNSW_LAT=2: never)
     static const int lat_cus = [] { int d = 0, c = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c; }();
     const uint32_t qsize = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
-    const size_t lat_fixed = (size_t)kLatQOff + lat_q_bytes(v.dim4, qsize) + lat_rows_bytes(v.dim4);
-    const bool lat_metric = v.metric == QV_COSINE || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
-    if (lat_env == 1 && lat_metric && hnsw_qlds_ok(v) && nq <= (uint32_t)lat_cus && nq <= grid && lat_fixed <= (size_t)160 * 1024) {
-        HnswOpts ol = o;
+    HnswOpts ol = o;
+    size_t lat_fixed = 0;
+    for (ol.lat_rows = 32; ol.lat_rows >= 8; ol.lat_rows >>= 1) {              // the hop's rows at once; half / a quarter of them where the dimension asks for it
+        lat_fixed = (size_t)kLatQOff + lat_q_bytes(v.dim4, qsize) + lat_rows_bytes(v.dim4, ol.lat_rows);
+        if (lat_fixed <= (size_t)160 * 1024) break;
+    }
+    const bool lat_metric = v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
+    if (lat_env == 1 && lat_metric && hnsw_qlds_ok(v) && nq <= (uint32_t)lat_cus && nq <= grid && ol.lat_rows >= 8) {
         ol.vis_lds = lat_fixed + (size_t)o.vis_cap * 4 <= (size_t)160 * 1024 ? 1u : 0u;
         const size_t lds_lat = lat_fixed + (ol.vis_lds ? (size_t)o.vis_cap * 4 : 0);
 #define QV_HWL(SS) QV_DISPATCH_METRIC(v.metric, {                                                                     \

@@ -175,6 +175,9 @@ def test_graph_replicas_round_robin_equals_one_graph():
     ("l2", 160, 2000, 32, 200),
     ("l1", 32, 1500, 16, 64),
     ("l2sq_f64", 224, 1200, 16, 300),
+    ("dot", 128, 1500, 16, 64),              # bound from the query's norm (k_hnsw_prep_queries) and the cached row norm
+    ("cosine", 1536, 1200, 32, 64),          # 32 rows of this dimension do not fit the LDS: rounds of 16
+    ("l2", 4096, 500, 16, 40),               # rounds of 8
 ])
 def test_split_chains_both_kernel_forms_identical_to_oracle(metric, dim, n, m, ef):
     """The metrics whose float64 chain the latency form evaluates as several lanes' and waves' partial chains and certifies
