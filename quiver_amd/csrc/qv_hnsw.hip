@@ -1218,7 +1218,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
 #endif
                     }
                     bool done = false;
-                    if constexpr (W > 1) { if (pend) done = insert_batch(kx, pend, ef); }
+                    if constexpr (W > 1) { if (pend) done = insert_batch(kx, pend, ef); }   // (measured in the wave-per-query form as well, through the slab buffers: no difference at full occupancy)
                     while (!done && pend) {
                         const uint32_t i = (uint32_t)__builtin_ctzll(pend);
                         pend &= pend - 1;
