@@ -255,7 +255,7 @@ int qv_index_profile_read(qv_index* idx, double* scan_ms_sum_out, uint64_t* laun
 /* ---- device-resident HNSW traversal ------------------------------------------------
  * Replaces hnsw.HNSW.Search (pkg/hnsw/hnsw.go:602-713) for a batch of queries: the graph a
  * host-side HNSW built (levels + per-level adjacency, hnsw.go:44-56) is uploaded once, then
- * whole queries are walked on the GPU, one wavefront per query, many in flight.  Node index
+ * whole queries are walked on the GPU, one wavefront (or, few queries at a time, one workgroup) per query.  Node index
  * == row of `idx` (the index must hold the nodes' vectors; QV_FLAG_ROWMAJOR makes the
  * per-hop row gathers contiguous).  Results equal the reference's searchLayer semantics
  * exactly (same heaps, same admission order, bit-identical distances).
