@@ -383,13 +383,13 @@ static int enqueue_search(qv_index* idx, const float* d_queries, uint32_t nq, ui
                 idx->prof_events.emplace_back(ev0, ev1);
             } else { ev0 = ev1 = nullptr; }
         }
-        if (d_tickets && qv::flat_small_applies(v, nq, kk)) {           // small collection: scan + merge in one launch
+        if (d_tickets && qv::flat_small_applies(v, nq, kk) && !qv::flat_split_applies(v, nq, kk)) {   // small collection: scan + merge in one launch
             hipError_t e = qv::launch_flat_small(v, d_queries, nq, kk, ws, d_tickets, d_rows_out, d_dist_out, nq == 1 ? done_flag : nullptr, done_seq, s, ev0, ev1);
             if (e != hipSuccess) return fail(QV_ERR_DEVICE, "small scan launch failed: %s", hipGetErrorString(e));
             if (flag_used) *flag_used = nq == 1 && done_flag != nullptr;
             return QV_OK;
         }
-        hipError_t e = qv::launch_flat_topk(v, plan, d_queries, nq, kk, ws, d_rows_out, d_dist_out, s, ev0, ev1, d_tickets);
+        hipError_t e = qv::launch_flat_topk(v, plan, d_queries, nq, kk, ws, d_rows_out, d_dist_out, s, ev0, ev1, d_tickets, nq == 1 ? done_flag : nullptr, done_seq, flag_used);
         if (e != hipSuccess) return fail(QV_ERR_DEVICE, "flat scan launch failed: %s", hipGetErrorString(e));
         return QV_OK;
     }

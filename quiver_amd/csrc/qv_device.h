@@ -122,7 +122,9 @@ hipError_t launch_fetch_rows(const IndexView& v, const uint32_t* d_rows, uint32_
 // workgroup of the scan merges the lists); without, scan + k_merge_lists.
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
-                            hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, uint32_t* d_tickets = nullptr);
+                            hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, uint32_t* d_tickets = nullptr,
+                            uint32_t* done_flag = nullptr, uint32_t done_seq = 0, bool* flag_used = nullptr);   // done_flag: see launch_flat_small (k_flat_scan_split only)
+bool flat_split_applies(const IndexView& v, uint32_t nq, uint32_t k);   // launch_flat_topk will take the tile-over-eight-waves form (given tickets)
 // The exact scan (k <= kMaxFusedK) for exactly the queries whose d_flags word is non-zero — the ones a filter handed back —, listed and
 // scanned on the device: nothing is read back.  Results replace rows / distances [q][k_stride] of those queries.  d_ws: redo_workspace_bytes.
 size_t redo_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t k);

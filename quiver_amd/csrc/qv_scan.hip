@@ -8,7 +8,7 @@ namespace qv {
 // grid = (workgroups, nq); each wave walks tiles gw, gw+tw, ... ; lane == row.
 // Output: partial[(q*gridDim.x + blockIdx.x)*k + i] = workgroup's i-th best key.
 
-__device__ void merge_lists_last_workgroup(const uint64_t* src, uint32_t n_lists, uint32_t k, uint32_t* rows_out, float* dist_out);
+__device__ void merge_lists_last_workgroup(const uint64_t* src, uint32_t n_lists, uint32_t k, uint32_t* rows_out, float* dist_out, uint32_t* done_flag = nullptr, uint32_t done_seq = 0);
 
 // FUSE: the workgroups publish their lists with returning atomic exchanges and take a ticket; the LAST one to finish merges all of
 // them (k_merge_lists' own code) and writes the final rows / distances — one launch per query instead of two (round 5: a single
@@ -86,6 +86,127 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
         __syncthreads();                                               // (wl is the merge's scratch next)
         merge_lists_last_workgroup(partial + (size_t)qi * gridDim.x * k, gridDim.x, k, rows_out + (size_t)qi * k, dist_out + (size_t)qi * k);
     }
+}
+
+// ---------------------------------------------------------------- flat scan of a short corpus: a tile over several waves --
+// k_flat_scan gives a wave whole tiles: 64 rows x dim x 4 bytes (196 KB at 768 dimensions) streamed through 16 loads in flight and a
+// dim-step float64 chain — ~30 us per tile whatever the corpus, which IS the scan below a few hundred thousand rows (measured, one
+// query, 768 dimensions: 10 k rows 31 us, 30 k 57 us, 100 k 72 us of kernel against 4 / 13 / 43 us of HBM time).  Here the eight waves
+// of a workgroup share a tile: wave w requests columns [w, w + 1) * dim / 8 of its 64 rows (every load in flight at once) and walks
+// them, lane == row, as a partial chain; the tile's consumer wave (they take turns) adds the eight partial sums and takes the float32
+// from the CERTIFICATE of qv_hnsw.hip ("a row's sum over several lanes, certified"): the reference's single chain lies within
+// B = (2 dim + 128) u |q| |r| of the partial chains' sum, the float32 is a monotone function of that sum, so when both ends of the
+// interval give the same float32 it is the reference's.  For cosine the query's norm is itself a sum here (the reference's is a chain
+// over the same squares): its relative uncertainty d goes into the interval as (|S| + B) 2 d — the quotient S / (|q| |r|) is the same
+// real number whether the error sits in S or in |q|.  A row that fails (a few in a million; every row at distance ~0) is walked again
+// as ONE chain by row_accumulate, with the query's norm as a chain as well: the reference's arithmetic, unchanged.
+// Lists are published and merged exactly as in k_flat_scan<., ., true> (returning exchanges, a ticket, the last workgroup merges).
+constexpr int kSplitWaves = 8;
+constexpr int kSplitBlock = 64 * kSplitWaves;
+template <int M> struct ScanSplitOK { static constexpr bool value = M == QV_COSINE || M == QV_DOT || M == QV_L2 || M == QV_L1 || M == QV_L2SQ_F64; };
+template <int M>
+__global__ void __launch_bounds__(kSplitBlock)
+k_flat_scan_split(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t* __restrict__ partial,
+                  uint32_t* __restrict__ tickets, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, uint32_t* done_flag, uint32_t done_seq) {
+    using Q = typename MT<M>::Q;
+    using A = typename MT<M>::A;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* q_lds = reinterpret_cast<Q*>(smem);
+    const size_t q_bytes = (((size_t)v.dim4 * 4 * sizeof(Q)) + 15) / 16 * 16;
+    double* part = reinterpret_cast<double*>(smem + q_bytes);                      // [2][kSplitWaves][64]
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + q_bytes + 2 * kSplitWaves * 64 * sizeof(double));   // [kSplitWaves][64]
+    __shared__ double s_red[kSplitWaves];
+    __shared__ uint32_t s_last;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qi = blockIdx.y;
+    const float* q = queries + (size_t)qi * v.dim;
+    stage_query<M>(q_lds, q, v.dim, v.dim4);
+    __syncthreads();
+    // |q|^2 as a sum over the workgroup (cosine, dot): its place in the certificate, see above.  (From the staged copy: the query
+    // may live in host memory.)
+    double qn_s = 0.0;
+    if constexpr (M == QV_COSINE || M == QV_DOT) {
+        double sq = 0.0;
+        for (uint32_t i = threadIdx.x; i < v.dim4 * 4; i += kSplitBlock) { const double a = (double)q_lds[i]; sq = __builtin_fma(a, a, sq); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq = sq + __shfl_xor(sq, off);
+        if (lane == 0) s_red[wave] = sq;
+        __syncthreads();
+        sq = s_red[0];
+#pragma unroll
+        for (int w = 1; w < kSplitWaves; w++) sq = sq + s_red[w];
+        qn_s = __builtin_sqrt(sq);
+    }
+    const double k_u = ((double)(2u * v.dim) + 128.0) * 0x1p-53;
+    QConst qc; qc.qn = qn_s; qc.qn32 = 0.0f;                                         // (cosine: used with the widened interval; the fallback makes its own)
+    QConst qc_exact; qc_exact.qn = 0.0; qc_exact.qn32 = 0.0f; bool have_exact = false;
+
+    const uint32_t kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    bool first = true;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t c_lo = wave * v.dim4 / kSplitWaves, c_hi = (wave + 1) * v.dim4 / kSplitWaves;
+    uint32_t it = 0;
+    for (uint32_t t = blockIdx.x; t < v.n_tiles; t += gridDim.x, it++) {
+        const uint32_t consumer = it % kSplitWaves;
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0; uint64_t am = 0;
+        if (wave == consumer) {                                                      // (requested before the columns: they have arrived by the time they are used)
+            if constexpr (MT<M>::needs_rnorm || M == QV_DOT) rn = v.rnorm[row];
+            am = v.alive[t];
+        }
+        A acc = 0;
+        if (c_lo < c_hi) acc = row_accumulate<M, 24, false, true, false>(tiles + ((size_t)t * v.dim4 + c_lo) * 64 + lane, 64, q_lds + (size_t)c_lo * 4, c_hi - c_lo);
+        double* pb = part + (size_t)(it & 1u) * kSplitWaves * 64;
+        pb[wave * 64 + lane] = (double)acc;
+        __syncthreads();                                                             // one barrier per tile: the buffer written two tiles ahead is free by then
+        if (wave != consumer) continue;
+        double sum = pb[lane];
+#pragma unroll
+        for (int w = 1; w < kSplitWaves; w++) sum = sum + pb[w * 64 + lane];
+        double b;
+        if constexpr (M == QV_COSINE || M == QV_DOT) b = k_u * qn_s * rn; else b = k_u * sum;
+        if constexpr (M == QV_COSINE) b = b + (__builtin_fabs(sum) + b) * (2.0 * k_u);    // the norm's own uncertainty (<= k_u / 2 + 3 u relative), twice over
+        const float d_lo = finalize<M>((A)(sum - b), qc, rn), d_hi = finalize<M>((A)(sum + b), qc, rn);
+        float dist = d_lo;
+        const bool live = (am >> lane) & 1ull;
+        const bool ok = __float_as_uint(d_lo) == __float_as_uint(d_hi) && d_lo == d_lo;
+        if (__ballot(live && !ok)) {
+            // the reference's own arithmetic for this tile: one chain per row (and for the query's norm, once per workgroup)
+            A qn2 = 0;
+            A ex;
+            if (!have_exact) { ex = row_accumulate<M, 16, true, true, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4, &qn2); qc_exact = qconst_from_norm2<M>(qn2); have_exact = true; }
+            else ex = row_accumulate<M, 16, false, true, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, q_lds, v.dim4);
+            const float de = finalize<M>(ex, qc_exact, rn);
+            if (!ok) dist = de;
+        }
+        const uint64_t key = live ? make_key(dist, row) : kDeadKey;
+        if (first) { list = wave_sort64(key, lane); thr = readlane64(list, kth); first = false; }
+        else list_insert(list, thr, key, kth, lane);
+    }
+    // the waves' lists -> wave 0 -> published; the last workgroup to finish merges (k_flat_scan<., ., true>'s protocol)
+    wl[wave * 64 + lane] = list;
+    __syncthreads();
+    if (wave == 0) {
+        if (first) { list = kDeadKey; thr = kDeadKey; }
+        for (uint32_t w = 1; w < kSplitWaves; w++) {
+            const uint64_t key = lane < k ? wl[w * 64 + lane] : kDeadKey;
+            if (first) { list = wave_sort64(key, lane); thr = readlane64(list, kth); first = false; }
+            else list_insert(list, thr, key, kth, lane);
+        }
+        uint64_t* mine = partial + ((size_t)qi * gridDim.x + blockIdx.x) * k;
+        if (lane < k) (void)atomicExch(reinterpret_cast<unsigned long long*>(&mine[lane]), (unsigned long long)list);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t last = 0;
+        if (lane == 0) last = atomicAdd(&tickets[qi], 1u) == gridDim.x - 1 ? 1u : 0u;
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (last && lane == 0) tickets[qi] = 0;
+        if (lane == 0) s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    merge_lists_last_workgroup(partial + (size_t)qi * gridDim.x * k, gridDim.x, k, rows_out + (size_t)qi * k, dist_out + (size_t)qi * k, done_flag, done_seq);
 }
 
 // ---------------------------------------------------------------- queries a filter handed back, redone WITHOUT the host --
@@ -594,7 +715,8 @@ constexpr int kMergeHeads = 128;                      // sampled list heads rank
 // published by other workgroups of the SAME launch (returning atomic exchanges, then a ticket: k_flat_scan<., ., true>) and are read
 // with agent-scope atomic loads; otherwise by an earlier launch, and plain loads do.
 template <bool AT>
-__device__ void merge_lists_body(const uint64_t* __restrict__ src, uint32_t n_lists, uint32_t k, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+__device__ void merge_lists_body(const uint64_t* __restrict__ src, uint32_t n_lists, uint32_t k, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out,
+                                 uint32_t* done_flag = nullptr, uint32_t done_seq = 0) {
     auto ld = [](const uint64_t* p) -> uint64_t {
         if constexpr (AT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else return *p;
@@ -722,10 +844,20 @@ __device__ void merge_lists_body(const uint64_t* __restrict__ src, uint32_t n_li
             list_insert(list, thr, key, kth, lane);
         }
     }
-    if (lane < k) {
-        bool dead = list == kDeadKey;
-        rows_out[lane] = dead ? 0xFFFFFFFFu : (uint32_t)list;
-        dist_out[lane] = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+    const bool dead = list == kDeadKey;
+    const uint32_t r_out = dead ? 0xFFFFFFFFu : (uint32_t)list;
+    const float d_out = dead ? __uint_as_float(0x7F800000u) : unord_f32((uint32_t)(list >> 32));
+    if (!done_flag) {
+        if (lane < k) { rows_out[lane] = r_out; dist_out[lane] = d_out; }
+    } else {
+        // the host polls a sequence number instead of waiting for the stream (k_flat_scan_small's hand-over: system-scope stores for
+        // the results, and once they are acknowledged the sequence number on the same path)
+        if (lane < k) {
+            __hip_atomic_store(&rows_out[lane], r_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dist_out[lane], d_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -737,8 +869,8 @@ k_merge_lists(const uint64_t* __restrict__ partial, uint32_t n_lists, uint32_t k
     merge_lists_body<false>(partial + (size_t)qi * n_lists * k, n_lists, k, rows_out + (size_t)qi * k, dist_out + (size_t)qi * k);
 }
 // (out of line: the scan's loop keeps its own register allocation and schedule — tests/test_isa_guard.py counts its loads in flight)
-__device__ __noinline__ void merge_lists_last_workgroup(const uint64_t* src, uint32_t n_lists, uint32_t k, uint32_t* rows_out, float* dist_out) {
-    merge_lists_body<true>(src, n_lists, k, rows_out, dist_out);
+__device__ __noinline__ void merge_lists_last_workgroup(const uint64_t* src, uint32_t n_lists, uint32_t k, uint32_t* rows_out, float* dist_out, uint32_t* done_flag, uint32_t done_seq) {
+    merge_lists_body<true>(src, n_lists, k, rows_out, dist_out, done_flag, done_seq);
 }
 
 // merge of (distance, row) pair lists, e.g. the all-gathered per-shard top-k of a sharded scan
@@ -911,9 +1043,20 @@ hipError_t launch_flat_wide(const IndexView& v, const ScanPlan& p, const float* 
     return launch_select_topk(lists, n, n, nq, kk, k_stride, sel_ws, d_rows_out, d_dist_out, s, false, false);
 }
 
+// A short corpus in the tile-over-eight-waves form (k_flat_scan_split): one query, a metric whose chain can be split and certified, rows
+// wide enough that a wave's own tile is the scan (measured: from 256 dimensions; at 128 the wave-per-tile kernels are quicker), short enough
+// that the fixed costs matter (beyond ~160 k rows both forms run at the memory's rate).  QV_SCAN_SPLIT=2: never.
+constexpr uint32_t kSplitMaxTiles = 2560;
+bool flat_split_applies(const IndexView& v, uint32_t nq, uint32_t k) {
+    static const int split = env_int("QV_SCAN_SPLIT", 1), split_max = env_int("QV_SCAN_SPLIT_MAX_TILES", (int)kSplitMaxTiles);
+    const bool split_metric = v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
+    const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)3 * kSplitWaves * 64 * sizeof(double) + 40 * 1024;   // + the merge's own arrays
+    return split == 1 && split_metric && nq == 1 && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= 64 && lds <= (size_t)160 * 1024 &&
+           v.n_tiles >= 2 && v.n_tiles <= (uint32_t)split_max;
+}
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
-                            hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_tickets) {
+                            hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_tickets, uint32_t* done_flag, uint32_t done_seq, bool* flag_used) {
     if (k == 0 || k > (uint32_t)kMaxFusedK || nq == 0) return hipErrorInvalidValue;
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
     uint64_t* partial = static_cast<uint64_t*>(d_ws);
@@ -939,10 +1082,10 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
             // HBM-bound pass of k_flat_scan_mq (0.45-0.65 ms): split it off.  Same stream, so the workspace is reused in order.
             const uint32_t rem = nq & 31u;
             if (nq > 32 && rem >= 1 && rem <= 8) {
-                e = launch_flat_topk(v, p, d_queries, nq - rem, k, d_ws, d_rows_out, d_dist_out, s, ev0, ev1, nullptr);
+                e = launch_flat_topk(v, p, d_queries, nq - rem, k, d_ws, d_rows_out, d_dist_out, s, ev0, ev1, nullptr, nullptr, 0, nullptr);
                 if (e != hipSuccess) return e;
                 return launch_flat_topk(v, p, d_queries + (size_t)(nq - rem) * v.dim, rem, k, d_ws, d_rows_out + (size_t)(nq - rem) * k,
-                                        d_dist_out + (size_t)(nq - rem) * k, s, nullptr, nullptr, nullptr);
+                                        d_dist_out + (size_t)(nq - rem) * k, s, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
             }
             uint32_t g64 = 0;
             if (trace) fprintf(stderr, "qv: scan kernel = k_flat_scan_mq64 (nq=%u, tiles=%u)\n", nq, v.n_tiles);
@@ -992,6 +1135,22 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
         // one query, the caller's tickets at hand: scan + merge in ONE launch (the last workgroup merges).  QV_SCAN_FUSE=0 (read once)
         // keeps the two launches, for measurements.
         static const int fuse = env_int("QV_SCAN_FUSE", 1);
+        if (d_tickets && fuse && flat_split_applies(v, nq, k)) {
+            static const int split_grid = env_int("QV_SCAN_SPLIT_GRID", 0);
+            const uint32_t grid = std::min<uint32_t>(v.n_tiles, std::min<uint32_t>(split_grid ? (uint32_t)split_grid : (uint32_t)p.cus, p.n_lists * 4u));
+            const size_t lds_s = query_lds_bytes(v.metric, v.dim4) + (size_t)3 * kSplitWaves * 64 * sizeof(double);
+            QV_DISPATCH_METRIC(v.metric, {
+                if constexpr (ScanSplitOK<MM>::value) {
+                    e = set_lds(k_flat_scan_split<MM>, lds_s);
+                    if (e != hipSuccess) return e;
+                    if (ev0) (void)hipEventRecord(ev0, s);
+                    hipLaunchKernelGGL((k_flat_scan_split<MM>), dim3(grid, nq), dim3(kSplitBlock), lds_s, s, v, d_queries, k, partial, d_tickets, d_rows_out, d_dist_out, done_flag, done_seq);
+                    if (ev1) (void)hipEventRecord(ev1, s);
+                }
+            });
+            if (flag_used) *flag_used = done_flag != nullptr;
+            return hipGetLastError();
+        }
         if (d_tickets && nq == 1 && fuse && p.grid > 1) {
             QV_DISPATCH_METRIC(v.metric, {
                 e = set_lds((k_flat_scan<MM, kUnroll, true>), lds);
