@@ -157,6 +157,8 @@ def compact_also(also, budget):
         elif key == "k_above_64":
             c["k_gt_64_ms"] = {k2[:-3]: _r(v2, 4) for k2, v2 in e.items() if k2.endswith("_ms")}
             c["k_gt_64_ms"]["same"] = all(v2 for k2, v2 in e.items() if k2.endswith("_same"))
+        elif key == "short_collections_single_query":
+            c["short_1q_p50_us"] = {k2: _r(v2.get("p50_us"), 3) for k2, v2 in e.items() if isinstance(v2, dict)}
         elif key == "pcie_inclusive_single_query":
             c["pcie_inclusive_qps"] = _r(e.get("qps"), 4)
         elif key == "concurrent_single_query_callers":
@@ -694,6 +696,32 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         c0.close()
     except Exception as ex:                                # noqa: BLE001
         also["config0_10kx128_single_query"] = {"error": str(ex)}
+    # one query per call on SHORT collections of 768-d rows (the sizes the reference's own deployments have): host pointers, p50 of 300 calls
+    # and the scan kernel's own time; since round 5 the tile-over-eight-waves form (k_flat_scan_split)
+    try:
+        ms_ = {}
+        for n_ in (10_000, 30_000, 100_000):
+            cs = quiver_amd.DeviceIndex(dim, a.metric, device=local_rank)
+            cs.add_synthetic(CORPUS_SEED, 0, n_)
+            for j in range(30):
+                cs.search(qs_host[j % 32], k)
+            lat_ = []
+            for j in range(300):
+                t1 = time.perf_counter(); rs_, ds_, _ = cs.search(qs_host[j % 32], k); lat_.append(time.perf_counter() - t1)
+            lat_.sort()
+            cs.profile(True)
+            for j in range(50):
+                cs.search(qs_host[j % 32], k)
+            kms_, kl_ = cs.profile_read(); cs.profile(False)
+            e_ = {"p50_us": lat_[150] * 1e6, "p99_us": lat_[297] * 1e6, "scan_kernel_us": kms_ / max(kl_, 1) * 1e3, "hbm_time_us": n_ * dim * 4 / (HBM_PEAK_GBS * 1e9) * 1e6}
+            if not a.no_cpu_baseline and n_ <= 30_000:
+                from tests import _oracle as O
+                e_["identical_to_oracle"] = bool(np.array_equal(rs_[0], O.exact_search(0, O.gen_rows(CORPUS_SEED, 0, n_, dim), qs_host[299 % 32], k)[0]))
+            ms_["%dkx%d" % (n_ // 1000, dim)] = e_
+            cs.close()
+        also["short_collections_single_query"] = ms_
+    except Exception as ex:                                # noqa: BLE001
+        also["short_collections_single_query"] = {"error": str(ex)}
     # configs[3]: HNSW M=16 (MaxM0=32) efConstruction=200 over 1M x 768, the graph INSERTION-BUILT on the device
     if not a.no_hnsw:
         from tests.bench.bench_hnsw_build import run as hnsw_run
