@@ -209,6 +209,119 @@ k_flat_scan_split(IndexView v, const float* __restrict__ queries, uint32_t k, ui
     merge_lists_last_workgroup(partial + (size_t)qi * gridDim.x * k, gridDim.x, k, rows_out + (size_t)qi * k, dist_out + (size_t)qi * k, done_flag, done_seq);
 }
 
+// The same for the few queries of a shared pass (concurrent callers on a short corpus: qv_coalesce.h): up to QB queries per workgroup row
+// (blockIdx.y = group of QB).  k_flat_scan_mq gives a wave whole tiles and QB chains of dim steps per row — 16 queries over 10 k x 768
+// took 280 us, all of it chains.  Here a wave converts each element of its columns once and feeds QB partial chains (768 fma + 96
+// converts per tile and wave at 768 dimensions and QB = 8: ~3 us, what the tile's bytes take to arrive); wave j is query j's consumer
+// on every tile, so its list is the workgroup's list for that query: no merge inside the workgroup.  Lists go to partial[q][grid][k];
+// k_merge_lists follows as for the other multi-query scans.
+template <int M, int QB>
+__global__ void __launch_bounds__(kSplitBlock)
+k_flat_scan_split_mq(IndexView v, const float* __restrict__ queries, uint32_t nq, uint32_t k, uint64_t* __restrict__ partial) {
+    static_assert(QB <= kSplitWaves, "one consumer wave per query");
+    using Q = typename MT<M>::Q;
+    using A = typename MT<M>::A;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const size_t q_stride = (size_t)v.dim4 * 4;                                    // elements per staged query
+    Q* q_lds = reinterpret_cast<Q*>(smem);                                         // [QB][dim4 * 4]
+    const size_t q_bytes = ((size_t)QB * q_stride * sizeof(Q) + 15) / 16 * 16;
+    double* part = reinterpret_cast<double*>(smem + q_bytes);                      // [QB][kSplitWaves][64]
+    __shared__ double s_red[QB][kSplitWaves];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t q0 = blockIdx.y * QB;
+    const uint32_t nqg = nq - q0 < (uint32_t)QB ? nq - q0 : (uint32_t)QB;          // queries of this group
+    for (uint32_t j = 0; j < (uint32_t)QB; j++) {
+        const float* q = queries + (size_t)(q0 + (j < nqg ? j : 0)) * v.dim;       // (slots past the group repeat its first query: computed, never written)
+        for (uint32_t i = threadIdx.x; i < q_stride; i += kSplitBlock) q_lds[j * q_stride + i] = i < v.dim ? (Q)q[i] : (Q)0;
+    }
+    __syncthreads();
+    double qn_s = 0.0;                                                             // of THIS wave's query (wave j consumes query j)
+    if constexpr (M == QV_COSINE || M == QV_DOT) {
+        for (uint32_t j = 0; j < (uint32_t)QB; j++) {
+            double sq = 0.0;
+            for (uint32_t i = threadIdx.x; i < q_stride; i += kSplitBlock) { const double a = (double)q_lds[j * q_stride + i]; sq = __builtin_fma(a, a, sq); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq = sq + __shfl_xor(sq, off);
+            if (lane == 0) s_red[j][wave] = sq;
+        }
+        __syncthreads();
+        if (wave < (uint32_t)QB) {
+            double sq = s_red[wave][0];
+#pragma unroll
+            for (int w = 1; w < kSplitWaves; w++) sq = sq + s_red[wave][w];
+            qn_s = __builtin_sqrt(sq);
+        }
+    }
+    const double k_u = ((double)(2u * v.dim) + 128.0) * 0x1p-53;
+    QConst qc; qc.qn = qn_s; qc.qn32 = 0.0f;
+    QConst qc_exact; qc_exact.qn = 0.0; qc_exact.qn32 = 0.0f; bool have_exact = false;
+    const uint32_t kth = k - 1;
+    uint64_t list = kDeadKey, thr = kDeadKey;
+    bool first = true;
+    const f4* tiles = reinterpret_cast<const f4*>(v.tiles);
+    const uint32_t c_lo = wave * v.dim4 / kSplitWaves, c_hi = (wave + 1) * v.dim4 / kSplitWaves;
+    const bool consumer = wave < nqg;
+    const Q* my_q = q_lds + (size_t)(wave < (uint32_t)QB ? wave : 0) * q_stride;
+    for (uint32_t t = blockIdx.x; t < v.n_tiles; t += gridDim.x) {
+        const uint32_t row = t * 64 + lane;
+        double rn = 0.0; uint64_t am = 0;
+        if (consumer) {
+            if constexpr (MT<M>::needs_rnorm || M == QV_DOT) rn = v.rnorm[row];
+            am = v.alive[t];
+        }
+        A acc[QB];
+#pragma unroll
+        for (int j = 0; j < QB; j++) acc[j] = 0;
+        const f4* p = tiles + ((size_t)t * v.dim4 + c_lo) * 64 + lane;
+        for (uint32_t c = c_lo; c < c_hi; c += 8) {                                  // eight chunks requested together, each element widened once for all queries
+            f4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = c + (uint32_t)u < c_hi ? p[(size_t)(c - c_lo + u) * 64] : f4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (c + (uint32_t)u < c_hi) {
+#pragma unroll
+                    for (int j = 0; j < QB; j++) {
+                        const Q* qq = q_lds + (size_t)j * q_stride + (size_t)(c + u) * 4;
+                        acc1<M>(acc[j], qq[0], x[u].x); acc1<M>(acc[j], qq[1], x[u].y); acc1<M>(acc[j], qq[2], x[u].z); acc1<M>(acc[j], qq[3], x[u].w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QB; j++) part[((size_t)j * kSplitWaves + wave) * 64 + lane] = (double)acc[j];
+        __syncthreads();
+        if (consumer) {
+            const double* pb = part + (size_t)wave * kSplitWaves * 64;
+            double sum = pb[lane];
+#pragma unroll
+            for (int w = 1; w < kSplitWaves; w++) sum = sum + pb[w * 64 + lane];
+            double b;
+            if constexpr (M == QV_COSINE || M == QV_DOT) b = k_u * qn_s * rn; else b = k_u * sum;
+            if constexpr (M == QV_COSINE) b = b + (__builtin_fabs(sum) + b) * (2.0 * k_u);
+            const float d_lo = finalize<M>((A)(sum - b), qc, rn), d_hi = finalize<M>((A)(sum + b), qc, rn);
+            float dist = d_lo;
+            const bool live = (am >> lane) & 1ull;
+            const bool ok = __float_as_uint(d_lo) == __float_as_uint(d_hi) && d_lo == d_lo;
+            if (__ballot(live && !ok)) {                                             // the reference's own chain for this tile and query
+                A qn2 = 0; A ex;
+                if (!have_exact) { ex = row_accumulate<M, 16, true, true, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, my_q, v.dim4, &qn2); qc_exact = qconst_from_norm2<M>(qn2); have_exact = true; }
+                else ex = row_accumulate<M, 16, false, true, false>(tiles + (size_t)t * v.dim4 * 64 + lane, 64, my_q, v.dim4);
+                const float de = finalize<M>(ex, qc_exact, rn);
+                if (!ok) dist = de;
+            }
+            const uint64_t key = live ? make_key(dist, row) : kDeadKey;
+            if (first) { list = wave_sort64(key, lane); thr = readlane64(list, kth); first = false; }
+            else list_insert(list, thr, key, kth, lane);
+        }
+        __syncthreads();                                                             // the partial sums are read before the next tile's are written
+    }
+    if (consumer && lane < k) partial[((size_t)(q0 + wave) * gridDim.x + blockIdx.x) * k + lane] = list;
+}
+
+
 // ---------------------------------------------------------------- queries a filter handed back, redone WITHOUT the host --
 // The matrix-core filter hands a query back when its candidate buffer overflows (flags[q] != 0: a loose sample bound, e.g. a corpus
 // stored cluster by cluster); such a query needs the exact scan.  Until round 5 the callers read the flags on the host — one round trip
@@ -1054,6 +1167,21 @@ bool flat_split_applies(const IndexView& v, uint32_t nq, uint32_t k) {
     return split == 1 && split_metric && nq == 1 && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= 64 && lds <= (size_t)160 * 1024 &&
            v.n_tiles >= 2 && v.n_tiles <= (uint32_t)split_max;
 }
+// ... and for the 2 .. 32 queries of a shared pass (k_flat_scan_split_mq, groups of up to 8 per workgroup row, every group reading the corpus
+// again): while the groups' reads stay under ~600 MB — measured against the multi-query kernels it replaces, us per call of 8 / 16 / 32 / 64
+// queries: 10 k x 768 66 / 87 / 96 / 143 against 119 / 208 / 214 / 218; 30 k x 768 81 / 111 / 162 / 269 against 119 / 212 / 215 / 241;
+// 100 k x 768 131 / 181 / 195 / 202 against 169 / 181 / 190 / 197; 10 k x 1536 93 / 99 / 135 / 234 against 182 / 346 / 350 / 349.
+// (QV_SCAN_SPLIT_MQ_MAX=1: never.)
+bool flat_split_mq_applies(const IndexView& v, uint32_t nq, uint32_t k) {
+    static const int split = env_int("QV_SCAN_SPLIT", 1), split_max = env_int("QV_SCAN_SPLIT_MAX_TILES", (int)kSplitMaxTiles), nq_max = env_int("QV_SCAN_SPLIT_MQ_MAX", 32);
+    const bool split_metric = v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
+    const uint32_t qsz = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
+    const uint32_t qb = nq <= 4 ? 4u : 8u;
+    const size_t lds = (size_t)qb * v.dim4 * 4 * qsz + (size_t)qb * kSplitWaves * 64 * sizeof(double) + 1024;
+    const uint64_t reads = (uint64_t)((nq + qb - 1) / qb) * v.n_tiles * v.dim4 * 1024ull;
+    return split == 1 && split_metric && nq >= 2 && nq <= (uint32_t)nq_max && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= 64 && lds <= (size_t)160 * 1024 &&
+           v.n_tiles >= 2 && v.n_tiles <= (uint32_t)split_max && reads <= 600ull * 1000 * 1000;
+}
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s,
                             hipEvent_t ev0, hipEvent_t ev1, uint32_t* d_tickets, uint32_t* done_flag, uint32_t done_seq, bool* flag_used) {
@@ -1062,6 +1190,32 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
     uint64_t* partial = static_cast<uint64_t*>(d_ws);
     hipError_t e = hipSuccess;
     static const int mq_min = env_int("QV_MQ_MIN", 2);                // nq >= this: queries share a corpus pass
+    if ((int)nq >= mq_min && flat_split_mq_applies(v, nq, k)) {
+        // a shared pass of a few queries over a short corpus of wide rows: the tile-over-eight-waves form, up to 8 queries per workgroup row
+        const uint32_t grid = std::min<uint32_t>(v.n_tiles, std::min<uint32_t>((uint32_t)p.cus, p.n_lists * 4u));
+        const uint32_t qsz = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
+#define QV_SMQ(MMM, QQ)                                                                                                     \
+        {                                                                                                                     \
+            const size_t lds_q = ((size_t)QQ * v.dim4 * 4 * qsz + 15) / 16 * 16 + (size_t)QQ * kSplitWaves * 64 * sizeof(double); \
+            e = set_lds(k_flat_scan_split_mq<MMM, QQ>, lds_q);                                                                \
+            if (e != hipSuccess) return e;                                                                                    \
+            if (ev0) (void)hipEventRecord(ev0, s);                                                                            \
+            hipLaunchKernelGGL((k_flat_scan_split_mq<MMM, QQ>), dim3(grid, (nq + QQ - 1) / QQ), dim3(kSplitBlock), lds_q, s, v, d_queries, nq, k, partial); \
+            if (ev1) (void)hipEventRecord(ev1, s);                                                                            \
+        }
+        QV_DISPATCH_METRIC(v.metric, {
+            if constexpr (ScanSplitOK<MM>::value) {
+                if (nq <= 4) QV_SMQ(MM, 4) else QV_SMQ(MM, 8)
+            }
+        });
+#undef QV_SMQ
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const uint32_t total = grid * k;
+        const uint32_t mblock = total >= 16 * 64 * 4 ? kMergeBlock : (total >= 4 * 64 ? 256 : 64);
+        hipLaunchKernelGGL(k_merge_lists, dim3(nq), dim3(mblock), 0, s, partial, grid, k, d_rows_out, d_dist_out);
+        return hipGetLastError();
+    }
     if ((int)nq >= mq_min) {
         // QB queries per corpus pass.  Measured on MI355X, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt):
         // QB=8 is HBM-bound (0.454 ms/pass), QB=16 is f64-VALU-bound (0.75 ms/pass, 12.0 ms per 256 queries).

@@ -46,12 +46,20 @@ def test_split_scan_equals_the_oracle(seed):
     mid = quiver_amd.metric_id(metric)
     qs = np.concatenate([_vectors(rng, 5, dim, style), rows[rng.integers(0, n, 5)], np.zeros((1, dim), np.float32)])
     for k in (1, 10, 64):
+        want = [O.exact_search(mid, rows, qs[i], k, alive=alive) for i in range(qs.shape[0])]
         for i in range(qs.shape[0]):
-            r, d, c = idx.search(qs[i:i + 1], k)                       # one query per call: the split form's only use
-            ro, do = O.exact_search(mid, rows, qs[i], k, alive=alive)
+            r, d, c = idx.search(qs[i:i + 1], k)                       # one query per call: k_flat_scan_split
+            ro, do = want[i]
             assert int(c[0]) == ro.size, (metric, dim, n, style, k, i)
             assert r[0, :ro.size].tolist() == ro.tolist(), (metric, dim, n, style, k, i)
             assert d[0, :ro.size].tobytes() == do.tobytes(), (metric, dim, n, style, k, i)
+        for lo, hi in ((0, 2), (1, 4), (0, 5), (2, 10), (0, 11)):    # the queries of a shared pass: k_flat_scan_split_mq, groups of 4 / 8
+            r, d, c = idx.search(qs[lo:hi], k)
+            for i in range(lo, hi):
+                ro, do = want[i]
+                assert int(c[i - lo]) == ro.size, (metric, dim, n, style, k, lo, hi, i)
+                assert r[i - lo, :ro.size].tolist() == ro.tolist(), (metric, dim, n, style, k, lo, hi, i)
+                assert d[i - lo, :ro.size].tobytes() == do.tobytes(), (metric, dim, n, style, k, lo, hi, i)
     idx.close()
 
 
