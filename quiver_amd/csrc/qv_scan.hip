@@ -1179,7 +1179,8 @@ bool flat_split_mq_applies(const IndexView& v, uint32_t nq, uint32_t k) {
     const uint32_t qb = nq <= 4 ? 4u : 8u;
     const size_t lds = (size_t)qb * v.dim4 * 4 * qsz + (size_t)qb * kSplitWaves * 64 * sizeof(double) + 1024;
     const uint64_t reads = (uint64_t)((nq + qb - 1) / qb) * v.n_tiles * v.dim4 * 1024ull;
-    return split == 1 && split_metric && nq >= 2 && nq <= (uint32_t)nq_max && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= 64 && lds <= (size_t)160 * 1024 &&
+    static const int min_dim4 = env_int("QV_SCAN_SPLIT_MQ_MIN_DIM4", 16);   // (from 64 dimensions: 10 k x 128, 8 / 16 / 32 queries per call 36 / 40 / 47 us against 64 / 98 / 98)
+    return split == 1 && split_metric && nq >= 2 && nq <= (uint32_t)nq_max && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= (uint32_t)min_dim4 && lds <= (size_t)160 * 1024 &&
            v.n_tiles >= 2 && v.n_tiles <= (uint32_t)split_max && reads <= 600ull * 1000 * 1000;
 }
 hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t k,
