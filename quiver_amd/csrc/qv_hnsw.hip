@@ -1,4 +1,5 @@
-// qv_hnsw.hip — device-resident HNSW traversal (exact-heap and wave-resident forms)
+// qv_hnsw.hip — device-resident HNSW traversal (exact-heap and wave-resident forms; each as a wave per query for thousands of
+// traversals in flight and, for batches of at most one query per CU, as a workgroup of eight waves per query: "the latency form")
 // (shared helpers, the arithmetic contract and the build flags: qv_kernels.h)
 #include "qv_kernels.h"
 
@@ -13,7 +14,8 @@ namespace qv {
 // one by one in adjacency order (:536-563) after their distances have been computed together:
 // lane i scores the i-th unvisited neighbour with the same sequential-over-dims arithmetic
 // as every other kernel here, so distances — hence every heap decision — are bit-identical
-// to the CPU restatement.
+// to the CPU restatement.  (The latency form adds a row's products as partial chains and takes the float32 from a certificate —
+// or, where that does not decide it, from the same single chain: see "a row's sum over several lanes, certified" below.)
 struct HRes { float dist; uint32_t idx; };
 constexpr int kHnswCandCap = 2048;     // candidate min-heap slots per query (overflow -> host path)
 constexpr int kHnswEfMax = 512;
