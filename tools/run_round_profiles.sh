@@ -35,3 +35,11 @@ cp $(find /tmp/rp_g -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_hnsw_
 python3 tools/dev_hnsw_tput.py 64,128,256,512 2>/dev/null | grep -E "^build|^ef" > gpurun_out/${tag}_hnsw_1Mx768.txt
 if [ -f quiver_amd/lib/libqv_prof.so ]; then QV_LIB_PATH=$root/quiver_amd/lib/libqv_prof.so python3 tools/dev_hnsw_phase.py 1000000 4 2>/dev/null | grep -A30 -e "---- search" | grep -E "^blk|^ef|^lat" | tail -3 > gpurun_out/${tag}_hnsw_lone_phases.txt; fi
 cat gpurun_out/${tag}_hnsw_1Mx768.txt; head -8 gpurun_out/${tag}_hnsw_build_search_1Mx768_kernel_stats.csv | cut -c1-200
+# round 5 (late): one query per call on short collections (k_flat_scan_split) under rocprofv3, and the shared-pass form by queries per call
+(cd /tmp && rm -rf /tmp/rp_s && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_s -o s -- python3 $root/tools/dev_mid_latency.py 768 10000,30000,100000 > $root/gpurun_out/${tag}_short_768_under_rocprof.txt 2>/dev/null)
+cp $(find /tmp/rp_s -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_short_768_kernel_stats.csv 2>/dev/null
+python3 tools/dev_mid_latency.py 768 128,5000,10000,30000,60000,100000,160000 2>/dev/null | grep "^rows" > gpurun_out/${tag}_short_latency.txt
+python3 tools/dev_mid_latency.py 1536 10000,30000 2>/dev/null | grep "^rows" >> gpurun_out/${tag}_short_latency.txt
+python3 tools/dev_mid_latency.py 256 10000,30000 2>/dev/null | grep "^rows" >> gpurun_out/${tag}_short_latency.txt
+python3 tools/dev_split_mq.py 768 2>/dev/null | grep "^rows" >> gpurun_out/${tag}_short_latency.txt
+cat gpurun_out/${tag}_short_latency.txt; head -4 gpurun_out/${tag}_short_768_kernel_stats.csv | cut -c1-200
