@@ -1157,14 +1157,16 @@ hipError_t launch_flat_wide(const IndexView& v, const ScanPlan& p, const float* 
 }
 
 // A short corpus in the tile-over-eight-waves form (k_flat_scan_split): one query, a metric whose chain can be split and certified, rows
-// wide enough that a wave's own tile is the scan (measured: from 256 dimensions; at 128 the wave-per-tile kernels are quicker), short enough
+// wide enough that a wave's own tile is the scan (it pays from 256 dimensions; at 128 the kernels are level and the single polled launch
+// wins 16 k - 60 k rows; at 64 nothing), short enough
 // that the fixed costs matter (beyond ~160 k rows both forms run at the memory's rate).  QV_SCAN_SPLIT=2: never.
 constexpr uint32_t kSplitMaxTiles = 2560;
 bool flat_split_applies(const IndexView& v, uint32_t nq, uint32_t k) {
     static const int split = env_int("QV_SCAN_SPLIT", 1), split_max = env_int("QV_SCAN_SPLIT_MAX_TILES", (int)kSplitMaxTiles);
     const bool split_metric = v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)3 * kSplitWaves * 64 * sizeof(double) + 40 * 1024;   // + the merge's own arrays
-    return split == 1 && split_metric && nq == 1 && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= 64 && lds <= (size_t)160 * 1024 &&
+    static const int min_dim4 = env_int("QV_SCAN_SPLIT_MIN_DIM4", 32);       // (128 dimensions: 16 k / 30 k rows 30.8 / 35.6 -> 26.9 / 28.9 us, the rest equal; 64 dimensions: no gain)
+    return split == 1 && split_metric && nq == 1 && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= (uint32_t)min_dim4 && lds <= (size_t)160 * 1024 &&
            v.n_tiles >= 2 && v.n_tiles <= (uint32_t)split_max;
 }
 // ... and for the 2 .. 32 queries of a shared pass (k_flat_scan_split_mq, groups of up to 8 per workgroup row, every group reading the corpus

@@ -33,7 +33,7 @@ def _vectors(rng, n, dim, style):
 def test_split_scan_equals_the_oracle(seed):
     rng = np.random.default_rng(4400 + seed)
     metric = METRICS[seed % 5]
-    dim = int(rng.choice([64, 100, 128, 256, 258, 300, 384, 768, 1000, 1536]))   # (below 256 dimensions only the shared-pass form applies)
+    dim = int(rng.choice([64, 100, 128, 256, 258, 300, 384, 768, 1000, 1536]))   # (below 128 dimensions only the shared-pass form applies)
     n = int(rng.choice([130, 700, 3000, 9000, 20000]))
     style = int(rng.integers(0, 4))
     rows = _vectors(rng, n, dim, style)
