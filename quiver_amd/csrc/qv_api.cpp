@@ -476,7 +476,8 @@ static int exact_search_host(qv_index* idx, const float* queries, uint32_t nq, u
     uint32_t* tickets = nullptr; uint32_t* flag = nullptr; bool flag_used = false;
     if (!c->tickets.p) { if ((rc = c->tickets.ensure(256))) return rc; HIPCHK(hipMemsetAsync(c->tickets.p, 0, 256, c->stream)); }   // (on the stream that reads them: see stream_workspace)
     tickets = static_cast<uint32_t*>(c->tickets.p);                    // single-launch scans: the small collection's, and one query over a large one
-    if (direct && q_direct) {
+    // (any single query whose scan is short enough to poll for: up to ~4 GB of rows, about half a millisecond)
+    if (direct && (q_direct || (nq == 1 && (uint64_t)idx->n_rows * idx->dim4 * 16 <= (4ull << 30)))) {
         if (!c->h_flag.p) { if ((rc = c->h_flag.ensure(64))) return rc; *static_cast<volatile uint32_t*>(c->h_flag.p) = 0; }
         flag = static_cast<uint32_t*>(c->h_flag.p);
         c->flag_seq++;

@@ -17,7 +17,8 @@ __device__ void merge_lists_last_workgroup(const uint64_t* src, uint32_t n_lists
 template <int M, int U, bool FUSE = false>
 __global__ void __launch_bounds__(kScanBlock)
 k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t* __restrict__ partial,
-            uint32_t* __restrict__ tickets = nullptr, uint32_t* __restrict__ rows_out = nullptr, float* __restrict__ dist_out = nullptr) {
+            uint32_t* __restrict__ tickets = nullptr, uint32_t* __restrict__ rows_out = nullptr, float* __restrict__ dist_out = nullptr,
+            uint32_t* done_flag = nullptr, uint32_t done_seq = 0) {
     using Q = typename MT<M>::Q;
     extern __shared__ __align__(16) unsigned char smem[];
     Q* q_lds = reinterpret_cast<Q*>(smem);
@@ -84,7 +85,7 @@ k_flat_scan(IndexView v, const float* __restrict__ queries, uint32_t k, uint64_t
         __syncthreads();
         if (!(uint32_t)wl[0]) return;
         __syncthreads();                                               // (wl is the merge's scratch next)
-        merge_lists_last_workgroup(partial + (size_t)qi * gridDim.x * k, gridDim.x, k, rows_out + (size_t)qi * k, dist_out + (size_t)qi * k);
+        merge_lists_last_workgroup(partial + (size_t)qi * gridDim.x * k, gridDim.x, k, rows_out + (size_t)qi * k, dist_out + (size_t)qi * k, done_flag, done_seq);
     }
 }
 
@@ -1313,9 +1314,10 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
                 e = set_lds((k_flat_scan<MM, kUnroll, true>), lds);
                 if (e != hipSuccess) return e;
                 if (ev0) (void)hipEventRecord(ev0, s);
-                hipLaunchKernelGGL((k_flat_scan<MM, kUnroll, true>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial, d_tickets, d_rows_out, d_dist_out);
+                hipLaunchKernelGGL((k_flat_scan<MM, kUnroll, true>), dim3(p.grid, nq), dim3(p.block), lds, s, v, d_queries, k, partial, d_tickets, d_rows_out, d_dist_out, done_flag, done_seq);
                 if (ev1) (void)hipEventRecord(ev1, s);
             });
+            if (flag_used) *flag_used = done_flag != nullptr;
             return hipGetLastError();
         }
     }
