@@ -1448,19 +1448,27 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     const uint32_t qsize = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
     HnswOpts ol = o;
     size_t lat_fixed = 0;
-    for (ol.lat_rows = 32; ol.lat_rows >= 8; ol.lat_rows >>= 1) {              // the hop's rows at once; half / a quarter of them where the dimension asks for it
+    // two tiers: up to one query per CU — 32 rows of a hop at once, the visited table in LDS, a CU per query; up to three per CU
+    // (QV_HNSW_LAT_TIER2, default 768 queries) — 16 rows at once and the visited table in global memory, so that two workgroups share a CU:
+    // one call of 384 / 512 / 768 / 1024 queries 6.75 / 7.13 / 7.47 / 7.89 ms a wave per query, 4.75 / 5.17 / 6.94 / 7.52 ms in this form (with the
+    // exact-heap pass of their flagged queries; 8192 queries: 319 k QPS a wave per query, 264 k in this form, 183 k one workgroup per CU)
+    static const int lat_tier2 = env_int("QV_HNSW_LAT_TIER2", 768);
+    const bool tier2 = nq > (uint32_t)lat_cus;
+    for (ol.lat_rows = tier2 ? 16u : 32u; ol.lat_rows >= 8; ol.lat_rows >>= 1) {   // the hop's rows at once; half / a quarter of them where the dimension asks for it
         lat_fixed = (size_t)kLatQOff + lat_q_bytes(v.dim4, qsize) + lat_rows_bytes(v.dim4, ol.lat_rows);
-        if (lat_fixed <= (size_t)160 * 1024) break;
+        if (lat_fixed <= (size_t)(tier2 ? 80 : 160) * 1024) break;
     }
     const bool lat_metric = v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
-    if (lat_env == 1 && lat_metric && hnsw_qlds_ok(v) && nq <= (uint32_t)lat_cus && nq <= grid && ol.lat_rows >= 8) {
-        ol.vis_lds = lat_fixed + (size_t)o.vis_cap * 4 <= (size_t)160 * 1024 ? 1u : 0u;
+    const uint32_t lat_nq_cap = std::max<uint32_t>((uint32_t)lat_cus, (uint32_t)lat_tier2);
+    if (lat_env == 1 && lat_metric && hnsw_qlds_ok(v) && nq <= lat_nq_cap && ol.lat_rows >= 8) {
+        ol.vis_lds = !tier2 && lat_fixed + (size_t)o.vis_cap * 4 <= (size_t)160 * 1024 ? 1u : 0u;
         const size_t lds_lat = lat_fixed + (ol.vis_lds ? (size_t)o.vis_cap * 4 : 0);
+        const uint32_t lat_grid = std::min<uint32_t>(nq, std::min<uint32_t>(grid, (uint32_t)lat_cus * (tier2 ? 2u : 1u)));
 #define QV_HWL(SS) QV_DISPATCH_METRIC(v.metric, {                                                                     \
         if constexpr (SplitOK<MM>::value) {                                                                           \
             e = set_lds(k_hnsw_search_wave<MM, 4, SS, true, kLatWaves>, lds_lat);                                             \
             if (e != hipSuccess) return e;                                                                            \
-            hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS, true, kLatWaves>), dim3(nq), dim3(64 * kLatWaves), lds_lat, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
+            hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS, true, kLatWaves>), dim3(lat_grid), dim3(64 * kLatWaves), lds_lat, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
                                static_cast<const double*>(d_qconst), nq, k, ef, ol,                                  \
                                d_rows_out, d_dist_out, d_count_out, d_evals_out);                                     \
         }                                                                                                             \
