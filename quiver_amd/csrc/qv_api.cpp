@@ -550,7 +550,17 @@ static int coalesce_lanes(const qv_index* idx) {
 int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k,
                     uint32_t* rows_out, float* dist_out, uint32_t* count_out) {
     if (!coalesce_applies(idx, queries, nq, k, rows_out, dist_out, count_out)) return search_direct(idx, queries, nq, k, rows_out, dist_out, count_out);
-    { const int lanes = coalesce_lanes(idx); idx->front.set_lanes(lanes, lanes == 1); }
+    {   // Lanes by size (coalesce_lanes); and on the smallest collections short shared passes: up to 32 queries a pass is the partial-chain
+        // form of the scan (k_flat_scan_split_mq: 16 queries over 10 k x 768 in 87 us), beyond it the multi-query kernels (64 queries: 215 us), so
+        // 16 per pass and four passes side by side carry more — callers on 10 k x 768 at 64 / 256 / 1024: 497 k / 473 k / 479 k QPS against 355 k /
+        // 280 k / 107 k with passes of up to 256; 10 k x 128: 517 k / 253 k / 256 k against 508 k / 181 k / 101 k.  From ~64 MiB the larger passes
+        // win again (30 k x 768 at 256 callers: 427 k against 263 k).  QV_FLAT_SMALL_GROUP overrides (measurements).
+        const int lanes = coalesce_lanes(idx);
+        idx->front.set_lanes(lanes, lanes == 1);
+        static const int small_group = getenv("QV_FLAT_SMALL_GROUP") ? atoi(getenv("QV_FLAT_SMALL_GROUP")) : 16;
+        const uint64_t bytes = (uint64_t)idx->n_rows * idx->dim4 * 16;
+        idx->front.set_max_group(lanes > 1 && bytes < ((uint64_t)64 << 20) ? (uint32_t)std::max(small_group, 8) : 256u);
+    }
     char err[256]; err[0] = 0;
     const int rc = idx->front.submit(
         0, queries, nq, idx->dim, k, rows_out, dist_out, count_out, nullptr,

@@ -149,6 +149,7 @@ class Front {
     // passes in flight at most, from now on (a handle whose pass cost changes with its size adjusts it; passes already running finish)
     // hold_open: whether a leader holds its group open for returning callers at all — worth it where a multi-query pass costs what a
     // single-query pass costs (a large scan, a traversal batch), not where grouping has a price and free lanes are the better answer
+    void set_max_group(uint32_t q) { max_q_.store(q < 1 ? 1 : q, std::memory_order_relaxed); }
     void set_lanes(int n, bool hold_open = true) { lanes_.store(n < 1 ? 1 : n, std::memory_order_relaxed); hold_open_.store(hold_open, std::memory_order_relaxed); }
 
     // solo():       run the caller's own request in its own buffers (what the entry point did before there was a front)
@@ -206,7 +207,7 @@ class Front {
                 }
                 done = grp || (has_lane && !open_group);                       // a place in a group, or a lane and nobody to wait for
                 // capacity of the group to be: twice what the last one held (the block is written once, never zero-filled)
-                if (!done) cap = std::min<uint32_t>(max_q_, std::max<uint32_t>(std::max<uint32_t>(64, nq), 2 * last_group_q_));
+                if (!done) cap = std::min<uint32_t>(max_q_.load(std::memory_order_relaxed), std::max<uint32_t>(std::max<uint32_t>(64, nq), 2 * last_group_q_));
             }
             if (hand_lane_to) { hand_lane_to->go.store(1, std::memory_order_release); futex_wake(&hand_lane_to->go, 1); }
             if (done) break;
@@ -358,7 +359,7 @@ class Front {
     uint32_t last_group_q_ = 0;
     std::atomic<int> lanes_;
     std::atomic<bool> hold_open_{true};
-    const uint32_t max_q_;
+    std::atomic<uint32_t> max_q_;
     const int linger_div_;
 };
 
