@@ -553,13 +553,19 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
     {   // Lanes by size (coalesce_lanes); and on the smallest collections short shared passes: up to 32 queries a pass is the partial-chain
         // form of the scan (k_flat_scan_split_mq: 16 queries over 10 k x 768 in 87 us), beyond it the multi-query kernels (64 queries: 215 us), so
         // 16 per pass and four passes side by side carry more — callers on 10 k x 768 at 64 / 256 / 1024: 497 k / 473 k / 479 k QPS against 355 k /
-        // 280 k / 107 k with passes of up to 256; 10 k x 128: 517 k / 253 k / 256 k against 508 k / 181 k / 101 k.  From ~64 MiB the larger passes
-        // win again (30 k x 768 at 256 callers: 427 k against 263 k).  QV_FLAT_SMALL_GROUP overrides (measurements).
+        // 280 k / 107 k with passes of up to 256; 10 k x 128: 517 k / 253 k / 256 k against 508 k / 181 k / 101 k.  QV_FLAT_SMALL_GROUP overrides (measurements).
         const int lanes = coalesce_lanes(idx);
         idx->front.set_lanes(lanes, lanes == 1);
-        static const int small_group = getenv("QV_FLAT_SMALL_GROUP") ? atoi(getenv("QV_FLAT_SMALL_GROUP")) : 16;
+        static const int small_group = getenv("QV_FLAT_SMALL_GROUP") ? atoi(getenv("QV_FLAT_SMALL_GROUP")) : 0;
         const uint64_t bytes = (uint64_t)idx->n_rows * idx->dim4 * 16;
-        idx->front.set_max_group(lanes > 1 && bytes < ((uint64_t)64 << 20) ? (uint32_t)std::max(small_group, 8) : 256u);
+        // (64 - 256 MiB, still four lanes: 30 k x 768 at 256 / 1024 callers 445 k / 483 k QPS with passes of up to 64 against 425 k / 210 k with 256 and
+        // 283 k / 261 k with 32; 60 k x 768 459 k / 459 k with 32 against 279 k / 99 k with 256 and 320 k / 156 k with 64; 80 k x 768 408 k / 392 k against 303 k / 105 k)
+        const uint32_t by_size = bytes < ((uint64_t)64 << 20) ? 16u : (bytes < ((uint64_t)128 << 20) ? 64u : 32u);
+        // (one lane, 256 MiB and more: 100 k x 768 at 256 / 1024 / 2048 callers 525 k / 463 k / 508 k QPS with passes of up to 128 against 350 k / 256 k / 189 k
+        // with 256; 300 k x 768 374 k / 375 k / 355 k against 302 k / 289 k / 405 k; 1M x 768 200 k / 191 k / 194 k against 207 k / 289 k / 304 k: 128 below 1 GiB)
+        static const int big_group = getenv("QV_FLAT_BIG_GROUP") ? atoi(getenv("QV_FLAT_BIG_GROUP")) : 0;
+        const uint32_t one_lane = big_group > 0 ? (uint32_t)std::max(big_group, 8) : (bytes < ((uint64_t)1 << 30) ? 128u : 256u);
+        idx->front.set_max_group(lanes > 1 ? (small_group > 0 ? (uint32_t)std::max(small_group, 8) : by_size) : one_lane);
     }
     char err[256]; err[0] = 0;
     const int rc = idx->front.submit(
