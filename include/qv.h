@@ -423,7 +423,9 @@ int         qv_abi_version(void);
 int         qv_device_count(void);
 /* One line naming the HIP runtime and the RCCL this process bound (version + file): "hip_runtime=7.2.x lib=...; rccl=2.27.7
  * lib=...".  Both resolve by soname to whatever the process loaded first (PyTorch bundles its own pair); qv_sharded_create
- * refuses an RCCL exchange when the two come from different installations.  For reports of multi-GPU runs. */
+ * refuses an RCCL exchange when the two come from different installations.  For reports of multi-GPU runs.  Also the process's
+ * GPU_MAX_HW_QUEUES (hardware queues per device; the HIP runtime reads it at its first call and defaults to 4): a host that serves
+ * concurrent callers sets it to 8 BEFORE its first HIP call — libqv never modifies the environment. */
 int         qv_runtime_info(char* out, size_t cap);
 /* Timing of the last qv_index_search_device-style launch is the caller's business
  * (HIP events on its stream); this returns static facts for reports. */

@@ -14,12 +14,8 @@
 namespace {
 thread_local char g_err[512] = "";
 
-// HIP streams share hardware queues, four per device by default (GPU_MAX_HW_QUEUES), and two streams on one queue run their kernels
-// one after another.  A process that serves concurrent callers holds a call context (a stream) per call in flight, the traversal
-// lanes of a graph and the shards' streams: measured, four concurrent traversal batches took 16.5 ms each on four queues and 9.0 ms
-// on eight.  The runtime reads the variable when it initialises (the first HIP call of the process), so this has to happen when the
-// library is loaded; an explicit setting in the environment wins.
-__attribute__((constructor)) void qv_more_hardware_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (GPU_MAX_HW_QUEUES — the HIP runtime's hardware queues per device, 4 by default — is the HOST's to set before its first HIP call:
+// INTEGRATION.md "Environment"; qv_runtime_info reports what the process has.  The library does not touch the environment.)
 }
 
 int qv_fail(int code, const char* fmt, ...) {

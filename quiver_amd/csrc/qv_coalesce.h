@@ -106,29 +106,36 @@ struct Group {
         if (with_evals) evals.assign(nq, 0);
     }
     // Every member's share: the first k of each of its queries' kmax results (top-k is a prefix of top-kmax under one total
-    // order); a count of 0xFFFFFFFF ("redo on the host", qv_graph_search) passes through.  early: only members whose queries are
-    // all final (count != not_final) get theirs now; members served in an early round are skipped later.
-    void scatter(bool early, uint32_t not_final = 0xFFFFFFFEu) {
-        if (delivered.size() != n_mem) delivered.assign(n_mem, 0);
-        for (uint32_t mi = 0; mi < n_mem; mi++) {
-            const Member& m = mbuf[mi];
-            if (delivered[mi]) continue;
-            if (early) {
-                bool fin = true;
-                for (uint32_t i = 0; i < m.nq; i++) if (count[m.q0 + i] == not_final) { fin = false; break; }
-                if (!fin) continue;
-            }
-            delivered[mi] = 1;
-            for (uint32_t i = 0; i < m.nq; i++) {
-                const size_t src = (size_t)(m.q0 + i) * kmax, dst = (size_t)i * m.k;
-                memcpy(m.rows_out + dst, rows.data() + src, (size_t)m.k * 4);
-                memcpy(m.dist_out + dst, dist.data() + src, (size_t)m.k * 4);
-                const uint32_t c = count[m.q0 + i];
-                m.count_out[i] = c == 0xFFFFFFFFu ? c : (c < m.k ? c : m.k);
-                if (m.evals_out && !evals.empty()) m.evals_out[i] = evals[m.q0 + i];
-            }
+    // order); a count of 0xFFFFFFFF ("redo on the host", qv_graph_search) passes through.
+    void give(const Member& m) {
+        for (uint32_t i = 0; i < m.nq; i++) {
+            const size_t src = (size_t)(m.q0 + i) * kmax, dst = (size_t)i * m.k;
+            memcpy(m.rows_out + dst, rows.data() + src, (size_t)m.k * 4);
+            memcpy(m.dist_out + dst, dist.data() + src, (size_t)m.k * 4);
+            const uint32_t c = count[m.q0 + i];
+            m.count_out[i] = c == 0xFFFFFFFFu ? c : (c < m.k ? c : m.k);
+            if (m.evals_out && !evals.empty()) m.evals_out[i] = evals[m.q0 + i];
         }
     }
+    // The early round: the members whose queries are all final (count != not_final) are marked in delivered[]; returns how many.
+    // delivered[] is written HERE ONLY, before the release store of phase = 1 — a rider reads its flag after loading phase == 1,
+    // possibly much later (descheduled between the two loads), so the final round must never store to it: a rider that saw the
+    // final round's mark would return before its results were written and the leader would then write into buffers the caller
+    // owns again (the thread sanitizer reports exactly that pair on tests/c/coalesce_harness.cpp).
+    uint32_t mark_early(uint32_t not_final = 0xFFFFFFFEu) {
+        delivered.assign(n_mem, 0);
+        uint32_t n = 0;
+        for (uint32_t mi = 0; mi < n_mem; mi++) {
+            const Member& m = mbuf[mi];
+            bool fin = true;
+            for (uint32_t i = 0; i < m.nq; i++) if (count[m.q0 + i] == not_final) { fin = false; break; }
+            if (fin) { delivered[mi] = 1; n++; }
+        }
+        return n;
+    }
+    void scatter_early() { for (uint32_t mi = 0; mi < n_mem; mi++) if (delivered[mi]) give(mbuf[mi]); }
+    // The final round: everybody the early round (if there was one) did not serve.  Reads delivered[], never writes it.
+    void scatter_rest() { for (uint32_t mi = 0; mi < n_mem; mi++) if (delivered.empty() || !delivered[mi]) give(mbuf[mi]); }
 };
 
 class Front {
@@ -259,22 +266,29 @@ class Front {
         // run() may call this once, when g.count says which queries are final (everything but the entries equal to 0xFFFFFFFE) and
         // the rest needs a second, slow pass (qv_graph_search's exact-heap redo): the lane goes to the next group and the members
         // whose queries are all final get their results now instead of waiting for the slowest query of the group.
+        uint32_t early_served = 0;
         auto early = [&] {
             if (alone || lane_released) return;
-            lane_released = true;
-            finish_lane(grp->n_mem, now_ns() - t0);
-            grp->scatter(true);
+            early_served = grp->mark_early();                                  // only they return now: the rest stays blocked in the second pass
+            lane_released = true;                                              // (mark_early may throw: nothing has changed before this line)
+            finish_lane(early_served, now_ns() - t0);
+            grp->scatter_early();
             grp->phase.store(1, std::memory_order_release);
             futex_wake(&grp->phase, INT_MAX);
             stats.early_rounds.fetch_add(1, std::memory_order_relaxed);
         };
+        int64_t pass_ns = 0;
         try {
             rc = alone ? solo() : run(*grp, early);
-        } catch (...) { rc = -7; }
+            pass_ns = now_ns() - t0;
+            if (!lane_released) finish_lane(grp->n_mem, pass_ns);              // the next group starts before this one's results are handed out
+            else credit_released(grp->n_mem - early_served);                   // the members the second pass kept are released now
+            if (!alone && rc == 0) grp->scatter_rest();
+        } catch (...) {
+            rc = -7;
+            if (!pass_ns) { pass_ns = now_ns() - t0; if (!lane_released) finish_lane(grp->n_mem, pass_ns); else credit_released(grp->n_mem - early_served); }
+        }
         if (rc != 0) snprintf(grp->err, sizeof(grp->err), "%s", rc == -7 && !*last_error() ? "out of host memory" : last_error());
-        const int64_t pass_ns = now_ns() - t0;
-        if (!lane_released) finish_lane(grp->n_mem, pass_ns);                  // the next group starts before this one's results are handed out
-        if (!alone && rc == 0) grp->scatter(false);
         grp->rc = rc;
         if (alone) stats.solo.fetch_add(1, std::memory_order_relaxed);
         else {
@@ -349,6 +363,15 @@ class Front {
             next = give_lane_locked();
         }
         if (next) { next->go.store(1, std::memory_order_release); futex_wake(&next->go, 1); }
+    }
+
+    // callers that a pass released without a lane changing hands (the members an early round left behind, when their group completes)
+    void credit_released(uint32_t callers) {
+        if (!callers) return;
+        std::lock_guard<SpinLock> l(mu_);
+        const int64_t now = now_ns();
+        released_ = (now - released_at_ < kReturnWindowNs ? released_ : 0) + callers;
+        released_at_ = now;
     }
 
     SpinLock mu_;

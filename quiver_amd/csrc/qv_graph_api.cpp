@@ -124,7 +124,6 @@ int graph_reserve(qv_graph* g, uint64_t nodes, uint64_t blocks) {
 // visited-set storage for a traversal with list capacity `ef` over the current node capacity
 int ensure_visited(qv_graph* g, uint32_t ef) {
     qv_index* idx = g->idx;
-    if (!g->grid) g->grid = qv::hnsw_wave_grid(idx->cus, idx->metric, idx->dim4);
     const uint32_t cap = qv::hnsw_vis_hash_cap(ef);
     if (cap > g->vis_hash_cap) {
         if (g->ev_last) HIPCHK(hipEventSynchronize(g->ev_last));
@@ -149,6 +148,9 @@ qv::HnswOpts wave_opts(qv_graph* g) { qv::HnswOpts o; o.vis = static_cast<uint32
 qv::HnswOpts heap_opts(qv_graph* g) { qv::HnswOpts o; o.vis = static_cast<uint32_t*>(g->vis_bits.p); o.vis_cap = g->vis_bits_words; return o; }
 
 int graph_common_init(qv_graph* g) {
+    // wave slots of the traversal kernel: a constant of (device, metric, dimension), fixed here once — concurrent qv_graph_search
+    // callers only ever read it
+    g->grid = qv::hnsw_wave_grid(g->idx->cus, g->idx->metric, g->idx->dim4);
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&g->ev_last, hipEventDisableTiming));
     return QV_OK;
@@ -231,7 +233,6 @@ struct GCtxGuard {
 // visited-set storage of one context for a batch of nq queries with list capacity ef: as many slots as the batch can occupy
 int ensure_visited_ctx(qv_graph* g, GraphCtx* c, uint32_t ef, uint32_t nq) {
     qv_index* idx = g->idx;
-    if (!g->grid) g->grid = qv::hnsw_wave_grid(idx->cus, idx->metric, idx->dim4);
     const uint32_t cap = qv::hnsw_vis_hash_cap(ef);
     const uint32_t slots = std::min(g->grid, std::max(nq, 1u));
     if (cap > c->vis_hash_cap || slots > c->vis_hash_slots) {

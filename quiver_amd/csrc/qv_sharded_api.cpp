@@ -215,6 +215,9 @@ int acquire_ctx(qv_sharded* s, CallCtx** out) {
     {
         std::lock_guard<std::mutex> g(s->ctx_mu);
         if (!s->free_ctx.empty()) { *out = s->free_ctx.back(); s->free_ctx.pop_back(); return QV_OK; }
+        // a parked surplus context is as good as a new one: a read-only workload with repeated bursts of more than kKeepCtx callers
+        // therefore never holds more contexts than its largest burst had callers (nothing reaps `retired` until the next mutation)
+        if (!s->retired.empty()) { *out = s->retired.back(); s->retired.pop_back(); return QV_OK; }
     }
     CallCtx* c = new (std::nothrow) CallCtx();
     if (!c) return fail(QV_ERR_OOM, "out of host memory");
@@ -865,9 +868,10 @@ int qv_runtime_info(char* out, size_t cap) {
     int hip_v = 0, nccl_v = 0;
     (void)hipRuntimeGetVersion(&hip_v);
     (void)ncclGetVersion(&nccl_v);
-    snprintf(out, cap, "hip_runtime=%d.%d.%d lib=%s; rccl=%d.%d.%d lib=%s", hip_v / 10000000, (hip_v / 100000) % 100, hip_v % 100000,
+    const char* hwq = getenv("GPU_MAX_HW_QUEUES");
+    snprintf(out, cap, "hip_runtime=%d.%d.%d lib=%s; rccl=%d.%d.%d lib=%s; GPU_MAX_HW_QUEUES=%s", hip_v / 10000000, (hip_v / 100000) % 100, hip_v % 100000,
              lib_of(reinterpret_cast<const void*>(&hipGetDeviceCount)).c_str(), nccl_v / 10000, (nccl_v / 100) % 100, nccl_v % 100,
-             lib_of(reinterpret_cast<const void*>(&ncclAllGather)).c_str());
+             lib_of(reinterpret_cast<const void*>(&ncclAllGather)).c_str(), hwq ? hwq : "unset (runtime default: 4)");
     return QV_OK;
 }
 

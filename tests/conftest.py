@@ -11,6 +11,9 @@ import sys
 
 import pytest
 
+# hardware queues per device for the concurrent-caller tests: the HOST's setting, before the first HIP call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

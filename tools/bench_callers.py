@@ -4,6 +4,7 @@ count on the flat index and on the device HNSW graph.  This is the traffic the r
 
     python tools/bench_callers.py [--rows 1000000] [--dim 768] [--graph-rows 1000000] [--seconds 2] [--out gpurun_out/callers.json]
 QV_COALESCE=0 in the environment turns the sharing off (every call on its own, as before round 5)."""
+import os; os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the host's setting, before the first HIP call
 import argparse
 import json
 import os
