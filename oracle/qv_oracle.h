@@ -106,6 +106,8 @@ int       qvo_hnsw_load_graph(qvo_hnsw*, uint32_t n, const float* rows, const in
 /* test scaffolding (not a reference function): install a ready-made single-layer graph; rows are borrowed */
 int       qvo_hnsw_load_flat(qvo_hnsw*, uint32_t n, const float* rows, const uint32_t* deg, const uint32_t* links,
                              uint32_t stride, uint32_t entry);
+/* test scaffolding (not a reference function): the next n level draws return levels[0..n) (borrowed until consumed) */
+void      qvo_hnsw_force_levels(qvo_hnsw*, const int8_t* levels, uint32_t n);
 /* the level law alone, for property tests: p(level>=l+1 | level>=l) = 0.25, <= min(MaxLevel,10) draws */
 int       qvo_hnsw_random_level(qvo_hnsw*);
 

@@ -42,6 +42,7 @@ struct qvo_hnsw {
     uint64_t rng;
     uint32_t* visited; uint32_t visited_cap; uint32_t epoch;
     uint64_t n_eval;
+    const int8_t* forced_levels; uint32_t forced_n, forced_i;         /* test scaffolding: qvo_hnsw_force_levels */
 };
 
 /* ---- heaps, hnsw.go:101-196 ------------------------------------------------------ */
@@ -122,17 +123,24 @@ int qvo_hnsw_node_level(const qvo_hnsw* h, uint32_t n) { return node_ok(h, n) ? 
 int qvo_hnsw_links(const qvo_hnsw* h, uint32_t n, int level, uint32_t* out, uint32_t cap) {
     if (!node_ok(h, n) || level < 0 || level > h->nodes[n].level) return -1;
     uint32_t c = h->nodes[n].conn_len[level]; if (c > cap) c = cap;
-    memcpy(out, h->nodes[n].conn[level], c * sizeof(uint32_t)); return (int)c;
+    if (c) memcpy(out, h->nodes[n].conn[level], c * sizeof(uint32_t));   /* (a list that was never appended to has no array: memcpy from NULL is undefined even for 0 bytes) */
+    return (int)c;
 }
 
 /* randomLevel, hnsw.go:716-738 */
 int qvo_hnsw_random_level(qvo_hnsw* h) {
+    if (h->forced_i < h->forced_n) return h->forced_levels[h->forced_i++];   /* (scaffolding: the caller drew the levels) */
     int level = 0;
     int maxAttempts = h->maxLevel < 10 ? h->maxLevel : 10;
     for (int i = 0; i < maxAttempts; i++) { if (rng_float64(h) < 0.25) level++; else break; }
     if (level >= h->maxLevel) level = h->maxLevel - 1;
     return level;
 }
+
+/* Test scaffolding, not a reference function: the next n level draws return levels[0..n) instead of consuming the RNG — for a
+ * caller that keeps the RNG on its own side (qv_graph_insert takes the levels of its nodes as an argument, include/qv.h).
+ * `levels` is BORROWED until consumed. */
+void qvo_hnsw_force_levels(qvo_hnsw* h, const int8_t* levels, uint32_t n) { h->forced_levels = levels; h->forced_n = n; h->forced_i = 0; }
 
 /* searchLayer, hnsw.go:471-580.  Returns count in *out (ascending), -1 on invalid entry. */
 static int search_layer(qvo_hnsw* h, const float* q, uint32_t entry, int ef, int level, res_t** out_p, int* out_cap) {
@@ -251,7 +259,7 @@ int64_t qvo_hnsw_insert(qvo_hnsw* h, const float* vec) {
     uint32_t idx = h->n_nodes;
     node_t* nd = &h->nodes[idx];
     nd->vec = (float*)malloc(h->dim * sizeof(float)); memcpy(nd->vec, vec, h->dim * sizeof(float));  /* :281-282 copy */
-    nd->level = level; nd->alive = 1;
+    nd->level = level; nd->alive = 1; nd->borrowed = 0;               /* (the node array grows by realloc: every field is set here) */
     nd->conn = (uint32_t**)calloc((size_t)level + 1, sizeof(uint32_t*));
     nd->conn_len = (uint32_t*)calloc((size_t)level + 1, sizeof(uint32_t));
     nd->conn_cap = (uint32_t*)calloc((size_t)level + 1, sizeof(uint32_t));
@@ -438,7 +446,7 @@ int qvo_hnsw_delete(qvo_hnsw* h, uint32_t idx) {
     for (int level = 0; level <= nd->level; level++) {                /* :762 */
         uint32_t n = nd->conn_len[level];
         uint32_t* snap = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));   /* Go ranges over the slice as it was */
-        memcpy(snap, nd->conn[level], n * sizeof(uint32_t));
+        if (n) memcpy(snap, nd->conn[level], n * sizeof(uint32_t));
         for (uint32_t j = 0; j < n; j++) {
             uint32_t ci = snap[j];
             if (!node_ok(h, ci)) continue;                            /* :770-772 */

@@ -599,7 +599,9 @@ Error HNSW::Search(const float* q, uint32_t len, int k, std::vector<HNSWResult>*
     bool device_current;
     {
         std::shared_lock<std::shared_mutex> l(mu_);                    // :603-604
-        device_current = dg_ != nullptr && !dg_dirty_.load() && !nodes_.empty() && size_ > 0 && k > 0 && k <= 512 && efS_ <= 512 && M_ <= 64 && maxM0_ <= 64 &&
+        bool uploaded;
+        { std::lock_guard<std::mutex> lk(dg_mu_); uploaded = dg_ != nullptr && !dg_dirty_.load(); }   // dg_ is written under dg_mu_ by whichever SEARCH uploads the copy
+        device_current = uploaded && !nodes_.empty() && size_ > 0 && k > 0 && k <= 512 && efS_ <= 512 && M_ <= 64 && maxM0_ <= 64 &&
                          (int)len == dim_;
         if (!device_current) return searchLocked(q, len, k, out);
     }

@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(ROOT, "oracle", "libqvoracle.so")
+# QV_ORACLE_LIB: another build of the same sources (tests/c/Makefile's oracle_asan: the sanitizer build, checker of the checker)
+_SO = os.environ.get("QV_ORACLE_LIB") or os.path.join(ROOT, "oracle", "libqvoracle.so")
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
