@@ -198,6 +198,9 @@ constexpr uint32_t kHnswTieFlag = 0xFFFFFFFEu;
 #ifndef QV_HNSW_LAT_WAVES
 #define QV_HNSW_LAT_WAVES 8
 #endif
+#ifndef QV_HNSW_SPEC1
+#define QV_HNSW_SPEC1 0                   // 1: the wave-per-query form also requests the likely next adjacency list a hop ahead (measurement)
+#endif
 constexpr int kHnswSlab = QV_HNSW_SLAB;   // chunks per slab (128 B of each row): 2 x 4 KiB of slab buffers per wave -> 16 waves per CU
                                           // (measured 5k x 768, efSearch 128: slab 8 -> 554k QPS, 16 -> 430k, 32 -> 209k: occupancy wins)
 constexpr int kHnswRound = 32;            // rows per round (MaxM0 = 32 by default: one round per hop)
@@ -941,6 +944,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     auto tick = [&](int ph) { uint64_t t = __builtin_readcyclecounter(); T[ph] += t - t_last; t_last = t; };
 #endif
 
+    constexpr bool kSpec = W > 1 || QV_HNSW_SPEC1 != 0;
     QConst qc;
     uint64_t key[S];          // ascending over index e = s*64 + lane; kDeadKey = empty
     uint64_t expd[S];         // wave-uniform: bit l of expd[s] = entry (s,l) already expanded
@@ -1099,7 +1103,14 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         return true;
     };
 
-    for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+    // the slot's next query: the call's counter (HnswOpts::next) when there is one, else a fixed stride
+    auto next_query = [&](uint32_t qi) -> uint32_t {
+        if (!o.next) return qi + gridDim.x;
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(o.next, 1u);
+        return gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    for (uint32_t qi = blockIdx.x; qi < nq; qi = next_query(qi)) {
         q_g = qblk + (size_t)qi * v.dim4 * 4;
         qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
         n_eval = 0; tie = false;
@@ -1160,7 +1171,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                         // level 0 of a graph without tombstones (every graph built on the device): the degree and the fixed-width list
                         // are requested together — one round trip instead of two dependent ones per hop
                         uint32_t cl;
-                        if (W > 1 && cur == spec) { deg = spec_deg; cl = spec_cl; }
+                        if (kSpec && cur == spec) { deg = spec_deg; cl = spec_cl; }
                         else { deg = g.l0_deg[cur]; cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu; }
                         if (lane < deg) { c = cl; fresh = c < g.n_nodes; }
 #ifdef QV_HNSW_PROF
@@ -1191,7 +1202,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     HTICK(1);
                     if (nb == 0) continue;
                 }
-                if constexpr (W > 1) {
+                if constexpr (kSpec) {
                     // The next pop is the first unexpanded entry — the one the list shows NOW unless this hop admits something
                     // closer.  Its adjacency list is requested before the hop's rows are evaluated and has arrived long before
                     // the pop: a hop's two dependent round trips (list, then rows) become one on most hops.
@@ -1333,7 +1344,9 @@ k_graph_link_dists(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
 // the wave kernel keeps no query in LDS: queries are pre-converted to the metric's Q type (zero-padded to dim4*4)
 // in global memory and read at wave-uniform addresses, i.e. by scalar loads into SGPR operands of v_fma_f64
 template <int M>
-__global__ void k_hnsw_prep_queries(const float* __restrict__ queries, uint32_t dim, uint32_t dim4, typename MT<M>::Q* __restrict__ qblk, double* __restrict__ qconst) {
+__global__ void k_hnsw_prep_queries(const float* __restrict__ queries, uint32_t dim, uint32_t dim4, typename MT<M>::Q* __restrict__ qblk, double* __restrict__ qconst,
+                                    uint32_t* __restrict__ next = nullptr) {
+    if (next && blockIdx.x == 0 && threadIdx.x == 0) *next = 0;     // the traversal's query counter (HnswOpts::next)
     using Q = typename MT<M>::Q;
     const float* q = queries + (size_t)blockIdx.x * dim;
     Q* out = qblk + (size_t)blockIdx.x * dim4 * 4;
@@ -1348,7 +1361,7 @@ __global__ void k_hnsw_prep_queries(const float* __restrict__ queries, uint32_t 
         qconst[(size_t)blockIdx.x * 2] = c.qn; qconst[(size_t)blockIdx.x * 2 + 1] = (double)c.qn32;
     }
 }
-size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4) { return (size_t)nq * dim4 * 4 * sizeof(double) + (size_t)nq * 2 * sizeof(double); }
+size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4) { return (size_t)nq * dim4 * 4 * sizeof(double) + (size_t)nq * 2 * sizeof(double) + 64; }   // + the query counter
 // candidate min-heap slots of the exact-heap kernel: admissions of one searchLayer grow like ef * (1 + ln(visited / ef))
 static uint32_t hnsw_cand_cap(uint32_t ef) { return ef > 256 ? 2 * (uint32_t)kHnswCandCap : (uint32_t)kHnswCandCap; }
 size_t hnsw_lds_bytes(uint32_t ef) {
@@ -1428,14 +1441,20 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     const size_t lds = hnsw_wave_lds_bytes(v.metric, v.dim4);
     hipError_t e = hipSuccess;
     double* d_qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qblk) + (size_t)nq * v.dim4 * 4 * sizeof(double));
+    // Queries are handed out through a counter: a batch of 8192 is two traversals per wave slot, their lengths differ (evaluations per
+    // query: 5th / 95th percentile 0.8 / 1.25 of the median at efSearch 128), and with a fixed stride of queries per slot the call lasts
+    // as long as its unluckiest pair while the other slots idle (QV_HNSW_DYN=0: fixed stride, as before round 6)
+    static const int dyn_env = env_int("QV_HNSW_DYN", 1);
+    uint32_t* d_next = dyn_env == 1 ? reinterpret_cast<uint32_t*>(d_qconst + (size_t)nq * 2) : nullptr;
+    HnswOpts on = o; on.next = d_next;
     QV_DISPATCH_METRIC(v.metric, {
-        hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst);
+        hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst, d_next);
     });
 #define QV_HWD(SS, DD) QV_DISPATCH_METRIC(v.metric, {                                                                \
         e = set_lds(k_hnsw_search_wave<MM, 4, SS, DD>, lds);                                                          \
         if (e != hipSuccess) return e;                                                                                \
         hipLaunchKernelGGL((k_hnsw_search_wave<MM, 4, SS, DD>), dim3(grid), dim3(64), lds, s, v, g, static_cast<const typename MT<MM>::Q*>(d_qblk), \
-                           static_cast<const double*>(d_qconst), nq, k, ef, o,                                       \
+                           static_cast<const double*>(d_qconst), nq, k, ef, on,                                      \
                            d_rows_out, d_dist_out, d_count_out, d_evals_out);                                         \
     })
     // the query through LDS for row-major indexes whose dimension is a multiple of 32 (QV_HNSW_QLDS=2: never)
@@ -1446,7 +1465,7 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     static const int lat_env = env_int("QV_HNSW_LAT", 1);                    // (QV_HNSW_LAT=2: never)
     static const int lat_cus = [] { int d = 0, c = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c; }();
     const uint32_t qsize = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
-    HnswOpts ol = o;
+    HnswOpts ol = on;
     size_t lat_fixed = 0;
     // two tiers: up to one query per CU — 32 rows of a hop at once, the visited table in LDS, a CU per query; up to three per CU
     // (QV_HNSW_LAT_TIER2, default 768 queries) — 16 rows at once and the visited table in global memory, so that two workgroups share a CU:

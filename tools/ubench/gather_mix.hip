@@ -1,0 +1,172 @@
+// What separates the traversal kernel's row stream (4.6 TB/s gathered, efSearch 128, 1M x 768) from the bare LDS-DMA stream of
+// gather_rows.hip (6.6 TB/s)?  The bare loop of that file, plus the traversal's other memory traffic and pauses switched on ONE AT A
+// TIME and then together:
+//   Q     the query's 256 bytes of a slab by LDS-DMA beside the rows (from a 6 KiB block per wave slot)
+//   N     a row-norm load per row at the start of a hop (8 bytes from an 8 MB table)
+//   A     the hop's dependent reads before its rows: a 128-byte adjacency line (128 MB table), then one returning atomicCAS per row
+//         into the slot's 32 KiB visited table (128 MB in all)
+//   V     the arithmetic: 32 elements of convert + float64 fma per slab on the low 32 lanes, operands from the slab in LDS
+//   G     a pause per hop (s_sleep) as long as the bookkeeping takes (list inserts, pops: ~15 % of a hop)
+// and three shapes of the stream itself:
+//   P512  pieces of 8 rows x 512 contiguous bytes (a slab = 8 rows) instead of 32 rows x 128 bytes: same bytes in flight, a quarter of
+//         the DRAM pages touched per slab
+//   B3    three slab buffers, two slabs in flight per wave (12 waves per CU)
+//   W     waves per CU
+// Prints gathered TB/s per configuration.  hipcc --offload-arch=gfx950 -O3 -o bin/gather_mix gather_mix.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ void glds16(const float* g, lds_u8* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+struct Cfg { int q, n, a, v, g, p512, nbuf; };
+
+template <int NBUF>
+__global__ void __launch_bounds__(64) k_mix(const float* __restrict__ rows, const uint32_t* __restrict__ ids, uint32_t hops, uint32_t rows_per_hop, uint32_t dim,
+                                          const double* __restrict__ qblk, const double* __restrict__ rnorm, const uint32_t* __restrict__ adj, uint32_t* __restrict__ vis,
+                                          uint32_t n_rows, Cfg c, double* out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    lds_u8* slabs = (lds_u8*)smem;                                   // NBUF x 4 KiB of rows, then NBUF x 256 B of query
+    lds_u8* qbuf = slabs + NBUF * 4096;
+    const uint32_t lane = threadIdx.x, drow = lane >> 3, dslot = lane & 7;
+    const uint32_t dim4 = dim / 4, nslab = dim4 / 8, ng = (rows_per_hop + 7) / 8;
+    const double* myq = qblk + (size_t)blockIdx.x * dim;
+    uint32_t* mytab = vis + (size_t)blockIdx.x * 8192;
+    double acc = 0.0, rn = 0.0;
+    uint32_t h_dep = 0;
+    for (uint32_t h = 0; h < hops; h++) {
+        const uint32_t* my = ids + ((size_t)blockIdx.x * hops + h) * 32;
+        uint32_t myid = my[lane < rows_per_hop ? lane : 0];
+        if (c.a) {
+            // adjacency line of a "popped" node (dependent on the previous hop through h_dep), then a CAS per row
+            const uint32_t node = (myid + h_dep) % n_rows;
+            const uint32_t link = adj[(size_t)__builtin_amdgcn_readfirstlane(node) * 32 + (lane & 31)];
+            uint32_t slot = ((myid * 0x9E3779B1u) >> 19) + (link & 0);
+            uint32_t old = 0;
+            if (lane < rows_per_hop) old = atomicCAS(&mytab[slot & 8191], 0xFFFFFFFFu, myid);
+            h_dep = __builtin_amdgcn_readfirstlane(old) & 1u;           // the next hop's node depends on this one's answers
+            myid += (old == 0x12345u);
+        }
+        if (c.n && lane < rows_per_hop) rn += rnorm[myid];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (!c.p512) {
+            const float* src[4];
+            for (int g = 0; g < 4; g++) { const uint32_t r = g * 8 + drow; const uint32_t id = __shfl(myid, r < rows_per_hop ? r : 0); src[g] = rows + (size_t)id * dim + ((dslot ^ drow ^ (g & 1)) * 4); }
+            auto issue = [&](uint32_t sl) {
+                lds_u8* b = slabs + (sl % NBUF) * 4096;
+                for (uint32_t g = 0; g < ng; g++) glds16(src[g] + (size_t)sl * 32, b + g * 1024);
+                if (c.q && lane < 16) glds16(reinterpret_cast<const float*>(myq + (size_t)sl * 32) + lane * 4, qbuf + (sl % NBUF) * 256);
+            };
+            for (uint32_t s0 = 0; s0 + 1 < (uint32_t)NBUF && s0 < nslab; s0++) issue(s0);
+            for (uint32_t sl = 0; sl < nslab; sl++) {
+                // slab sl has landed when at most (NBUF - 2) younger slabs are outstanding
+                if (NBUF == 2 || sl + 1 >= nslab) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (NBUF == 3 || sl + 2 >= nslab) { if (c.q) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else { if (c.q) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+                if (sl + NBUF - 1 < nslab) issue(sl + NBUF - 1);
+                const lds_u8* b = slabs + (sl % NBUF) * 4096;
+                if (c.v) {
+                    if (lane < 32) {
+                        const uint32_t mg = lane >> 3, mr = lane & 7, msw = mr ^ (mg & 1);
+                        const lds_u8* mine = b + mg * 1024 + mr * 128;
+                        const __attribute__((address_space(3))) double* qq = (const __attribute__((address_space(3))) double*)(qbuf + (sl % NBUF) * 256);
+#pragma unroll
+                        for (int ch = 0; ch < 8; ch++) {
+                            const float4 x = *(const __attribute__((address_space(3))) float4*)(mine + ((ch ^ msw) << 4));
+                            const double q0 = c.q ? qq[ch * 4] : 1.0, q1 = c.q ? qq[ch * 4 + 1] : 1.0, q2 = c.q ? qq[ch * 4 + 2] : 1.0, q3 = c.q ? qq[ch * 4 + 3] : 1.0;
+                            acc = __builtin_fma((double)x.x, q0, acc); acc = __builtin_fma((double)x.y, q1, acc);
+                            acc = __builtin_fma((double)x.z, q2, acc); acc = __builtin_fma((double)x.w, q3, acc);
+                        }
+                    }
+                } else {
+                    acc += (double)*(const __attribute__((address_space(3))) unsigned*)(b + lane * 16);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            // slabs of 8 rows x 512 bytes: lane (r, s) fetches 16 bytes at row r, byte 16 s + 128 j of the slab's 512 (j = 0..3, one instruction each)
+            const uint32_t nsub = dim * 4 / 512;                          // 6 column slabs of 512 B
+            const uint32_t ngr = (rows_per_hop + 7) / 8;                  // row groups of 8
+            const uint32_t total = ngr * nsub;
+            auto issue = [&](uint32_t t) {
+                const uint32_t gr = t / nsub, cs = t % nsub;
+                const uint32_t r = gr * 8 + drow; const uint32_t id = __shfl(myid, r < rows_per_hop ? r : 0);
+                const float* s = rows + (size_t)id * dim + cs * 128 + dslot * 4;
+                lds_u8* b = slabs + (t % NBUF) * 4096;
+                for (int j = 0; j < 4; j++) glds16(s + j * 32, b + j * 1024);
+            };
+            for (uint32_t s0 = 0; s0 + 1 < (uint32_t)NBUF && s0 < total; s0++) issue(s0);
+            for (uint32_t t = 0; t < total; t++) {
+                if (NBUF == 2 || t + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (t + NBUF - 1 < total) issue(t + NBUF - 1);
+                acc += (double)*(const __attribute__((address_space(3))) unsigned*)(slabs + (t % NBUF) * 4096 + lane * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        if (c.g) for (int i = 0; i < c.g; i++) __builtin_amdgcn_s_sleep(127);     // 127 x 64 cycles ~ 3.4 us at 2.4 GHz each
+    }
+    if (acc == 0.12345 || rn == 0.54321) out[0] = acc;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t n = 1000000, dim = 768, hops = 48;
+    float* d; hipMalloc(&d, (size_t)n * dim * 4);
+    {   // non-constant contents
+        std::vector<float> hsrc(1 << 20); for (size_t i = 0; i < hsrc.size(); i++) hsrc[i] = (float)((i * 2654435761u) & 0xFFFF) * 1e-5f;
+        for (size_t off = 0; off < (size_t)n * dim; off += hsrc.size()) hipMemcpy(d + off, hsrc.data(), std::min(hsrc.size(), (size_t)n * dim - off) * 4, hipMemcpyHostToDevice);
+    }
+    double* out; hipMalloc(&out, 64);
+    double* qblk; hipMalloc(&qblk, (size_t)4096 * dim * 8); hipMemset(qblk, 0, (size_t)4096 * dim * 8);
+    double* rnorm; hipMalloc(&rnorm, (size_t)n * 8); hipMemset(rnorm, 0, (size_t)n * 8);
+    uint32_t* adj; hipMalloc(&adj, (size_t)n * 32 * 4); hipMemset(adj, 0, (size_t)n * 32 * 4);
+    uint32_t* vis; hipMalloc(&vis, (size_t)4096 * 8192 * 4);
+    struct Run { const char* name; Cfg c; int wpc; uint32_t rph; };
+    const Run runs[] = {
+        {"bare stream, 21 rows/hop (gather_rows.hip)", {0, 0, 0, 0, 0, 0, 2}, 16, 21},
+        {"bare stream, 31 rows/hop",                   {0, 0, 0, 0, 0, 0, 2}, 16, 31},
+        {"+ Q (query slab by DMA)",                    {1, 0, 0, 0, 0, 0, 2}, 16, 31},
+        {"+ N (row norms)",                            {0, 1, 0, 0, 0, 0, 2}, 16, 31},
+        {"+ A (adjacency line + CAS per row)",         {0, 0, 1, 0, 0, 0, 2}, 16, 31},
+        {"+ V (convert + fma chain)",                  {0, 0, 0, 1, 0, 0, 2}, 16, 31},
+        {"+ Q + V",                                    {1, 0, 0, 1, 0, 0, 2}, 16, 31},
+        {"+ G (3.4 us pause per hop)",                 {0, 0, 0, 0, 1, 0, 2}, 16, 31},
+        {"+ G (10 us pause per hop)",                  {0, 0, 0, 0, 3, 0, 2}, 16, 31},
+        {"Q + N + A + V",                              {1, 1, 1, 1, 0, 0, 2}, 16, 31},
+        {"Q + N + A + V + G(3.4)",                     {1, 1, 1, 1, 1, 0, 2}, 16, 31},
+        {"Q + N + A + V + G(10)",                      {1, 1, 1, 1, 3, 0, 2}, 16, 31},
+        {"bare, 8 rows x 512 B pieces",                {0, 0, 0, 0, 0, 1, 2}, 16, 32},
+        {"bare, 8 rows x 512 B pieces, 3 buffers",     {0, 0, 0, 0, 0, 1, 3}, 12, 32},
+        {"bare, 3 buffers (2 slabs in flight), 12 w",  {0, 0, 0, 0, 0, 0, 3}, 12, 31},
+        {"Q + N + A + V, 3 buffers, 12 waves",         {1, 1, 1, 1, 0, 0, 3}, 12, 31},
+        {"Q + N + A + V + G(3.4), 3 buffers, 12 w",    {1, 1, 1, 1, 1, 0, 3}, 12, 31},
+        {"bare, 4 buffers (3 in flight), 9 waves",     {0, 0, 0, 0, 0, 0, 4}, 9, 31},
+        {"bare, 8 waves/CU",                           {0, 0, 0, 0, 0, 0, 2}, 8, 31},
+        {"bare, 12 waves/CU",                          {0, 0, 0, 0, 0, 0, 2}, 12, 31},
+    };
+    for (const Run& r : runs) {
+        const uint32_t grid = 256 * r.wpc;
+        std::vector<uint32_t> ids((size_t)grid * hops * 32);
+        uint64_t s = 88172645463325252ull;
+        for (auto& x : ids) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (uint32_t)(s % n); }
+        uint32_t* dids; hipMalloc(&dids, ids.size() * 4); hipMemcpy(dids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice);
+        hipMemset(vis, 0xFF, (size_t)4096 * 8192 * 4);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const size_t lds = (size_t)r.c.nbuf * (4096 + 256) + 64;
+        auto launch = [&] {
+            if (r.c.nbuf == 2) hipLaunchKernelGGL(k_mix<2>, dim3(grid), dim3(64), lds, 0, d, dids, hops, r.rph, dim, qblk, rnorm, adj, vis, n, r.c, out);
+            else if (r.c.nbuf == 3) hipLaunchKernelGGL(k_mix<3>, dim3(grid), dim3(64), lds, 0, d, dids, hops, r.rph, dim, qblk, rnorm, adj, vis, n, r.c, out);
+            else hipLaunchKernelGGL(k_mix<4>, dim3(grid), dim3(64), lds, 0, d, dids, hops, r.rph, dim, qblk, rnorm, adj, vis, n, r.c, out);
+        };
+        launch();
+        hipEventRecord(e0); launch(); hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double bytes = (double)grid * hops * r.rph * dim * 4;
+        printf("%-46s %2d waves/CU: %7.3f ms  %.2f TB/s gathered, %.1f us per hop and wave\n", r.name, r.wpc, ms, bytes / (ms * 1e-3) / 1e12, ms * 1e3 / hops);
+        fflush(stdout);
+        hipFree(dids);
+    }
+    return 0;
+}
