@@ -440,6 +440,24 @@ def preflight_devices(torch, need, rank=0):
     return ndev
 
 
+def preflight_one_runtime():
+    """libqv's RCCL / HIP runtime and torch's are the SAME files: every librccl / libamdhip64 mapped into this process, by real path.
+    Two copies of either (torch's bundled pair beside /opt/rocm's) is the mix that hung a collective in round 2 and ran unnoticed
+    through a green single-GPU record in round 5: fail fast, with both paths.  Returns the one pair."""
+    import re
+    libs = {}
+    with open("/proc/self/maps") as f:
+        for line in f:
+            m = re.search(r"(/\S*/(librccl|libamdhip64)\.so[^\s]*)", line)
+            if m:
+                libs.setdefault(m.group(2), set()).add(os.path.realpath(m.group(1)))
+    twice = {k: sorted(v) for k, v in libs.items() if len(v) > 1}
+    if twice:
+        raise SystemExit("[preflight] FAILED: two copies of a runtime library in one process: %s (import torch before quiver_amd, or point "
+                         "LD_LIBRARY_PATH at one installation)" % twice)
+    return {k: next(iter(v)) for k, v in libs.items()}
+
+
 def preflight_abi(a):
     """one process, qv_sharded_*: the handle over --gpus devices created (ncclCommInitAll, or peer access with --peer-copy), one
     search on a 64-row-per-shard corpus checked against one index, destroyed"""
@@ -449,6 +467,7 @@ def preflight_abi(a):
     t0 = time.perf_counter()
     ndev = preflight_devices(torch, a.gpus)
     _say("libqv bound: " + runtime_info())
+    _say("one runtime pair in the process: %s" % preflight_one_runtime())
     if ndev < a.gpus and not a.peer_copy:
         raise SystemExit("[preflight] FAILED: --abi-sharded --gpus %d needs %d devices, %d visible (--peer-copy co-locates shards for a dry run)" % (a.gpus, a.gpus, ndev))
     devices = [g % max(ndev, 1) for g in range(a.gpus)]
@@ -489,6 +508,7 @@ def preflight_ranks(torch, dist, rank, world, device_id, backend, full):
         if full:
             from quiver_amd.device_index import runtime_info
             _say("libqv bound: " + runtime_info())
+            _say("one runtime pair in the process: %s" % preflight_one_runtime())
 
 
 # ---------------------------------------------------------------------------------------------- one process, C-ABI sharding

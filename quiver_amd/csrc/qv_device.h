@@ -67,6 +67,8 @@ struct HnswOpts {
     uint32_t        vis_cap   = 0;        // per slot: hash entries (power of two) / bitmap words
     uint32_t        vis_lds   = 0;        // set by launch_hnsw_search_wave for its latency form: the hash table is in LDS
     uint32_t        lat_rows  = 32;       // set by the launchers for the latency form: rows of a hop requested at once (32 / 16 / 8 by dimension)
+    const float*    q32       = nullptr;  // set by launch_hnsw_search_wave: the caller's queries as they came ([nq][dim] float32), what the front keeps in LDS
+    uint32_t        front     = 0;        // set by launch_hnsw_search_wave for its wave-per-query form: which parts of the round-6 hop are on (qv_hnsw.hip)
     uint32_t*       next      = nullptr;  // set by launch_hnsw_search_wave: the call's query counter (zeroed by k_hnsw_prep_queries): a wave slot that
                                           // finishes its traversal takes the next unclaimed query instead of a fixed stride of them
 };

@@ -198,9 +198,6 @@ constexpr uint32_t kHnswTieFlag = 0xFFFFFFFEu;
 #ifndef QV_HNSW_LAT_WAVES
 #define QV_HNSW_LAT_WAVES 8
 #endif
-#ifndef QV_HNSW_SPEC1
-#define QV_HNSW_SPEC1 0                   // 1: the wave-per-query form also requests the likely next adjacency list a hop ahead (measurement)
-#endif
 constexpr int kHnswSlab = QV_HNSW_SLAB;   // chunks per slab (128 B of each row): 2 x 4 KiB of slab buffers per wave -> 16 waves per CU
                                           // (measured 5k x 768, efSearch 128: slab 8 -> 554k QPS, 16 -> 430k, 32 -> 209k: occupancy wins)
 constexpr int kHnswRound = 32;            // rows per round (MaxM0 = 32 by default: one round per hop)
@@ -397,6 +394,8 @@ __device__ __forceinline__ float hnsw_eval_rows(const IndexView& v, const lds_u3
 // buffers) and are read with uniform-address ds_reads one 16-byte chunk ahead of the arithmetic: the broadcast costs LDS
 // bandwidth instead of VALU issue slots, and no load with a register destination is left in the loop.
 constexpr int kHnswQBufBytes = kHnswSlab * 4 * 8;          // one slab of query values (32 x float64; float32 metrics use half)
+// LDS of one wave of the wave-per-query form: batch[64] | 2 row slabs | 2 query slabs | pos[32] + pad | (resident query)
+constexpr int kHnswWaveFixedLds = 64 * 4 + 2 * kHnswSlabBytes + 2 * kHnswQBufBytes + 32 * 4 + 64;
 static inline bool hnsw_qlds_ok(const IndexView& v) { return v.rowmaj != nullptr && (v.dim & 31u) == 0 && v.dim >= 32; }
 
 template <typename Q>
@@ -463,6 +462,112 @@ __device__ __forceinline__ float hnsw_eval_rows_qlds(const IndexView& v, const l
         if (me) out = finalize<M>(acc, qc, rn);
     }
     return out;
+}
+
+// ---- a hop whose first slab is already there ------------------------------------------------------------------------------
+// The wave-per-query traversal requests slab 0 of EVERY link of the popped node before it knows which of them are new (beside the
+// visited test, which is the other round trip it would otherwise wait for): the rows sit at their adjacency positions in slab
+// buffer 0.  Then the new ones are compacted (batch[0..n)), slabs 1.. are requested for those only, and lane r walks slab 0 of its
+// row at the row's adjacency position `pos` and the later slabs at position r.  Same arithmetic, same order, one round trip less.
+//
+// The query is RESIDENT in LDS as the caller's float32 words (3 KiB at 768 dimensions; widening a float32 to the metric's Q type is
+// exact, so k_hnsw_prep_queries' converted block and this give the same operand): a lane reads ONE word of it per slab (lane i:
+// element 32 sl + i) and each step takes its operand by v_readlane.  Round 5 streamed the converted query slab by slab (an LDS-DMA
+// per slab and wave) and read it with two uniform-address ds_read_b128 per four steps: 16 LDS instructions per slab for the query
+// against 8 for the rows, on an LDS that also takes every row byte from the DMA.  tools/ubench/gather_mix.hip, 12 waves per CU:
+// the bare row stream 6.63 TB/s; with the chain and the round-5 query path 6.13; with this 6.54.
+template <int M>
+__device__ __forceinline__ void slab_accumulate_qreg(typename MT<M>::A& acc, const lds_u8* buf, uint32_t r, uint32_t qw) {
+    typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    typedef typename MT<M>::Q Q;
+    const uint32_t mg = r >> 3, mr = r & 7, msw = mr ^ (mg & 1);
+    const lds_u8* mine = buf + mg * 1024 + mr * 128;
+    f4 x[2];
+    x[0] = *(lds_f4p)(mine + ((0u ^ msw) << 4));
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int cur = c & 1, nxt = cur ^ 1;
+        if (c + 1 < 8) x[nxt] = *(lds_f4p)(mine + (((uint32_t)(c + 1) ^ msw) << 4));
+        const Q q0 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, 4 * c)), q1 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, 4 * c + 1));
+        const Q q2 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, 4 * c + 2)), q3 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, 4 * c + 3));
+        acc1<M>(acc, q0, x[cur].x); acc1<M>(acc, q1, x[cur].y); acc1<M>(acc, q2, x[cur].z); acc1<M>(acc, q3, x[cur].w);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// The caller has waited for slab 0 (vmcnt(0)).  n <= 32.  qres: the query's float32 words in LDS.
+template <int M>
+__device__ __forceinline__ float hnsw_eval_hop_front(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l, const QConst& qc, uint32_t n, uint32_t pos, uint32_t lane,
+                                                     const lds_u32* qres) {
+    const uint32_t nslab = v.dim4 >> 3;
+    const bool me = lane < n;
+    const uint32_t myrow = me ? batch_l[lane] : 0u;
+    double rn = 0.0;
+    if constexpr (MT<M>::needs_rnorm) { if (me) rn = v.rnorm[myrow]; }          // (used at the end: lands beside slab 1)
+    DmaRole role;
+    dma_role(role, v.rowmaj, v.dim, batch_l, n, lane);
+    typename MT<M>::A acc = 0;
+    uint32_t qw = qres[lane & 31u];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (uint32_t sl = 0; sl < nslab; sl++) {
+        if (sl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // slab sl has landed
+        uint32_t qn = 0;
+        if (sl + 1 < nslab) {                                           // the next slab lands while this one is consumed
+            dma_issue_slab<kHnswSlab>(role, sl + 1, v.dim4, slabs_l + ((sl + 1) & 1) * kHnswSlabBytes);
+            qn = qres[(sl + 1) * 32u + (lane & 31u)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (me) slab_accumulate_qreg<M>(acc, slabs_l + (sl & 1) * kHnswSlabBytes, sl ? lane : pos, qw);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this slab's buffer is read before it is refilled
+        qw = qn;
+    }
+    return me ? finalize<M>(acc, qc, rn) : 0.0f;
+}
+
+// ---- visited set in buckets (wave-per-query traversal) ------------------------------------------------------------------------
+// The table of a wave slot as buckets of 16 words (64 bytes: one request).  A test reads the node's whole bucket: ONE round trip
+// says present / absent and where the first free word is.  The open-addressed form took one dependent round trip per probe, and
+// the slowest of a hop's 32 lanes decided: at the end of an efSearch-128 search (4.7 k of 8 k words used) two to three per hop.
+// A bucket fills from word 0 up; a full bucket sends its keys on to the next one, so a lookup goes on exactly while the bucket it
+// read has no free word.  The table belongs to ONE wave slot and the lanes of a hop carry distinct nodes (repeats inside an
+// adjacency list are masked before), so "absent" is final when it is read; claiming the free word is an atomicCAS only because two
+// lanes of one hop can pick the same word — the loser tests and claims again (vis_bucket_settle) — and its answer is not needed
+// before the hop's rows have been walked.
+__device__ __forceinline__ bool vis_bucket_test(uint32_t* tab, uint32_t bmask, uint32_t bshift, uint32_t node, bool active, uint32_t*& word) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    uint32_t b = (node * 0x9E3779B1u) >> bshift;
+    bool fresh = false, pend = active;
+    word = nullptr;
+    while (__ballot(pend)) {
+        if (pend) {
+            // sc1: served by L2, where the claims (atomics) are made — a plain load could hit a line this CU's L1 kept from an earlier
+            // hop, without the words claimed since.  (The wait also covers the slab-0 requests issued before the test.)
+            const uint32_t* p = tab + (size_t)b * 16;
+            u4 w0, w1, w2, w3;
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(p) : "memory");
+            const uint32_t w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+            uint32_t hit = 0, empty = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { hit |= (w[i] == node) ? 1u : 0u; empty |= (w[i] == kVisEmpty) ? (1u << i) : 0u; }
+            if (hit) pend = false;
+            else if (empty) { fresh = true; word = tab + (size_t)b * 16 + (uint32_t)__builtin_ctz(empty); pend = false; }
+            else b = (b + 1) & bmask;
+        }
+    }
+    return fresh;
+}
+// the claims of a hop (old = what atomicCAS(word, empty, node) returned): a lane that lost its word to another lane of the hop goes again
+__device__ __forceinline__ void vis_bucket_settle(uint32_t* tab, uint32_t bmask, uint32_t bshift, uint32_t node, bool fresh, uint32_t old) {
+    bool lost = fresh && old != kVisEmpty;
+    while (__ballot(lost)) {
+        uint32_t* word;
+        (void)vis_bucket_test(tab, bmask, bshift, node, lost, word);       // (absent, by construction: finds the next free word)
+        uint32_t o2 = kVisEmpty;
+        if (lost) o2 = atomicCAS(word, kVisEmpty, node);
+        lost = lost && o2 != kVisEmpty;
+    }
 }
 
 // ---- a row's sum over several lanes, certified -----------------------------------------------------------------------
@@ -915,6 +1020,13 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     const Q* q_g = qblk;                                                   // this wave's query, zero-padded to dim4*4, in the metric's Q type
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* tab = o.vis + (size_t)blockIdx.x * o.vis_cap;               // this wave slot's visited hash table
+    // wave-per-query form (W == 1), row-major index, dimension a multiple of 32 (launch_hnsw_search_wave sets o.front):
+    //   bit 0  the hop's front: slab 0 of every link requested beside the visited test, the visited set in buckets, the query resident
+    //          in LDS as float32 words (behind the slab buffers) and broadcast by v_readlane (hnsw_eval_hop_front)
+    //   bit 1  the adjacency list of the likely next pop requested a hop ahead
+    const bool front = W == 1 && QLDS && (o.front & 1u);
+    lds_u32w pos_l = (lds_u32w)(slabs_l + 2 * kHnswSlabBytes + 2 * kHnswQBufBytes);   // [32] adjacency position of the r-th new neighbour
+    const lds_u32* qres_l = (const lds_u32*)(slabs_l + kHnswWaveFixedLds - 64 * 4);   // [dim] the query's float32 words (front only)
     // W > 1, the latency form (see LatLds): wave 0 runs everything below, the other waves only take their share of each hop's rows
     LatLds L;
     L.batch = (lds_u32*)batch_l; L.ctrl = (lds_u32*)batch_l + 64; L.part = (lds_u8*)smem + 512; L.q = (lds_u8*)smem + kLatQOff;
@@ -934,6 +1046,8 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         }
     }
     // wave 0's own LDS traffic (batch[] written by some lanes, read by others): LDS operations of one wave execute in order
+    // (one wave's LDS operations execute in order: no barrier, and — unlike __syncthreads — no wait for the vector-memory queue)
+    auto wfence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     auto wsync = [&]() { if constexpr (W > 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); };
     const bool build = o.qlevel != nullptr;
     // a graph without tombstones (every graph built on the device) needs no level[] lookup to know a node is there
@@ -944,7 +1058,7 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
     auto tick = [&](int ph) { uint64_t t = __builtin_readcyclecounter(); T[ph] += t - t_last; t_last = t; };
 #endif
 
-    constexpr bool kSpec = W > 1 || QV_HNSW_SPEC1 != 0;
+    const bool kSpec = W > 1 || (W == 1 && QLDS && (o.front & 2u));   // the likely next adjacency list requested a hop ahead
     QConst qc;
     uint64_t key[S];          // ascending over index e = s*64 + lane; kDeadKey = empty
     uint64_t expd[S];         // wave-uniform: bit l of expd[s] = entry (s,l) already expanded
@@ -1114,6 +1228,14 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
         q_g = qblk + (size_t)qi * v.dim4 * 4;
         qc.qn = qconst[(size_t)qi * 2]; qc.qn32 = (float)qconst[(size_t)qi * 2 + 1];
         n_eval = 0; tie = false;
+        if (front) {                                                    // the query's float32 words into LDS, once per traversal
+            const uint32_t qbytes = v.dim * 4u;
+            const float* q32 = o.q32 + (size_t)qi * v.dim;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the previous traversal's reads of it are done)
+            for (uint32_t off = 0; off < qbytes; off += 1024)
+                if (off + lane * 16 < qbytes) glds16(q32 + (off >> 2) + lane * 4, (lds_u8*)qres_l + off);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if constexpr (W > 1) {                                          // the query into LDS (the other waves are at their barrier)
             const uint32_t qbytes = v.dim4 * 4 * (uint32_t)sizeof(Q);
             for (uint32_t off = 0; off < qbytes; off += 1024)
@@ -1133,6 +1255,10 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             const uint32_t hmask = hcap - 1, hshift = (uint32_t)__builtin_clz(hcap) + 1;   // 32 - log2(hcap)
             const uint32_t hlimit = hcap - (hcap >> 2);
             uint32_t n_vis = 1;
+            // level 0 of a graph without tombstones and at most 32 links per node: the hop's front (slab 0 beside the visited test,
+            // visited set in buckets — one scheme per searchLayer: its table starts empty)
+            const bool bucketed = front && level == 0 && !g.has_dead && g.max_m0 <= 32u;
+            const uint32_t bmask = (hcap >> 4) - 1, bshift = hshift + 4;
             if (vis_lds) vis_hash_clear_lds(tab_l, hcap, lane); else vis_hash_clear(tab, hcap, lane);   // :483-488
 #pragma unroll
             for (int s2 = 0; s2 < S; s2++) { key[s2] = kDeadKey; expd[s2] = 0; }
@@ -1142,10 +1268,16 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             uint32_t spec = 0xFFFFFFFFu, spec_deg = 0, spec_cl = 0xFFFFFFFFu;
             for (;;) {
                 uint32_t nb;
+                bool fronted = false, ffresh = false; uint32_t fc = 0xFFFFFFFFu, fold = kVisEmpty, fpos = 0; uint32_t* fword = nullptr;
                 if (first) {                                                 // :492-506: the entry point itself
                     first = false;
                     wsync();
-                    if (lane == 0) { if (vis_lds) (void)vis_hash_insert_lds(tab_l, hmask, hshift, entry); else (void)vis_hash_insert(tab, hmask, hshift, entry); batch[0] = entry; }
+                    if (lane == 0) {
+                        if (vis_lds) (void)vis_hash_insert_lds(tab_l, hmask, hshift, entry);
+                        else if (bucketed) (void)atomicCAS(tab + (size_t)((entry * 0x9E3779B1u) >> bshift) * 16, kVisEmpty, entry);   // (word 0 of its bucket: the table is empty)
+                        else (void)vis_hash_insert(tab, hmask, hshift, entry);
+                        batch[0] = entry;
+                    }
                     wsync();
                     nb = 1;
                 } else {
@@ -1165,6 +1297,43 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                         if (same) { tie = true; break; }
                     }
                     HTICK(0);
+                    if (bucketed) {
+                        if (cur >= g.n_nodes) continue;
+                        uint32_t fdeg, cl;
+                        if (kSpec && cur == spec) { fdeg = spec_deg; cl = spec_cl; }
+                        else { fdeg = g.l0_deg[cur]; cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu; }
+                        if (fdeg > 32u) fdeg = 32u;
+                        fc = lane < fdeg ? cl : 0xFFFFFFFFu;
+                        bool valid = fc < g.n_nodes;
+                        if ((repeats_in_list(fc, fdeg) >> lane) & 1ull) valid = false;   // (a repeated node counts at its first occurrence, see below)
+                        const uint64_t vm = __ballot(valid);
+                        if (!vm) continue;
+                        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)fc, (int)__builtin_ctzll(vm));
+                        wfence();                                            // the previous hop's reads of batch[] / pos[] are done
+                        if (lane < 32u) batch[32 + lane] = valid ? fc : c0;   // every adjacency position names a row that exists
+                        wfence();
+                        HTICK(2);
+                        {
+                            DmaRole r0;
+                            dma_role(r0, v.rowmaj, v.dim, batch_l + 32, fdeg, lane);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            dma_issue_slab<kHnswSlab>(r0, 0, v.dim4, slabs_l);       // slab 0 of every link, beside the visited test
+                        }
+                        ffresh = vis_bucket_test(tab, bmask, bshift, fc, valid, fword);
+                        HTICK(3);
+                        const uint64_t fm = __ballot(ffresh);
+                        nb = (uint32_t)__builtin_popcountll(fm);
+                        n_vis += nb;
+                        if (n_vis > hlimit) { tie = true; break; }
+                        if (nb == 0) continue;                               // (slab 0 has landed with the test's answer: nothing left in flight)
+                        fold = kVisEmpty;
+                        if (ffresh) fold = atomicCAS(fword, kVisEmpty, fc);  // its answer is looked at after the rows
+                        if (ffresh) { const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1)); batch[rank] = fc; pos_l[rank] = lane; }
+                        wfence();
+                        fpos = lane < nb ? pos_l[lane] : 0u;
+                        fronted = true;
+                        HTICK(1);
+                    } else {
                     uint32_t deg = 0; const uint32_t* links = nullptr;
                     uint32_t c = 0xFFFFFFFFu; bool fresh = false;
                     if (level == 0 && !g.has_dead && cur < g.n_nodes) {
@@ -1201,8 +1370,9 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     wsync();
                     HTICK(1);
                     if (nb == 0) continue;
+                    }
                 }
-                if constexpr (kSpec) {
+                if (kSpec) {
                     // The next pop is the first unexpanded entry — the one the list shows NOW unless this hop admits something
                     // closer.  Its adjacency list is requested before the hop's rows are evaluated and has arrived long before
                     // the pop: a hop's two dependent round trips (list, then rows) become one on most hops.
@@ -1218,7 +1388,13 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                         else spec = 0xFFFFFFFFu;
                     }
                 }
-                const uint64_t kx = eval_keys(nb); n_eval += nb;
+                uint64_t kx;
+                if (fronted) {
+                    const float dd = hnsw_eval_hop_front<M>(v, batch_l, slabs_l, qc, nb, fpos, lane, qres_l);
+                    kx = lane < nb ? make_key(dd, batch_l[lane]) : kDeadKey;
+                    vis_bucket_settle(tab, bmask, bshift, fc, ffresh, fold);
+                } else kx = eval_keys(nb);
+                n_eval += nb;
                 HTICK(7);
                 {   // admissions in adjacency order (:553-560).  The worst value only ever decreases, so a neighbour that is not below
                     // it now never will be: one ballot drops those up front (most of a hop once the list is full)
@@ -1423,11 +1599,24 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
 }
 
 // wave-resident form: the list in registers, the LDS for the row slabs; tie-flagged queries report kHnswTieFlag
-size_t hnsw_wave_lds_bytes(int /*metric*/, uint32_t /*dim4*/) { return 64 * sizeof(uint32_t) + 2 * (size_t)kHnswSlabBytes + 2 * (size_t)kHnswQBufBytes + 64; }
+// What the wave-per-query form does beyond round 5's (bits of HnswOpts::front; QV_HNSW_FRONT, default 3: all of it; 0: as before):
+//   1  the hop's front — slab 0 of every link requested beside the visited test, the visited set in buckets of 16 words, the query
+//      resident in LDS and broadcast by v_readlane
+//   2  the adjacency list of the likely next pop requested a hop ahead
+// Measured on the 1M x 768 graph, efSearch 128 (profiles/r06_hnsw_front.txt); the pieces were sized with tools/ubench/gather_mix.hip.
+static uint32_t hnsw_front_bits() { static const int b = env_int("QV_HNSW_FRONT", 3); return (uint32_t)b & 3u; }
+size_t hnsw_wave_lds_bytes(int /*metric*/, uint32_t dim4) {
+    const bool qres = (hnsw_front_bits() & 1u) && (dim4 & 7u) == 0 && dim4 >= 8;      // (a row-major index is the launcher's other condition; without one the room stays unused)
+    return (size_t)kHnswWaveFixedLds + (qres ? (size_t)dim4 * 16 : 0);
+}
 uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4) {
     const size_t lds = hnsw_wave_lds_bytes(metric, dim4);
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (size_t)(160 * 1024) / lds));
-    static const int cap = env_int("QV_HNSW_WAVES_PER_CU", 16);
+    // Resident traversals per CU.  The gather saturates the memory system well below 16: measured 8 / 10 / 12 / 14 / 16 per CU on the
+    // 1M x 768 graph, efSearch 128, 32768 queries per call: 354 k / 370 k / 339 k / 341 k / 331 k queries/s (round 5's form; the bare
+    // row stream of tools/ubench/gather_mix.hip: 6.6 TB/s at 8 and 12 per CU, 5.8 at 16) — and every one fewer is 4 KiB of rows less in
+    // flight competing for the same DRAM pages.  (With the query resident a wave takes 12 KiB of LDS at 768 dimensions: 13 fit.)
+    static const int cap = env_int("QV_HNSW_WAVES_PER_CU", 12);
     per_cu = std::min<uint32_t>(per_cu, (uint32_t)cap);
     return (uint32_t)cus * per_cu;
 }
@@ -1447,6 +1636,8 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     static const int dyn_env = env_int("QV_HNSW_DYN", 1);
     uint32_t* d_next = dyn_env == 1 ? reinterpret_cast<uint32_t*>(d_qconst + (size_t)nq * 2) : nullptr;
     HnswOpts on = o; on.next = d_next;
+    on.front = hnsw_qlds_ok(v) ? hnsw_front_bits() : 0u;
+    on.q32 = d_queries;
     QV_DISPATCH_METRIC(v.metric, {
         hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<typename MT<MM>::Q*>(d_qblk), d_qconst, d_next);
     });
@@ -1465,7 +1656,7 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     static const int lat_env = env_int("QV_HNSW_LAT", 1);                    // (QV_HNSW_LAT=2: never)
     static const int lat_cus = [] { int d = 0, c = 0; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d); return c; }();
     const uint32_t qsize = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
-    HnswOpts ol = on;
+    HnswOpts ol = on; ol.front = 0;
     size_t lat_fixed = 0;
     // two tiers: up to one query per CU — 32 rows of a hop at once, the visited table in LDS, a CU per query; up to three per CU
     // (QV_HNSW_LAT_TIER2, default 768 queries) — 16 rows at once and the visited table in global memory, so that two workgroups share a CU:

@@ -208,3 +208,62 @@ def test_split_chains_both_kernel_forms_identical_to_oracle(metric, dim, n, m, e
         assert d[i, :c[i]].tobytes() == do[:c[i]].tobytes(), i
         if c[i] == k:
             assert int(ev[i]) == eo - 1, i
+
+
+@pytest.mark.parametrize("metric,dim,m,ef,max_level,style", [
+    ("cosine", 768, 16, 128, 1, 0),
+    ("cosine", 64, 16, 64, 3, 2),            # multi-level: nodes repeated inside a level-0 list (the self-link quirk) count at their first occurrence
+    ("l2", 96, 16, 200, 1, 0),
+    ("l2sq", 128, 8, 40, 3, 1),              # exact ties everywhere: flagged queries go through the exact-heap kernel
+    ("dot", 160, 16, 128, 1, 0),
+    ("l1", 32, 16, 64, 3, 0),
+    ("cosine_f32", 256, 16, 128, 1, 2),
+    ("l2_f32", 64, 4, 16, 1, 0),
+    ("dot_f32", 384, 16, 300, 1, 0),         # 5 list registers per lane
+    ("l2sq_f64", 224, 16, 512, 1, 0),        # 9 list registers per lane
+    ("cosine", 1536, 16, 128, 1, 0),
+    ("cosine", 100, 16, 64, 1, 0),           # not a multiple of 32: the wave form WITHOUT the round-6 front (query streamed, open-addressed visited set)
+    ("l2", 64, 32, 64, 1, 0),                # MaxM0 = 64 > 32 links: likewise
+])
+def test_wave_per_query_form_with_the_round6_front_identical_to_oracle(metric, dim, m, ef, max_level, style):
+    """A call of more than 768 queries takes the wave-per-query form of the traversal (k_hnsw_search_wave<.., W = 1>), whose hop —
+    on a row-major index with a dimension that is a multiple of 32 and at most 32 links per node — requests slab 0 of every link
+    beside the visited test, keeps the visited set in buckets, the query resident in LDS as float32 words broadcast by v_readlane,
+    and the next adjacency list a hop ahead (qv_hnsw.hip, HnswOpts::front).  Rows, float32 bits, counts and evaluation counts must
+    equal the oracle's HNSW.Search (pkg/hnsw/hnsw.go:602-713) on the exported graph, and the latency form's (batches of 64)."""
+    from quiver_amd.device_index import DeviceGraph, random_levels
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("%s/%d/%d" % (metric, dim, m)).encode()))
+    n, k, nq = 2500, 10, 900
+    if style == 1:
+        rows = rng.choice(np.array([-2.0, -1.0, -0.5, 0.0, 0.5, 1.0, 3.0], np.float32), size=(n, dim)).astype(np.float32)
+    elif style == 2:
+        c = rng.standard_normal((60, dim)).astype(np.float32)
+        rows = (c[rng.integers(0, 60, n)] + (rng.standard_normal((n, dim)) * 1e-3).astype(np.float32)).astype(np.float32)
+        rows[rng.integers(0, n, n // 10)] = rows[rng.integers(0, n, n // 10)]
+    else:
+        rows = O.gen_rows(6161, 0, n, dim)
+    rows = np.ascontiguousarray(rows)
+    idx = quiver_amd.DeviceIndex(dim, metric, rowmajor=True)
+    idx.add(rows)
+    levels = random_levels(n, max_level, 5)
+    g = DeviceGraph.build(idx, levels, m=m, max_m0=2 * m, ef_construction=60)
+    info = g.info()
+    lv, l0_deg, l0_links, up_off, up_links = g.export()
+    o = O.HNSW(quiver_amd.metric_id(metric), dim, M=m, maxM0=2 * m, efConstruction=60, efSearch=ef, maxLevel=max_level, seed=5)
+    o.load_graph(rows, lv, 2 * m, m, l0_deg, l0_links, up_off, up_links, info["entry"], info["cur_level"])
+    qs = np.concatenate([O.gen_rows(6162, 0, nq - 300, dim) if style == 0 else rows[rng.integers(0, n, nq - 300)] + np.float32(0.01),
+                         rows[rng.integers(0, n, 300)]]).astype(np.float32)
+    r, d, c, ev = g.search(qs, k, ef, with_evals=True)                       # 900 > 768 queries: a wave per query
+    for lo in range(0, nq, 128):                                             # <= 256 queries: the latency form (for its metrics)
+        r2, d2, c2, ev2 = g.search(qs[lo:lo + 128], k, ef, with_evals=True)
+        assert np.array_equal(c2, c[lo:lo + 128]) and np.array_equal(ev2, ev[lo:lo + 128]), lo
+        for i in range(c2.shape[0]):
+            assert r2[i, :c2[i]].tolist() == r[lo + i, :c2[i]].tolist() and d2[i, :c2[i]].tobytes() == d[lo + i, :c2[i]].tobytes(), (lo, i)
+    for i in range(0, nq, 11):
+        ro, do, eo = o.search(qs[i], k, with_evals=True)
+        assert c[i] <= k
+        assert r[i, :c[i]].tolist() == ro[:c[i]].tolist(), i
+        assert d[i, :c[i]].tobytes() == do[:c[i]].tobytes(), i
+        if c[i] == k:
+            assert int(ev[i]) == eo - 1, i

@@ -41,12 +41,14 @@ sp = torch.cuda.current_stream().cuda_stream
 for nq in nqs:
     g.search_device(dq.data_ptr(), nq, k, ef, dr.data_ptr(), dd.data_ptr(), dc.data_ptr(), de.data_ptr(), sp)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()          # (stream 0 = the graph's own stream: torch events on the current stream would not see it)
+    each = []                         # (stream 0 = the graph's own stream: torch events on the current stream would not see it)
     for _ in range(reps):
+        t0 = time.perf_counter()
         g.search_device(dq.data_ptr(), nq, k, ef, dr.data_ptr(), dd.data_ptr(), dc.data_ptr(), de.data_ptr(), sp)
-    torch.cuda.synchronize()
-    t = (time.perf_counter() - t0) / reps
+        torch.cuda.synchronize()
+        each.append(time.perf_counter() - t0)
+    t = sum(each) / reps
     ev = de[:nq].cpu().numpy().astype(np.int64); cnt = dc[:nq].cpu().numpy().view(np.uint32)
-    print(json.dumps({"ef": ef, "nq": nq, "ms": round(t * 1e3, 3), "qps": round(nq / t), "evals_per_query": round(float(ev.mean()), 1),
+    print(json.dumps({"ef": ef, "nq": nq, "ms": round(t * 1e3, 3), "each_ms": [round(x * 1e3, 2) for x in each], "qps": round(nq / t), "evals_per_query": round(float(ev.mean()), 1),
                       "evals_p5_p50_p95_max": [int(np.percentile(ev, p)) for p in (5, 50, 95, 100)],
                       "gathered_GBps": round(float(ev.sum()) * D * 4 / t / 1e9, 1), "flagged": int((cnt == 0xFFFFFFFE).sum())}), flush=True)

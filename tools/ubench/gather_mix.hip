@@ -22,7 +22,8 @@ typedef __attribute__((address_space(3))) unsigned char lds_u8;
 __device__ __forceinline__ void glds16(const float* g, lds_u8* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
-struct Cfg { int q, n, a, v, g, p512, nbuf; };
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct Cfg { int q, n, a, v, g, p512, nbuf, s, v64, nowait; };
 
 template <int NBUF>
 __global__ void __launch_bounds__(64) k_mix(const float* __restrict__ rows, const uint32_t* __restrict__ ids, uint32_t hops, uint32_t rows_per_hop, uint32_t dim,
@@ -37,6 +38,7 @@ __global__ void __launch_bounds__(64) k_mix(const float* __restrict__ rows, cons
     uint32_t* mytab = vis + (size_t)blockIdx.x * 8192;
     double acc = 0.0, rn = 0.0;
     uint32_t h_dep = 0;
+    const uint64_t c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (uint32_t h = 0; h < hops; h++) {
         const uint32_t* my = ids + ((size_t)blockIdx.x * hops + h) * 32;
         uint32_t myid = my[lane < rows_per_hop ? lane : 0];
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(64) k_mix(const float* __restrict__ rows, cons
             myid += (old == 0x12345u);
         }
         if (c.n && lane < rows_per_hop) rn += rnorm[myid];
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (c.nowait) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (!c.p512) {
             const float* src[4];
             for (int g = 0; g < 4; g++) { const uint32_t r = g * 8 + drow; const uint32_t id = __shfl(myid, r < rows_per_hop ? r : 0); src[g] = rows + (size_t)id * dim + ((dslot ^ drow ^ (g & 1)) * 4); }
@@ -69,21 +71,85 @@ __global__ void __launch_bounds__(64) k_mix(const float* __restrict__ rows, cons
                 if (sl + NBUF - 1 < nslab) issue(sl + NBUF - 1);
                 const lds_u8* b = slabs + (sl % NBUF) * 4096;
                 if (c.v) {
-                    if (lane < 32) {
-                        const uint32_t mg = lane >> 3, mr = lane & 7, msw = mr ^ (mg & 1);
+                    if (lane < 32 || c.v64) {
+                        const uint32_t mg = (lane & 31) >> 3, mr = lane & 7, msw = mr ^ (mg & 1);
                         const lds_u8* mine = b + mg * 1024 + mr * 128;
                         const __attribute__((address_space(3))) double* qq = (const __attribute__((address_space(3))) double*)(qbuf + (sl % NBUF) * 256);
+                        if (c.v == 1) {                                   // the kernel's chain: operands from LDS, convert + float64 fma
 #pragma unroll
-                        for (int ch = 0; ch < 8; ch++) {
-                            const float4 x = *(const __attribute__((address_space(3))) float4*)(mine + ((ch ^ msw) << 4));
-                            const double q0 = c.q ? qq[ch * 4] : 1.0, q1 = c.q ? qq[ch * 4 + 1] : 1.0, q2 = c.q ? qq[ch * 4 + 2] : 1.0, q3 = c.q ? qq[ch * 4 + 3] : 1.0;
-                            acc = __builtin_fma((double)x.x, q0, acc); acc = __builtin_fma((double)x.y, q1, acc);
-                            acc = __builtin_fma((double)x.z, q2, acc); acc = __builtin_fma((double)x.w, q3, acc);
+                            for (int ch = 0; ch < 8; ch++) {
+                                const f4 x = *(const __attribute__((address_space(3))) f4*)(mine + ((ch ^ msw) << 4));
+                                const double q0 = c.q ? qq[ch * 4] : 1.0, q1 = c.q ? qq[ch * 4 + 1] : 1.0, q2 = c.q ? qq[ch * 4 + 2] : 1.0, q3 = c.q ? qq[ch * 4 + 3] : 1.0;
+                                acc = __builtin_fma((double)x.x, q0, acc); acc = __builtin_fma((double)x.y, q1, acc);
+                                acc = __builtin_fma((double)x.z, q2, acc); acc = __builtin_fma((double)x.w, q3, acc);
+                            }
+                        } else if (c.v == 2) {                            // the LDS reads alone
+                            uint32_t t = 0;
+#pragma unroll
+                            for (int ch = 0; ch < 8; ch++) {
+                                const f4 x = *(const __attribute__((address_space(3))) f4*)(mine + ((ch ^ msw) << 4));
+                                t ^= __float_as_uint(x.x) ^ __float_as_uint(x.y) ^ __float_as_uint(x.z) ^ __float_as_uint(x.w);
+                            }
+                            acc += (double)(t & 1u);
+                        } else if (c.v == 3) {                            // the float64 chain alone (operands in registers)
+                            float xx = (float)acc + 1.0f;
+#pragma unroll
+                            for (int e = 0; e < 32; e++) { asm volatile("" : "+v"(xx)); acc = __builtin_fma((double)xx, 1.0000001, acc); }
+                        } else if (c.v == 8) {                            // the query's 32 values of the slab: ONE ds_read_b64 per lane, broadcast by v_readlane
+                            const double qv = qq[lane & 31];
+                            const uint32_t qlo = (uint32_t)__double2loint(qv), qhi = (uint32_t)__double2hiint(qv);
+#pragma unroll
+                            for (int ch = 0; ch < 8; ch++) {
+                                const f4 x = *(const __attribute__((address_space(3))) f4*)(mine + ((ch ^ msw) << 4));
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const double q = __hiloint2double((int)__builtin_amdgcn_readlane((int)qhi, ch * 4 + e), (int)__builtin_amdgcn_readlane((int)qlo, ch * 4 + e));
+                                    acc = __builtin_fma((double)(e == 0 ? x.x : e == 1 ? x.y : e == 2 ? x.z : x.w), q, acc);
+                                }
+                            }
+                        } else if (c.v == 5) {                            // two phases: the slab's 8 chunks into registers, then the float64 chain on registers
+                            f4 x[8];
+#pragma unroll
+                            for (int ch = 0; ch < 8; ch++) x[ch] = *(const __attribute__((address_space(3))) f4*)(mine + ((ch ^ msw) << 4));
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int ch = 0; ch < 8; ch++) {
+                                acc = __builtin_fma((double)x[ch].x, 1.0000001, acc); acc = __builtin_fma((double)x[ch].y, 1.0000001, acc);
+                                acc = __builtin_fma((double)x[ch].z, 1.0000001, acc); acc = __builtin_fma((double)x[ch].w, 1.0000001, acc);
+                            }
+                        } else if (c.v == 6) {                            // chunk by chunk: read one, wait for it, its four steps (the reads spread over the whole chain)
+#pragma unroll
+                            for (int ch = 0; ch < 8; ch++) {
+                                const f4 x = *(const __attribute__((address_space(3))) f4*)(mine + ((ch ^ msw) << 4));
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                acc = __builtin_fma((double)x.x, 1.0000001, acc); acc = __builtin_fma((double)x.y, 1.0000001, acc);
+                                acc = __builtin_fma((double)x.z, 1.0000001, acc); acc = __builtin_fma((double)x.w, 1.0000001, acc);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        } else if (c.v == 7) {                            // float32 chain four times as long (as long as the float64 one), operands from LDS
+                            float a32 = (float)acc;
+#pragma unroll
+                            for (int ch = 0; ch < 8; ch++) {
+                                const f4 x = *(const __attribute__((address_space(3))) f4*)(mine + ((ch ^ msw) << 4));
+#pragma unroll
+                                for (int r = 0; r < 4; r++) { a32 = __builtin_fmaf(x.x, 1.0001f, a32); a32 = __builtin_fmaf(x.y, 1.0001f, a32); a32 = __builtin_fmaf(x.z, 1.0001f, a32); a32 = __builtin_fmaf(x.w, 1.0001f, a32); }
+                            }
+                            acc = (double)a32;
+                        } else {                                          // a float32 chain of the same length, operands from LDS
+                            float a32 = (float)acc;
+#pragma unroll
+                            for (int ch = 0; ch < 8; ch++) {
+                                const f4 x = *(const __attribute__((address_space(3))) f4*)(mine + ((ch ^ msw) << 4));
+                                a32 = __builtin_fmaf(x.x, 1.0001f, a32); a32 = __builtin_fmaf(x.y, 1.0001f, a32); a32 = __builtin_fmaf(x.z, 1.0001f, a32); a32 = __builtin_fmaf(x.w, 1.0001f, a32);
+                            }
+                            acc = (double)a32;
                         }
                     }
                 } else {
                     acc += (double)*(const __attribute__((address_space(3))) unsigned*)(b + lane * 16);
                 }
+                if (c.s) __builtin_amdgcn_s_sleep(12);                     // 12 x 64 cycles ~ 0.33 us: as long as the chain, without the arithmetic
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else {
@@ -108,11 +174,12 @@ __global__ void __launch_bounds__(64) k_mix(const float* __restrict__ rows, cons
         }
         if (c.g) for (int i = 0; i < c.g; i++) __builtin_amdgcn_s_sleep(127);     // 127 x 64 cycles ~ 3.4 us at 2.4 GHz each
     }
+    if (blockIdx.x == 5 && lane == 0) { out[1] = (double)(__builtin_readcyclecounter() - c0); out[2] = (double)(wall_clock64() - w0); }
     if (acc == 0.12345 || rn == 0.54321) out[0] = acc;
 }
 
 int main(int argc, char** argv) {
-    const uint32_t n = 1000000, dim = 768, hops = 48;
+    const uint32_t n = 1000000, dim = 768, hops = 192;
     float* d; hipMalloc(&d, (size_t)n * dim * 4);
     {   // non-constant contents
         std::vector<float> hsrc(1 << 20); for (size_t i = 0; i < hsrc.size(); i++) hsrc[i] = (float)((i * 2654435761u) & 0xFFFF) * 1e-5f;
@@ -125,26 +192,18 @@ int main(int argc, char** argv) {
     uint32_t* vis; hipMalloc(&vis, (size_t)4096 * 8192 * 4);
     struct Run { const char* name; Cfg c; int wpc; uint32_t rph; };
     const Run runs[] = {
-        {"bare stream, 21 rows/hop (gather_rows.hip)", {0, 0, 0, 0, 0, 0, 2}, 16, 21},
-        {"bare stream, 31 rows/hop",                   {0, 0, 0, 0, 0, 0, 2}, 16, 31},
-        {"+ Q (query slab by DMA)",                    {1, 0, 0, 0, 0, 0, 2}, 16, 31},
-        {"+ N (row norms)",                            {0, 1, 0, 0, 0, 0, 2}, 16, 31},
-        {"+ A (adjacency line + CAS per row)",         {0, 0, 1, 0, 0, 0, 2}, 16, 31},
-        {"+ V (convert + fma chain)",                  {0, 0, 0, 1, 0, 0, 2}, 16, 31},
-        {"+ Q + V",                                    {1, 0, 0, 1, 0, 0, 2}, 16, 31},
-        {"+ G (3.4 us pause per hop)",                 {0, 0, 0, 0, 1, 0, 2}, 16, 31},
-        {"+ G (10 us pause per hop)",                  {0, 0, 0, 0, 3, 0, 2}, 16, 31},
-        {"Q + N + A + V",                              {1, 1, 1, 1, 0, 0, 2}, 16, 31},
-        {"Q + N + A + V + G(3.4)",                     {1, 1, 1, 1, 1, 0, 2}, 16, 31},
-        {"Q + N + A + V + G(10)",                      {1, 1, 1, 1, 3, 0, 2}, 16, 31},
-        {"bare, 8 rows x 512 B pieces",                {0, 0, 0, 0, 0, 1, 2}, 16, 32},
-        {"bare, 8 rows x 512 B pieces, 3 buffers",     {0, 0, 0, 0, 0, 1, 3}, 12, 32},
-        {"bare, 3 buffers (2 slabs in flight), 12 w",  {0, 0, 0, 0, 0, 0, 3}, 12, 31},
-        {"Q + N + A + V, 3 buffers, 12 waves",         {1, 1, 1, 1, 0, 0, 3}, 12, 31},
-        {"Q + N + A + V + G(3.4), 3 buffers, 12 w",    {1, 1, 1, 1, 1, 0, 3}, 12, 31},
-        {"bare, 4 buffers (3 in flight), 9 waves",     {0, 0, 0, 0, 0, 0, 4}, 9, 31},
-        {"bare, 8 waves/CU",                           {0, 0, 0, 0, 0, 0, 2}, 8, 31},
-        {"bare, 12 waves/CU",                          {0, 0, 0, 0, 0, 0, 2}, 12, 31},
+        {"bare",                                       {0, 0, 0, 0, 0, 0, 2, 0, 0, 0}, 12, 31},
+        {"+ V, query values by ds_read_b128 (Q DMA)",  {1, 0, 0, 1, 0, 0, 2, 0, 0, 0}, 12, 31},
+        {"+ V, query values by readlane (Q DMA)",      {1, 0, 0, 8, 0, 0, 2, 0, 0, 0}, 12, 31},
+        {"+ V, query by readlane, resident (no DMA)",  {0, 0, 0, 8, 0, 0, 2, 0, 0, 0}, 12, 31},
+        {"+ two phases, constant multiplier",          {0, 0, 0, 5, 0, 0, 2, 0, 0, 0}, 12, 31},
+        {"bare",                                       {0, 0, 0, 0, 0, 0, 2, 0, 0, 0}, 10, 31},
+        {"+ V, query values by ds_read_b128 (Q DMA)",  {1, 0, 0, 1, 0, 0, 2, 0, 0, 0}, 10, 31},
+        {"+ V, query by readlane, resident (no DMA)",  {0, 0, 0, 8, 0, 0, 2, 0, 0, 0}, 10, 31},
+        {"N + A + V readlane resident",                {0, 1, 1, 8, 0, 0, 2, 0, 0, 1}, 10, 31},
+        {"N + V readlane resident (A hidden)",         {0, 1, 0, 8, 0, 0, 2, 0, 0, 1}, 10, 31},
+        {"N + V readlane resident (A hidden)",         {0, 1, 0, 8, 0, 0, 2, 0, 0, 1}, 12, 31},
+        {"Q + N + A + V (round 5's hop)",              {1, 1, 1, 1, 0, 0, 2, 0, 0, 0}, 16, 31},
     };
     for (const Run& r : runs) {
         const uint32_t grid = 256 * r.wpc;
@@ -164,7 +223,9 @@ int main(int argc, char** argv) {
         hipEventRecord(e0); launch(); hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double bytes = (double)grid * hops * r.rph * dim * 4;
-        printf("%-46s %2d waves/CU: %7.3f ms  %.2f TB/s gathered, %.1f us per hop and wave\n", r.name, r.wpc, ms, bytes / (ms * 1e-3) / 1e12, ms * 1e3 / hops);
+        double hout[3]; hipMemcpy(hout, out, 24, hipMemcpyDeviceToHost);
+        printf("%-46s %2d waves/CU: %7.3f ms  %.2f TB/s gathered, %.1f us per hop and wave, shader clock %.2f GHz\n", r.name, r.wpc, ms, bytes / (ms * 1e-3) / 1e12, ms * 1e3 / hops,
+               hout[1] / (hout[2] * 10.0));
         fflush(stdout);
         hipFree(dids);
     }
