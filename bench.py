@@ -146,7 +146,8 @@ def compact_also(also, budget):
                           "ef": pick.get("ef_search"), "qps": _r(g.get("qps_device_resident"), 4),
                           # recall of the graph results alone, and of HNSW.Search as the reference defines it (with its exact top-up of under-filled queries)
                           "recall10_vs_exact": _r(g.get("recall_at_10_graph_results_only"), 4), "recall10_with_topup": _r(sc.get("recall_at_10_vs_exact"), 4),
-                          "gather_frac": _r(g.get("gathered_GBps", 0.0) / HBM_PEAK_GBS, 3)})
+                          "gather_frac": _r(g.get("gathered_GBps", 0.0) / HBM_PEAK_GBS, 3),
+                          "of_bare_row_stream": _r(g.get("gathered_frac_of_bare_row_stream"), 3)})
             cpu = (e.get("cpu_traversal_same_graph") or {}).get("by_ef") or []
             cpick = next((x for x in cpu if pick and x.get("ef_search") == pick.get("ef_search")), None)
             if cpick:
@@ -180,6 +181,8 @@ def compact_also(also, budget):
                 o.update({"bound": rf.get("bound"), "kernel_ms": _r(rf.get("kernel_ms"), 4), "frac": _r(rf.get("frac"), 3)})
                 if "end_to_end_frac" in rf:
                     o["e2e"] = _r(rf["end_to_end_frac"], 3)
+                if "frac_of_bare_mfma_loop" in rf and rf.get("bare_mfma_loop_clock_ghz"):
+                    o.update({"of_bare_loop": _r(rf["frac_of_bare_mfma_loop"], 3), "clock_ghz": _r(rf["bare_mfma_loop_clock_ghz"], 3), "at_clock": _r(rf.get("frac_at_the_held_clock"), 3)})
             c[short] = o
     shed = [k for k in c if "10M" in k] + [k for k in c if k.endswith("_dot")] + ["b_small_1Mx768_ms"] + [k for k in c if "bf16x3" in k] + list(c)
     dropped = 0

@@ -208,8 +208,11 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
 
 
 // grid: persistent waves; wave g -> query 64-block (g % nqb64), row groups (g / nqb64) + i*stride; a row group = 2 tiles = 128 rows
+#ifndef QV_MFMA_F32_WPS
+#define QV_MFMA_F32_WPS 1                  // waves per SIMD of the fp32-MFMA filter (measurement: 2 = two workgroups per CU, operands two steps deep)
+#endif
 template <int METRIC>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, QV_MFMA_F32_WPS)
 k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
               uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
     __shared__ __align__(16) float s_c[4][64], s_m[8][64];                        // this wave's 64 queries' filter constants
@@ -276,6 +279,19 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
                     for (int j = 0; j < 4; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][d], B[j][d], acc[i][j], 0, 0, 0);
         };
+#if QV_MFMA_F32_WPS == 2
+        // two waves per SIMD cover each other's waits: operands one step ahead (24 registers less: no spill at 256 per wave)
+        f4 A0[2], B0[4], A1[2], B1[4];
+        load(0, A0, B0);
+        uint32_t st = 0;
+        for (; st + 2 <= steps; st += 2) {
+            load(st + 1, A1, B1); __builtin_amdgcn_sched_barrier(0);
+            mma(A0, B0);          __builtin_amdgcn_sched_barrier(0);
+            load(st + 2, A0, B0); __builtin_amdgcn_sched_barrier(0);
+            mma(A1, B1);          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st < steps) { mma(A0, B0); st++; }
+#else
         // 3-deep software pipeline over the K steps (operands for steps s+1, s+2 in flight while s computes)
         f4 A0[2], B0[4], A1[2], B1[4], A2[2], B2[4];
         load(0, A0, B0);
@@ -291,6 +307,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         }
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
+#endif
 
         filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
     }
@@ -1945,7 +1962,7 @@ int filter_mode(const IndexView& v) {
 // the 64-key wave lists (k_sample_bound, k_rescore_select).  Above 64 there is no choice; QV_BATCHED_SELECT_FROM (read once) moves
 // the switch down for measurements.
 static bool batched_large_k(uint32_t k) {
-    static const int from = env_int("QV_BATCHED_SELECT_FROM", kMaxFusedK + 1);
+    static const int from = dev_env_int("QV_BATCHED_SELECT_FROM", kMaxFusedK + 1);
     return k > (uint32_t)kMaxFusedK || (int)k >= from;
 }
 // ---- MFMA batched path --------------------------------------------------------------
@@ -1954,7 +1971,7 @@ static bool batched_large_k(uint32_t k) {
 // (10M rows or k = 64 with the former fixed 8192 overflowed nearly every query into the exact redo: 256 x 10M x 768 took 108 ms).
 uint32_t batched_sample_rows(const IndexView& v, uint32_t k) {
     const uint32_t n_rows = v.n_rows;
-    static const int forced = env_int("QV_MFMA_SAMPLE_ROWS", 0);
+    static const int forced = dev_env_int("QV_MFMA_SAMPLE_ROWS", 0);
     if (forced > 0) return std::min<uint32_t>(n_rows, (uint32_t)forced);
     // ~1536 expected candidates (3 sigma of the k-th order statistic at k = 10 stays under the 4096 slots), in whole multiples
     // of 8192 rows = 128 tiles: with 16 query groups that is one full round of the 2048 scan waves per multiple
@@ -1979,7 +1996,7 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     const int min_q = filter_mode(v) >= 2 ? 9 : 32;
     // millions of query-rows.  Round 2's one-term filter moved the crossover down: 16 / 64 queries x 100k x 768 take 0.17 / 0.18 ms here against
     // 0.30 / 0.57 ms on the exact multi-query scan, x 400k rows 0.36 / 0.37 against 0.59 / 1.65 (8 M query-rows was the three-term crossover)
-    static const int min_work_m = env_int("QV_MFMA_MIN_MROWS", 1);
+    static const int min_work_m = dev_env_int("QV_MFMA_MIN_MROWS", 1);
     return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxBatchedK && nq >= (uint32_t)min_q &&
            v.n_rows >= (uint32_t)min_rows && (uint64_t)nq * v.n_rows >= (uint64_t)min_work_m * 1000000ull;
 }
@@ -2064,10 +2081,10 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     // a quarter of the matrix cycles); the index's choice (qv_index_set_filter), so one process can compare them
     const int fmode = filter_mode(v);
     const int bf = fmode >= 2 ? 1 : 0;                                 // bfloat16 operand layout
-    static const int sample_gemm = env_int("QV_MFMA_SAMPLE_GEMM", 1);
-    static const int share_env = env_int("QV_MFMA_SHARE_ROWS", 1);
+    static const int sample_gemm = dev_env_int("QV_MFMA_SAMPLE_GEMM", 1);
+    static const int share_env = dev_env_int("QV_MFMA_SHARE_ROWS", 1);
     const bool shared = bf && (nq_pad / 64) % 4 == 0 && share_env == 1;
-    static const int q64_env = env_int("QV_MFMA_Q64", 1);                                     // 2 = off
+    static const int q64_env = dev_env_int("QV_MFMA_Q64", 1);                                     // 2 = off
     const uint32_t fsteps0 = (v.dim4 + 3) / 4;
     const bool q64_shape = bf && fmode == 3 && nq_pad == 64 && q64_env == 1 && (v.dim4 & 3u) == 0 && fsteps0 % 4 == 0 && fsteps0 >= 8 && fsteps0 <= 64;
     const bool q64f = q64_shape && v.bf16 == nullptr;                     // the one-block kernel on float32 rows (round 4)
@@ -2075,7 +2092,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     const int gmode = !bf ? 0 : (fmode == 3 && (shared || q64) ? 2 : 1);   // which filter_gamma the main pass obeys (one term: the shared kernels and the one-block kernel)
     // one-term filter on float32 rows at a dimension the eight-wave kernel's loop does not divide: its zero-padded form (round 4);
     // the query operands are then laid out once more, padded, after the sample pass has read them in its own layout
-    static const int w8_env0 = env_int("QV_MFMA_W8", 1);
+    static const int w8_env0 = dev_env_int("QV_MFMA_W8", 1);
     const bool w8_exact = (v.dim4 & 3u) == 0 && fsteps0 % 8 == 0 && fsteps0 >= 16;
     const bool pad_main = gmode == 2 && shared && !q64 && w8_env0 == 1 && !w8_exact;
     hipError_t e = hipSuccess;
@@ -2093,8 +2110,8 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t sgroups = (vs.n_rows + 127) / 128, all_groups = v.n_tiles / 2;
         const uint32_t gstep = sgroups && all_groups > sgroups ? all_groups / sgroups : 1u;
         // one-term path: the sample on the eight-wave one-term kernel (QV_MFMA_SAMPLE1=2: on the three-term kernel, as the other filters' samples)
-        static const int sample1_env = env_int("QV_MFMA_SAMPLE1", 1);
-        static const int w8s_env = env_int("QV_MFMA_W8", 1);
+        static const int sample1_env = dev_env_int("QV_MFMA_SAMPLE1", 1);
+        static const int w8s_env = dev_env_int("QV_MFMA_W8", 1);
         const bool sample1 = sample1_env == 1 && w8s_env == 1 && gmode == 2 && shared && (v.dim4 & 3u) == 0 && fsteps0 % 8 == 0 && fsteps0 >= 16;
         const uint32_t gs1 = grid_multiple(std::min<uint32_t>((uint32_t)cus, sgroups * (nq_pad >> 8)), std::max<uint32_t>(nq_pad >> 8, 1u));
         // large k: the k-th smallest bound by two histogram windows over the bounds (no wave list holds k keys), per-query state in the selection's workspace
@@ -2103,7 +2120,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t hgrid = std::max(1u, std::min(256u, (vs.n_rows + 16 * kSelBlock - 1) / (16 * kSelBlock)));
         // the eight-wave sample kernel hands out one value per query and 128-row group when the groups outnumber k at least four times
         const uint32_t sample_groups = (vs.n_rows + 127) / 128;
-        static const int gmin_env = env_int("QV_MFMA_SAMPLE_GROUP_MIN", 1);                      // 2 = every row's bound (round 3)
+        static const int gmin_env = dev_env_int("QV_MFMA_SAMPLE_GROUP_MIN", 1);                      // 2 = every row's bound (round 3)
         // How the bound is taken from the sample's per-row upper bounds: k_sample_select (per-thread chunk minima, then the rows of the k
         // best chunks: the exact k-th smallest row bound, in LDS) while k chunks fit its LDS — k <= 128 at a million rows; beyond, the
         // histogram kernels (k_sample_hist: two radix windows over every row's bound) or, up to 64, k_sample_bound's wave lists.
@@ -2112,7 +2129,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t gmin_mode = gmin_env == 3 && sample1 ? 1u : 0u;
         const bool group_min = gmin_mode != 0 && sample_groups >= 4 * k && sample_groups <= 4096;
         const uint32_t gmin_vals = sample_groups;
-        static const int sel2_env = env_int("QV_MFMA_SAMPLE_SELECT", 1);                        // 2 = k_sample_bound (wave lists) as in round 3
+        static const int sel2_env = dev_env_int("QV_MFMA_SAMPLE_SELECT", 1);                        // 2 = k_sample_bound (wave lists) as in round 3
         const bool sel2 = sel2_env == 1 && !group_min && sample_select_applies(vs.n_rows, k);
         const size_t sel2_lds = sel2 ? sample_select_lds_bytes(vs.n_rows, k) : 0;
 #define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? 1u : 0u); \
@@ -2137,7 +2154,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     // 3. MFMA filter
     const uint32_t nqb64 = nq_pad / 64;
     // one 4-wave workgroup per CU (512-register waves); every query block gets the same number of waves
-    const uint32_t grid = grid_multiple((uint32_t)cus, nqb64 / std::gcd(nqb64, 4u));
+    const uint32_t grid = grid_multiple((uint32_t)cus * (!bf && !q64 ? QV_MFMA_F32_WPS : 1), nqb64 / std::gcd(nqb64, 4u));
     if (ev0) (void)hipEventRecord(ev0, s);
     if (q64) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
@@ -2157,9 +2174,9 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
         const uint32_t gs = grid_multiple((uint32_t)cus, nqb64 / 4);      // every row group is walked by nqb64/4 workgroups
         const uint32_t fsteps = (v.dim4 + 3) / 4;
-        static const int bfrows_env = env_int("QV_MFMA_BF16_ROWS", 1);                        // 2 = ignore the index's bfloat16 plane
+        static const int bfrows_env = dev_env_int("QV_MFMA_BF16_ROWS", 1);                        // 2 = ignore the index's bfloat16 plane
         const bool bfrows = gmode == 2 && v.bf16 != nullptr && bfrows_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;
-        static const int w8_env = env_int("QV_MFMA_W8", 1);                                   // 2 = the four-wave kernel (k_bf16x3_filter_shared<., 1>)
+        static const int w8_env = dev_env_int("QV_MFMA_W8", 1);                                   // 2 = the four-wave kernel (k_bf16x3_filter_shared<., 1>)
         const bool w8 = w8_env == 1 && (v.dim4 & 3u) == 0 && fsteps % 8 == 0 && fsteps >= 16;       // rounds of two steps, four in flight: a multiple of 4 rounds, at least 6
 #ifdef QV_VARIANTS
         // Measurement build only (make VARIANTS=1 -> libqv_dev.so; profiles/r03_batched_epilogue.txt has what each measured): the
@@ -2183,16 +2200,24 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const bool qreg = gmode == 2 && (bfrows || w8) && qreg_filter_applies(v, nq_pad, bfrows);   // query operands in registers (qv_qreg.hip)
         // shipped: the bfloat16 copy's own kernel when the index keeps one; 256 rows per round on float32 rows (k_bf16x1_filter_w8x2)
         // where the dimension allows the eight-wave shape; the four-wave shared-row kernels otherwise
+// (the one-term filter as four waves, k_bf16x3_filter_shared<., 1>: only QV_MFMA_W8=2 of the measurement build reaches it — every shape the
+// eight-wave kernel's loop does not divide takes its zero-padded form, pad_main)
+#ifdef QV_VARIANTS
+#define QV_FS_ONE_TERM_4W(MMM) else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt);
+#else
+#define QV_FS_ONE_TERM_4W(MMM)
+#endif
 #define QV_FS(MMM) { QV_FS_VARIANTS(MMM)                                                                                                                                           \
                      if (qreg) { e = launch_qreg_filter(v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, bfrows, cus, s); if (e != hipSuccess) return e; } \
                      else if (bfrows) hipLaunchKernelGGL((k_bf16rows_filter<MMM>), dim3(grid_multiple(2 * (uint32_t)cus, nqb64 / 4)), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (gmode == 2 && w8) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 4, 4>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
                      else if (pad_main) hipLaunchKernelGGL((k_bf16x1_filter_w8x2<MMM, 4, 4, true>), dim3(gs), dim3(512), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
-                     else if (gmode == 2) hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 1, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); \
+                     QV_FS_ONE_TERM_4W(MMM)                                                                                                                                           \
                      else hipLaunchKernelGGL((k_bf16x3_filter_shared<MMM, 3, 8>), dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt); }
         if (v.metric == QV_COSINE) QV_FS(QV_COSINE) else if (v.metric == QV_DOT) QV_FS(QV_DOT) else QV_FS(QV_L2)
 #undef QV_FS
 #undef QV_FS_VARIANTS
+#undef QV_FS_ONE_TERM_4W
     } else if (bf) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
         if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u, 1u);
@@ -2208,10 +2233,14 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     // a gather of dim4 separate lines and the pass is a chain of dim4 / U dependent round trips — 8 / 16 / 32 / 48 / 64 per round:
     // 64.4 / 58.0 / 54.2 / 55.3 / 55.6 us per launch at 256 x 1M x 768 (left to the compiler's own schedule, as the streaming scans
     // are for cosine, deeper rounds were slower: 90 us at 16)
-    static const int rs_u = env_int("QV_MFMA_RESCORE_U", 32);
+    static const int rs_u = dev_env_int("QV_MFMA_RESCORE_U", 32);
 #define QV_RS1(MMM, UU) { e = set_lds(k_rescore_select<MMM, UU>, lds); if (e != hipSuccess) return e;                                   \
         hipLaunchKernelGGL((k_rescore_select<MMM, UU>), dim3(nq), dim3(256), lds, s, v, d_queries, cand, cscore, cnt, k, d_rows_out, d_dist_out, ovf, eq); }
+#ifdef QV_VARIANTS
 #define QV_RS(MMM) { if (rs_u == 8) QV_RS1(MMM, 8) else QV_RS1(MMM, 32) }
+#else
+#define QV_RS(MMM) { (void)rs_u; QV_RS1(MMM, 32) }
+#endif
     if (large_k) {
         // intervals -> H (k-th smallest upper bound) -> survivors -> exact distances -> the k best; srows / sdist take the first
         // selection's output (the sample's bound in sdist has been consumed by k_mfma_prep)

@@ -309,7 +309,11 @@ class Front {
     static constexpr int64_t kLingerMaxNs = 1000000;
     bool waiting_for_lane() const { for (auto& g : pending_) if (!g->has_lane) return true; return false; }   // (under mu_)
     // how long a group may be held open for the callers the last pass released: 1 / linger_div of a pass, 1 ms at most (under mu_)
+#ifdef QV_VARIANTS
     static int env_linger_div() { static const int d = getenv("QV_COALESCE_LINGER_DIV") && atoi(getenv("QV_COALESCE_LINGER_DIV")) > 0 ? atoi(getenv("QV_COALESCE_LINGER_DIV")) : 0; return d; }   // (measurement switch, read once)
+#else
+    static int env_linger_div() { return 0; }
+#endif
     int64_t linger_ns() const { return hold_open_.load(std::memory_order_relaxed) ? std::min<int64_t>(pass_ns_ / linger_div_, kLingerMaxNs) : 0; }
 
     // Closed-loop callers come back TOGETHER, a few microseconds after the pass that served them ends — just after the next group

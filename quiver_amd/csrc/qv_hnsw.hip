@@ -1550,7 +1550,7 @@ uint32_t hnsw_grid(int cus, uint32_t ef, uint32_t nq) {
 }
 // visited hash entries per wave slot: ~64 x ef (a search with ef = 128 evaluates ~4-5 k nodes of a 1M-node graph), 3/4 usable
 uint32_t hnsw_vis_hash_cap(uint32_t ef) {
-    static const int mult = env_int("QV_HNSW_VIS_MULT", 64);
+    static const int mult = dev_env_int("QV_HNSW_VIS_MULT", 64);
     uint32_t cap = 4096;
     while (cap < (uint32_t)mult * ef && cap < 262144u) cap <<= 1;
     return cap;
@@ -1604,7 +1604,7 @@ hipError_t launch_hnsw_search(const IndexView& v, const GraphView& g, const floa
 //      resident in LDS and broadcast by v_readlane
 //   2  the adjacency list of the likely next pop requested a hop ahead
 // Measured on the 1M x 768 graph, efSearch 128 (profiles/r06_hnsw_front.txt); the pieces were sized with tools/ubench/gather_mix.hip.
-static uint32_t hnsw_front_bits() { static const int b = env_int("QV_HNSW_FRONT", 3); return (uint32_t)b & 3u; }
+static uint32_t hnsw_front_bits() { static const int b = dev_env_int("QV_HNSW_FRONT", 3); return (uint32_t)b & 3u; }
 size_t hnsw_wave_lds_bytes(int /*metric*/, uint32_t dim4) {
     const bool qres = (hnsw_front_bits() & 1u) && (dim4 & 7u) == 0 && dim4 >= 8;      // (a row-major index is the launcher's other condition; without one the room stays unused)
     return (size_t)kHnswWaveFixedLds + (qres ? (size_t)dim4 * 16 : 0);
@@ -1633,7 +1633,7 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     // Queries are handed out through a counter: a batch of 8192 is two traversals per wave slot, their lengths differ (evaluations per
     // query: 5th / 95th percentile 0.8 / 1.25 of the median at efSearch 128), and with a fixed stride of queries per slot the call lasts
     // as long as its unluckiest pair while the other slots idle (QV_HNSW_DYN=0: fixed stride, as before round 6)
-    static const int dyn_env = env_int("QV_HNSW_DYN", 1);
+    static const int dyn_env = dev_env_int("QV_HNSW_DYN", 1);
     uint32_t* d_next = dyn_env == 1 ? reinterpret_cast<uint32_t*>(d_qconst + (size_t)nq * 2) : nullptr;
     HnswOpts on = o; on.next = d_next;
     on.front = hnsw_qlds_ok(v) ? hnsw_front_bits() : 0u;
@@ -1649,7 +1649,7 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
                            d_rows_out, d_dist_out, d_count_out, d_evals_out);                                         \
     })
     // the query through LDS for row-major indexes whose dimension is a multiple of 32 (QV_HNSW_QLDS=2: never)
-    static const int qlds_env = env_int("QV_HNSW_QLDS", 1);
+    static const int qlds_env = dev_env_int("QV_HNSW_QLDS", 1);
     const bool deep = qlds_env == 1 && hnsw_qlds_ok(v);
     // The latency form (a workgroup of four waves and a CU's LDS per query) for batches that would leave most CUs idle anyway:
     // at most one query per CU, a metric whose chain can be split and certified, rows of a hop + query within the LDS.
@@ -1662,7 +1662,7 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     // (QV_HNSW_LAT_TIER2, default 768 queries) — 16 rows at once and the visited table in global memory, so that two workgroups share a CU:
     // one call of 384 / 512 / 768 / 1024 queries 6.75 / 7.13 / 7.47 / 7.89 ms a wave per query, 4.75 / 5.17 / 6.94 / 7.52 ms in this form (with the
     // exact-heap pass of their flagged queries; 8192 queries: 319 k QPS a wave per query, 264 k in this form, 183 k one workgroup per CU)
-    static const int lat_tier2 = env_int("QV_HNSW_LAT_TIER2", 768);
+    static const int lat_tier2 = dev_env_int("QV_HNSW_LAT_TIER2", 768);
     const bool tier2 = nq > (uint32_t)lat_cus;
     for (ol.lat_rows = tier2 ? 16u : 32u; ol.lat_rows >= 8; ol.lat_rows >>= 1) {   // the hop's rows at once; half / a quarter of them where the dimension asks for it
         lat_fixed = (size_t)kLatQOff + lat_q_bytes(v.dim4, qsize) + lat_rows_bytes(v.dim4, ol.lat_rows);

@@ -298,6 +298,14 @@ constexpr int kScanWaves = kScanBlock / 64;
 // ---------------------------------------------------------------- launcher helpers --
 constexpr int kUnroll = 16;
 
+// A switch of the MEASUREMENT build only (make VARIANTS=1 -> libqv_dev.so): the product library takes the default — its dispatch
+// is what the oracle-checked tests cover (tools/kernel_coverage.py), and an operator has no use for a tuning knob of one kernel.
+// The product's own switches (INTEGRATION.md "Environment") go through env_int.
+#ifdef QV_VARIANTS
+#define dev_env_int(name, dflt) env_int(name, dflt)
+#else
+#define dev_env_int(name, dflt) (dflt)
+#endif
 static inline int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     if (!e || !*e) return dflt;

@@ -299,7 +299,7 @@ static hipError_t refresh_bf16(const IndexView& v, uint32_t t0, uint32_t t1, hip
 hipError_t launch_ingest(const IndexView& v, const float* d_rows, uint32_t row0, uint32_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint32_t t0 = row0 / 64, t1 = (row0 + n - 1) / 64;
-    static const int tiled = env_int("QV_INGEST_TILED", 1);
+    static const int tiled = dev_env_int("QV_INGEST_TILED", 1);
     if ((v.dim & 3) == 0 && tiled == 1 && (reinterpret_cast<uintptr_t>(d_rows) & 15) == 0) {
         hipLaunchKernelGGL(k_ingest_tiled, dim3(t1 - t0 + 1), dim3(256), 0, s, v, d_rows, row0, n, t0);
         hipError_t e0 = hipGetLastError();

@@ -35,7 +35,7 @@ static Mq64Shape mq64_shape(uint32_t nq) {
     // queries/pass, 8 waves per CU with two blocks per wave.  Measured at 1M x 768 cosine with the bounded kernel
     // (tools/sweep_shapes.py, profiles/r02_batch_shapes.txt): a lone 16-query pass 0.98 ms, further ones 0.75 ms each; 32-query
     // passes 1.15 ms, then 0.85-0.99 ms each — so only a batch of 16 or fewer queries goes in the 16-query shape.
-    static const int forced = env_int("QV_MQ64_MODE", 0) - 1;        // env value 1..3 -> mode 0..2 (0 = choose per batch)
+    static const int forced = dev_env_int("QV_MQ64_MODE", 0) - 1;        // env value 1..3 -> mode 0..2 (0 = choose per batch)
     int mode = forced;
     if (mode < 0) mode = nq <= 16 ? 0 : 2;
     if (mode == 0) return {1, 1, 8, 4, 2};
@@ -585,7 +585,7 @@ hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_que
     uint32_t grid = std::max(1u, std::min(want, (uint32_t)cus * (uint32_t)sh.wgs));
     // the sample: one tile per wave of `sgrid` workgroups, spread evenly over the corpus (QV_MQ64_SAMPLE tiles, 0 = no sample
     // pass: every wave learns its thresholds from its own tiles, the round-1 behaviour)
-    static const int sample_env = env_int("QV_MQ64_SAMPLE", 256);
+    static const int sample_env = dev_env_int("QV_MQ64_SAMPLE", 256);
     const uint32_t stiles = std::min<uint32_t>(std::min<uint32_t>((uint32_t)std::max(sample_env, 0), v.n_tiles / 8), 4u * (uint32_t)cus);   // the partial buffer holds 8 lists per CU and query
     const uint32_t sgrid = stiles / (uint32_t)sh.w;
     const uint32_t n_s = sgrid * (uint32_t)sh.w, step_s = n_s ? v.n_tiles / n_s : 1;
@@ -619,10 +619,16 @@ hipError_t launch_flat_scan_mq64(const IndexView& v, int cus, const float* d_que
         }                                                                                                                         \
         if (ev1) (void)hipEventRecord(ev1, s);                                                                                    \
     }
+#ifdef QV_VARIANTS                                        // (the two-sets-sharing-tiles shape: QV_MQ64_MODE=2 of the measurement build only)
 #define QV_MQ64_SHAPES(MMM)                                                                  \
     if (sh.h == 1 && sh.nb == 1) QV_MQ64(MMM, 1, 1, 8, 4, 2)                                  \
     else if (sh.h == 2) QV_MQ64(MMM, 2, 1, 8, 4, 1)                                           \
     else QV_MQ64(MMM, 1, 2, 4, 8, 1)
+#else
+#define QV_MQ64_SHAPES(MMM)                                                                  \
+    if (sh.h == 1 && sh.nb == 1) QV_MQ64(MMM, 1, 1, 8, 4, 2)                                  \
+    else QV_MQ64(MMM, 1, 2, 4, 8, 1)
+#endif
     if (v.metric == QV_COSINE) { QV_MQ64_SHAPES(QV_COSINE) } else { QV_MQ64_SHAPES(QV_DOT) }
 #undef QV_MQ64_SHAPES
 #undef QV_MQ64

@@ -321,7 +321,7 @@ k_qreg_filter(IndexView v, const uint4* __restrict__ Qbf, const float* __restric
 // (read once) turns it off for measurements.
 static int qreg_steps(const IndexView& v) { return (v.dim & 15u) == 0 && v.dim4 * 4 == v.dim ? (int)(v.dim / 16) : 0; }
 bool qreg_filter_applies(const IndexView& v, uint32_t nq_pad, bool bfrows) {
-    static const int env = env_int("QV_QREG", 1);
+    static const int env = dev_env_int("QV_QREG", 1);
     if (env != 1 || nq_pad < 256 || (nq_pad & 255u)) return false;
     const int st = qreg_steps(v);
     (void)bfrows;

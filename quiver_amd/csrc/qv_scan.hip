@@ -1065,13 +1065,13 @@ ScanPlan plan_scan(uint32_t n_tiles, int cus) {
     p.block = kScanBlock;
     p.cus = (uint32_t)(cus > 0 ? cus : 1);
     uint32_t want = (n_tiles + kScanWaves - 1) / kScanWaves;          // one tile per wave at most
-    static const int wg_per_cu = env_int("QV_SCAN_WG_PER_CU", 2);     // 2 workgroups = 8 waves per CU: measured best (profiles/r01_sweep.txt)
+    static const int wg_per_cu = dev_env_int("QV_SCAN_WG_PER_CU", 2);     // 2 workgroups = 8 waves per CU: measured best (profiles/r01_sweep.txt)
     uint32_t cap = (uint32_t)cus * (uint32_t)wg_per_cu;
     p.grid = want < cap ? want : cap;
     if (p.grid == 0) p.grid = 1;
     // even shares: with T tiles per wave at most, use only as many waves as leave nobody a tile short
     // (1M rows on 256 CUs: 15625 tiles over 2048 waves = 7 or 8 each -> 1954 waves x 8)
-    static const int balance = env_int("QV_SCAN_BALANCE", 1);
+    static const int balance = dev_env_int("QV_SCAN_BALANCE", 1);
     if (balance == 1 && want > cap) {
         const uint32_t waves = p.grid * kScanWaves;
         const uint32_t per = (n_tiles + waves - 1) / waves;
@@ -1163,10 +1163,10 @@ hipError_t launch_flat_wide(const IndexView& v, const ScanPlan& p, const float* 
 // that the fixed costs matter (beyond ~160 k rows both forms run at the memory's rate).  QV_SCAN_SPLIT=2: never.
 constexpr uint32_t kSplitMaxTiles = 2560;
 bool flat_split_applies(const IndexView& v, uint32_t nq, uint32_t k) {
-    static const int split = env_int("QV_SCAN_SPLIT", 1), split_max = env_int("QV_SCAN_SPLIT_MAX_TILES", (int)kSplitMaxTiles);
+    static const int split = dev_env_int("QV_SCAN_SPLIT", 1), split_max = dev_env_int("QV_SCAN_SPLIT_MAX_TILES", (int)kSplitMaxTiles);
     const bool split_metric = v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)3 * kSplitWaves * 64 * sizeof(double) + 40 * 1024;   // + the merge's own arrays
-    static const int min_dim4 = env_int("QV_SCAN_SPLIT_MIN_DIM4", 32);       // (128 dimensions: 16 k / 30 k rows 30.8 / 35.6 -> 26.9 / 28.9 us, the rest equal; 64 dimensions: no gain)
+    static const int min_dim4 = dev_env_int("QV_SCAN_SPLIT_MIN_DIM4", 32);       // (128 dimensions: 16 k / 30 k rows 30.8 / 35.6 -> 26.9 / 28.9 us, the rest equal; 64 dimensions: no gain)
     return split == 1 && split_metric && nq == 1 && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= (uint32_t)min_dim4 && lds <= (size_t)160 * 1024 &&
            v.n_tiles >= 2 && v.n_tiles <= (uint32_t)split_max;
 }
@@ -1176,13 +1176,13 @@ bool flat_split_applies(const IndexView& v, uint32_t nq, uint32_t k) {
 // 100 k x 768 131 / 181 / 195 / 202 against 169 / 181 / 190 / 197; 10 k x 1536 93 / 99 / 135 / 234 against 182 / 346 / 350 / 349.
 // (QV_SCAN_SPLIT_MQ_MAX=1: never.)
 bool flat_split_mq_applies(const IndexView& v, uint32_t nq, uint32_t k) {
-    static const int split = env_int("QV_SCAN_SPLIT", 1), split_max = env_int("QV_SCAN_SPLIT_MAX_TILES", (int)kSplitMaxTiles), nq_max = env_int("QV_SCAN_SPLIT_MQ_MAX", 32);
+    static const int split = dev_env_int("QV_SCAN_SPLIT", 1), split_max = dev_env_int("QV_SCAN_SPLIT_MAX_TILES", (int)kSplitMaxTiles), nq_max = dev_env_int("QV_SCAN_SPLIT_MQ_MAX", 32);
     const bool split_metric = v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L1 || v.metric == QV_L2SQ_F64;
     const uint32_t qsz = (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2SQ_F64) ? 8u : 4u;
     const uint32_t qb = nq <= 4 ? 4u : 8u;
     const size_t lds = (size_t)qb * v.dim4 * 4 * qsz + (size_t)qb * kSplitWaves * 64 * sizeof(double) + 1024;
     const uint64_t reads = (uint64_t)((nq + qb - 1) / qb) * v.n_tiles * v.dim4 * 1024ull;
-    static const int min_dim4 = env_int("QV_SCAN_SPLIT_MQ_MIN_DIM4", 16);   // (from 64 dimensions: 10 k x 128, 8 / 16 / 32 queries per call 36 / 40 / 47 us against 64 / 98 / 98)
+    static const int min_dim4 = dev_env_int("QV_SCAN_SPLIT_MQ_MIN_DIM4", 16);   // (from 64 dimensions: 10 k x 128, 8 / 16 / 32 queries per call 36 / 40 / 47 us against 64 / 98 / 98)
     return split == 1 && split_metric && nq >= 2 && nq <= (uint32_t)nq_max && k >= 1 && k <= (uint32_t)kMaxFusedK && v.dim4 >= (uint32_t)min_dim4 && lds <= (size_t)160 * 1024 &&
            v.n_tiles >= 2 && v.n_tiles <= (uint32_t)split_max && reads <= 600ull * 1000 * 1000;
 }
@@ -1193,7 +1193,7 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + (size_t)kScanWaves * 64 * sizeof(uint64_t);
     uint64_t* partial = static_cast<uint64_t*>(d_ws);
     hipError_t e = hipSuccess;
-    static const int mq_min = env_int("QV_MQ_MIN", 2);                // nq >= this: queries share a corpus pass
+    static const int mq_min = dev_env_int("QV_MQ_MIN", 2);                // nq >= this: queries share a corpus pass
     if ((int)nq >= mq_min && flat_split_mq_applies(v, nq, k)) {
         // a shared pass of a few queries over a short corpus of wide rows: the tile-over-eight-waves form, up to 8 queries per workgroup row
         const uint32_t grid = std::min<uint32_t>(v.n_tiles, std::min<uint32_t>((uint32_t)p.cus, p.n_lists * 4u));
@@ -1223,16 +1223,16 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
     if ((int)nq >= mq_min) {
         // QB queries per corpus pass.  Measured on MI355X, 256 x 1M x 768 cosine (profiles/r01_sweep_mq.txt):
         // QB=8 is HBM-bound (0.454 ms/pass), QB=16 is f64-VALU-bound (0.75 ms/pass, 12.0 ms per 256 queries).
-        static const int mq_qb_env = env_int("QV_MQ_QB", 0), mq_wg = env_int("QV_MQ_WG_PER_CU", 2);
+        static const int mq_qb_env = dev_env_int("QV_MQ_QB", 0), mq_wg = dev_env_int("QV_MQ_WG_PER_CU", 2);
         // the all-float32 metrics spill ~330 SGPRs at 16 queries per pass (16 x 4 scalar query values per chunk on top of the
         // list state): 16 queries take 1.73 ms in one pass and 1.02 ms in two passes of 8 (1M x 768) -> 8 per pass for them
         const bool f32_acc = v.metric == QV_L2SQ || v.metric == QV_COSINE_F32 || v.metric == QV_L2_F32 || v.metric == QV_DOT_F32;
-        const int qb = mq_qb_env ? mq_qb_env : (nq >= 9 ? (f32_acc ? 8 : 16) : (nq >= 5 ? 8 : 4));
+        const int qb = mq_qb_env ? (f32_acc && mq_qb_env == 16 ? 8 : mq_qb_env) : (nq >= 9 ? (f32_acc ? 8 : 16) : (nq >= 5 ? 8 : 4));
         const uint32_t want = (v.n_tiles + kScanWaves - 1) / kScanWaves;
         const uint32_t grid = std::max(1u, std::min(want, (uint32_t)mq_wg * (p.grid / 2 ? p.grid / 2 : 1)));   // p.grid = 2 WG/CU * CUs
         void* qblk = static_cast<char*>(d_ws) + scan_workspace_bytes(p, nq, k);   // tail of the workspace
         // >= 9 cosine/dot queries: the same exact arithmetic on the f64 matrix cores (qv_mq64.hip), 16 or 32 queries per pass
-        static const int mq64_min = env_int("QV_MQ64_MIN", 9);
+        static const int mq64_min = dev_env_int("QV_MQ64_MIN", 9);
         static const int trace = env_int("QV_TRACE", 0);                  // QV_TRACE=1: name the scan kernel chosen, on stderr
         // (not for short scans: its first tile per wave pays 16 out-of-line sorts; measured slower below ~4 tiles per wave)
         if ((int)nq >= mq64_min && mq_qb_env == 0 && v.n_tiles >= 16u * p.grid && mq64_blocks(v.metric, v.dim4, nq) != 0) {
@@ -1266,7 +1266,8 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
             hipLaunchKernelGGL((k_flat_scan_mq<MMM, 4, QQ, true>), dim3(grid, groups), dim3(p.block), lds_mq, s, v, d_queries, static_cast<const QT*>(qblk), nq, k, partial); \
             if (ev1) (void)hipEventRecord(ev1, s);                                                                            \
         }
-        if (qb == 16) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 16) }); }
+        // (16 per pass never for the all-float32 metrics, see f32_acc above: their instantiations are not built)
+        if (qb == 16) { QV_DISPATCH_METRIC(v.metric, { if constexpr (MM == QV_L2SQ || MM == QV_COSINE_F32 || MM == QV_L2_F32 || MM == QV_DOT_F32) return hipErrorInvalidValue; else QV_MQ_LAUNCH(MM, 16) }); }
         else if (qb == 8) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 8) }); }
         else if (qb == 4) { QV_DISPATCH_METRIC(v.metric, { QV_MQ_LAUNCH(MM, 4) }); }
         else return hipErrorInvalidValue;
@@ -1279,7 +1280,8 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
         hipLaunchKernelGGL(k_merge_lists, dim3(nq), dim3(mblock), 0, s, partial, grid, k, d_rows_out, d_dist_out);
         return hipGetLastError();
     }
-    static const int unroll = env_int("QV_SCAN_UNROLL", kUnroll);     // tuning knob (cosine only): loads in flight per wave
+#ifdef QV_VARIANTS
+    static const int unroll = env_int("QV_SCAN_UNROLL", kUnroll);     // tuning knob of the measurement build (cosine only): loads in flight per wave
     if (v.metric == QV_COSINE && unroll != kUnroll) {
 #define QV_SCAN_U(UU)                                                                                             \
         case UU: e = set_lds(k_flat_scan<QV_COSINE, UU>, lds); if (e != hipSuccess) return e;                    \
@@ -1289,12 +1291,13 @@ hipError_t launch_flat_topk(const IndexView& v, const ScanPlan& p, const float* 
         switch (unroll) { QV_SCAN_U(4) QV_SCAN_U(8) QV_SCAN_U(12) QV_SCAN_U(24) QV_SCAN_U(32) default: return hipErrorInvalidValue; }
 #undef QV_SCAN_U
     } else
+#endif
     {
         // one query, the caller's tickets at hand: scan + merge in ONE launch (the last workgroup merges).  QV_SCAN_FUSE=0 (read once)
         // keeps the two launches, for measurements.
-        static const int fuse = env_int("QV_SCAN_FUSE", 1);
+        static const int fuse = dev_env_int("QV_SCAN_FUSE", 1);
         if (d_tickets && fuse && flat_split_applies(v, nq, k)) {
-            static const int split_grid = env_int("QV_SCAN_SPLIT_GRID", 0);
+            static const int split_grid = dev_env_int("QV_SCAN_SPLIT_GRID", 0);
             const uint32_t grid = std::min<uint32_t>(v.n_tiles, std::min<uint32_t>(split_grid ? (uint32_t)split_grid : (uint32_t)p.cus, p.n_lists * 4u));
             const size_t lds_s = query_lds_bytes(v.metric, v.dim4) + (size_t)3 * kSplitWaves * 64 * sizeof(double);
             QV_DISPATCH_METRIC(v.metric, {
@@ -1354,9 +1357,12 @@ hipError_t launch_flat_redo_flagged(const IndexView& v, const ScanPlan& p, const
     hipError_t e = hipSuccess;
     for (uint32_t first = 0; first < nq; first += kRedoSlots) {
         QV_DISPATCH_METRIC(v.metric, {
-            e = set_lds((k_flat_scan_redo<MM, kUnroll>), lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_flat_scan_redo<MM, kUnroll>), dim3(p.grid), dim3(p.block), lds, s, v, d_queries, k, k_stride, list, count, first, partial, count + 1, d_rows_out, d_dist_out);
+            // (the flags come from the batched filter path: its four metrics)
+            if constexpr (MM == QV_COSINE || MM == QV_L2 || MM == QV_L2SQ || MM == QV_DOT) {
+                e = set_lds((k_flat_scan_redo<MM, kUnroll>), lds);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((k_flat_scan_redo<MM, kUnroll>), dim3(p.grid), dim3(p.block), lds, s, v, d_queries, k, k_stride, list, count, first, partial, count + 1, d_rows_out, d_dist_out);
+            } else return hipErrorInvalidValue;
         });
     }
     return hipGetLastError();

@@ -108,6 +108,23 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
             return "k_qreg_filter (bfloat16 copy)" if plane else "k_qreg_filter (float32 rows)"
         return "k_bf16rows_filter (bfloat16 copy)" if plane and dim % 128 == 0 else "k_bf16x1_filter_w8x2 (float32 rows)"
 
+    def bare_mfma_f32():
+        """the chip's bare v_mfma_f32_32x32x2_f32 issue rate under load, one and two waves per SIMD, with the shader clock it held
+        (tools/native/qv_ubench.hip; k_mfma_filter runs one wave per SIMD)"""
+        try:
+            import ctypes as C
+            ub = C.CDLL(os.path.join(ROOT, "quiver_amd", "lib", "libqvubench.so"))
+            ub.qvu_mfma_f32_rate.restype = C.c_int
+            ub.qvu_mfma_f32_rate.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+            r = {}
+            for w in (1, 2):
+                tf, ghz = C.c_double(0.0), C.c_double(0.0)
+                if ub.qvu_mfma_f32_rate(w, C.byref(tf), C.byref(ghz)) == 0:
+                    r[w] = (tf.value, ghz.value)
+            return r
+        except Exception:                                    # noqa: BLE001
+            return {}
+
     def mfma_entry(index, label, want_rows, want_dist, rows_n=1_000_000, kernel="bf16x3", plane=False):
         index.set_filter(kernel)                                # qv_index_set_filter: the index's own choice of filter kernel
         d_flags = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
@@ -128,7 +145,8 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
         mf_ms = msm / max(nm, 1)
         flop = 2.0 * nqb * rows_n * dim
         index.set_filter("auto")
-        return {
+        bare = bare_mfma_f32() if kernel == "fp32" else {}
+        entry = {
             "workload": "256 queries x %dx768 %s, k=10 (BASELINE configs[2]): %s filter + exact re-score, device-resident queries and "
                         "results (sample scan, prep, filter, re-score all inside the timed region)"
                         % (rows_n, label, "fp32-MFMA (v_mfma_f32_32x32x2_f32: the dense fp32 GEMM as written)" if kernel == "fp32" else
@@ -155,6 +173,15 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
                           "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 3.0 * flop / (mf_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
                           "matrix_flop_per_launch": 3.0 * flop, "fp32_equivalent_tflops_end_to_end": flop / dtm / 1e12,
                           "times_the_fp32_mfma_peak_end_to_end": flop / dtm / 1e12 / MFMA_F32_PEAK_TF})}
+        if bare.get(1):
+            # what the instruction itself reaches on this box, right now: the kernel holds ONE wave per SIMD (336 registers: a 64 x 128 tile
+            # of accumulators + three steps of operands), and a lone wave leaves a few cycles between two matrix instructions
+            rf = entry["roofline"]
+            rf.update({"bare_mfma_loop_tflops_1_wave_per_simd": bare[1][0], "bare_mfma_loop_clock_ghz": bare[1][1],
+                       "bare_mfma_loop_tflops_2_waves_per_simd": (bare.get(2) or (None, None))[0],
+                       "frac_of_bare_mfma_loop": rf["achieved"] / bare[1][0],
+                       "peak_at_the_held_clock_tflops": MFMA_F32_PEAK_TF * bare[1][1] / 2.4, "frac_at_the_held_clock": rf["achieved"] / (MFMA_F32_PEAK_TF * bare[1][1] / 2.4)})
+        return entry
     # more than 64 results per query (round 4): the negative-example branches fetch max(2k, 30) (hybrid_index.go:516-522), BatchSearch
     # takes any k (:677-811).  k = 100 and 1000, one query (10M and 1M rows) and 256 queries x 1M rows; checked against the full ranking.
     try:

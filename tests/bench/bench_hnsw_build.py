@@ -113,6 +113,23 @@ def run(rows=1_000_000, dim=768, metric="cosine", m=16, efc=200, max_level=16, b
                       "search_complete": {"qps": nq / (t_host + t_top), "recall_at_%d_vs_exact" % k: hit_full / (nq * k),
                                           "what": "HNSW.Search as the reference defines it: graph traversal, then the exact top-k for queries the graph under-filled (hnsw.go:676-710)"}})
     out["search"] = sweep
+    # the ceiling of `gathered_GBps` on THIS box: the bare random-row stream in the traversal's own shape (32 rows x 128-byte pieces per
+    # slab by LDS-DMA, two slab buffers per wave, 12 waves per CU, a table of the corpus's size; no arithmetic, no bookkeeping) —
+    # tools/native/qv_ubench.hip (a measurement library beside libqv, not part of it)
+    try:
+        import ctypes as C
+        ub = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "quiver_amd", "lib", "libqvubench.so"))
+        ub.qvu_gather_rate.restype = C.c_int
+        ub.qvu_gather_rate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+        table = torch.empty((N, D), dtype=torch.float32, device="cuda")
+        tb = C.c_double(0.0)
+        if ub.qvu_gather_rate(table.data_ptr(), N, D, 12, C.byref(tb)) == 0:
+            out["bare_row_stream_GBps_this_box"] = tb.value * 1e3
+            for e in sweep:
+                e["graph_traversal"]["gathered_frac_of_bare_row_stream"] = e["graph_traversal"]["gathered_GBps"] / (tb.value * 1e3)
+        del table
+    except Exception as ex:                                  # noqa: BLE001  (a ceiling beside the measurement, never a reason to lose it)
+        out["bare_row_stream_GBps_this_box"] = "unmeasured: %s" % ex
     if callers:
         # The traffic the reference's host produces: HNSW.Search under a read lock, one query per call, a goroutine per request
         # (hnsw.go:602-606, adapter.go:253-279).  Native threads through qv_graph_search with nq = 1 (tools/native/qv_callers.cpp); every

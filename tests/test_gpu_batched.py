@@ -295,7 +295,8 @@ def test_rows_near_flt_max_are_not_lost_by_the_filter():
     assert _eq(exact, idx.search(qs, 10, batched=True))
 
 
-@pytest.mark.parametrize("metric,dim", [("cosine", 768), ("dot_product", 256), ("euclidean", 128), ("squared_euclidean", 384), ("cosine", 96)])
+@pytest.mark.parametrize("metric,dim", [("cosine", 768), ("dot_product", 256), ("euclidean", 128), ("squared_euclidean", 384), ("cosine", 96),
+                                        ("cosine", 256), ("euclidean", 1024)])      # (k_bf16rows_filter for every metric: a multiple of 128 dimensions outside the query-resident kernel's three)
 def test_bf16_row_plane_gives_the_same_results_and_follows_every_mutation(metric, dim):
     """QV_FLAG_BF16_ROWS: the one-term filter reads the index's bfloat16 copy of the rows (dimensions that are a multiple of 128;
     others keep converting the float32 rows).  The plane is refreshed by add (host / device / synthetic, across a regrow) and
@@ -479,7 +480,8 @@ def test_cluster_stored_corpus_at_768_dimensions_keeps_the_filter_path():
 
 @pytest.mark.parametrize("bf16_rows", [False, True])
 @pytest.mark.parametrize("metric,dim,nq", [("cosine", 768, 256), ("dot_product", 512, 600), ("euclidean", 384, 130), ("squared_euclidean", 768, 257),
-                                           ("cosine", 512, 256), ("dot_product", 384, 512)])
+                                           ("cosine", 512, 256), ("dot_product", 384, 512),
+                                           ("cosine", 384, 256), ("euclidean", 512, 256), ("dot_product", 768, 256)])   # every (metric, dimension, plane) instantiation
 def test_query_resident_filter_against_the_exact_scan(metric, dim, nq, bf16_rows):
     """k_qreg_filter (qv_qreg.hip; 384, 512 and 768 dimensions, whole workgroups of 256 queries): the queries' operands stay in
     registers and the rows arrive by LDS-DMA, from the float32 tiles or from the bfloat16 copy.  Ragged last tile, tombstones in

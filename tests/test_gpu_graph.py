@@ -260,10 +260,15 @@ def test_wave_per_query_form_with_the_round6_front_identical_to_oracle(metric, d
         assert np.array_equal(c2, c[lo:lo + 128]) and np.array_equal(ev2, ev[lo:lo + 128]), lo
         for i in range(c2.shape[0]):
             assert r2[i, :c2[i]].tolist() == r[lo + i, :c2[i]].tolist() and d2[i, :c2[i]].tobytes() == d[lo + i, :c2[i]].tobytes(), (lo, i)
+    filled = 0
     for i in range(0, nq, 11):
         ro, do, eo = o.search(qs[i], k, with_evals=True)
         assert c[i] <= k
-        assert r[i, :c[i]].tolist() == ro[:c[i]].tolist(), i
-        assert d[i, :c[i]].tobytes() == do[:c[i]].tobytes(), i
-        if c[i] == k:
+        if c[i] == k:                                # filled by the graph search alone: rows, bits and evaluation counts
+            assert r[i].tolist() == ro.tolist(), i
+            assert d[i].tobytes() == do.tobytes(), i
             assert int(ev[i]) == eo - 1, i
+            filled += 1
+        # (under-filled — the level quirk's islands on a multi-level graph — the reference answers with the exact top-k, hnsw.go:676-710:
+        # the host layer's job, tests/test_gpu_host.py; the graph results themselves are pinned by the latency form above)
+    assert filled > 0 or max_level > 1

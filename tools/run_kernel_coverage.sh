@@ -17,7 +17,8 @@ for chunk in "tests/test_gpu_flat.py tests/test_gpu_small.py tests/test_gpu_scan
     n=$((n + 1))
     files=""; for f in $chunk; do [ -f $f ] && files="$files $f"; done
     (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $cov/c$n -o t -- python3 -m pytest -q -m gpu -p no:cacheprovider --rootdir $root $(for f in $files; do echo $root/$f; done) > $cov/c$n.log 2>&1)
-    echo "chunk $n rc=$? : $(tail -1 $cov/c$n.log)"
+    echo "chunk $n rc=$? : $(grep -E "passed|failed" $cov/c$n.log | tail -1)"
+    grep -E "^FAILED|^ERROR" $cov/c$n.log | head -20
 done
 # any -m gpu test file not named above would be missed silently: list them
 for f in tests/test_*.py; do grep -q "pytest.mark.gpu" $f && ! grep -q "$(basename $f)" $0 && echo "NOT TRACED: $f"; done
