@@ -212,6 +212,7 @@ uint32_t qv_index_dim(const qv_index* idx) { return idx ? idx->dim : 0; }
 int qv_index_metric(const qv_index* idx) { return idx ? idx->metric : -1; }
 
 int qv_index_add_device(qv_index* idx, const float* d_rows, uint32_t n, uint32_t* first_row_out, void* stream) {
+    if (idx) idx->row_writes++;
     if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
     if (first_row_out) *first_row_out = idx->n_rows;
     if (n == 0) return QV_OK;
@@ -231,6 +232,7 @@ int qv_index_add_device(qv_index* idx, const float* d_rows, uint32_t n, uint32_t
 }
 
 int qv_index_add(qv_index* idx, const float* rows, uint32_t n, uint32_t* first_row_out) {
+    if (idx) idx->row_writes++;
     if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
     if (first_row_out) *first_row_out = idx->n_rows;
     if (n == 0) return QV_OK;
@@ -263,6 +265,7 @@ int qv_index_add(qv_index* idx, const float* rows, uint32_t n, uint32_t* first_r
 }
 
 int qv_index_add_synthetic(qv_index* idx, uint64_t seed, uint64_t gen_row0, uint32_t n, uint32_t* first_row_out) {
+    if (idx) idx->row_writes++;
     if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
     if (first_row_out) *first_row_out = idx->n_rows;
     if (n == 0) return QV_OK;
@@ -300,6 +303,7 @@ int qv_index_remove(qv_index* idx, const uint32_t* rows, uint32_t n) {
 }
 
 int qv_index_update(qv_index* idx, uint32_t row, const float* vec) {
+    if (idx) idx->row_writes++;
     if (!idx) return fail(QV_ERR_INVALID_ARG, "index is null");
     if (!vec) return fail(QV_ERR_INVALID_ARG, "vector is null");
     if (row >= idx->n_rows) return fail(QV_ERR_OUT_OF_RANGE, "row %u out of range (rows: %u)", row, idx->n_rows);

@@ -86,6 +86,7 @@ struct qv_index {
     uint64_t flags = 0;
     int filter = 0;                            // qv_index_set_filter
     uint32_t n_rows = 0, n_live = 0;
+    uint64_t row_writes = 0;                   // bumped by every call that writes row CONTENTS (add / update): copies kept elsewhere (a graph's hubs) compare it
     uint64_t cap_tiles = 0;
     float* d_tiles = nullptr;
     double* d_rnorm = nullptr;

@@ -67,6 +67,12 @@ struct HnswOpts {
     uint32_t        vis_cap   = 0;        // per slot: hash entries (power of two) / bitmap words
     uint32_t        vis_lds   = 0;        // set by launch_hnsw_search_wave for its latency form: the hash table is in LDS
     uint32_t        lat_rows  = 32;       // set by the launchers for the latency form: rows of a hop requested at once (32 / 16 / 8 by dimension)
+    // the hubs (qv_graph_api.cpp graph_hubs): rows most traversals read are not read at all — their distances to every query of the call
+    // are computed up front by a dense pass (k_hub_table) and looked up
+    uint32_t*       hist      = nullptr;  // [n_nodes] += 1 per evaluated row (the sampling pass that chooses the hubs)
+    const float*    hub_tab   = nullptr;  // [nq][hub_H] distance(query, hub)
+    const uint16_t* l0_hub    = nullptr;  // [n_nodes][max_m0] the hub slot of every level-0 link (0xFFFF: not a hub)
+    uint32_t        hub_H     = 0;        // hubs (0: none)
     const float*    q32       = nullptr;  // set by launch_hnsw_search_wave: the caller's queries as they came ([nq][dim] float32), what the front keeps in LDS
     uint32_t        front     = 0;        // set by launch_hnsw_search_wave for its wave-per-query form: which parts of the round-6 hop are on (qv_hnsw.hip)
     uint32_t*       next      = nullptr;  // set by launch_hnsw_search_wave: the call's query counter (zeroed by k_hnsw_prep_queries): a wave slot that
@@ -187,6 +193,10 @@ uint32_t hnsw_vis_hash_cap(uint32_t ef);                 // hash entries per wav
 
 // wave-resident form (no LDS heaps); count_out = 0xFFFFFFFE for queries that met equal distances / NaN
 uint32_t hnsw_wave_grid(int cus, int metric, uint32_t dim4);
+hipError_t launch_hub_build(const IndexView& v, const GraphView& g, const uint32_t* d_hub_rows, uint32_t H, float* d_hub_tiles, double* d_hub_rnorm,
+                            uint16_t* d_slot_of, uint16_t* d_l0_hub, hipStream_t s);
+hipError_t launch_hub_table(const IndexView& v, const float* d_hub_tiles, const double* d_hub_rnorm, uint32_t H, const float* d_queries, void* d_qblk, uint32_t nq,
+                            float* d_table, int cus, hipStream_t s);
 size_t hnsw_qblk_bytes(uint32_t nq, uint32_t dim4);   // workspace for the converted queries + per-query constants
 hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const float* d_queries, void* d_qblk, uint32_t nq, uint32_t k, uint32_t ef,
                                    const HnswOpts& o, uint32_t grid, uint32_t* d_rows_out, float* d_dist_out,

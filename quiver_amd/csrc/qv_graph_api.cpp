@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <functional>
+#include <shared_mutex>
 
 // Everything ONE host-pointer traversal call owns while it runs: stream, converted-query workspace, result buffers, its redo
 // list and its visited sets.  The reference searches under a read lock (hnsw.go:602-606; a goroutine per query, adapter.go:253-279),
@@ -16,14 +17,14 @@ struct GraphCtx {
     hipStream_t stream = nullptr;
     Buf vis_hash; uint32_t vis_hash_cap = 0, vis_hash_slots = 0;      // wave kernel: a hash table per wave slot
     Buf vis_bits; uint32_t vis_bits_words = 0, vis_bits_slots = 0;    // exact-heap kernel: a bitmap per slot
-    Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev, s_redo, s_counters;
+    Buf d_q, d_qblk, d_rows, d_dist, d_cnt, d_ev, s_redo, s_counters, hub_table;
     PinBuf h_stage[2]; hipEvent_t ev_stage[2] = {nullptr, nullptr};
     PinBuf h_counters, h_out;
     hipEvent_t ev_block = nullptr;       // blocking-sync event: a thread that runs a shared batch sleeps until the device is done instead of spinning
     void release() {
         if (stream) (void)hipStreamSynchronize(stream);
         vis_hash.release(); vis_bits.release();
-        d_q.release(); d_qblk.release(); d_rows.release(); d_dist.release(); d_cnt.release(); d_ev.release(); s_redo.release(); s_counters.release();
+        d_q.release(); d_qblk.release(); d_rows.release(); d_dist.release(); d_cnt.release(); d_ev.release(); s_redo.release(); s_counters.release(); hub_table.release();
         for (int i = 0; i < 2; i++) { h_stage[i].release(); if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]); ev_stage[i] = nullptr; }
         h_counters.release(); h_out.release();
         if (ev_block) (void)hipEventDestroy(ev_block);
@@ -61,6 +62,15 @@ struct qv_graph {
     static int lanes() { static const int n = getenv("QV_GRAPH_LANES") ? std::max(1, atoi(getenv("QV_GRAPH_LANES"))) : 2; return n; }   // (measurement switch, read once)
     static uint32_t max_group() { static const uint32_t n = getenv("QV_GRAPH_MAX_GROUP") ? (uint32_t)std::max(1, atoi(getenv("QV_GRAPH_MAX_GROUP"))) : 256u; return n; }
     qvco::Front front{lanes(), max_group()};
+    // The hubs (qv_hnsw.hip "hubs"): the rows most traversals read, chosen by a sampling pass of the first large call, copied into
+    // tiles of their own; a large call computes its queries' distances to all of them up front (k_hub_table) and its hops look them
+    // up.  Valid while the graph has the nodes and the index the row contents they were taken from.
+    struct Hubs {
+        std::shared_mutex mu;                   // calls that use the hubs hold it shared while they enqueue; a (re)build holds it alone
+        uint32_t H = 0;
+        uint32_t nodes_at = 0xFFFFFFFFu; uint64_t writes_at = ~0ull;   // the state they were sampled in (H == 0: sampled, nothing worth it)
+        Buf tiles, rnorm, rows, l0_hub, slot_of, hist, table;          // table: the device form's (host-form contexts have their own)
+    } hubs;
     hipStream_t stream = nullptr;
     hipEvent_t ev_last = nullptr;               // end of the most recent traversal: the next one (on any stream) waits for it
     Buf d_qblk, d_rows, d_dist, d_cnt, d_ev;
@@ -203,6 +213,7 @@ void qv_graph_destroy(qv_graph* g) {
     g->vis_hash.release(); g->vis_bits.release();
     g->d_qblk.release(); g->d_rows.release(); g->d_dist.release(); g->d_cnt.release(); g->d_ev.release();
     g->h_counters.release();
+    { auto& hb = g->hubs; hb.tiles.release(); hb.rnorm.release(); hb.rows.release(); hb.l0_hub.release(); hb.slot_of.release(); hb.hist.release(); hb.table.release(); }
     g->b_self.release(); g->b_keys_a.release(); g->b_keys_b.release(); g->b_hist.release(); g->b_seg.release(); g->b_redo.release(); g->b_counters.release();
     delete g;
 }
@@ -225,6 +236,110 @@ int acquire_gctx(qv_graph* g, GraphCtx** out) {
     *out = c;
     return QV_OK;
 }
+// ---- the wave traversal of one call (with the graph's hubs in the measurement build) ---------------------------------------------------
+constexpr uint32_t kHubMinQueries = 2048;      // calls below this never sample, build or use hubs (the dense pass costs ~0.4 us per query and 64 hubs)
+constexpr uint32_t kHubSample = 1024;          // queries of the sampling pass
+constexpr uint32_t kHubMax = 16384;            // hubs at most (a 16-bit slot per link)
+bool hubs_possible(const qv_graph* g, uint32_t nq) {
+    // measured and NOT shipped (qv_hnsw.hip "hubs": the benchmark's corpora have no hubs to speak of): the measurement build with
+    // QV_HNSW_HUBS=1 samples, builds and uses them; the product library never does
+#ifdef QV_VARIANTS
+    static const bool on = getenv("QV_HNSW_HUBS") && atoi(getenv("QV_HNSW_HUBS")) == 1;
+#else
+    constexpr bool on = false;
+#endif
+    if (!on) return false;
+    const qv_index* idx = g->idx;
+    return nq >= kHubMinQueries && idx->d_rowmaj && (idx->dim & 31u) == 0 && idx->dim >= 32 && !g->g.has_dead && g->g.max_m0 <= 32u && g->g.n_nodes >= 4096u;
+}
+// sample the call's first queries, choose the hubs, build their copies (synchronous: once per graph state).  Holds hubs.mu alone.
+int hubs_build(qv_graph* g, const float* dq, void* qblk, uint32_t nq, uint32_t k, uint32_t ef, qv::HnswOpts wo, uint32_t grid,
+               uint32_t* d_rows, float* d_dist, uint32_t* d_cnt, uint32_t* d_ev, hipStream_t s) {
+    qv_index* idx = g->idx;
+    auto& hb = g->hubs;
+    HIPCHK(hipDeviceSynchronize());                                      // nothing in flight reads the arrays that are about to be replaced
+    hb.H = 0; hb.nodes_at = g->g.n_nodes; hb.writes_at = idx->row_writes;
+    const uint32_t n = g->g.n_nodes, ns = std::min(nq, kHubSample);
+    int rc;
+    if ((rc = hb.hist.ensure((size_t)n * 4))) return rc;
+    HIPCHK(hipMemsetAsync(hb.hist.p, 0, (size_t)n * 4, s));
+    wo.hist = static_cast<uint32_t*>(hb.hist.p);
+    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, qblk, ns, k, ef, wo, std::min(grid, ns), d_rows, d_dist, d_cnt, d_ev, s);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hub sampling launch failed: %s", hipGetErrorString(e));
+    std::vector<uint32_t> h(n);
+    HIPCHK(hipMemcpyAsync(h.data(), hb.hist.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // a hub is worth its column of the table when more than ~one query in twelve reads it: 2 D flops per (query, hub) at the dense
+    // pass's ~30 TFLOP/s against 4 D bytes per read at the gather's ~5 TB/s
+    const uint32_t thr = std::max(2u, ns / 12u);
+    std::vector<std::pair<uint32_t, uint32_t>> cand;                     // (reads, row)
+    for (uint32_t i = 0; i < n; i++) if (h[i] >= thr) cand.emplace_back(h[i], i);
+    std::sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    uint32_t H = (uint32_t)std::min<size_t>(cand.size(), kHubMax) / 64u * 64u;
+    static const bool trace0 = getenv("QV_TRACE") && atoi(getenv("QV_TRACE")) > 0;
+    if (trace0) { std::vector<uint32_t> srt(h); std::sort(srt.begin(), srt.end(), std::greater<uint32_t>()); uint64_t tot = 0, cum = 0; for (uint32_t x : srt) tot += x;
+                  for (uint32_t i = 0; i < n; i++) { cum += srt[i]; if (i + 1 == 64 || i + 1 == 1024 || i + 1 == 8192 || i + 1 == 65536 || i + 1 == 262144)
+                      fprintf(stderr, "qv: graph hubs: the %u most-read rows take %.1f %% of the sample's reads (rank %u is read by %u of %u queries)\n", i + 1, 100.0 * (double)cum / (double)tot, i + 1, srt[i], ns); } }
+    if (trace0 && H < 64) { uint64_t tot = 0; uint32_t mx = 0; for (uint32_t i = 0; i < n; i++) { tot += h[i]; mx = std::max(mx, h[i]); }
+                            fprintf(stderr, "qv: graph hubs: none (%zu rows read by >= %u of %u sampled queries; %llu reads counted, the most-read row %u times)\n", cand.size(), thr, ns, (unsigned long long)tot, mx); }
+    if (H < 64) return QV_OK;                                            // nothing worth it on this graph and these queries
+    std::vector<uint32_t> rows(H);
+    for (uint32_t i = 0; i < H; i++) rows[i] = cand[i].second;
+    if ((rc = hb.rows.ensure((size_t)H * 4)) || (rc = hb.tiles.ensure((size_t)(H / 64) * idx->tile_bytes())) || (rc = hb.rnorm.ensure((size_t)H * 8)) ||
+        (rc = hb.slot_of.ensure((size_t)n * 2)) || (rc = hb.l0_hub.ensure((size_t)n * g->g.max_m0 * 2)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(hb.rows.p, rows.data(), (size_t)H * 4, hipMemcpyHostToDevice, s));
+    e = qv::launch_hub_build(idx->view(), g->g, static_cast<const uint32_t*>(hb.rows.p), H, static_cast<float*>(hb.tiles.p), static_cast<double*>(hb.rnorm.p),
+                             static_cast<uint16_t*>(hb.slot_of.p), static_cast<uint16_t*>(hb.l0_hub.p), s);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hub build launch failed: %s", hipGetErrorString(e));
+    HIPCHK(hipStreamSynchronize(s));                                     // (`rows` leaves scope)
+    hb.H = H;
+    static const bool trace = getenv("QV_TRACE") && atoi(getenv("QV_TRACE")) > 0;
+    if (trace) fprintf(stderr, "qv: graph hubs: %u rows read by >= %u of %u sampled queries (%zu candidates), %.1f MB of copies\n", H, thr, ns, cand.size(), (double)H * idx->dim * 4 / 1e6);
+    return QV_OK;
+}
+// One call's wave traversal.  table: where this caller keeps its hub table (grown here).
+int traverse_wave(qv_graph* g, const float* dq, void* qblk, Buf* table, uint32_t nq, uint32_t k, uint32_t ef, qv::HnswOpts wo, uint32_t grid,
+                  uint32_t* d_rows, float* d_dist, uint32_t* d_cnt, uint32_t* d_ev, hipStream_t s) {
+    qv_index* idx = g->idx;
+    auto& hb = g->hubs;
+    if (hubs_possible(g, nq)) {
+        {
+            std::shared_lock<std::shared_mutex> rl(hb.mu);
+            const bool current = hb.nodes_at == g->g.n_nodes && hb.writes_at == idx->row_writes;
+            if (!current) {
+                rl.unlock();
+                std::unique_lock<std::shared_mutex> wl(hb.mu);
+                if (!(hb.nodes_at == g->g.n_nodes && hb.writes_at == idx->row_writes)) {
+                    const int rc = hubs_build(g, dq, qblk, nq, k, ef, wo, grid, d_rows, d_dist, d_cnt, d_ev, s);
+                    if (rc != QV_OK) return rc;
+                }
+            }
+        }
+        std::shared_lock<std::shared_mutex> rl(hb.mu);
+        if (hb.H && hb.nodes_at == g->g.n_nodes && hb.writes_at == idx->row_writes) {
+            // the table of the whole call where it stays under 2 GiB, else in pieces of that size (each piece a launch of its own)
+            const uint32_t piece = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(nq, ((uint64_t)2 << 30) / ((uint64_t)hb.H * 4)));
+            int rc = table->ensure((size_t)std::min(nq, piece) * hb.H * 4);
+            if (rc != QV_OK) return rc;
+            wo.l0_hub = static_cast<const uint16_t*>(hb.l0_hub.p); wo.hub_H = hb.H; wo.hub_tab = static_cast<const float*>(table->p);
+            for (uint32_t q0 = 0; q0 < nq; q0 += piece) {
+                const uint32_t m = std::min(piece, nq - q0);
+                const float* dqm = dq + (size_t)q0 * idx->dim;
+                hipError_t e = qv::launch_hub_table(idx->view(), static_cast<const float*>(hb.tiles.p), static_cast<const double*>(hb.rnorm.p), hb.H, dqm, qblk, m,
+                                                    static_cast<float*>(table->p), idx->cus, s);
+                if (e == hipSuccess) e = qv::launch_hnsw_search_wave(idx->view(), g->g, dqm, qblk, m, k, ef, wo, std::min(grid, m), d_rows + (size_t)q0 * k, d_dist + (size_t)q0 * k,
+                                                                     d_cnt + q0, d_ev ? d_ev + q0 : nullptr, s);
+                if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+            }
+            return QV_OK;
+        }
+    }
+    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, qblk, nq, k, ef, wo, grid, d_rows, d_dist, d_cnt, d_ev, s);
+    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+    return QV_OK;
+}
+
 struct GCtxGuard {
     qv_graph* g; GraphCtx* c;
     ~GCtxGuard() { if (c) { std::lock_guard<std::mutex> l(g->ctx_mu); g->free_ctx.push_back(c); } }
@@ -308,8 +423,8 @@ int graph_search_ctx(qv_graph* g, GraphCtx* c, const float* queries, uint32_t nq
     uint32_t* d_rows = static_cast<uint32_t*>(c->d_rows.p); float* d_dist = static_cast<float*>(c->d_dist.p);
     uint32_t* d_cnt = static_cast<uint32_t*>(c->d_cnt.p); uint32_t* d_ev = static_cast<uint32_t*>(c->d_ev.p);
     qv::HnswOpts wo; wo.vis = static_cast<uint32_t*>(c->vis_hash.p); wo.vis_cap = c->vis_hash_cap;
-    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, dq, c->d_qblk.p, nq, k, ef_search, wo, std::min(c->vis_hash_slots, nq), d_rows, d_dist, d_cnt, d_ev, c->stream);
-    if (e == hipSuccess) e = qv::launch_build_compact_redo(d_cnt, nq, static_cast<uint32_t*>(c->s_redo.p), counters, c->stream);
+    if ((rc = traverse_wave(g, dq, c->d_qblk.p, &c->hub_table, nq, k, ef_search, wo, std::min(c->vis_hash_slots, nq), d_rows, d_dist, d_cnt, d_ev, c->stream))) return rc;
+    hipError_t e = qv::launch_build_compact_redo(d_cnt, nq, static_cast<uint32_t*>(c->s_redo.p), counters, c->stream);
     if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
     uint32_t* hc = static_cast<uint32_t*>(c->h_counters.p);
     // small result sets come back through one pinned buffer (a copy into pageable memory is staged by the runtime, chunk by chunk)
@@ -443,9 +558,7 @@ int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uin
     if (qv::hnsw_qblk_bytes(nq, idx->dim4) > g->d_qblk.cap) HIPCHK(hipEventSynchronize(g->ev_last));
     if ((rc = g->d_qblk.ensure(qv::hnsw_qblk_bytes(nq, idx->dim4)))) return rc;
     const uint32_t grid = std::min(g->grid, nq);
-    hipError_t e = qv::launch_hnsw_search_wave(idx->view(), g->g, d_queries, g->d_qblk.p, nq, k, ef_search, wave_opts(g), grid,
-                                               d_rows_out, d_dist_out, d_count_out, d_evals_out, s);
-    if (e != hipSuccess) return fail(QV_ERR_DEVICE, "hnsw search launch failed: %s", hipGetErrorString(e));
+    if ((rc = traverse_wave(g, d_queries, g->d_qblk.p, &g->hubs.table, nq, k, ef_search, wave_opts(g), grid, d_rows_out, d_dist_out, d_count_out, d_evals_out, s))) return rc;
     HIPCHK(hipEventRecord(g->ev_last, s));
     return QV_OK;
 }

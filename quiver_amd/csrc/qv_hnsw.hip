@@ -524,6 +524,57 @@ __device__ __forceinline__ float hnsw_eval_hop_front(const IndexView& v, const l
     return me ? finalize<M>(acc, qc, rn) : 0.0f;
 }
 
+#ifdef QV_HNSW_P512
+// EXPERIMENT of the measurement build (tools/build_variant.sh p512 qv_hnsw.hip -DQV_HNSW_P512), TIMING ONLY: a hop's rows in groups of 8,
+// 512 contiguous bytes of each row per slab (a quarter of the address translations and DRAM pages of the 128-byte pieces), eight lanes
+// per row each walking 16 elements of the slab, the eight partial chains added WITHOUT the certificate — so the distances are not the
+// reference's bits and no test may run on this build.  What it answers: is the 512-byte shape worth building the certificate for?
+template <int M>
+__device__ __forceinline__ float hnsw_eval_hop_p512(const IndexView& v, const lds_u32* batch_l, lds_u8* slabs_l, const QConst& qc, uint32_t n, uint32_t lane, const lds_u32* qres) {
+    typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    const uint32_t drow = lane >> 3, dslot = lane & 7;
+    const uint32_t ncs = v.dim >> 7, ngr = (n + 7) >> 3, total = ngr * ncs;
+    double rn = 0.0;
+    if constexpr (MT<M>::needs_rnorm) { if (lane < n) rn = v.rnorm[batch_l[lane]]; }
+    float mine = 0.0f;
+    double acc = 0.0;
+    auto issue = [&](uint32_t t) {
+        const uint32_t gr = t / ncs, cs = t - gr * ncs, r = gr * 8 + drow;
+        const uint32_t row = batch_l[r < n ? r : 0u];
+        const float* src = v.rowmaj + (size_t)row * v.dim + cs * 128 + dslot * 4;
+        lds_u8* b = slabs_l + (t & 1) * kHnswSlabBytes;
+#pragma unroll
+        for (int j = 0; j < 4; j++) glds16(src + j * 32, b + j * 1024);
+    };
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    issue(0);
+    for (uint32_t t = 0; t < total; t++) {
+        const uint32_t gr = t / ncs, cs = t - gr * ncs;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 1 < total) issue(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const lds_u8* b = slabs_l + (t & 1) * kHnswSlabBytes;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f4 x = *(lds_f4p)(b + j * 1024 + lane * 16);
+            const f4 q = *(lds_f4p)((const lds_u8*)qres + (cs * 128 + j * 32 + dslot * 4) * 4);
+            acc = __builtin_fma((double)q.x, (double)x.x, acc); acc = __builtin_fma((double)q.y, (double)x.y, acc);
+            acc = __builtin_fma((double)q.z, (double)x.z, acc); acc = __builtin_fma((double)q.w, (double)x.w, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (cs == ncs - 1) {
+            double s = acc;
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            const double got = __shfl(s, (int)(((lane - gr * 8) & 7u) * 8u));
+            if (lane >= gr * 8 && lane < gr * 8 + 8 && lane < n) mine = finalize<M>(got, qc, rn);
+            acc = 0.0;
+        }
+    }
+    return mine;
+}
+#endif
+
 // ---- visited set in buckets (wave-per-query traversal) ------------------------------------------------------------------------
 // The table of a wave slot as buckets of 16 words (64 bytes: one request).  A test reads the node's whole bucket: ONE round trip
 // says present / absent and where the first free word is.  The open-addressed form took one dependent round trip per probe, and
@@ -996,7 +1047,11 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                 if (lane == 0) o.self_dist[qi] = bd[0];
             }
         }
+#ifdef QV_HNSW_HIST
+        if (lane == 0) count_out[qi] = cnt;
+#else
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
+#endif
         wsync();
 #ifdef QV_HNSW_PROF
         if (lane == 0 && blockIdx.x == 1) printf("heap kernel q%u: pop %llu links+vis %llu eval %llu insert %llu other %llu (x10 ns) hops %llu evals %u\n", qi, T[0], T[1], T[2], T[3], T[5], hops, n_eval);
@@ -1265,10 +1320,11 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
             n_list = 0;
             bool first = true;
             // latency form: the adjacency list of the entry most likely to be popped next, requested a hop ahead (see below)
-            uint32_t spec = 0xFFFFFFFFu, spec_deg = 0, spec_cl = 0xFFFFFFFFu;
+            uint32_t spec = 0xFFFFFFFFu, spec_deg = 0, spec_cl = 0xFFFFFFFFu, spec_hl = 0xFFFFu;
             for (;;) {
                 uint32_t nb;
-                bool fronted = false, ffresh = false; uint32_t fc = 0xFFFFFFFFu, fold = kVisEmpty, fpos = 0; uint32_t* fword = nullptr;
+                bool fronted = false, ffresh = false, fhub = false; uint32_t fc = 0xFFFFFFFFu, fold = kVisEmpty, fpos = 0, nrow = 0, frank = 0; uint32_t* fword = nullptr;
+                uint64_t fmask = 0; float fdtab = 0.0f;
                 if (first) {                                                 // :492-506: the entry point itself
                     first = false;
                     wsync();
@@ -1299,38 +1355,53 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     HTICK(0);
                     if (bucketed) {
                         if (cur >= g.n_nodes) continue;
-                        uint32_t fdeg, cl;
-                        if (kSpec && cur == spec) { fdeg = spec_deg; cl = spec_cl; }
-                        else { fdeg = g.l0_deg[cur]; cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu; }
+                        uint32_t fdeg, cl, hl;
+                        if (kSpec && cur == spec) { fdeg = spec_deg; cl = spec_cl; hl = spec_hl; }
+                        else {
+                            fdeg = g.l0_deg[cur]; cl = lane < g.max_m0 ? g.l0_links[(size_t)cur * g.max_m0 + lane] : 0xFFFFFFFFu;
+                            hl = (o.l0_hub && lane < g.max_m0) ? (uint32_t)o.l0_hub[(size_t)cur * g.max_m0 + lane] : 0xFFFFu;
+                        }
                         if (fdeg > 32u) fdeg = 32u;
                         fc = lane < fdeg ? cl : 0xFFFFFFFFu;
                         bool valid = fc < g.n_nodes;
                         if ((repeats_in_list(fc, fdeg) >> lane) & 1ull) valid = false;   // (a repeated node counts at its first occurrence, see below)
                         const uint64_t vm = __ballot(valid);
                         if (!vm) continue;
-                        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)fc, (int)__builtin_ctzll(vm));
-                        wfence();                                            // the previous hop's reads of batch[] / pos[] are done
-                        if (lane < 32u) batch[32 + lane] = valid ? fc : c0;   // every adjacency position names a row that exists
-                        wfence();
-                        HTICK(2);
-                        {
+                        // a HUB's distance comes from the call's hub table (HnswOpts::hub_tab, see k_hub_table): no row is read for it
+                        fhub = valid && hl < o.hub_H;
+                        const uint64_t vrow = __ballot(valid && !fhub);       // links whose rows are read
+                        if (vrow) {
+                            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)fc, (int)__builtin_ctzll(vrow));
+                            wfence();                                        // the previous hop's reads of batch[] / pos[] are done
+                            if (lane < 32u) batch[32 + lane] = (valid && !fhub) ? fc : c0;   // every adjacency position names a row that exists
+                            wfence();
+                            HTICK(2);
                             DmaRole r0;
                             dma_role(r0, v.rowmaj, v.dim, batch_l + 32, fdeg, lane);
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            dma_issue_slab<kHnswSlab>(r0, 0, v.dim4, slabs_l);       // slab 0 of every link, beside the visited test
+#ifndef QV_HNSW_P512
+                            dma_issue_slab<kHnswSlab>(r0, 0, v.dim4, slabs_l);       // slab 0 of every such link, beside the visited test
+#endif
                         }
+                        float dtab = 0.0f;
+                        if (fhub) dtab = o.hub_tab[(size_t)qi * o.hub_H + hl];   // (asked for before it is known to be new: it lands with the test)
                         ffresh = vis_bucket_test(tab, bmask, bshift, fc, valid, fword);
                         HTICK(3);
-                        const uint64_t fm = __ballot(ffresh);
-                        nb = (uint32_t)__builtin_popcountll(fm);
+                        fmask = __ballot(ffresh);
+                        nb = (uint32_t)__builtin_popcountll(fmask);
                         n_vis += nb;
                         if (n_vis > hlimit) { tie = true; break; }
                         if (nb == 0) continue;                               // (slab 0 has landed with the test's answer: nothing left in flight)
                         fold = kVisEmpty;
                         if (ffresh) fold = atomicCAS(fword, kVisEmpty, fc);  // its answer is looked at after the rows
-                        if (ffresh) { const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1)); batch[rank] = fc; pos_l[rank] = lane; }
+                        if (o.hist && ffresh) atomicAdd(&o.hist[fc], 1u);    // (the sampling pass that chooses the hubs)
+                        const uint64_t frow = fmask & vrow;                  // new AND read from its row: compacted for slabs 1..
+                        nrow = (uint32_t)__builtin_popcountll(frow);
+                        frank = (uint32_t)__builtin_popcountll(frow & ((1ull << lane) - 1));
+                        if ((frow >> lane) & 1ull) { batch[frank] = fc; pos_l[frank] = lane; }
                         wfence();
-                        fpos = lane < nb ? pos_l[lane] : 0u;
+                        fpos = lane < nrow ? pos_l[lane] : 0u;
+                        fdtab = dtab;
                         fronted = true;
                         HTICK(1);
                     } else {
@@ -1384,24 +1455,42 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                             const uint64_t m = __ballot(key[s2] != kDeadKey) & ~expd[s2];
                             if (m) spec = (uint32_t)readlane64(key[s2], (uint32_t)__builtin_ctzll(m));
                         }
-                        if (spec < g.n_nodes) { spec_deg = g.l0_deg[spec]; spec_cl = lane < g.max_m0 ? g.l0_links[(size_t)spec * g.max_m0 + lane] : 0xFFFFFFFFu; }
+                        if (spec < g.n_nodes) {
+                            spec_deg = g.l0_deg[spec]; spec_cl = lane < g.max_m0 ? g.l0_links[(size_t)spec * g.max_m0 + lane] : 0xFFFFFFFFu;
+                            spec_hl = (o.l0_hub && lane < g.max_m0) ? (uint32_t)o.l0_hub[(size_t)spec * g.max_m0 + lane] : 0xFFFFu;
+                        }
                         else spec = 0xFFFFFFFFu;
                     }
                 }
                 uint64_t kx;
+                uint64_t have;                                               // the lanes of kx that hold a neighbour (adjacency order = lane order)
                 if (fronted) {
-                    const float dd = hnsw_eval_hop_front<M>(v, batch_l, slabs_l, qc, nb, fpos, lane, qres_l);
-                    kx = lane < nb ? make_key(dd, batch_l[lane]) : kDeadKey;
+                    float dd = 0.0f;
+                    if (nrow) {
+#ifdef QV_HNSW_P512
+                        if constexpr (M == QV_COSINE || M == QV_DOT) dd = hnsw_eval_hop_p512<M>(v, batch_l, slabs_l, qc, nrow, lane, qres_l);
+                        else dd = hnsw_eval_hop_front<M>(v, batch_l, slabs_l, qc, nrow, fpos, lane, qres_l);
+#else
+                        dd = hnsw_eval_hop_front<M>(v, batch_l, slabs_l, qc, nrow, fpos, lane, qres_l);
+#endif
+                    }
+                    // back to the adjacency positions: the lane of link p takes its row's distance from compacted lane frank(p), or the hub table's
+                    const float drow = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)(frank << 2), (int)__float_as_uint(dd)));
+                    kx = ffresh ? make_key(fhub ? fdtab : drow, fc) : kDeadKey;
+                    have = fmask;
                     vis_bucket_settle(tab, bmask, bshift, fc, ffresh, fold);
-                } else kx = eval_keys(nb);
+#ifdef QV_HNSW_HIST
+                    if (evals_out && ffresh) atomicAdd(&evals_out[fc], 1u);   // (measurement build: evals_out is a [n_nodes] visit histogram)
+#endif
+                } else { kx = eval_keys(nb); have = __ballot(lane < nb); }
                 n_eval += nb;
                 HTICK(7);
                 {   // admissions in adjacency order (:553-560).  The worst value only ever decreases, so a neighbour that is not below
                     // it now never will be: one ballot drops those up front (most of a hop once the list is full)
-                    uint64_t pend = __ballot(lane < nb);
+                    uint64_t pend = have;
                     if (n_list >= ef) {
                         const uint32_t w = (uint32_t)(entry_at(ef - 1) >> 32);
-                        pend = __ballot(lane < nb && (uint32_t)(kx >> 32) < w);
+                        pend = have & __ballot((uint32_t)(kx >> 32) < w);
 #ifdef QV_HNSW_PROF
                         full_hops++; full_rows += nb; surv_hops += pend != 0; surv_rows += (uint64_t)__builtin_popcountll(pend);
 #endif
@@ -1696,6 +1785,122 @@ hipError_t launch_hnsw_search_wave(const IndexView& v, const GraphView& g, const
     return hipGetLastError();
 }
 
+
+// ---- hubs ---------------------------------------------------------------------------------------------------------------------
+// MEASUREMENT BUILD ONLY (make VARIANTS=1, QV_HNSW_HUBS=1): built in round 6, measured, not shipped.  The idea: rows that most traversals
+// of a batch read are not gathered at all —
+//   * a sampling pass (the call's first 1024 queries, HnswOpts::hist) counts reads per row; rows read by more than one sampled query in
+//     sixteen become hubs — a copy of them in the tile layout (k_hub_gather) and, beside every level-0 adjacency list, the hub slot of each
+//     link (k_hub_links), kept with the graph until it changes;
+//   * per call, k_hub_table computes distance(query, hub) for EVERY query and hub as a dense pass — mq_tile: the multi-query scan's loop,
+//     one lane per row, eight queries per pass, the same chain in the same order — at the f64 vector rate (~30 TFLOP/s) instead of the
+//     gather's;
+//   * a hop looks a hub's distance up (4 bytes) and reads rows only for the rest.
+// Results cannot change (a table entry is the distance the hop would have computed, bit for bit; a hub is still "visited", admitted and
+// counted: tests/test_gpu_graph.py::test_a_large_call_equals_the_latency_form_the_oracle_and_sees_updates passes with it on) — but the
+// premise does not hold on the corpora of the benchmark: on the 1M x 768 graphs (i.i.d. rows and the 16-dimensional subspace alike) the
+// 8192 most-read rows take 6-7 % of a batch's reads and only ~50 rows are read by more than one query in twelve (QV_TRACE=1 prints the
+// distribution of the sampling pass), so the table would cost twice what it saves and the selection rule declines.  It stays here for
+// corpora with real hubs; the product library neither samples nor builds it (hubs_possible, qv_graph_api.cpp).
+#ifdef QV_VARIANTS
+template <int M, int QB>
+__global__ void __launch_bounds__(256, 2)
+k_hub_table(const float* __restrict__ hub_tiles, const double* __restrict__ hub_rnorm, uint32_t n_hub_tiles, uint32_t dim, uint32_t dim4,
+            const float* __restrict__ queries, const double* __restrict__ qconst, uint32_t nq, float* __restrict__ table) {
+    using Q = typename MT<M>::Q;
+    using A = typename MT<M>::A;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Q* ql = reinterpret_cast<Q*>(smem);                                          // [dim4*4][QB]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t q0 = blockIdx.y * QB;
+    for (uint32_t i = threadIdx.x; i < dim4 * 4 * QB; i += blockDim.x) {
+        const uint32_t d = i / QB, qq = i % QB;
+        const uint32_t qi = q0 + qq < nq ? q0 + qq : nq - 1;
+        ql[i] = d < dim ? (Q)queries[(size_t)qi * dim + d] : (Q)0;
+    }
+    __syncthreads();
+    QConst qc[QB];
+#pragma unroll
+    for (int j = 0; j < QB; j++) { const uint32_t qi = q0 + j < nq ? q0 + j : nq - 1; qc[j].qn = qconst[(size_t)qi * 2]; qc[j].qn32 = (float)qconst[(size_t)qi * 2 + 1]; }
+    const f4* tiles = reinterpret_cast<const f4*>(hub_tiles);
+    const size_t H = (size_t)n_hub_tiles * 64;
+    for (uint32_t t = blockIdx.x * 4 + wave; t < n_hub_tiles; t += gridDim.x * 4) {
+        A acc[QB], qa[QB];
+        mq_tile<M, 4, QB, false>(tiles + (size_t)t * dim4 * 64 + lane, ql, dim4, acc, qa);
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = hub_rnorm[(size_t)t * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < QB; j++)
+            if (q0 + j < nq) table[(size_t)(q0 + j) * H + (size_t)t * 64 + lane] = finalize<M>(acc[j], qc[j], rn);
+    }
+}
+// hub h's row (tile layout) into slot h of the hub tiles; one block per hub, one thread per 16-byte chunk
+__global__ void k_hub_gather(IndexView v, const uint32_t* __restrict__ hub_rows, uint32_t H, float* __restrict__ hub_tiles, double* __restrict__ hub_rnorm) {
+    const uint32_t h = blockIdx.x;
+    if (h >= H) return;
+    const uint32_t row = hub_rows[h];
+    const f4* src = reinterpret_cast<const f4*>(v.tiles) + (size_t)(row >> 6) * v.dim4 * 64 + (row & 63u);
+    f4* dst = reinterpret_cast<f4*>(hub_tiles) + (size_t)(h >> 6) * v.dim4 * 64 + (h & 63u);
+    for (uint32_t c = threadIdx.x; c < v.dim4; c += blockDim.x) dst[(size_t)c * 64] = src[(size_t)c * 64];
+    if (threadIdx.x == 0) hub_rnorm[h] = v.rnorm ? v.rnorm[row] : 0.0;
+}
+__global__ void k_hub_slots(const uint32_t* __restrict__ hub_rows, uint32_t H, uint16_t* __restrict__ slot_of) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < H) slot_of[hub_rows[h]] = (uint16_t)h;
+}
+__global__ void k_hub_links(const uint32_t* __restrict__ l0_links, const uint32_t* __restrict__ l0_deg, uint32_t n_nodes, uint32_t max_m0,
+                            const uint16_t* __restrict__ slot_of, uint16_t* __restrict__ l0_hub) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_nodes * max_m0) return;
+    const uint32_t node = (uint32_t)(i / max_m0), j = (uint32_t)(i % max_m0);
+    const uint32_t c = j < l0_deg[node] ? l0_links[i] : 0xFFFFFFFFu;
+    l0_hub[i] = c < n_nodes ? slot_of[c] : (uint16_t)0xFFFFu;
+}
+
+#endif
+// the hubs' copies and the link -> hub slot map (d_slot_of: [n_nodes] scratch)
+hipError_t launch_hub_build(const IndexView& v, const GraphView& g, const uint32_t* d_hub_rows, uint32_t H, float* d_hub_tiles, double* d_hub_rnorm,
+                            uint16_t* d_slot_of, uint16_t* d_l0_hub, hipStream_t s) {
+#ifndef QV_VARIANTS
+    (void)v; (void)g; (void)d_hub_rows; (void)H; (void)d_hub_tiles; (void)d_hub_rnorm; (void)d_slot_of; (void)d_l0_hub; (void)s;
+    return hipErrorNotSupported;
+#else
+    if (H == 0 || (H & 63u) || H > 65535u - 63u) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_slot_of, 0xFF, (size_t)g.n_nodes * sizeof(uint16_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_hub_gather, dim3(H), dim3(256), 0, s, v, d_hub_rows, H, d_hub_tiles, d_hub_rnorm);
+    hipLaunchKernelGGL(k_hub_slots, dim3((H + 255) / 256), dim3(256), 0, s, d_hub_rows, H, d_slot_of);
+    const size_t n = (size_t)g.n_nodes * g.max_m0;
+    hipLaunchKernelGGL(k_hub_links, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, g.l0_links, g.l0_deg, g.n_nodes, g.max_m0, d_slot_of, d_l0_hub);
+    return hipGetLastError();
+#endif
+}
+// table[q][h] = distance(query q, hub h) for the call's nq queries; d_qblk as for launch_hnsw_search_wave (the queries are converted here
+// for their constants; the traversal's launcher converts them again: 20 us)
+hipError_t launch_hub_table(const IndexView& v, const float* d_hub_tiles, const double* d_hub_rnorm, uint32_t H, const float* d_queries, void* d_qblk, uint32_t nq,
+                            float* d_table, int cus, hipStream_t s) {
+#ifndef QV_VARIANTS
+    (void)v; (void)d_hub_tiles; (void)d_hub_rnorm; (void)H; (void)d_queries; (void)d_qblk; (void)nq; (void)d_table; (void)cus; (void)s;
+    return hipErrorNotSupported;
+#else
+    if (nq == 0 || H == 0) return hipSuccess;
+    double* d_qconst = reinterpret_cast<double*>(static_cast<unsigned char*>(d_qblk) + (size_t)nq * v.dim4 * 4 * sizeof(double));
+    hipError_t e = hipSuccess;
+    constexpr int QB = 8;
+    const uint32_t n_tiles = H / 64, groups = (nq + QB - 1) / QB;
+    const uint32_t gx = std::max(1u, std::min((n_tiles + 3) / 4, std::max(1u, (uint32_t)cus * 2u / std::max(1u, std::min(groups, (uint32_t)cus * 2u)))));
+    QV_DISPATCH_METRIC(v.metric, {
+        using Q = typename MT<MM>::Q;
+        hipLaunchKernelGGL((k_hnsw_prep_queries<MM>), dim3(nq), dim3(64), 0, s, d_queries, v.dim, v.dim4, static_cast<Q*>(d_qblk), d_qconst, (uint32_t*)nullptr);
+        const size_t lds = (size_t)v.dim4 * 4 * QB * sizeof(Q);
+        e = set_lds((k_hub_table<MM, QB>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_hub_table<MM, QB>), dim3(gx, groups), dim3(256), lds, s, d_hub_tiles, d_hub_rnorm, n_tiles, v.dim, v.dim4, d_queries,
+                           static_cast<const double*>(d_qconst), nq, d_table);
+    });
+    return hipGetLastError();
+#endif
+}
 
 // distances of every link of nodes [n0, n0 + nq) (see k_graph_link_dists); d_qblk: hnsw_qblk_bytes(nq, dim4)
 hipError_t launch_graph_link_dists(const IndexView& v, const GraphView& g, void* d_qblk, uint32_t n0, uint32_t nq, float* d_l0_dist, float* d_up_dist,

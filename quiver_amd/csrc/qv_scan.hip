@@ -622,45 +622,7 @@ k_flat_scan_wide(IndexView v, const float* __restrict__ queries, uint32_t k, uin
 // sequential chain over dims 0..D-1.  The query block sits in LDS interleaved by query
 // (q_lds[dim][QB]) so one ds_read_b128 feeds two (f64) or four (f32) queries of one dim.
 // grid = (workgroups, ceil(nq/QB)); partial layout identical to k_flat_scan.
-// one tile for QB queries: acc[j] = Σ_d f(q_j[d], row[d]); FIRST also accumulates the query norms
-template <int M, int U, int QB, bool FIRST>
-__device__ __forceinline__ void mq_tile(const f4* __restrict__ p, const typename MT<M>::Q* __restrict__ q_lds, uint32_t dim4,
-                                        typename MT<M>::A (&acc)[QB], typename MT<M>::A (&qa)[QB]) {
-    using Q = typename MT<M>::Q;
-    constexpr int VW = 16 / sizeof(Q);                          // queries per 16-byte LDS read (2 doubles or 4 floats)
-    typedef Q qvec __attribute__((ext_vector_type(VW)));
-    static_assert(QB % VW == 0, "QB must be a multiple of the LDS vector width");
-#pragma unroll
-    for (int j = 0; j < QB; j++) { acc[j] = 0; if constexpr (FIRST) qa[j] = 0; }
-    auto chunk = [&](uint32_t c, f4 x) {
-        const qvec* qq = reinterpret_cast<const qvec*>(q_lds + (size_t)c * 4 * QB);
-        const float e[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-#pragma unroll
-            for (int g = 0; g < QB / VW; g++) {
-                const qvec a = qq[d * (QB / VW) + g];             // one ds_read_b128, broadcast to the wave
-#pragma unroll
-                for (int t = 0; t < VW; t++) {
-                    const int j = g * VW + t;
-                    acc1<M>(acc[j], a[t], e[d]);
-                    if constexpr (FIRST && M == QV_COSINE) qa[j] = __builtin_fma(a[t], a[t], qa[j]);
-                    else if constexpr (FIRST && M == QV_COSINE_F32) { float pp = a[t] * a[t]; qa[j] = qa[j] + pp; }
-                }
-            }
-        }
-    };
-    uint32_t c0 = 0;
-    for (; c0 + U <= dim4; c0 += U) {
-        f4 x[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) x[u] = __builtin_nontemporal_load(&p[(size_t)(c0 + u) * 64]);
-#pragma unroll
-        for (int u = 0; u < U; u++) chunk(c0 + u, x[u]);
-    }
-    for (; c0 < dim4; c0++) chunk(c0, __builtin_nontemporal_load(&p[(size_t)c0 * 64]));
-}
-
+// (mq_tile — one tile for QB queries — lives in qv_kernels.h: the traversal's hub table uses it too)
 // query blocks for the scalar-operand variant: qblk[group][dim4*4][QB] in the metric's Q type
 template <int M, int QB>
 __global__ void k_prep_qblk(const float* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t dim4, typename MT<M>::Q* __restrict__ qblk) {

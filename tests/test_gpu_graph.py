@@ -272,3 +272,37 @@ def test_wave_per_query_form_with_the_round6_front_identical_to_oracle(metric, d
         # (under-filled — the level quirk's islands on a multi-level graph — the reference answers with the exact top-k, hnsw.go:676-710:
         # the host layer's job, tests/test_gpu_host.py; the graph results themselves are pinned by the latency form above)
     assert filled > 0 or max_level > 1
+
+
+@pytest.mark.parametrize("metric,dim,ef", [("cosine", 64, 64), ("l2", 96, 128), ("dot", 128, 40), ("l2sq", 32, 64), ("cosine_f32", 64, 300), ("l1", 64, 64)])
+def test_a_large_call_equals_the_latency_form_the_oracle_and_sees_updates(metric, dim, ef):
+    """A call of thousands of queries (a wave per query, queries through the counter) against the same queries in calls of 256 (the
+    latency form) and the oracle: rows, float32 bits, counts, evaluation counts; and rows rewritten afterwards (qv_index_update) must be
+    seen by both.  (The measurement build's hub table — QV_HNSW_HUBS=1, qv_hnsw.hip "hubs" — is checked by this test too: it keeps
+    copies of rows.)"""
+    n, m, k, nq = 6000, 16, 10, 2304
+    mid = quiver_amd.metric_id(metric)
+    rows = O.gen_rows(3131, 0, n, dim)
+    idx, deg, links = _knn_graph(rows, metric, m)
+    g = quiver_amd.DeviceGraph(idx, np.zeros(n, np.int8), deg, links, entry=9)
+    qs = np.concatenate([O.gen_rows(3132, 0, nq - 256, dim), rows[np.arange(256) * 17 % n]])
+
+    def check(rows_now):
+        o = O.HNSW(mid, dim, M=m // 2, maxM0=m, efSearch=ef, maxLevel=1, seed=1)
+        o.load_flat(rows_now, deg, links, 9)
+        r, d, c, ev = g.search(qs, k, ef, with_evals=True)                   # 2304 queries: hubs
+        for lo in range(0, nq, 256):                                         # 256 queries: the latency form, no hubs
+            r2, d2, c2, ev2 = g.search(qs[lo:lo + 256], k, ef, with_evals=True)
+            assert np.array_equal(c2, c[lo:lo + 256]) and np.array_equal(ev2, ev[lo:lo + 256]), lo
+            assert np.array_equal(r2, r[lo:lo + 256]) and np.array_equal(d2.view(np.uint32), d[lo:lo + 256].view(np.uint32)), lo
+        for i in range(0, nq, 97):
+            ro, do, eo = o.search(qs[i], k, with_evals=True)
+            assert c[i] == k and r[i].tolist() == ro.tolist() and d[i].tobytes() == do.tobytes() and int(ev[i]) == eo - 1, i
+
+    check(rows)
+    rows2 = rows.copy()
+    hot = np.unique(links[9])[:8]                                            # the entry point's neighbours: read by every traversal
+    for j in hot:
+        rows2[j] = -rows[j] if metric != "l2sq" else rows[j] * np.float32(1.5)
+        idx.update(int(j), rows2[j])
+    check(rows2)
