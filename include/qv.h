@@ -37,6 +37,17 @@
  *   - "_device" variants take device pointers and a hipStream_t (passed as
  *     void*), enqueue work and return without synchronising, so a caller can keep
  *     queries and results resident in HBM and time with HIP events.
+ *   - rows are float32 at this seam.  arrowindex.Graph keeps float64 vectors
+ *     (pkg/arrowindex/graph.go:136-140, :796-858); its only producer in the
+ *     reference, ArrowHNSWIndex, widens float32 columns (index/arrow_hnsw.go:
+ *     222-225), for which QV_L2SQ_F64 over float32 rows is lossless.  Genuine
+ *     float64 input is narrowed on add: the host layer warns
+ *     (quiver_amd/arrowindex.py), nothing fails silently.
+ *   - platform: the library is built for MI355X hosts — Linux on x86-64.  The
+ *     front that lets concurrent callers share passes waits on futex words and
+ *     spins with the x86 PAUSE instruction (quiver_amd/csrc/qv_coalesce.h); the
+ *     library never modifies the process environment (GPU_MAX_HW_QUEUES is the
+ *     host's to set: INTEGRATION.md).
  */
 #ifndef QV_H
 #define QV_H
