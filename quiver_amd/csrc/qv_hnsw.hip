@@ -1393,7 +1393,11 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                         if (n_vis > hlimit) { tie = true; break; }
                         if (nb == 0) continue;                               // (slab 0 has landed with the test's answer: nothing left in flight)
                         fold = kVisEmpty;
+#ifdef QV_HNSW_NOCAS
+                        if (ffresh) __builtin_nontemporal_store(fc, fword);   // (measurement, TIMING ONLY: two lanes of a hop may pick the same word)
+#else
                         if (ffresh) fold = atomicCAS(fword, kVisEmpty, fc);  // its answer is looked at after the rows
+#endif
                         if (o.hist && ffresh) atomicAdd(&o.hist[fc], 1u);    // (the sampling pass that chooses the hubs)
                         const uint64_t frow = fmask & vrow;                  // new AND read from its row: compacted for slabs 1..
                         nrow = (uint32_t)__builtin_popcountll(frow);
