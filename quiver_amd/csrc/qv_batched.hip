@@ -297,18 +297,6 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         load(0, A0, B0);
         load(1, A1, B1);
         uint32_t st = 0;
-#ifdef QV_MFMA_F32_INTERLEAVE
-        // measurement: a step's six operand loads spread between its 32 matrix instructions (one load, five MFMAs, ...) instead of a burst
-        // before them — a lone wave per SIMD issues the burst while the matrix pipe drains
-#define QV_ILV() { for (int i_ = 0; i_ < 6; i_++) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); } __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
-        for (; st + 3 <= steps; st += 3) {
-            __builtin_amdgcn_sched_barrier(0);
-            load(st + 2, A2, B2); mma(A0, B0); QV_ILV() __builtin_amdgcn_sched_barrier(0);
-            load(st + 3, A0, B0); mma(A1, B1); QV_ILV() __builtin_amdgcn_sched_barrier(0);
-            load(st + 4, A1, B1); mma(A2, B2); QV_ILV() __builtin_amdgcn_sched_barrier(0);
-        }
-#undef QV_ILV
-#else
         for (; st + 3 <= steps; st += 3) {                          // sched_barrier: keep the issue order as written
             load(st + 2, A2, B2); __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the loads next to their
             mma(A0, B0);          __builtin_amdgcn_sched_barrier(0);   //  first use and waits vmcnt(0) mid-loop)
@@ -317,7 +305,6 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
             load(st + 4, A1, B1); __builtin_amdgcn_sched_barrier(0);
             mma(A2, B2);          __builtin_amdgcn_sched_barrier(0);
         }
-#endif
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
 #endif

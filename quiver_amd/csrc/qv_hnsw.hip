@@ -1047,11 +1047,7 @@ k_hnsw_search(IndexView v, GraphView g, const typename MT<M>::Q* __restrict__ qb
                 if (lane == 0) o.self_dist[qi] = bd[0];
             }
         }
-#ifdef QV_HNSW_HIST
-        if (lane == 0) count_out[qi] = cnt;
-#else
         if (lane == 0) { count_out[qi] = cnt; if (evals_out) evals_out[qi] = n_eval; }
-#endif
         wsync();
 #ifdef QV_HNSW_PROF
         if (lane == 0 && blockIdx.x == 1) printf("heap kernel q%u: pop %llu links+vis %llu eval %llu insert %llu other %llu (x10 ns) hops %llu evals %u\n", qi, T[0], T[1], T[2], T[3], T[5], hops, n_eval);
@@ -1392,11 +1388,29 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                         n_vis += nb;
                         if (n_vis > hlimit) { tie = true; break; }
                         if (nb == 0) continue;                               // (slab 0 has landed with the test's answer: nothing left in flight)
+                        // Claiming the free words WITHOUT atomics: the table is this wave slot's alone, so the only contenders for a word are the
+                        // hop's own lanes — those whose nodes fall into one bucket all saw the same first free word.  They take consecutive
+                        // words in lane order (a bucket fills from word 0 up, so the words behind the first free one are free too); a lane
+                        // that would run past its bucket's end is left to vis_bucket_settle (test again + atomicCAS, after the rows).
+                        // 39 M returning atomics per 8192 traversals cost 4.5 % of the call (profiles/r06_hnsw_front.txt).
                         fold = kVisEmpty;
-#ifdef QV_HNSW_NOCAS
-                        if (ffresh) __builtin_nontemporal_store(fc, fword);   // (measurement, TIMING ONLY: two lanes of a hop may pick the same word)
+#ifdef QV_HNSW_CAS_CLAIMS
+                        if (ffresh) fold = atomicCAS(fword, kVisEmpty, fc);  // (measurement build: the claim as a returning atomic, as first built)
 #else
-                        if (ffresh) fold = atomicCAS(fword, kVisEmpty, fc);  // its answer is looked at after the rows
+                        {
+                            const uint32_t bid = (uint32_t)(reinterpret_cast<uintptr_t>(fword) >> 6);
+                            uint32_t brank = 0;
+                            for (uint64_t mm = fmask; mm; mm &= mm - 1) {
+                                const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+                                const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)bid, (int)j);
+                                brank += (bid == bj && lane > j) ? 1u : 0u;
+                            }
+                            if (ffresh) {
+                                const uint32_t fe = (uint32_t)(reinterpret_cast<uintptr_t>(fword) >> 2) & 15u;
+                                if (fe + brank < 16u) __builtin_nontemporal_store(fc, fword + brank);
+                                else fold = 0u;                              // (any value but "empty": settled later)
+                            }
+                        }
 #endif
                         if (o.hist && ffresh) atomicAdd(&o.hist[fc], 1u);    // (the sampling pass that chooses the hubs)
                         const uint64_t frow = fmask & vrow;                  // new AND read from its row: compacted for slabs 1..
@@ -1483,9 +1497,6 @@ k_hnsw_search_wave(IndexView v, GraphView g, const typename MT<M>::Q* __restrict
                     kx = ffresh ? make_key(fhub ? fdtab : drow, fc) : kDeadKey;
                     have = fmask;
                     vis_bucket_settle(tab, bmask, bshift, fc, ffresh, fold);
-#ifdef QV_HNSW_HIST
-                    if (evals_out && ffresh) atomicAdd(&evals_out[fc], 1u);   // (measurement build: evals_out is a [n_nodes] visit histogram)
-#endif
                 } else { kx = eval_keys(nb); have = __ballot(lane < nb); }
                 n_eval += nb;
                 HTICK(7);
