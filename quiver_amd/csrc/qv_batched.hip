@@ -1947,6 +1947,228 @@ k_cand_exact(IndexView v, const float* __restrict__ queries, const uint32_t* __r
     if (i < cap) keys_ex[(size_t)q * cap + i] = key;
 }
 
+// The same, a WAVE per 32 survivors of one query — the traversal's row machinery (qv_hnsw.hip: hnsw_eval_hop_front) on a list of
+// rows that is known up front.  A lane per row walking its 192 chunks asks for one line per step and waits for it (k_cand_exact:
+// 2.0 TB/s of useful bytes from the row-major copy, 0.73 from the tiles at k = 1000); here the wave's 64 lanes request 128 bytes
+// of each of the 32 rows per slab straight into LDS (global_load_lds, 16 bytes per lane, two 4 KiB buffers: slab s + 1 is in
+// flight while lanes 0-31 walk slab s of their rows in element order), and the query stays in LDS as the caller's float32 words,
+// a word per lane and slab, handed to the steps by v_readlane.  Rows come from the row-major copy when the index keeps one
+// (a row's slab piece = 128 contiguous bytes = two 64-byte requests, all used) and from the tiles otherwise (a row's chunk c is 16
+// bytes at tile + c KiB: one 64-byte request per 16 bytes, 4 x the bytes — the layout's price, paid here at the rate of a
+// stream of independent requests instead of a chain of round trips).  Arithmetic: acc1 / finalize, element order, as everywhere.
+typedef __attribute__((address_space(3))) unsigned char rs_lds_u8;
+typedef __attribute__((address_space(3))) uint32_t rs_lds_u32;
+constexpr uint32_t kRsSlabBytes = 32 * 8 * 16;
+__device__ __forceinline__ void rs_glds16(const float* g, rs_lds_u8* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+template <int M>
+__global__ void __launch_bounds__(64)
+k_cand_exact_wave(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ surv, const uint32_t* __restrict__ n_surv, uint32_t cap,
+                  const double* __restrict__ qnorms, uint64_t* __restrict__ keys_ex) {
+    using Q = typename MT<M>::Q;
+    typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    extern __shared__ __align__(16) unsigned char smem[];
+    rs_lds_u8* slabs = (rs_lds_u8*)smem;                               // 2 x 4 KiB
+    rs_lds_u32* qres = (rs_lds_u32*)(slabs + 2 * kRsSlabBytes);        // the query, float32 words, zero beyond dim: nslab x 32
+    // grid (nq, cap / 32): the query in x, so that the few working groups of every query spread over the XCDs (see k_cand_exact)
+    const uint32_t q = blockIdx.x, base = blockIdx.y * 32u, lane = threadIdx.x;
+    const uint32_t ns = n_surv[q];
+    if (base >= ns) { if (lane < 32 && base + lane < cap) keys_ex[(size_t)q * cap + base + lane] = kDeadKey; return; }
+    const uint32_t n = ns - base < 32u ? ns - base : 32u;
+    const uint32_t nslab = (v.dim4 + 7) >> 3;
+    const bool me = lane < n;
+    // lanes beyond the count take the group's first row: valid memory, LDS slots nobody reads
+    const uint32_t myrow = surv[(size_t)q * cap + base + (me ? lane : 0u)];
+    double rn = 0.0;
+    if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[myrow];
+    for (uint32_t i = lane; i < nslab * 32u; i += 64u) qres[i] = i < v.dim ? __float_as_uint(queries[(size_t)q * v.dim + i]) : 0u;
+    // this lane's requests: row (8 g + lane / 8) of group g, slot lane % 8; the slot's chunk is swizzled by the row so that the
+    // walkers' 16-byte reads (32 lanes, rows 128 bytes apart) spread over the banks
+    const uint32_t drow = lane >> 3, dslot = lane & 7u, ng = (n + 7u) >> 3;
+    const bool rm = v.rowmaj != nullptr && (v.dim & 3u) == 0;
+    const size_t cstride = rm ? 4 : 256;                                // floats between two chunks of a row
+    const float* src[4]; uint32_t sw[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t r = (uint32_t)__shfl((int)myrow, (int)((uint32_t)g * 8u + drow));
+        sw[g] = dslot ^ drow ^ ((uint32_t)g & 1u);
+        src[g] = (rm ? v.rowmaj + (size_t)r * v.dim : v.tiles + ((size_t)(r >> 6) * v.dim4 * 64 + (r & 63u)) * 4) + (size_t)sw[g] * cstride;
+    }
+    auto issue = [&](uint32_t sl) {
+        rs_lds_u8* buf = slabs + (sl & 1u) * kRsSlabBytes;
+        const uint32_t c0 = sl * 8u;
+        if (c0 + 8u <= v.dim4) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) if ((uint32_t)g < ng) rs_glds16(src[g] + (size_t)c0 * cstride, buf + g * 1024);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; g++) if ((uint32_t)g < ng && c0 + sw[g] < v.dim4) rs_glds16(src[g] + (size_t)c0 * cstride, buf + g * 1024);
+        }
+    };
+    issue(0);
+    typename MT<M>::A acc = 0;
+    const uint32_t mg = lane >> 3, mr = lane & 7u, msw = mr ^ (mg & 1u);   // (as a walker: lane = row of the group, lanes 0..31)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the query words are in LDS (a single wave: no barrier)
+    uint32_t qw = qres[lane & 31u];
+    for (uint32_t sl = 0; sl < nslab; sl++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // slab sl has landed
+        uint32_t qn = 0;
+        if (sl + 1 < nslab) { issue(sl + 1); qn = qres[(sl + 1) * 32u + (lane & 31u)]; }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t nc = v.dim4 - sl * 8u < 8u ? v.dim4 - sl * 8u : 8u;
+        if (me) {
+            const rs_lds_u8* mine = slabs + (sl & 1u) * kRsSlabBytes + (mg & 3u) * 1024 + mr * 128;
+            if (nc == 8u) {
+                f4 x[2];
+                x[0] = *(lds_f4p)(mine + ((0u ^ msw) << 4));
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int cur = c & 1, nxt = cur ^ 1;
+                    if (c + 1 < 8) x[nxt] = *(lds_f4p)(mine + (((uint32_t)(c + 1) ^ msw) << 4));
+                    const Q q0 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, 4 * c)), q1 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, 4 * c + 1));
+                    const Q q2 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, 4 * c + 2)), q3 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, 4 * c + 3));
+                    acc1<M>(acc, q0, x[cur].x); acc1<M>(acc, q1, x[cur].y); acc1<M>(acc, q2, x[cur].z); acc1<M>(acc, q3, x[cur].w);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (uint32_t c = 0; c < nc; c++) {                       // the last slab of a row whose chunk count is no multiple of 8
+                    const f4 x = *(lds_f4p)(mine + ((c ^ msw) << 4));
+                    const int cl = __builtin_amdgcn_readfirstlane((int)(4 * c));      // (v_readlane ignores the exec mask: lanes beyond the count still hold the query)
+                    const Q q0 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, cl)), q1 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, cl + 1));
+                    const Q q2 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, cl + 2)), q3 = (Q)__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)qw, cl + 3));
+                    acc1<M>(acc, q0, x.x); acc1<M>(acc, q1, x.y); acc1<M>(acc, q2, x.z); acc1<M>(acc, q3, x.w);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this slab's buffer is read before it is refilled
+        qw = qn;
+    }
+    QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+    if constexpr (M == QV_COSINE) qc.qn = qnorms[2 * q + 1];
+    if (lane < 32 && base + lane < cap) keys_ex[(size_t)q * cap + base + lane] = me ? make_key(finalize<M>(acc, qc, rn), myrow) : kDeadKey;
+}
+
+// Many survivors and no row-major copy: a pass over the TILES instead of a gather.  From the tiles a survivor's row costs a 64-byte
+// request per 16-byte chunk — 12 KiB for a 3 KiB row — and at k = 1000 the 540 000 survivors of 256 queries over a million rows
+// (35 per 64-row tile) ask for more than twice the corpus: 1.7 ms.  Here the (query, row) pairs are sorted by tile (count, scan,
+// scatter: three small kernels), and a wave per tile streams the tile through LDS slab by slab — contiguous KiBs, every byte used,
+// tiles without a survivor not touched — while each lane walks ITS pair: the row's chunk from LDS, the query's from L1/L2 (a
+// lane's own 16 bytes per chunk; consecutive chunks share a line).  A tile with more than 64 pairs is streamed once more per 64.
+// Same chain per pair as everywhere (acc1 / finalize in element order), keys into the pairs' own slots.
+__global__ void __launch_bounds__(256)
+k_tp_count(const uint32_t* __restrict__ surv, const uint32_t* __restrict__ n_surv, uint32_t cap, uint32_t* __restrict__ tile_cnt, uint64_t* __restrict__ keys_ex) {
+    const uint32_t q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    if (i < n_surv[q]) atomicAdd(&tile_cnt[surv[(size_t)q * cap + i] >> 6], 1u);
+    else keys_ex[(size_t)q * cap + i] = kDeadKey;
+}
+// exclusive scan of the tiles' counts (one workgroup: 15 625 tiles per million rows); the counts become zero: the scatter's cursors
+__global__ void __launch_bounds__(1024)
+k_tp_scan(uint32_t* __restrict__ tile_cnt, uint32_t n_tiles, uint32_t* __restrict__ tile_off) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 4096) {
+        const uint32_t t0 = base + threadIdx.x * 4;
+        uint32_t c[4], mine = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { c[u] = t0 + u < n_tiles ? tile_cnt[t0 + u] : 0u; mine += c[u]; }
+        const uint32_t inc = wave_incl_scan(mine, lane);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (uint32_t x = 0; x < wave; x++) before += wsum[x];
+        uint32_t run = before + inc - mine;
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (t0 + u < n_tiles) { tile_off[t0 + u] = run; tile_cnt[t0 + u] = 0u; run += c[u]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_off[n_tiles] = carry_s;
+}
+__global__ void __launch_bounds__(256)
+k_tp_scatter(const uint32_t* __restrict__ surv, const uint32_t* __restrict__ n_surv, uint32_t cap, const uint32_t* __restrict__ tile_off,
+             uint32_t* __restrict__ tile_cnt, uint2* __restrict__ pairs) {
+    const uint32_t q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap || i >= n_surv[q]) return;
+    const uint32_t row = surv[(size_t)q * cap + i], t = row >> 6;
+    pairs[tile_off[t] + atomicAdd(&tile_cnt[t], 1u)] = make_uint2(q * cap + i, row);      // (nq x cap < 2^32: the launcher's condition)
+}
+constexpr uint32_t kTpSlabBytes = 8 * 1024;                                // 8 chunks of the tile's 64 rows
+template <int M>
+__global__ void __launch_bounds__(64)
+k_tp_exact(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ tile_off, const uint2* __restrict__ pairs, uint32_t cap,
+           const double* __restrict__ qnorms, uint64_t* __restrict__ keys_ex) {
+    using Q = typename MT<M>::Q;
+    typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    extern __shared__ __align__(16) unsigned char smem[];
+    rs_lds_u8* slabs = (rs_lds_u8*)smem;                               // 2 x 8 KiB
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    const uint32_t p_lo = tile_off[t], p_hi = tile_off[t + 1];
+    if (p_lo == p_hi) return;
+    const float* tile = v.tiles + (size_t)t * v.dim4 * 256 + lane * 4;  // this lane's 16 bytes of every chunk's KiB
+    const uint32_t nslab = (v.dim4 + 7) >> 3;
+    auto issue = [&](uint32_t sl) {
+        rs_lds_u8* buf = slabs + (sl & 1u) * kTpSlabBytes;
+        const uint32_t c0 = sl * 8u;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) if (c0 + c < v.dim4) rs_glds16(tile + (size_t)(c0 + c) * 256, buf + c * 1024);
+    };
+    for (uint32_t p0 = p_lo; p0 < p_hi; p0 += 64) {
+        const bool me = p0 + lane < p_hi;
+        const uint2 pr = pairs[me ? p0 + lane : p_lo];
+        const uint32_t q = pr.x / cap, r = pr.y & 63u;
+#ifdef QV_TP_QBROADCAST
+        const f4* qp = reinterpret_cast<const f4*>(queries + (size_t)(pairs[p_lo].x / cap) * v.dim);   // TIMING ONLY: one query for all lanes
+#else
+        const f4* qp = reinterpret_cast<const f4*>(queries + (size_t)q * v.dim);       // (dim % 4 == 0: the launcher's condition)
+#endif
+        double rn = 0.0;
+        if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[pr.y];
+        QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
+        if constexpr (M == QV_COSINE) qc.qn = qnorms[2 * q + 1];
+        f4 qa[8], qb[8];
+        auto qload = [&](f4* dst, uint32_t sl) {
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++) { const uint32_t cc = sl * 8u + c < v.dim4 ? sl * 8u + c : v.dim4 - 1; dst[c] = qp[cc]; }
+        };
+        auto walk = [&](typename MT<M>::A& acc, const f4* qq, uint32_t sl) {
+            const rs_lds_u8* mine = slabs + (sl & 1u) * kTpSlabBytes + r * 16;
+            const uint32_t nc = v.dim4 - sl * 8u < 8u ? v.dim4 - sl * 8u : 8u;
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++) {
+                if (c < nc) {
+                    const f4 x = *(lds_f4p)(mine + c * 1024);
+                    acc1<M>(acc, (Q)qq[c].x, x.x); acc1<M>(acc, (Q)qq[c].y, x.y); acc1<M>(acc, (Q)qq[c].z, x.z); acc1<M>(acc, (Q)qq[c].w, x.w);
+                }
+            }
+        };
+        typename MT<M>::A acc = 0;
+        issue(0); qload(qa, 0);
+        for (uint32_t sl = 0; sl < nslab; sl += 2) {                    // two slabs per turn: the query registers alternate without copies
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (sl + 1 < nslab) { issue(sl + 1); qload(qb, sl + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            walk(acc, qa, sl);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (sl + 1 >= nslab) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (sl + 2 < nslab) { issue(sl + 2); qload(qa, sl + 2); }
+            __builtin_amdgcn_sched_barrier(0);
+            walk(acc, qb, sl + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (me) keys_ex[pr.x] = make_key(finalize<M>(acc, qc, rn), pr.y);
+    }
+}
+
 // 1 = fp32 MFMA chain (BASELINE configs[2] as written), 2 = bfloat16 x 3, 3 = bfloat16 x 1; QV_MFMA_FILTER unset: the one-term
 // filter up to 1536 dimensions, three terms above.  Its window (2 x 7.9e-3 |q||r|) is measured in units of the scores' spread,
 // which shrinks like 1/sqrt(dim) on unstructured data: 256 queries x 3 GB of rows take 1.93 / 1.14 / 1.08 / 1.39 / 1.34 / 2.55 ms at
@@ -2026,7 +2248,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     b += (size_t)nq * ccap * 8;                              // candidates: rows + fp32 scores
     b += (size_t)nq * 8 + 256;                               // capacity word + counters, overflow flags
     if (batched_large_k(k))                                  // keys of the upper bounds and of the exact distances, lower bounds, survivors, counters, norms, selection
-        b += (size_t)nq * ccap * (8 + 8 + 4 + 4) + (size_t)nq * (4 + 16) + 1024 + select_workspace_bytes(nq, k);
+        b += (size_t)nq * ccap * (8 + 8 + 4 + 4) + (size_t)nq * (4 + 16) + 1024 + select_workspace_bytes(nq, k) + (size_t)(v.n_tiles + 2) * 8 + 512;
     b += (size_t)nq * k * 8;                                 // sample rows/dist
     b += (size_t)nq * k * 16 + 256;                          // k_sample_bound's partial lists (up to four parts per query)
     b += (size_t)nq_pad * batched_sample_rows(v, k) * 4 + (size_t)nq_pad * (batched_sample_rows(v, k) / 128 + 2) * 4 + 256;   // the sample's scores (bfloat16 filter: bound without an exact scan) and per-group minima
@@ -2056,7 +2278,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     uint32_t* cnt = reinterpret_cast<uint32_t*>(w + off) + 1; off += (size_t)nq * 4 + 4;   // cnt[-1]: the capacity, for the filter kernels
     uint32_t* ovf = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
     // large k: the selections' arrays
-    uint64_t* keys_hi = nullptr; uint64_t* keys_ex = nullptr; float* lo_b = nullptr; uint32_t* surv = nullptr; uint32_t* nsurv = nullptr; double* qnorms = nullptr; void* sel_ws = nullptr;
+    uint64_t* keys_hi = nullptr; uint64_t* keys_ex = nullptr; float* lo_b = nullptr; uint32_t* surv = nullptr; uint32_t* nsurv = nullptr; double* qnorms = nullptr; void* sel_ws = nullptr; uint32_t* tp_cnt = nullptr; uint32_t* tp_off = nullptr;
     if (large_k) {
         off = (off + 255) / 256 * 256;
         keys_hi = reinterpret_cast<uint64_t*>(w + off); off += (size_t)nq * ccap * 8;
@@ -2067,6 +2289,9 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         nsurv = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * 4;
         off = (off + 255) / 256 * 256;
         sel_ws = w + off; off += select_workspace_bytes(nq, k);
+        tp_cnt = reinterpret_cast<uint32_t*>(w + off); off += (size_t)(v.n_tiles + 2) * 4;
+        tp_off = reinterpret_cast<uint32_t*>(w + off); off += (size_t)(v.n_tiles + 2) * 4;
+        off = (off + 255) / 256 * 256;
     }
     uint32_t* srows = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * k * 4;
     float* sdist = reinterpret_cast<float*>(w + off); off += (size_t)nq * k * 4;
@@ -2246,13 +2471,28 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         // selection's output (the sample's bound in sdist has been consumed by k_mfma_prep)
         const dim3 cgrid((ccap + 255) / 256, nq);
         const size_t lds_x = query_lds_bytes(v.metric, v.dim4);
+        const size_t lds_w = 2 * (size_t)kRsSlabBytes + (size_t)((v.dim4 + 7) / 8) * 128;
+        static const int wave_mode = dev_env_int("QV_LK_EXACT_WAVE", 1);
+        const bool wave_exact = wave_mode == 1 && lds_w <= 64 * 1024;
+        // gather or tile pass: ~2.1 k survivors per query of unstructured rows, 12 KiB of requests each at ~3.5 TB/s, against the
+        // corpus once at ~5.5 TB/s and 60 us for the three sorting kernels (256 queries x 1M x 768: from k ~ 300)
+        static const int tp_mode = dev_env_int("QV_LK_TILE_PASS", 1);   // 2 = never, 3 = always (measurements)
+        const double t_gather = 2.1 * k * nq * (double)v.dim4 * 64.0 / 3.5e12, t_pass = (double)v.n_rows * v.dim4 * 16.0 / 5.5e12 + 60e-6;
+        const bool tile_pass = v.rowmaj == nullptr && (v.dim & 3u) == 0 && (uint64_t)nq * ccap < (1ull << 32) && tp_mode != 2 && (tp_mode == 3 || t_gather > t_pass);
 #define QV_LK(MMM) { e = set_lds(k_cand_qnorms<MMM>, (size_t)v.dim * 4); if (e != hipSuccess) return e;                                                 \
         hipLaunchKernelGGL(k_cand_qnorms<MMM>, dim3(nq), dim3(64), (size_t)v.dim * 4, s, d_queries, v.dim, qnorms);                                         \
         hipLaunchKernelGGL(k_cand_bounds<MMM>, cgrid, dim3(256), 0, s, v, cand, cscore, cnt, ccap, eq, qnorms, keys_hi, lo_b, ovf, nsurv);                 \
         e = launch_select_topk(keys_hi, ccap, ccap, nq, k, k, sel_ws, srows, sdist, s, false, false); if (e != hipSuccess) return e;                       \
         hipLaunchKernelGGL(k_cand_survive, cgrid, dim3(256), 0, s, cand, cnt, ccap, lo_b, sdist, k, surv, nsurv);                                          \
-        e = set_lds(k_cand_exact<MMM, 32>, lds_x); if (e != hipSuccess) return e;                                                                           \
-        hipLaunchKernelGGL((k_cand_exact<MMM, 32>), dim3(nq, (ccap + 255) / 256), dim3(256), lds_x, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex);                         \
+        if (tile_pass) {                                                                                                                                    \
+            (void)hipMemsetAsync(tp_cnt, 0, (size_t)(v.n_tiles + 1) * 4, s);                                                                                 \
+            hipLaunchKernelGGL(k_tp_count, cgrid, dim3(256), 0, s, surv, nsurv, ccap, tp_cnt, keys_ex);                                                     \
+            hipLaunchKernelGGL(k_tp_scan, dim3(1), dim3(1024), 0, s, tp_cnt, v.n_tiles, tp_off);                                                            \
+            hipLaunchKernelGGL(k_tp_scatter, cgrid, dim3(256), 0, s, surv, nsurv, ccap, tp_off, tp_cnt, reinterpret_cast<uint2*>(keys_hi));                \
+            hipLaunchKernelGGL(k_tp_exact<MMM>, dim3(v.n_tiles), dim3(64), 2 * (size_t)kTpSlabBytes, s, v, d_queries, tp_off, reinterpret_cast<const uint2*>(keys_hi), ccap, qnorms, keys_ex); \
+        } else if (wave_exact) { hipLaunchKernelGGL(k_cand_exact_wave<MMM>, dim3(nq, ccap / 32), dim3(64), lds_w, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex); }     \
+        else { e = set_lds(k_cand_exact<MMM, 32>, lds_x); if (e != hipSuccess) return e;                                                                    \
+        hipLaunchKernelGGL((k_cand_exact<MMM, 32>), dim3(nq, (ccap + 255) / 256), dim3(256), lds_x, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex); }                       \
         e = launch_select_topk(keys_ex, ccap, ccap, nq, k, k, sel_ws, d_rows_out, d_dist_out, s, false, false); if (e != hipSuccess) return e; }
         if (v.metric == QV_COSINE) QV_LK(QV_COSINE) else if (v.metric == QV_DOT) QV_LK(QV_DOT) else if (v.metric == QV_L2) QV_LK(QV_L2) else QV_LK(QV_L2SQ)
 #undef QV_LK

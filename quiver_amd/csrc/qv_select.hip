@@ -131,8 +131,11 @@ k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
 #define SELTK()
 #endif
     SELTK();
-    uint32_t nc = s->n_cand < cap ? s->n_cand : cap;
-    const uint64_t* src = cand + (size_t)q * cap;
+    // st == nullptr: no global windows ran — the query's n keys (n <= cap) come straight from the array and the selection happens
+    // here (launch_select_topk: a few thousand keys per query, where six launches cost more than the work)
+    const bool direct = st == nullptr;
+    uint32_t nc = direct ? n : (s->n_cand < cap ? s->n_cand : cap);
+    const uint64_t* src = direct ? keys + (size_t)q * stride : cand + (size_t)q * cap;
     for (uint32_t i = threadIdx.x; i < nc; i += kSelSortBlock) a[i] = src[i];
     const uint32_t lane_ = lane, wave_ = wave;
     // hh[0 .. nb) holds a histogram (nb <= 4096, already synchronised): the digit d whose bin holds the krem-th key in bin order,
@@ -158,7 +161,7 @@ k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
         d_out = r_d; cum_out = r_cum; bucket_out = r_bucket;
         __syncthreads();
     };
-    if (!s->done) {
+    if (!direct && !s->done) {
         // more equal distances than the sort holds: the answer takes the k_rem of them with the smallest rows
         const unsigned long long tie = s->prefix >> 32;
         const uint32_t want = s->k_rem;
@@ -363,6 +366,14 @@ hipError_t launch_select_topk(const uint64_t* d_keys, size_t stride, uint32_t n,
     hipError_t e = hipSuccess;
     // 8 KiB of keys per workgroup and round; enough workgroups to fill the chip, no more than the keys can feed
     const uint32_t grid = std::max(1u, std::min(1024u, (n + 4 * 2 * kSelBlock - 1) / (4 * 2 * kSelBlock)));
+    if (!window0_counted && n <= 16384u) {
+        // few keys per query (the candidate lists of a batch: 4096-16384 slots): one workgroup per query takes them all into LDS
+        const size_t lds_d = (size_t)std::max<uint32_t>(n, 64u) * sizeof(uint64_t);
+        e = set_lds(k_select_sort, lds_d);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_select_sort, dim3(nq), dim3(kSelSortBlock), lds_d, s, d_keys, stride, n, kk, k_stride, n, (SelState*)nullptr, (const uint64_t*)nullptr, d_rows_out, d_dist_out, 0);
+        return hipGetLastError();
+    }
     if (!window0_counted) {
         e = select_prepare(d_ws, nq, kk, &st, &hist, s);
         if (e != hipSuccess) return e;

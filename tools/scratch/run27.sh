@@ -1,0 +1,18 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; root=$PWD
+export TMPDIR=/tmp DEV_REPS=30
+out=$root/gpurun_out/r06_largek_before.txt; : > $out
+for k in 100 1000; do for rm in 0 1; do
+  export DEV_ROWMAJOR=$rm
+  d=/tmp/lk_${k}_$rm; rm -rf $d
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $d -o p -- python3 $root/tools/dev_batched.py cosine 256 1000000 768 $k > /tmp/lk.log 2>&1)
+  echo "== k=$k rowmajor=$rm  $(grep batched /tmp/lk.log | cut -c1-140)" >> $out
+  f=$(find $d -name "*kernel_stats.csv" | head -1)
+  python3 - "$f" >> $out <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"]
+    if any(x in n for x in ("rescore", "cand_", "qreg", "sample", "prep", "select", "filter")) and int(r["Calls"]) >= 30:
+        print("  %-70s calls %4s avg %8.1f us" % (n[:70], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+done; done
+cat $out
