@@ -1900,10 +1900,13 @@ k_cand_bounds(IndexView v, const uint32_t* __restrict__ cand_rows, const float* 
 // survivors: candidates whose lower bound does not exceed H_q = the k-th smallest upper bound (sel_dist[q][k - 1]; +inf = keep all)
 __global__ void __launch_bounds__(256)
 k_cand_survive(const uint32_t* __restrict__ cand_rows, const uint32_t* __restrict__ cand_cnt, uint32_t cap, const float* __restrict__ lo_in,
-               const float* __restrict__ sel_dist, uint32_t k, uint32_t* __restrict__ surv, uint32_t* __restrict__ n_surv) {
+               const float* __restrict__ sel_dist, uint32_t k, uint32_t* __restrict__ surv, uint32_t* __restrict__ n_surv,
+               const float* __restrict__ guess /* [nq][ks] or null */, uint32_t ks, uint32_t* __restrict__ overflow) {
     const uint32_t q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x, lane = lane_id();
     const uint32_t cnt = cand_cnt[q] <= cap ? cand_cnt[q] : 0u;
     const float H = sel_dist[(size_t)q * k + (k - 1)];
+    // a guessed bound U holds when k candidates are at most U away (batched_guess); if not, the query is handed back
+    if (guess != nullptr && !(H <= guess[(size_t)q * ks + (ks - 1)])) { if (i == 0) overflow[q] = 1; return; }
     const bool take = i < cnt && lo_in[(size_t)q * cap + i] <= H;
     const uint64_t m = __ballot(take);
     if (m == 0) return;
@@ -1913,6 +1916,7 @@ k_cand_survive(const uint32_t* __restrict__ cand_rows, const uint32_t* __restric
     if (take) surv[(size_t)q * cap + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = cand_rows[(size_t)q * cap + i];
 }
 
+#ifdef QV_VARIANTS
 // exact distances of the survivors: the scan's arithmetic, a lane per row (its chunks are a gather: requests pinned per block);
 // keys (distance, row), dead beyond the survivors.
 template <int M, int U>
@@ -1947,6 +1951,7 @@ k_cand_exact(IndexView v, const float* __restrict__ queries, const uint32_t* __r
     if (i < cap) keys_ex[(size_t)q * cap + i] = key;
 }
 
+#endif
 // The same, a WAVE per 32 survivors of one query — the traversal's row machinery (qv_hnsw.hip: hnsw_eval_hop_front) on a list of
 // rows that is known up front.  A lane per row walking its 192 chunks asks for one line per step and waits for it (k_cand_exact:
 // 2.0 TB/s of useful bytes from the row-major copy, 0.73 from the tiles at k = 1000); here the wave's 64 lanes request 128 bytes
@@ -2099,71 +2104,78 @@ k_tp_scatter(const uint32_t* __restrict__ surv, const uint32_t* __restrict__ n_s
     const uint32_t row = surv[(size_t)q * cap + i], t = row >> 6;
     pairs[tile_off[t] + atomicAdd(&tile_cnt[t], 1u)] = make_uint2(q * cap + i, row);      // (nq x cap < 2^32: the launcher's condition)
 }
-constexpr uint32_t kTpSlabBytes = 8 * 1024;                                // 8 chunks of the tile's 64 rows
-template <int M>
+// SL chunks per slab: the tile's (SL KiB: 64 rows x SL x 16 bytes, a KiB per request instruction) and the 64 pairs' queries' (SL KiB:
+// 64 x SL x 16 bytes, SL lanes per query and instruction = 16 SL bytes contiguous per query), both by global_load_lds, both double-
+// buffered.  (A first form read the queries with a 16-byte load per lane and chunk: 64 different lines per instruction, 300 of its
+// 876 us at k = 1000.)  The queries' pieces are swizzled by the pair so that the walkers' 16-byte reads spread over the banks.
+template <int M, int SL>
 __global__ void __launch_bounds__(64)
 k_tp_exact(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ tile_off, const uint2* __restrict__ pairs, uint32_t cap,
            const double* __restrict__ qnorms, uint64_t* __restrict__ keys_ex) {
     using Q = typename MT<M>::Q;
     typedef const __attribute__((address_space(3))) f4* lds_f4p;
+    constexpr uint32_t kSlab = SL * 1024, kPer = 64 / SL;              // bytes of a slab; pairs per query-request instruction
     extern __shared__ __align__(16) unsigned char smem[];
-    rs_lds_u8* slabs = (rs_lds_u8*)smem;                               // 2 x 8 KiB
+    rs_lds_u8* tbuf = (rs_lds_u8*)smem;                                // 2 x SL KiB: the tile
+    rs_lds_u8* qbuf = tbuf + 2 * kSlab;                                // 2 x SL KiB: the pairs' queries
     const uint32_t t = blockIdx.x, lane = threadIdx.x;
     const uint32_t p_lo = tile_off[t], p_hi = tile_off[t + 1];
     if (p_lo == p_hi) return;
     const float* tile = v.tiles + (size_t)t * v.dim4 * 256 + lane * 4;  // this lane's 16 bytes of every chunk's KiB
-    const uint32_t nslab = (v.dim4 + 7) >> 3;
-    auto issue = [&](uint32_t sl) {
-        rs_lds_u8* buf = slabs + (sl & 1u) * kTpSlabBytes;
-        const uint32_t c0 = sl * 8u;
-#pragma unroll
-        for (uint32_t c = 0; c < 8; c++) if (c0 + c < v.dim4) rs_glds16(tile + (size_t)(c0 + c) * 256, buf + c * 1024);
-    };
+    const uint32_t nslab = (v.dim4 + SL - 1) / SL;
+    const uint32_t dpair = lane / SL, dslot = lane % SL;               // as a requester of query pieces: pair (j kPer + dpair) in instruction j
+    auto swz = [](uint32_t p) { return SL == 8 ? (p >> 1) & 7u : (p >> 2) & 3u; };
     for (uint32_t p0 = p_lo; p0 < p_hi; p0 += 64) {
         const bool me = p0 + lane < p_hi;
-        const uint2 pr = pairs[me ? p0 + lane : p_lo];
+        const uint2 pr = pairs[me ? p0 + lane : p_lo];                 // lanes beyond the count: the tile's first pair (valid memory, results dropped)
         const uint32_t q = pr.x / cap, r = pr.y & 63u;
-#ifdef QV_TP_QBROADCAST
-        const f4* qp = reinterpret_cast<const f4*>(queries + (size_t)(pairs[p_lo].x / cap) * v.dim);   // TIMING ONLY: one query for all lanes
-#else
-        const f4* qp = reinterpret_cast<const f4*>(queries + (size_t)q * v.dim);       // (dim % 4 == 0: the launcher's condition)
-#endif
         double rn = 0.0;
         if constexpr (MT<M>::needs_rnorm) rn = v.rnorm[pr.y];
         QConst qc; qc.qn = 0.0; qc.qn32 = 0.0f;
         if constexpr (M == QV_COSINE) qc.qn = qnorms[2 * q + 1];
-        f4 qa[8], qb[8];
-        auto qload = [&](f4* dst, uint32_t sl) {
+        uint32_t qoff[SL], qsw[SL];                                    // float offsets of this lane's piece per instruction (nq x dim < 2^32)
 #pragma unroll
-            for (uint32_t c = 0; c < 8; c++) { const uint32_t cc = sl * 8u + c < v.dim4 ? sl * 8u + c : v.dim4 - 1; dst[c] = qp[cc]; }
-        };
-        auto walk = [&](typename MT<M>::A& acc, const f4* qq, uint32_t sl) {
-            const rs_lds_u8* mine = slabs + (sl & 1u) * kTpSlabBytes + r * 16;
-            const uint32_t nc = v.dim4 - sl * 8u < 8u ? v.dim4 - sl * 8u : 8u;
+        for (uint32_t j = 0; j < (uint32_t)SL; j++) {
+            const uint32_t pj = j * kPer + dpair;
+            qsw[j] = dslot ^ swz(pj);
+            qoff[j] = (uint32_t)__shfl((int)q, (int)pj) * v.dim + qsw[j] * 4u;
+        }
+        auto issue = [&](uint32_t sl) {
+            rs_lds_u8* tb = tbuf + (sl & 1u) * kSlab;
+            rs_lds_u8* qb = qbuf + (sl & 1u) * kSlab;
+            const uint32_t c0 = sl * SL;
+            if (c0 + SL <= v.dim4) {
 #pragma unroll
-            for (uint32_t c = 0; c < 8; c++) {
-                if (c < nc) {
-                    const f4 x = *(lds_f4p)(mine + c * 1024);
-                    acc1<M>(acc, (Q)qq[c].x, x.x); acc1<M>(acc, (Q)qq[c].y, x.y); acc1<M>(acc, (Q)qq[c].z, x.z); acc1<M>(acc, (Q)qq[c].w, x.w);
-                }
+                for (uint32_t c = 0; c < (uint32_t)SL; c++) rs_glds16(tile + (size_t)(c0 + c) * 256, tb + c * 1024);
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)SL; j++) rs_glds16(queries + qoff[j] + (size_t)c0 * 4, qb + j * 1024);
+            } else {
+#pragma unroll
+                for (uint32_t c = 0; c < (uint32_t)SL; c++) if (c0 + c < v.dim4) rs_glds16(tile + (size_t)(c0 + c) * 256, tb + c * 1024);
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)SL; j++) if (c0 + qsw[j] < v.dim4) rs_glds16(queries + qoff[j] + (size_t)c0 * 4, qb + j * 1024);
             }
         };
         typename MT<M>::A acc = 0;
-        issue(0); qload(qa, 0);
-        for (uint32_t sl = 0; sl < nslab; sl += 2) {                    // two slabs per turn: the query registers alternate without copies
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (sl + 1 < nslab) { issue(sl + 1); qload(qb, sl + 1); }
+        const uint32_t msw = swz(lane);
+        issue(0);
+        for (uint32_t sl = 0; sl < nslab; sl++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // slab sl has landed
+            if (sl + 1 < nslab) issue(sl + 1);
             __builtin_amdgcn_sched_barrier(0);
-            walk(acc, qa, sl);
+            const rs_lds_u8* tm = tbuf + (sl & 1u) * kSlab + r * 16;
+            const rs_lds_u8* qm = qbuf + (sl & 1u) * kSlab + lane * (SL * 16);
+            const uint32_t nc = v.dim4 - sl * SL < (uint32_t)SL ? v.dim4 - sl * SL : (uint32_t)SL;
+#pragma unroll
+            for (uint32_t c = 0; c < (uint32_t)SL; c++) {
+                if (c < nc) {
+                    const f4 x = *(lds_f4p)(tm + c * 1024);
+                    const f4 y = *(lds_f4p)(qm + ((c ^ msw) << 4));
+                    acc1<M>(acc, (Q)y.x, x.x); acc1<M>(acc, (Q)y.y, x.y); acc1<M>(acc, (Q)y.z, x.z); acc1<M>(acc, (Q)y.w, x.w);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (sl + 1 >= nslab) break;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (sl + 2 < nslab) { issue(sl + 2); qload(qa, sl + 2); }
-            __builtin_amdgcn_sched_barrier(0);
-            walk(acc, qb, sl + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // both buffers of this slab are read before they are refilled
         }
         if (me) keys_ex[pr.x] = make_key(finalize<M>(acc, qc, rn), pr.y);
     }
@@ -2191,6 +2203,26 @@ static bool batched_large_k(uint32_t k) {
 // Rows of the exact sample scan that bounds each query's k-th distance.  A sample of S of N rows lets about k*N/S rows through
 // the filter per query; the candidate buffer holds kMfmaCandCap (4096), so S grows with N and k to keep that near 1536
 // (10M rows or k = 64 with the former fixed 8192 overflowed nearly every query into the exact redo: 256 x 10M x 768 took 108 ms).
+// More than 64 results per query over a large corpus: the bound is a GUESS, verified afterwards.  The k-th smallest bound of a sample is
+// a valid bound whatever the sample, but a tight one needs a sample of about N / 2 at k = 1000 — half the filter's work again and two
+// histogram passes over 128 M bounds (0.86 of 2.26 ms at 256 x 1M x 768).  Instead: 65 536 rows spread over the corpus, and the bound
+// at the rank the k-th row is expected at in it, r = k S / N, plus four standard deviations of that count (+ 2).  Nothing guarantees
+// that k rows of the corpus lie under it — so the batch checks: H, the k-th smallest UPPER bound among the rows the filter let through,
+// must not exceed the guess U (k_cand_survive).  Then k rows are at most H away, every row the filter dropped is farther than U >= H,
+// and the answer is among the candidates; otherwise the query is handed back (redo flag) as an overflowing one is.
+constexpr uint32_t kGuessSampleRows = 65536;
+static bool batched_large_k(uint32_t k);
+static bool batched_guess(const IndexView& v, uint32_t k) {
+    static const int on = dev_env_int("QV_LK_GUESS", 1);
+    return on == 1 && batched_large_k(k) && v.n_rows >= 4 * kGuessSampleRows;
+}
+static uint32_t guess_rank(uint32_t n_rows, uint32_t srows, uint32_t k) {
+    const double r = (double)k * srows / (double)n_rows;
+    return std::min<uint32_t>((uint32_t)std::ceil(r + 4.0 * std::sqrt(r) + 2.0), srows);
+}
+uint32_t batched_sample_rows(const IndexView& v, uint32_t k);
+uint32_t batched_sample_rank(const IndexView& v, uint32_t k) { return batched_guess(v, k) ? guess_rank(v.n_rows, batched_sample_rows(v, k), k) : k; }
+uint32_t batched_cand_cap(uint32_t k);
 uint32_t batched_sample_rows(const IndexView& v, uint32_t k) {
     const uint32_t n_rows = v.n_rows;
     static const int forced = dev_env_int("QV_MFMA_SAMPLE_ROWS", 0);
@@ -2205,7 +2237,14 @@ uint32_t batched_sample_rows(const IndexView& v, uint32_t k) {
     const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / per + 8191) / 8192 * 8192;
     uint64_t cap_rows = n_rows;
     if (batched_large_k(k)) cap_rows = std::max<uint64_t>(32768, ((uint64_t)n_rows / 2 + 8191) / 8192 * 8192);   // the sample costs a pass over its rows: half the corpus at most
-    return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n_rows, cap_rows), std::max<uint64_t>(one ? 32768 : 8192, want));
+    const uint32_t full = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n_rows, cap_rows), std::max<uint64_t>(one ? 32768 : 8192, want));
+    if (!batched_guess(v, k)) return full;
+    // a guessed bound: the smallest sample whose rank leaves the expected candidates (rows under the bound x the filter's window: ~4.6 x
+    // with one term) within half the slots — 65 536 rows at 1M x k = 100 .. 4096, 524 288 at 10M x k = 100 — and never more than the rule above
+    const double f = one ? 4.6 : 1.2;
+    uint32_t srows = kGuessSampleRows;
+    while (srows < full && guess_rank(n_rows, srows, k) * ((double)n_rows / srows) * f > 0.5 * batched_cand_cap(k)) srows *= 2;
+    return std::min(srows, full);
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     // Measured crossover against the exact multi-query scans (256 queries x 768 dims, host pointers for the filter): 12k-16k
@@ -2298,6 +2337,10 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     off = (off + 255) / 256 * 256;
     float* sparts = reinterpret_cast<float*>(w + off); off += (size_t)nq * k * 16;
     const uint32_t bparts = nq <= 64 ? 4u : (nq <= 128 ? 2u : 1u);       // (four parts at 256 queries: 44 -> 74 us, every workgroup stages its query again)
+    // a guessed bound (batched_guess): rank ks of the small sample, kept in ubuf for the check after the filter (sdist is overwritten by the first selection)
+    const bool guess = batched_guess(v, k);
+    const uint32_t ks = batched_sample_rank(v, k);
+    float* ubuf = guess ? sparts : sdist;
     // 1. per-query upper bound U_q of the k-th distance from a sample (the first rows)
     IndexView vs = v;
     vs.n_rows = batched_sample_rows(v, k);
@@ -2341,7 +2384,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t gs1 = grid_multiple(std::min<uint32_t>((uint32_t)cus, sgroups * (nq_pad >> 8)), std::max<uint32_t>(nq_pad >> 8, 1u));
         // large k: the k-th smallest bound by two histogram windows over the bounds (no wave list holds k keys), per-query state in the selection's workspace
         SelState* sst = nullptr; uint32_t* shist = nullptr;
-        if (large_k) { e = select_prepare(sel_ws, nq, k, &sst, &shist, s); if (e != hipSuccess) return e; }
+        if (large_k) { e = select_prepare(sel_ws, nq, ks, &sst, &shist, s); if (e != hipSuccess) return e; }
         const uint32_t hgrid = std::max(1u, std::min(256u, (vs.n_rows + 16 * kSelBlock - 1) / (16 * kSelBlock)));
         // the eight-wave sample kernel hands out one value per query and 128-row group when the groups outnumber k at least four times
         const uint32_t sample_groups = (vs.n_rows + 127) / 128;
@@ -2355,20 +2398,20 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const bool group_min = gmin_mode != 0 && sample_groups >= 4 * k && sample_groups <= 4096;
         const uint32_t gmin_vals = sample_groups;
         static const int sel2_env = dev_env_int("QV_MFMA_SAMPLE_SELECT", 1);                        // 2 = k_sample_bound (wave lists) as in round 3
-        const bool sel2 = sel2_env == 1 && !group_min && sample_select_applies(vs.n_rows, k);
-        const size_t sel2_lds = sel2 ? sample_select_lds_bytes(vs.n_rows, k) : 0;
+        const bool sel2 = sel2_env == 1 && !group_min && sample_select_applies(vs.n_rows, ks);
+        const size_t sel2_lds = sel2 ? sample_select_lds_bytes(vs.n_rows, ks) : 0;
 #define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? 1u : 0u); \
                      else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
                      if (group_min) { /* the bound is selected inside k_mfma_prep from the group minima */ } \
                      else if (sel2) { e = set_lds(k_sample_select<MMM>, sel2_lds); if (e != hipSuccess) return e; \
-                                      hipLaunchKernelGGL(k_sample_select<MMM>, dim3(nq), dim3(1024), sel2_lds, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); } \
-                     else if (large_k) { hipLaunchKernelGGL(k_sample_hist<0>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
-                                    hipLaunchKernelGGL(k_sample_hist<1>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, k, sst, shist); \
-                                    hipLaunchKernelGGL(k_sample_bound_from_state<MMM>, dim3((nq + 255) / 256), dim3(256), 0, s, sst, nq, k, (float)filter_gamma(v.dim, 0) * 1.000001f, sdist); } \
+                                      hipLaunchKernelGGL(k_sample_select<MMM>, dim3(nq), dim3(1024), sel2_lds, s, sscore, vs.n_rows, ks, (float)filter_gamma(v.dim, 0) * 1.000001f, ubuf); } \
+                     else if (large_k) { hipLaunchKernelGGL(k_sample_hist<0>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, ks, sst, shist); \
+                                    hipLaunchKernelGGL(k_sample_hist<1>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, ks, sst, shist); \
+                                    hipLaunchKernelGGL(k_sample_bound_from_state<MMM>, dim3((nq + 255) / 256), dim3(256), 0, s, sst, nq, ks, (float)filter_gamma(v.dim, 0) * 1.000001f, ubuf); } \
                      else hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
-        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k && !group_min && !sel2 ? sparts : sdist, large_k || group_min || sel2 ? 1u : bparts, k, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u, group_min ? sscore : nullptr, gmin_vals);
+        hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k && !group_min && !sel2 ? sparts : ubuf, large_k || group_min || sel2 ? 1u : bparts, ks, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u, group_min ? sscore : nullptr, gmin_vals);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
         e = launch_flat_topk(vs, ps, d_queries, nq, k, d_ws, srows, sdist, s);
@@ -2473,29 +2516,36 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const size_t lds_x = query_lds_bytes(v.metric, v.dim4);
         const size_t lds_w = 2 * (size_t)kRsSlabBytes + (size_t)((v.dim4 + 7) / 8) * 128;
         static const int wave_mode = dev_env_int("QV_LK_EXACT_WAVE", 1);
-        const bool wave_exact = wave_mode == 1 && lds_w <= 64 * 1024;
+        const bool wave_exact = wave_mode == 1;                          // (2: the lane-per-row kernel of rounds 4-5, measurement build only)
         // gather or tile pass: ~2.1 k survivors per query of unstructured rows, 12 KiB of requests each at ~3.5 TB/s, against the
         // corpus once at ~5.5 TB/s and 60 us for the three sorting kernels (256 queries x 1M x 768: from k ~ 300)
         static const int tp_mode = dev_env_int("QV_LK_TILE_PASS", 1);   // 2 = never, 3 = always (measurements)
         const double t_gather = 2.1 * k * nq * (double)v.dim4 * 64.0 / 3.5e12, t_pass = (double)v.n_rows * v.dim4 * 16.0 / 5.5e12 + 60e-6;
-        const bool tile_pass = v.rowmaj == nullptr && (v.dim & 3u) == 0 && (uint64_t)nq * ccap < (1ull << 32) && tp_mode != 2 && (tp_mode == 3 || t_gather > t_pass);
+        const bool tile_pass = v.rowmaj == nullptr && (v.dim & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_queries) & 15u) == 0 && (uint64_t)nq * ccap < (1ull << 32) && (uint64_t)nq * v.dim < (1ull << 32) && tp_mode != 2 && (tp_mode == 3 || t_gather > t_pass);
+#ifdef QV_VARIANTS
+#define QV_LK_LANE(MMM) { e = set_lds(k_cand_exact<MMM, 32>, lds_x); if (e != hipSuccess) return e;                                                         \
+        hipLaunchKernelGGL((k_cand_exact<MMM, 32>), dim3(nq, (ccap + 255) / 256), dim3(256), lds_x, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex); }
+#else
+#define QV_LK_LANE(MMM) { (void)lds_x; return hipErrorNotSupported; }
+#endif
 #define QV_LK(MMM) { e = set_lds(k_cand_qnorms<MMM>, (size_t)v.dim * 4); if (e != hipSuccess) return e;                                                 \
         hipLaunchKernelGGL(k_cand_qnorms<MMM>, dim3(nq), dim3(64), (size_t)v.dim * 4, s, d_queries, v.dim, qnorms);                                         \
         hipLaunchKernelGGL(k_cand_bounds<MMM>, cgrid, dim3(256), 0, s, v, cand, cscore, cnt, ccap, eq, qnorms, keys_hi, lo_b, ovf, nsurv);                 \
         e = launch_select_topk(keys_hi, ccap, ccap, nq, k, k, sel_ws, srows, sdist, s, false, false); if (e != hipSuccess) return e;                       \
-        hipLaunchKernelGGL(k_cand_survive, cgrid, dim3(256), 0, s, cand, cnt, ccap, lo_b, sdist, k, surv, nsurv);                                          \
+        hipLaunchKernelGGL(k_cand_survive, cgrid, dim3(256), 0, s, cand, cnt, ccap, lo_b, sdist, k, surv, nsurv, guess ? ubuf : (const float*)nullptr, ks, ovf);                                          \
         if (tile_pass) {                                                                                                                                    \
             (void)hipMemsetAsync(tp_cnt, 0, (size_t)(v.n_tiles + 1) * 4, s);                                                                                 \
             hipLaunchKernelGGL(k_tp_count, cgrid, dim3(256), 0, s, surv, nsurv, ccap, tp_cnt, keys_ex);                                                     \
             hipLaunchKernelGGL(k_tp_scan, dim3(1), dim3(1024), 0, s, tp_cnt, v.n_tiles, tp_off);                                                            \
             hipLaunchKernelGGL(k_tp_scatter, cgrid, dim3(256), 0, s, surv, nsurv, ccap, tp_off, tp_cnt, reinterpret_cast<uint2*>(keys_hi));                \
-            hipLaunchKernelGGL(k_tp_exact<MMM>, dim3(v.n_tiles), dim3(64), 2 * (size_t)kTpSlabBytes, s, v, d_queries, tp_off, reinterpret_cast<const uint2*>(keys_hi), ccap, qnorms, keys_ex); \
-        } else if (wave_exact) { hipLaunchKernelGGL(k_cand_exact_wave<MMM>, dim3(nq, ccap / 32), dim3(64), lds_w, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex); }     \
-        else { e = set_lds(k_cand_exact<MMM, 32>, lds_x); if (e != hipSuccess) return e;                                                                    \
-        hipLaunchKernelGGL((k_cand_exact<MMM, 32>), dim3(nq, (ccap + 255) / 256), dim3(256), lds_x, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex); }                       \
+            hipLaunchKernelGGL((k_tp_exact<MMM, 8>), dim3(v.n_tiles), dim3(64), 4 * 8192, s, v, d_queries, tp_off, reinterpret_cast<const uint2*>(keys_hi), ccap, qnorms, keys_ex); \
+        } else if (wave_exact) { e = set_lds(k_cand_exact_wave<MMM>, lds_w); if (e != hipSuccess) return e;                                                  \
+            hipLaunchKernelGGL(k_cand_exact_wave<MMM>, dim3(nq, ccap / 32), dim3(64), lds_w, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex); }        \
+        else QV_LK_LANE(MMM)                                                                                                                                \
         e = launch_select_topk(keys_ex, ccap, ccap, nq, k, k, sel_ws, d_rows_out, d_dist_out, s, false, false); if (e != hipSuccess) return e; }
         if (v.metric == QV_COSINE) QV_LK(QV_COSINE) else if (v.metric == QV_DOT) QV_LK(QV_DOT) else if (v.metric == QV_L2) QV_LK(QV_L2) else QV_LK(QV_L2SQ)
 #undef QV_LK
+#undef QV_LK_LANE
         *d_overflow_out = ovf;
         return hipGetLastError();
     }

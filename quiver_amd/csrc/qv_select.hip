@@ -368,7 +368,9 @@ hipError_t launch_select_topk(const uint64_t* d_keys, size_t stride, uint32_t n,
     const uint32_t grid = std::max(1u, std::min(1024u, (n + 4 * 2 * kSelBlock - 1) / (4 * 2 * kSelBlock)));
     if (!window0_counted && n <= 16384u) {
         // few keys per query (the candidate lists of a batch: 4096-16384 slots): one workgroup per query takes them all into LDS
-        const size_t lds_d = (size_t)std::max<uint32_t>(n, 64u) * sizeof(uint64_t);
+        uint32_t m_sort = 64;                                             // the sort pads what it keeps to a power of two that holds kk
+        while (m_sort < kk) m_sort <<= 1;
+        const size_t lds_d = (size_t)std::max<uint32_t>(n, m_sort) * sizeof(uint64_t);
         e = set_lds(k_select_sort, lds_d);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_select_sort, dim3(nq), dim3(kSelSortBlock), lds_d, s, d_keys, stride, n, kk, k_stride, n, (SelState*)nullptr, (const uint64_t*)nullptr, d_rows_out, d_dist_out, 0);

@@ -528,6 +528,75 @@ def test_batched_large_k_equals_exact_scan(metric, nq, k):
         assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
 
 
+@pytest.mark.parametrize("metric,dim,nq,k,rowmajor", [
+    ("cosine", 100, 64, 100, True), ("dot_product", 100, 48, 200, True), ("euclidean", 256, 40, 300, True), ("squared_euclidean", 72, 64, 129, True),   # k_cand_exact_wave on the row-major copy (100, 72: a last slab of 1 chunk)
+    ("cosine", 50, 64, 100, False), ("squared_euclidean", 100, 64, 80, False), ("dot_product", 36, 40, 70, False), ("euclidean", 50, 33, 65, False),    # ... on the tiles, padded rows (dim % 4 != 0) and short last slabs
+    ("euclidean", 256, 256, 700, False), ("squared_euclidean", 100, 300, 1000, False), ("cosine", 72, 300, 1000, False)])                               # k_tp_exact (the tile pass) for the other metrics, a short last slab
+def test_batched_large_k_layouts_and_odd_dimensions(metric, dim, nq, k, rowmajor):
+    """the exact passes of a large-k batch: a wave per 32 survivors (row-major copy or tiles) and, for many survivors, the pass over the tiles"""
+    import quiver_amd as q
+    n = 120_000
+    idx = q.DeviceIndex(dim, metric, rowmajor=rowmajor)
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    batched = idx.search(qs, k, batched=True)
+    assert _eq(_exact(idx, qs, k), batched)
+    corpus = O.gen_rows(20260424, 0, n, dim)
+    for i in (0, nq - 1):
+        er, ed = O.exact_search(q.metric_id(metric), corpus, qs[i], k)
+        assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
+
+
+@pytest.mark.parametrize("metric,k", [("cosine", 100), ("dot_product", 1000), ("euclidean", 300), ("squared_euclidean", 65)])
+def test_batched_large_k_guessed_bound_on_a_large_corpus(metric, k):
+    """from 262 144 rows the bound of a large-k batch is a guess from 65 536 sample rows, checked after the filter (batched_guess)"""
+    import quiver_amd as q
+    n, dim, nq = 300_000, 64, 96
+    idx = q.DeviceIndex(dim, metric)
+    idx.add_synthetic(20260424, 0, n)
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    batched = idx.search(qs, k, batched=True)
+    assert _eq(_exact(idx, qs, k), batched)
+    corpus = O.gen_rows(20260424, 0, n, dim)
+    for i in (0, nq - 1):
+        er, ed = O.exact_search(q.metric_id(metric), corpus, qs[i], k)
+        assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
+
+
+def test_batched_large_k_guessed_bound_that_fails_is_handed_back():
+    """clusters of 256 rows = two 128-row groups, stored one after the other; the sample takes every fourth group, so half of the clusters have
+    HALF their rows in it (expected: 22 %) and the others none.  A query at the centre of an over-sampled cluster gets a bound under which
+    fewer than k rows of the corpus lie: the check after the filter (H <= U) hands it back and the exact scan answers it.  Either way the
+    answer is the exact scan's."""
+    import torch
+    import quiver_amd as q
+    dim, k, per = 64, 200, 256
+    rng = np.random.default_rng(5)
+    centers = rng.standard_normal((1172, dim)).astype(np.float32)
+    rows = np.concatenate([c + 0.02 * rng.standard_normal((per, dim)).astype(np.float32) for c in centers])       # 300 032 rows
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add(rows)
+    qs = np.concatenate([centers[0:40:2], centers[1:41:2], rng.standard_normal((24, dim)).astype(np.float32)]).astype(np.float32)
+    nq = len(qs)
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    fl = torch.zeros((nq,), dtype=torch.int32, device="cuda")
+    idx.search_batched_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    flagged = fl.cpu().numpy() != 0
+    assert flagged.any() and not flagged.all(), "this corpus no longer makes a guessed bound fail for some queries only (%d of %d handed back)" % (flagged.sum(), nq)
+    got = idx.search(qs, k, batched=True)                                   # the host call redoes the handed-back queries
+    assert _eq(_exact(idx, qs, k), got)
+    hr, hd = dr.cpu().numpy().view(np.uint32), dd.cpu().numpy()
+    for i in range(nq):
+        if i in (0, 1, 20, 21, nq - 1) or not flagged[i]:
+            if not flagged[i]: assert np.array_equal(hr[i], got[0][i]) and np.array_equal(_bits(hd[i]), _bits(got[1][i])), i
+        if i in (0, 1, 20, 21, nq - 1):
+            er, ed = O.exact_search(0, rows, qs[i], k)
+            assert np.array_equal(got[0][i], er), i
+            assert np.array_equal(_bits(got[1][i]), _bits(ed)), i
+
+
 def test_batched_large_k_ties_tombstones_and_a_clustered_corpus():
     """duplicated rows (exact ties, resolved by row), dead rows, and a corpus stored cluster by cluster so that the sample's
     bound is loose for some queries (candidate overflow -> the caller's exact redo)"""
