@@ -1897,6 +1897,74 @@ k_cand_bounds(IndexView v, const uint32_t* __restrict__ cand_rows, const float* 
     keys_hi[(size_t)q * cap + i] = key;
 }
 
+// k_cand_qnorms, k_cand_bounds, the selection of H and k_cand_survive in ONE kernel, a workgroup per query, while a query's candidate slots
+// (as ordered 32-bit keys) and the query fit LDS — up to 32 768 slots = 2 048 results.  Five launches on the batch's critical path
+// (63 us of 880 at k = 100, 122 of 1530 at k = 1000, 256 x 1M x 768) for work that is a few thousand candidates per query.
+// Phases: the query into LDS and |q| (any order); lane 0 of wave 0 walks the cosine norm's chain (distances.go:20) while the other
+// waves turn scores into intervals (lower bounds to lo_out, upper bounds' keys to LDS); H = the k-th smallest upper bound
+// (block_kth_smallest); the guess's check; the candidates with lo <= H compacted into surv.
+template <int M>
+__global__ void __launch_bounds__(1024)
+k_cand_narrow(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_score,
+              const uint32_t* __restrict__ cand_cnt, uint32_t cap, const float* __restrict__ eq, uint32_t k, const float* __restrict__ guess, uint32_t ks,
+              double* __restrict__ qnorms, float* __restrict__ lo_out, uint32_t* __restrict__ surv, uint32_t* __restrict__ n_surv, uint32_t* __restrict__ overflow) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* s_keys = reinterpret_cast<uint32_t*>(smem);                  // [cap]
+    float* ql = reinterpret_cast<float*>(smem + (size_t)cap * 4);          // [dim]
+    __shared__ uint32_t s_bins[256];
+    __shared__ uint32_t s_scal[4];
+    __shared__ double s_part[16];
+    __shared__ uint32_t s_n;
+    const uint32_t q = blockIdx.x, t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+    const uint32_t cnt_raw = cand_cnt[q];
+    const uint32_t cnt = cnt_raw <= cap ? cnt_raw : 0u;
+    if (t == 0) { s_n = 0; if (cnt_raw > cap) overflow[q] = 1; }           // (more candidates than slots: the caller redoes this query with the exact scan)
+    const float* src = queries + (size_t)q * v.dim;
+    double n2 = 0.0;
+    for (uint32_t i = t; i < v.dim; i += 1024) { const float x = src[i]; ql[i] = x; const double a = (double)x; n2 = __builtin_fma(a, a, n2); }
+    n2 = wave_sum_f64(n2);
+    if (lane == 0) s_part[wave] = n2;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) tot += s_part[w];
+    const double qn = __builtin_sqrt(tot);
+    if (t == 0) {
+        double exact = 0.0;
+        if constexpr (M == QV_COSINE) { double ma = 0.0; for (uint32_t i = 0; i < v.dim; i++) { const double a = (double)ql[i]; ma = __builtin_fma(a, a, ma); } exact = __builtin_sqrt(ma); }
+        qnorms[2 * q] = qn; qnorms[2 * q + 1] = exact;
+    }
+    const double ea = (double)eq[2 * q], eb = (double)eq[2 * q + 1], gref = filter_gamma(v.dim, 0);
+    if (wave != 0 || M != QV_COSINE) {                                     // (cosine: wave 0 is busy with the chain; its share goes to the others)
+        const uint32_t first = M == QV_COSINE ? t - 64 : t, step = M == QV_COSINE ? 960u : 1024u;
+        for (uint32_t i = first; i < cnt; i += step) {
+            const uint32_t row = cand_rows[(size_t)q * cap + i];
+            const double rn = v.rnorm[row];
+            float lo, hi;
+            score_interval<M>((double)cand_score[(size_t)q * cap + i], qn, qn, rn, ea * rn + eb * (double)v.rres[row], gref, lo, hi);
+            lo_out[(size_t)q * cap + i] = lo;
+            s_keys[i] = ord_f32(hi);
+        }
+    }
+    __syncthreads();
+    const uint32_t hkey = block_kth_smallest(s_keys, cnt, k, s_bins, s_scal);
+    const float H = hkey == 0xFFFFFFFFu ? __builtin_inff() : unord_f32(hkey);
+    // a guessed bound U holds when k candidates are at most U away (batched_guess); if not, the query is handed back
+    if (guess != nullptr && !(H <= guess[(size_t)q * ks + (ks - 1)])) { if (t == 0) { overflow[q] = 1; n_surv[q] = 0; } return; }
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 1024) {
+        const uint32_t i = i0 + t;
+        const bool take = i < cnt && lo_out[(size_t)q * cap + i] <= H;
+        const uint64_t m = __ballot(take);
+        if (m == 0) continue;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&s_n, (uint32_t)__builtin_popcountll(m));
+        base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(m));
+        if (take) surv[(size_t)q * cap + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = cand_rows[(size_t)q * cap + i];
+    }
+    __syncthreads();
+    if (t == 0) n_surv[q] = s_n;
+}
+
 // survivors: candidates whose lower bound does not exceed H_q = the k-th smallest upper bound (sel_dist[q][k - 1]; +inf = keep all)
 __global__ void __launch_bounds__(256)
 k_cand_survive(const uint32_t* __restrict__ cand_rows, const uint32_t* __restrict__ cand_cnt, uint32_t cap, const float* __restrict__ lo_in,
@@ -2514,6 +2582,9 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         // selection's output (the sample's bound in sdist has been consumed by k_mfma_prep)
         const dim3 cgrid((ccap + 255) / 256, nq);
         const size_t lds_x = query_lds_bytes(v.metric, v.dim4);
+        const size_t lds_n = (size_t)ccap * 4 + (size_t)v.dim * 4;
+        static const int narrow_mode = dev_env_int("QV_LK_NARROW", 1);
+        const bool narrow = narrow_mode == 1 && lds_n <= 140 * 1024;       // (beyond: k_cand_qnorms, k_cand_bounds, the selection's kernels, k_cand_survive)
         const size_t lds_w = 2 * (size_t)kRsSlabBytes + (size_t)((v.dim4 + 7) / 8) * 128;
         static const int wave_mode = dev_env_int("QV_LK_EXACT_WAVE", 1);
         const bool wave_exact = wave_mode == 1;                          // (2: the lane-per-row kernel of rounds 4-5, measurement build only)
@@ -2529,10 +2600,13 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
 #define QV_LK_LANE(MMM) { (void)lds_x; return hipErrorNotSupported; }
 #endif
 #define QV_LK(MMM) { e = set_lds(k_cand_qnorms<MMM>, (size_t)v.dim * 4); if (e != hipSuccess) return e;                                                 \
+        if (narrow) { e = set_lds(k_cand_narrow<MMM>, lds_n); if (e != hipSuccess) return e;                                                                \
+        hipLaunchKernelGGL(k_cand_narrow<MMM>, dim3(nq), dim3(1024), lds_n, s, v, d_queries, cand, cscore, cnt, ccap, eq, k, guess ? ubuf : (const float*)nullptr, ks, qnorms, lo_b, surv, nsurv, ovf); \
+        } else {                                                                                                                                            \
         hipLaunchKernelGGL(k_cand_qnorms<MMM>, dim3(nq), dim3(64), (size_t)v.dim * 4, s, d_queries, v.dim, qnorms);                                         \
         hipLaunchKernelGGL(k_cand_bounds<MMM>, cgrid, dim3(256), 0, s, v, cand, cscore, cnt, ccap, eq, qnorms, keys_hi, lo_b, ovf, nsurv);                 \
         e = launch_select_topk(keys_hi, ccap, ccap, nq, k, k, sel_ws, srows, sdist, s, false, false); if (e != hipSuccess) return e;                       \
-        hipLaunchKernelGGL(k_cand_survive, cgrid, dim3(256), 0, s, cand, cnt, ccap, lo_b, sdist, k, surv, nsurv, guess ? ubuf : (const float*)nullptr, ks, ovf);                                          \
+        hipLaunchKernelGGL(k_cand_survive, cgrid, dim3(256), 0, s, cand, cnt, ccap, lo_b, sdist, k, surv, nsurv, guess ? ubuf : (const float*)nullptr, ks, ovf); }                                          \
         if (tile_pass) {                                                                                                                                    \
             (void)hipMemsetAsync(tp_cnt, 0, (size_t)(v.n_tiles + 1) * 4, s);                                                                                 \
             hipLaunchKernelGGL(k_tp_count, cgrid, dim3(256), 0, s, surv, nsurv, ccap, tp_cnt, keys_ex);                                                     \

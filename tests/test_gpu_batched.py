@@ -511,7 +511,8 @@ def test_query_resident_filter_against_the_exact_scan(metric, dim, nq, bf16_rows
 # still be the exact scan's, row for row and bit for bit.
 
 @pytest.mark.parametrize("metric,nq,k", [("cosine", 256, 100), ("cosine", 64, 65), ("dot_product", 100, 128), ("euclidean", 40, 300),
-                                         ("squared_euclidean", 256, 129), ("cosine", 16, 1000), ("dot_product", 300, 2048), ("cosine", 32, 4096)])
+                                         ("squared_euclidean", 256, 129), ("cosine", 16, 1000), ("dot_product", 300, 2048), ("cosine", 32, 4096),
+                                         ("dot_product", 16, 4096), ("euclidean", 24, 3000), ("squared_euclidean", 12, 2100)])   # (above 2048: the narrowing as separate kernels)
 def test_batched_large_k_equals_exact_scan(metric, nq, k):
     import quiver_amd as q
     n, dim = 200_000, 256
