@@ -186,7 +186,9 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
     # takes any k (:677-811).  k = 100 and 1000, one query (10M and 1M rows) and 256 queries x 1M rows; checked against the full ranking.
     try:
         ks_entry = {"workload": "k above the 64-key wave list: single query (wide wave lists to 128, one key per row + radix selection to 8192) and "
-                                "256-query batches (filter + re-score with radix selections to 2048); ms per call, device-resident"}
+                                "256-query batches (filter + re-score to 4096: round 6 — the bound a guess from 65 536 sample rows checked after the "
+                                "filter, the candidates narrowed by one kernel per query, the survivors' exact distances by a wave per 32 rows or, for "
+                                "many survivors, one pass over the tiles; profiles/r06_largek_pmc.txt); ms per call, device-resident"}
         for label_k, index_k, rows_k in (("1x%dM" % (a.rows // 1_000_000), idx, a.rows), ("1x1M", idx1, 1_000_000)):
             full_r = torch.empty((1, rows_k), dtype=torch.int32, device="cuda"); full_d = torch.empty((1, rows_k), dtype=torch.float32, device="cuda")
             index_k.search_device(d_q.data_ptr(), 1, rows_k, full_r.data_ptr(), full_d.data_ptr(), sp)      # the full ranking (radix sort): the checker
@@ -201,7 +203,7 @@ def also_entries(a, torch, quiver_amd, idx, d_q, qs_host, local_rank):
                 ks_entry["%s_k%d_ms" % (label_k, kk_)] = (time.perf_counter() - t4) / 20 * 1e3
                 ks_entry["%s_k%d_same" % (label_k, kk_)] = bool(torch.equal(rr_, full_r[:, :kk_]) and torch.equal(dd_.view(torch.int32), full_d[:, :kk_].view(torch.int32)))
             del full_r, full_d
-        for kk_ in (10, 64, 100, 1000):
+        for kk_ in (10, 64, 100, 1000, 4096):
             rb_ = torch.empty((nqb, kk_), dtype=torch.int32, device="cuda"); db_ = torch.empty((nqb, kk_), dtype=torch.float32, device="cuda")
             fl_ = torch.zeros((nqb,), dtype=torch.int32, device="cuda")
             for _ in range(3):                             # (first launches of a shape: workspace growth, clocks)
