@@ -24,6 +24,7 @@ SHAPES = {
     "flat_64q_k10_1Mx768":   ("qv_index_search", "cosine", 1_000_000, 768, 64, 10, "flat"),
     "flat_256q_k10_1Mx768":  ("qv_index_search", "cosine", 1_000_000, 768, 256, 10, "flat"),
     "flat_256q_k100_1Mx768": ("qv_index_search", "cosine", 1_000_000, 768, 256, 100, "flat"),
+    "flat_256q_k1000_1Mx768": ("qv_index_search", "cosine", 1_000_000, 768, 256, 1000, "flat"),
     "flat_256q_k10_1Mx768_bf16rows": ("qv_index_search, QV_FLAG_BF16_ROWS", "cosine", 1_000_000, 768, 256, 10, "flat_bf16"),
     "flat_256q_k10_1Mx768_fp32": ("qv_index_search, qv_index_set_filter(fp32)", "dot_product", 1_000_000, 768, 256, 10, "flat_fp32"),
     "flat_256q_k10_1Mx2048": ("qv_index_search", "cosine", 400_000, 2048, 256, 10, "flat"),
