@@ -1907,8 +1907,10 @@ template <int M>
 __global__ void __launch_bounds__(1024)
 k_cand_narrow(IndexView v, const float* __restrict__ queries, const uint32_t* __restrict__ cand_rows, const float* __restrict__ cand_score,
               const uint32_t* __restrict__ cand_cnt, uint32_t cap, const float* __restrict__ eq, uint32_t k, const float* __restrict__ guess, uint32_t ks,
-              double* __restrict__ qnorms, float* __restrict__ lo_out, uint32_t* __restrict__ surv, uint32_t* __restrict__ n_surv, uint32_t* __restrict__ overflow) {
+              double* __restrict__ qnorms, float* __restrict__ lo_out, uint32_t* __restrict__ surv, uint32_t* __restrict__ n_surv, uint32_t* __restrict__ overflow,
+              uint32_t* __restrict__ zero_words, uint32_t n_zero /* the tile pass's counters, cleared here for k_tp_count (a memset of its own: three fill kernels, 25 us) */) {
     extern __shared__ __align__(16) unsigned char smem[];
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n_zero; i += gridDim.x * 1024u) zero_words[i] = 0u;
     uint32_t* s_keys = reinterpret_cast<uint32_t*>(smem);                  // [cap]
     float* ql = reinterpret_cast<float*>(smem + (size_t)cap * 4);          // [dim]
     __shared__ uint32_t s_bins[256];
@@ -2452,7 +2454,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const uint32_t gs1 = grid_multiple(std::min<uint32_t>((uint32_t)cus, sgroups * (nq_pad >> 8)), std::max<uint32_t>(nq_pad >> 8, 1u));
         // large k: the k-th smallest bound by two histogram windows over the bounds (no wave list holds k keys), per-query state in the selection's workspace
         SelState* sst = nullptr; uint32_t* shist = nullptr;
-        if (large_k) { e = select_prepare(sel_ws, nq, ks, &sst, &shist, s); if (e != hipSuccess) return e; }
+
         const uint32_t hgrid = std::max(1u, std::min(256u, (vs.n_rows + 16 * kSelBlock - 1) / (16 * kSelBlock)));
         // the eight-wave sample kernel hands out one value per query and 128-row group when the groups outnumber k at least four times
         const uint32_t sample_groups = (vs.n_rows + 127) / 128;
@@ -2468,6 +2470,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         static const int sel2_env = dev_env_int("QV_MFMA_SAMPLE_SELECT", 1);                        // 2 = k_sample_bound (wave lists) as in round 3
         const bool sel2 = sel2_env == 1 && !group_min && sample_select_applies(vs.n_rows, ks);
         const size_t sel2_lds = sel2 ? sample_select_lds_bytes(vs.n_rows, ks) : 0;
+        if (large_k && !sel2 && !group_min) { e = select_prepare(sel_ws, nq, ks, &sst, &shist, s); if (e != hipSuccess) return e; }   // (the histogram kernels' state)
 #define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? 1u : 0u); \
                      else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
                      if (group_min) { /* the bound is selected inside k_mfma_prep from the group minima */ } \
@@ -2601,14 +2604,14 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
 #endif
 #define QV_LK(MMM) { e = set_lds(k_cand_qnorms<MMM>, (size_t)v.dim * 4); if (e != hipSuccess) return e;                                                 \
         if (narrow) { e = set_lds(k_cand_narrow<MMM>, lds_n); if (e != hipSuccess) return e;                                                                \
-        hipLaunchKernelGGL(k_cand_narrow<MMM>, dim3(nq), dim3(1024), lds_n, s, v, d_queries, cand, cscore, cnt, ccap, eq, k, guess ? ubuf : (const float*)nullptr, ks, qnorms, lo_b, surv, nsurv, ovf); \
+        hipLaunchKernelGGL(k_cand_narrow<MMM>, dim3(nq), dim3(1024), lds_n, s, v, d_queries, cand, cscore, cnt, ccap, eq, k, guess ? ubuf : (const float*)nullptr, ks, qnorms, lo_b, surv, nsurv, ovf, tp_cnt, tile_pass ? v.n_tiles + 1 : 0u); \
         } else {                                                                                                                                            \
         hipLaunchKernelGGL(k_cand_qnorms<MMM>, dim3(nq), dim3(64), (size_t)v.dim * 4, s, d_queries, v.dim, qnorms);                                         \
         hipLaunchKernelGGL(k_cand_bounds<MMM>, cgrid, dim3(256), 0, s, v, cand, cscore, cnt, ccap, eq, qnorms, keys_hi, lo_b, ovf, nsurv);                 \
         e = launch_select_topk(keys_hi, ccap, ccap, nq, k, k, sel_ws, srows, sdist, s, false, false); if (e != hipSuccess) return e;                       \
         hipLaunchKernelGGL(k_cand_survive, cgrid, dim3(256), 0, s, cand, cnt, ccap, lo_b, sdist, k, surv, nsurv, guess ? ubuf : (const float*)nullptr, ks, ovf); }                                          \
         if (tile_pass) {                                                                                                                                    \
-            (void)hipMemsetAsync(tp_cnt, 0, (size_t)(v.n_tiles + 1) * 4, s);                                                                                 \
+            if (!narrow) (void)hipMemsetAsync(tp_cnt, 0, (size_t)(v.n_tiles + 1) * 4, s);                                                                                 \
             hipLaunchKernelGGL(k_tp_count, cgrid, dim3(256), 0, s, surv, nsurv, ccap, tp_cnt, keys_ex);                                                     \
             hipLaunchKernelGGL(k_tp_scan, dim3(1), dim3(1024), 0, s, tp_cnt, v.n_tiles, tp_off);                                                            \
             hipLaunchKernelGGL(k_tp_scatter, cgrid, dim3(256), 0, s, surv, nsurv, ccap, tp_off, tp_cnt, reinterpret_cast<uint2*>(keys_hi));                \

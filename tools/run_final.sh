@@ -1,3 +1,6 @@
+#!/bin/bash
+# The round's final validation on the GPU box: every -m gpu test, the round's profiles and PMC records, the kernel-coverage map.
+#   gpurun --timeout 5400 -- bash tools/run_final.sh
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 1800 python3 -m pytest tests -m gpu -x -q > gpurun_out/r06_gpu_tests.txt 2>&1; tail -3 gpurun_out/r06_gpu_tests.txt
