@@ -214,8 +214,8 @@ int qv_index_search_batched(qv_index* idx, const float* queries, uint32_t nq, ui
 int qv_index_set_filter(qv_index* idx, int filter);
 
 /* Device-pointer form of the batched path: enqueues on `stream`, no sync.  d_redo_flags_out[nq]
- * (uint32) is set to 1 for queries whose candidate buffer overflowed or — more than 64 results per query over 262 144 rows or
- * more, where the k-th distance's bound is a guess from a 65 536-row sample — whose guess did not hold (fewer than k candidates
+ * (uint32) is set to 1 for queries whose candidate buffer overflowed or — 16 or more results per query over 131 072 rows or
+ * more, where the k-th distance's bound is a guess from a sample of 32 768 rows or more — whose guess did not hold (fewer than k candidates
  * within it): the caller must redo those with qv_index_search_device (their result rows are unspecified).  Returns QV_ERR_UNSUPPORTED when
  * the MFMA path does not apply (metric, k > 4096, small corpus, too few queries): use qv_index_search_device. */
 int qv_index_search_batched_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,

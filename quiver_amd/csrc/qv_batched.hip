@@ -2262,12 +2262,16 @@ int filter_mode(const IndexView& v) {
     const int m = v.filter >= 1 && v.filter <= 3 ? v.filter : env_default;
     return m == 1 ? 1 : (m == 2 ? 2 : (m == 3 ? 3 : (v.dim <= 1536 ? 3 : 2)));
 }
-// From how many results per query the batch's selections are radix selections over key arrays (k_sample_hist, k_cand_*) instead of
-// the 64-key wave lists (k_sample_bound, k_rescore_select).  Above 64 there is no choice; QV_BATCHED_SELECT_FROM (read once) moves
-// the switch down for measurements.
-static bool batched_large_k(uint32_t k) {
-    static const int from = dev_env_int("QV_BATCHED_SELECT_FROM", kMaxFusedK + 1);
-    return k > (uint32_t)kMaxFusedK || (int)k >= from;
+// From how many results per query the batch takes the selection path (a guessed bound, k_cand_narrow, a wave per 32 survivors or the tile
+// pass, k_select_sort) instead of the 64-key wave lists (the sample's exact k-th bound, k_rescore_select).  Above 64 there is no choice.
+// Below, round 6's selection path wins from k = 16 wherever its bound can be a guess (256 x 1M x 768, same box: k = 16 0.670 against
+// 0.698 ms, 32: 0.728 / 0.769, 64: 0.806 / 0.916; k = 10: 0.677 / 0.670): the wave lists' work grows with k — a sample of k N / 384
+// rows, k dependent inserts per list — and the selections' does not.  QV_BATCHED_SELECT_FROM (measurement build) moves the switch.
+constexpr uint32_t kGuessSampleRows = 32768;
+static bool guess_eligible(const IndexView& v) { return v.n_rows >= 4 * kGuessSampleRows; }
+static bool batched_large_k(const IndexView& v, uint32_t k) {
+    static const int from = dev_env_int("QV_BATCHED_SELECT_FROM", 16);
+    return k > (uint32_t)kMaxFusedK || ((int)k >= from && guess_eligible(v));
 }
 // ---- MFMA batched path --------------------------------------------------------------
 // Rows of the exact sample scan that bounds each query's k-th distance.  A sample of S of N rows lets about k*N/S rows through
@@ -2275,16 +2279,14 @@ static bool batched_large_k(uint32_t k) {
 // (10M rows or k = 64 with the former fixed 8192 overflowed nearly every query into the exact redo: 256 x 10M x 768 took 108 ms).
 // More than 64 results per query over a large corpus: the bound is a GUESS, verified afterwards.  The k-th smallest bound of a sample is
 // a valid bound whatever the sample, but a tight one needs a sample of about N / 2 at k = 1000 — half the filter's work again and two
-// histogram passes over 128 M bounds (0.86 of 2.26 ms at 256 x 1M x 768).  Instead: 65 536 rows spread over the corpus, and the bound
+// histogram passes over 128 M bounds (0.86 of 2.26 ms at 256 x 1M x 768).  Instead: 32 768 rows or more (batched_sample_rows) spread over the corpus, and the bound
 // at the rank the k-th row is expected at in it, r = k S / N, plus four standard deviations of that count (+ 2).  Nothing guarantees
 // that k rows of the corpus lie under it — so the batch checks: H, the k-th smallest UPPER bound among the rows the filter let through,
 // must not exceed the guess U (k_cand_survive).  Then k rows are at most H away, every row the filter dropped is farther than U >= H,
 // and the answer is among the candidates; otherwise the query is handed back (redo flag) as an overflowing one is.
-constexpr uint32_t kGuessSampleRows = 65536;
-static bool batched_large_k(uint32_t k);
 static bool batched_guess(const IndexView& v, uint32_t k) {
     static const int on = dev_env_int("QV_LK_GUESS", 1);
-    return on == 1 && batched_large_k(k) && v.n_rows >= 4 * kGuessSampleRows;
+    return on == 1 && batched_large_k(v, k) && guess_eligible(v);
 }
 static uint32_t guess_rank(uint32_t n_rows, uint32_t srows, uint32_t k) {
     const double r = (double)k * srows / (double)n_rows;
@@ -2303,17 +2305,21 @@ uint32_t batched_sample_rows(const IndexView& v, uint32_t k) {
     // lets ~4.6 x as many rows through at the same bound: four times the sample keeps the candidate count where it was
     const bool one = filter_mode(v) == 3;
     // beyond 64 results per query the candidate slots grow with k (batched_cand_cap): half the sample, twice the candidates
-    const uint64_t per = (one ? 384 : 1536) * (batched_large_k(k) ? 2 : 1);
+    const uint64_t per = (one ? 384 : 1536) * (batched_large_k(v, k) ? 2 : 1);
     const uint64_t want = ((uint64_t)n_rows * std::max(k, 1u) / per + 8191) / 8192 * 8192;
     uint64_t cap_rows = n_rows;
-    if (batched_large_k(k)) cap_rows = std::max<uint64_t>(32768, ((uint64_t)n_rows / 2 + 8191) / 8192 * 8192);   // the sample costs a pass over its rows: half the corpus at most
+    if (batched_large_k(v, k)) cap_rows = std::max<uint64_t>(32768, ((uint64_t)n_rows / 2 + 8191) / 8192 * 8192);   // the sample costs a pass over its rows: half the corpus at most
     const uint32_t full = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n_rows, cap_rows), std::max<uint64_t>(one ? 32768 : 8192, want));
     if (!batched_guess(v, k)) return full;
     // a guessed bound: the smallest sample whose rank leaves the expected candidates (rows under the bound x the filter's window: ~4.6 x
-    // with one term) within half the slots — 65 536 rows at 1M x k = 100 .. 4096, 524 288 at 10M x k = 100 — and never more than the rule above
+    // with one term) within the slots with four standard deviations to spare — 32 768 rows at 1M x k = 16 .. 64 and 1000 .. 4096, 65 536 at k = 100, 524 288 at 10M x k = 100 — and never more than the rule above
     const double f = one ? 4.6 : 1.2;
     uint32_t srows = kGuessSampleRows;
-    while (srows < full && guess_rank(n_rows, srows, k) * ((double)n_rows / srows) * f > 0.5 * batched_cand_cap(k)) srows *= 2;
+    auto fits = [&](uint32_t sr) {                                      // rows under the bound ~ Gamma(rank): mean rank N / S, four of its standard deviations above
+        const double rank = guess_rank(n_rows, sr, k);
+        return rank * ((double)n_rows / sr) * f * (1.0 + 4.0 / std::sqrt(rank)) <= 0.9 * batched_cand_cap(k);
+    };
+    while (srows < full && !fits(srows)) srows *= 2;
     return std::min(srows, full);
 }
 bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
@@ -2334,7 +2340,6 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
 // candidate slots per query: kMfmaCandCap up to 64 results; beyond, 16 k rounded up to a power of two (the sample is capped at
 // half the corpus there, so the expected candidates grow with k: about 2 f k with f ~ 4.6 for the one-term filter)
 uint32_t batched_cand_cap(uint32_t k) {
-    if (!batched_large_k(k)) return (uint32_t)kMfmaCandCap;
     uint32_t c = (uint32_t)kMfmaCandCap;
     while (c < 16u * k) c <<= 1;
     return c;
@@ -2356,7 +2361,7 @@ size_t batched_workspace_bytes(const IndexView& v, const ScanPlan& p, uint32_t n
     b += (size_t)nq_pad * 20;                                // cq, mq (m_q and b_q), eq
     b += (size_t)nq * ccap * 8;                              // candidates: rows + fp32 scores
     b += (size_t)nq * 8 + 256;                               // capacity word + counters, overflow flags
-    if (batched_large_k(k))                                  // keys of the upper bounds and of the exact distances, lower bounds, survivors, counters, norms, selection
+    if (batched_large_k(v, k))                               // keys of the upper bounds and of the exact distances, lower bounds, survivors, counters, norms, selection
         b += (size_t)nq * ccap * (8 + 8 + 4 + 4) + (size_t)nq * (4 + 16) + 1024 + select_workspace_bytes(nq, k) + (size_t)(v.n_tiles + 2) * 8 + 512;
     b += (size_t)nq * k * 8;                                 // sample rows/dist
     b += (size_t)nq * k * 16 + 256;                          // k_sample_bound's partial lists (up to four parts per query)
@@ -2380,7 +2385,7 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     float* mq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // m_q, b_q
     float* eq = reinterpret_cast<float*>(w + off); off += (size_t)nq_pad * 8;      // the scores' error bound per query (k_mfma_prep -> k_rescore_select)
     const uint32_t ccap = batched_cand_cap(k);
-    const bool large_k = batched_large_k(k);
+    const bool large_k = batched_large_k(v, k);
     uint32_t* cand = reinterpret_cast<uint32_t*>(w + off); off += (size_t)nq * ccap * 4;
     float* cscore = reinterpret_cast<float*>(w + off); off += (size_t)nq * ccap * 4;
     off = (off + 255) / 256 * 256;

@@ -532,9 +532,10 @@ def test_batched_large_k_equals_exact_scan(metric, nq, k):
 @pytest.mark.parametrize("metric,dim,nq,k,rowmajor", [
     ("cosine", 100, 64, 100, True), ("dot_product", 100, 48, 200, True), ("euclidean", 256, 40, 300, True), ("squared_euclidean", 72, 64, 129, True),   # k_cand_exact_wave on the row-major copy (100, 72: a last slab of 1 chunk)
     ("cosine", 50, 64, 100, False), ("squared_euclidean", 100, 64, 80, False), ("dot_product", 36, 40, 70, False), ("euclidean", 50, 33, 65, False),    # ... on the tiles, padded rows (dim % 4 != 0) and short last slabs
-    ("euclidean", 256, 256, 700, False), ("squared_euclidean", 100, 300, 1000, False), ("cosine", 72, 300, 1000, False)])                               # k_tp_exact (the tile pass) for the other metrics, a short last slab
+    ("euclidean", 256, 256, 700, False), ("squared_euclidean", 100, 300, 1000, False), ("cosine", 72, 300, 1000, False), ("dot_product", 64, 40, 600, False)])                               # k_tp_exact (the tile pass) for the other metrics, a short last slab
 def test_batched_large_k_layouts_and_odd_dimensions(metric, dim, nq, k, rowmajor):
-    """the exact passes of a large-k batch: a wave per 32 survivors (row-major copy or tiles) and, for many survivors, the pass over the tiles"""
+    """the exact passes of a large-k batch: a wave per 32 survivors (row-major copy or tiles) and, for many survivors, the pass over the tiles;
+    120 000 rows: below the guessed bound's range, so the sample is half the corpus and its bound exact (the histogram kernels from k ~ 400)"""
     import quiver_amd as q
     n = 120_000
     idx = q.DeviceIndex(dim, metric, rowmajor=rowmajor)
@@ -550,7 +551,7 @@ def test_batched_large_k_layouts_and_odd_dimensions(metric, dim, nq, k, rowmajor
 
 @pytest.mark.parametrize("metric,k", [("cosine", 100), ("dot_product", 1000), ("euclidean", 300), ("squared_euclidean", 65)])
 def test_batched_large_k_guessed_bound_on_a_large_corpus(metric, k):
-    """from 262 144 rows the bound of a large-k batch is a guess from 65 536 sample rows, checked after the filter (batched_guess)"""
+    """from 131 072 rows the bound of a batch with k >= 16 is a guess from 32 768 sample rows or more, checked after the filter (batched_guess)"""
     import quiver_amd as q
     n, dim, nq = 300_000, 64, 96
     idx = q.DeviceIndex(dim, metric)
@@ -562,6 +563,26 @@ def test_batched_large_k_guessed_bound_on_a_large_corpus(metric, k):
     for i in (0, nq - 1):
         er, ed = O.exact_search(q.metric_id(metric), corpus, qs[i], k)
         assert np.array_equal(batched[0][i], er) and np.array_equal(_bits(batched[1][i]), _bits(ed))
+
+
+def test_batched_large_k_guessed_bound_with_most_rows_dead():
+    """the guessed rank counts on k S / N live rows of the sample lying under the k-th distance; with 70 % of the rows removed far fewer do,
+    the guess is too tight for most queries, and the hand-back answers them — the result is the exact scan's over the live rows either way"""
+    import quiver_amd as q
+    n, dim, nq, k = 300_000, 64, 40, 120
+    idx = q.DeviceIndex(dim, "cosine")
+    idx.add_synthetic(20260424, 0, n)
+    rng = np.random.default_rng(9)
+    dead = rng.choice(n, int(0.7 * n), replace=False).astype(np.uint32)
+    idx.remove(dead)
+    alive = np.ones(n, bool); alive[dead] = False
+    qs = O.gen_rows(20260425, 0, nq, dim)
+    got = idx.search(qs, k, batched=True)
+    assert _eq(_exact(idx, qs, k), got)
+    corpus = O.gen_rows(20260424, 0, n, dim)
+    for i in (0, nq - 1):
+        er, ed = O.exact_search(0, corpus, qs[i], k, alive=alive)
+        assert np.array_equal(got[0][i], er) and np.array_equal(_bits(got[1][i]), _bits(ed))
 
 
 def test_batched_large_k_guessed_bound_that_fails_is_handed_back():
