@@ -1605,6 +1605,9 @@ k_sample_select(const float* __restrict__ bounds, uint32_t srows, uint32_t k, fl
     }
 }
 
+// (round 3's selection by sorted wave lists: since round 6 every shape that reached it takes k_sample_select or the selection path;
+// kept in the measurement build behind QV_MFMA_SAMPLE_SELECT=2)
+#ifdef QV_VARIANTS
 template <int M>
 __global__ void __launch_bounds__(1024)
 k_sample_bound(const float* __restrict__ bounds, uint32_t srows, uint32_t k, float gref, float* __restrict__ sample_dist, uint32_t parts) {
@@ -1663,6 +1666,7 @@ k_sample_bound(const float* __restrict__ bounds, uint32_t srows, uint32_t k, flo
         else if (lane < k) sample_dist[((size_t)qi * parts + part) * k + lane] = val;
     }
 }
+#endif
 
 // Exact re-scoring of one query's candidates + top-k; one workgroup per query.
 // Stage 1 narrows the candidates with their fp32 scores: with d~ the approximate distance and
@@ -2251,6 +2255,8 @@ k_tp_exact(IndexView v, const float* __restrict__ queries, const uint32_t* __res
     }
 }
 
+hipError_t launch_select_topk_counted(const uint64_t* d_keys, size_t stride, uint32_t n, const uint32_t* d_counts, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                                      uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);   // qv_select.hip
 // 1 = fp32 MFMA chain (BASELINE configs[2] as written), 2 = bfloat16 x 3, 3 = bfloat16 x 1; QV_MFMA_FILTER unset: the one-term
 // filter up to 1536 dimensions, three terms above.  Its window (2 x 7.9e-3 |q||r|) is measured in units of the scores' spread,
 // which shrinks like 1/sqrt(dim) on unstructured data: 256 queries x 3 GB of rows take 1.93 / 1.14 / 1.08 / 1.39 / 1.34 / 2.55 ms at
@@ -2271,7 +2277,13 @@ constexpr uint32_t kGuessSampleRows = 32768;
 static bool guess_eligible(const IndexView& v) { return v.n_rows >= 4 * kGuessSampleRows; }
 static bool batched_large_k(const IndexView& v, uint32_t k) {
     static const int from = dev_env_int("QV_BATCHED_SELECT_FROM", 16);
-    return k > (uint32_t)kMaxFusedK || ((int)k >= from && guess_eligible(v));
+    if (k > (uint32_t)kMaxFusedK) return true;
+    if (!guess_eligible(v)) return false;
+    if ((int)k >= from) return true;
+    // a corpus so large that the wave lists' sample (k N / 384 rows: 45 M rows up at k = 15) outgrows k_sample_select's LDS: the guess's small sample
+    const uint64_t per = filter_mode(v) == 3 ? 384 : 1536;
+    const uint64_t want = ((uint64_t)v.n_rows * std::max(k, 1u) / per + 8191) / 8192 * 8192;
+    return !sample_select_applies((uint32_t)std::min<uint64_t>(v.n_rows, want), k);
 }
 // ---- MFMA batched path --------------------------------------------------------------
 // Rows of the exact sample scan that bounds each query's k-th distance.  A sample of S of N rows lets about k*N/S rows through
@@ -2476,6 +2488,11 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         const bool sel2 = sel2_env == 1 && !group_min && sample_select_applies(vs.n_rows, ks);
         const size_t sel2_lds = sel2 ? sample_select_lds_bytes(vs.n_rows, ks) : 0;
         if (large_k && !sel2 && !group_min) { e = select_prepare(sel_ws, nq, ks, &sst, &shist, s); if (e != hipSuccess) return e; }   // (the histogram kernels' state)
+#ifdef QV_VARIANTS
+#define QV_SB_LISTS(MMM) hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts);
+#else
+#define QV_SB_LISTS(MMM) return hipErrorNotSupported;     /* unreachable: k_sample_select applies to every sample of at least 4096 rows with k <= 64 */
+#endif
 #define QV_SB(MMM) { if (sample1) hipLaunchKernelGGL((k_bf16x1_filter_w8<MMM == QV_L2SQ ? QV_L2 : MMM, 8, 4, 1, false, false, true>), dim3(gs1), dim3(512), 0, s, v, Qbf, cq, eq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep, group_min ? 1u : 0u); \
                      else hipLaunchKernelGGL(k_bf16x3_filter<MMM == QV_L2SQ ? QV_L2 : MMM>, dim3(gs), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, sscore, vs.n_rows, gstep); \
                      if (group_min) { /* the bound is selected inside k_mfma_prep from the group minima */ } \
@@ -2484,9 +2501,10 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
                      else if (large_k) { hipLaunchKernelGGL(k_sample_hist<0>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, ks, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_hist<1>, dim3(hgrid, nq), dim3(kSelBlock), 0, s, sscore, vs.n_rows, ks, sst, shist); \
                                     hipLaunchKernelGGL(k_sample_bound_from_state<MMM>, dim3((nq + 255) / 256), dim3(256), 0, s, sst, nq, ks, (float)filter_gamma(v.dim, 0) * 1.000001f, ubuf); } \
-                     else hipLaunchKernelGGL(k_sample_bound<MMM>, dim3(nq, bparts), dim3(1024), 0, s, sscore, vs.n_rows, k, (float)filter_gamma(v.dim, 0) * 1.000001f, bparts > 1 ? sparts : sdist, bparts); }
+                     else QV_SB_LISTS(MMM) }
         if (v.metric == QV_COSINE) QV_SB(QV_COSINE) else if (v.metric == QV_DOT) QV_SB(QV_DOT) else if (v.metric == QV_L2) QV_SB(QV_L2) else QV_SB(QV_L2SQ)
 #undef QV_SB
+#undef QV_SB_LISTS
         hipLaunchKernelGGL(k_mfma_prep, dim3(nq_pad), dim3(64), 0, s, d_queries, nq, nq_pad, v.dim, v.dim4, bparts > 1 && !large_k && !group_min && !sel2 ? sparts : ubuf, large_k || group_min || sel2 ? 1u : bparts, ks, v.metric, Qt, cq, mq, eq, cnt, ovf, gmode, pad_main ? 3 : (bf ? 2 : 3), ccap, pad_main ? w8x2_rounds(v.dim4) : 0u, group_min ? sscore : nullptr, gmin_vals);
     } else {
         ScanPlan ps = plan_scan(vs.n_tiles, cus);
@@ -2624,7 +2642,8 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         } else if (wave_exact) { e = set_lds(k_cand_exact_wave<MMM>, lds_w); if (e != hipSuccess) return e;                                                  \
             hipLaunchKernelGGL(k_cand_exact_wave<MMM>, dim3(nq, ccap / 32), dim3(64), lds_w, s, v, d_queries, surv, nsurv, ccap, qnorms, keys_ex); }        \
         else QV_LK_LANE(MMM)                                                                                                                                \
-        e = launch_select_topk(keys_ex, ccap, ccap, nq, k, k, sel_ws, d_rows_out, d_dist_out, s, false, false); if (e != hipSuccess) return e; }
+        e = ccap <= 16384u ? launch_select_topk_counted(keys_ex, ccap, ccap, nsurv, nq, k, k, d_rows_out, d_dist_out, s)                                   \
+                          : launch_select_topk(keys_ex, ccap, ccap, nq, k, k, sel_ws, d_rows_out, d_dist_out, s, false, false); if (e != hipSuccess) return e; }
         if (v.metric == QV_COSINE) QV_LK(QV_COSINE) else if (v.metric == QV_DOT) QV_LK(QV_DOT) else if (v.metric == QV_L2) QV_LK(QV_L2) else QV_LK(QV_L2SQ)
 #undef QV_LK
 #undef QV_LK_LANE

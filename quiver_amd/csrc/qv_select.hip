@@ -114,7 +114,8 @@ k_select_compact(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, u
 // the keys were built over a candidate list rather than over the corpus.
 __global__ void __launch_bounds__(kSelSortBlock)
 k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint32_t kk, uint32_t k_stride, uint32_t cap,
-              SelState* __restrict__ st, const uint64_t* __restrict__ cand, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, int ordered) {
+              SelState* __restrict__ st, const uint64_t* __restrict__ cand, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, int ordered,
+              const uint32_t* __restrict__ counts = nullptr /* direct form: live keys of query q are keys[q][0 .. counts[q]) */) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* a = reinterpret_cast<uint64_t*>(smem);                   // [cap]
     __shared__ uint32_t wcnt[kSelSortBlock / 64];
@@ -134,7 +135,7 @@ k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
     // st == nullptr: no global windows ran — the query's n keys (n <= cap) come straight from the array and the selection happens
     // here (launch_select_topk: a few thousand keys per query, where six launches cost more than the work)
     const bool direct = st == nullptr;
-    uint32_t nc = direct ? n : (s->n_cand < cap ? s->n_cand : cap);
+    uint32_t nc = direct ? (counts != nullptr && counts[q] < n ? counts[q] : n) : (s->n_cand < cap ? s->n_cand : cap);
     const uint64_t* src = direct ? keys + (size_t)q * stride : cand + (size_t)q * cap;
     for (uint32_t i = threadIdx.x; i < nc; i += kSelSortBlock) a[i] = src[i];
     const uint32_t lane_ = lane, wave_ = wave;
@@ -329,6 +330,20 @@ k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
                                            tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
 #endif
 #undef SELTK
+}
+
+// The direct form over lists whose live keys are a counted prefix (a batch's exact distances: survivors first, dead slots behind): only the
+// prefix is read — 2 100 of 16 384 slots at k = 1000.  n <= 16384.
+hipError_t launch_select_topk_counted(const uint64_t* d_keys, size_t stride, uint32_t n, const uint32_t* d_counts, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                                      uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    if (nq == 0 || kk == 0 || kk > (uint32_t)kMaxSelectK || kk > k_stride || n == 0 || n > 16384u || kk > n || d_counts == nullptr) return hipErrorInvalidValue;
+    uint32_t m_sort = 64;
+    while (m_sort < kk) m_sort <<= 1;
+    const size_t lds_d = (size_t)std::max<uint32_t>(n, m_sort) * sizeof(uint64_t);
+    hipError_t e = set_lds(k_select_sort, lds_d);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_select_sort, dim3(nq), dim3(kSelSortBlock), lds_d, s, d_keys, stride, n, kk, k_stride, n, (SelState*)nullptr, (const uint64_t*)nullptr, d_rows_out, d_dist_out, 0, d_counts);
+    return hipGetLastError();
 }
 
 uint32_t select_cap(uint32_t kk) { return kk <= 4096 ? 8192u : 16384u; }   // sort capacity: twice the largest k it serves (64 / 128 KB of LDS)

@@ -9,3 +9,5 @@ bash tools/run_round_pmc.sh r06 > gpurun_out/r06_round_pmc.log 2>&1
 bash tools/run_kernel_coverage.sh $PWD/gpurun_out/r06_kernel_coverage.txt > gpurun_out/r06_cov.log 2>&1
 grep -E "^chunk|FAILED|NOT TRACED" gpurun_out/r06_cov.log; head -3 gpurun_out/r06_kernel_coverage.txt
 head -c 3000 gpurun_out/r06_bench_n1.jsonl; echo; cat gpurun_out/r06_hnsw_1Mx768.txt; cat gpurun_out/r06_10Mx768_pmc.json
+bash tools/run_largek_pmc.sh > gpurun_out/r06_largek_pmc.log 2>&1; tail -3 gpurun_out/r06_largek_pmc.txt
+bash tools/run_dispatch_table.sh gpurun_out/r06_dispatch_table.md > /dev/null 2>&1; grep -c "^|" gpurun_out/r06_dispatch_table.md
