@@ -532,7 +532,8 @@ def test_batched_large_k_equals_exact_scan(metric, nq, k):
 @pytest.mark.parametrize("metric,dim,nq,k,rowmajor", [
     ("cosine", 100, 64, 100, True), ("dot_product", 100, 48, 200, True), ("euclidean", 256, 40, 300, True), ("squared_euclidean", 72, 64, 129, True),   # k_cand_exact_wave on the row-major copy (100, 72: a last slab of 1 chunk)
     ("cosine", 50, 64, 100, False), ("squared_euclidean", 100, 64, 80, False), ("dot_product", 36, 40, 70, False), ("euclidean", 50, 33, 65, False),    # ... on the tiles, padded rows (dim % 4 != 0) and short last slabs
-    ("euclidean", 256, 256, 700, False), ("squared_euclidean", 100, 300, 1000, False), ("cosine", 72, 300, 1000, False), ("dot_product", 64, 40, 600, False)])                               # k_tp_exact (the tile pass) for the other metrics, a short last slab
+    ("euclidean", 256, 256, 700, False), ("squared_euclidean", 100, 300, 1000, False), ("cosine", 72, 300, 1000, False), ("dot_product", 64, 40, 600, False),
+    ("cosine", 2048, 32, 100, False), ("dot_product", 2048, 64, 500, False), ("euclidean", 1536, 24, 70, True)])                                         # wide rows: 64 / 48 slabs a row, the query's 8 / 6 KiB in LDS                               # k_tp_exact (the tile pass) for the other metrics, a short last slab
 def test_batched_large_k_layouts_and_odd_dimensions(metric, dim, nq, k, rowmajor):
     """the exact passes of a large-k batch: a wave per 32 survivors (row-major copy or tiles) and, for many survivors, the pass over the tiles;
     120 000 rows: below the guessed bound's range, so the sample is half the corpus and its bound exact (the histogram kernels from k ~ 400)"""

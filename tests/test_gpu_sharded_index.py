@@ -57,6 +57,30 @@ def test_any_k_equals_oracle(n_shards, metric):
     sh.close()
 
 
+@pytest.mark.parametrize("k", [40, 100])
+def test_batches_on_shards_large_enough_for_a_guessed_bound(k):
+    """three co-located shards of 150 000 rows: each shard's batch takes the selection path with a guessed bound (16 or more results per query
+    over 131 072 rows or more); half of the rows sit in clusters of 256 stored one after the other, so some guesses fail and their queries come
+    back flagged — redone on the device (k <= 64) or from the host's flag read (k > 64).  Equal to one index's exact scan."""
+    dim, per, nq = 64, 150_000, 48
+    rng = np.random.default_rng(17)
+    centers = rng.standard_normal((per * 3 // 2 // 256, dim)).astype(np.float32)
+    clustered = np.concatenate([c + 0.02 * rng.standard_normal((256, dim)).astype(np.float32) for c in centers])
+    rows = np.concatenate([clustered, O.gen_rows(61, 0, 3 * per - len(clustered), dim)])
+    one = quiver_amd.DeviceIndex(dim, "cosine", filter="off")
+    one.add(rows)
+    qs = np.concatenate([centers[0:32:2], centers[1:33:2], O.gen_rows(62, 0, nq - 32, dim)]).astype(np.float32)
+    er, ed, _ = one.search(qs, k)
+    sh = quiver_amd.ShardedIndex(dim, "cosine", devices=[0, 0, 0], peer_copy=True)
+    gids = sh.add(rows)
+    r, d, c = sh.search(qs, k)
+    pos = {int(g): i for i, g in enumerate(gids)}
+    back = np.vectorize(lambda g: pos[int(g)])(r)                                 # global row ids back to positions in `rows`
+    assert (c == k).all()
+    assert np.array_equal(back, er.astype(back.dtype)) and np.array_equal(d.view(np.uint32), ed.view(np.uint32))
+    sh.close(); one.close()
+
+
 @pytest.mark.parametrize("n_shards", SHARDS)
 def test_masked_search_equals_oracle_over_the_selected_rows(n_shards):
     mid, dim, n = 0, 40, 2500
