@@ -408,10 +408,11 @@ int qv_sharded_search_negative(qv_sharded* s, const float* query, const float* n
 int qv_sharded_distance_rows(qv_sharded* s, const float* query, const uint32_t* global_rows, uint32_t n, float* dist_out);
 /* Queries and results resident on the FIRST device.  The work is enqueued on the handle's own streams and ordered after
  * what `stream` (a stream of the first device; null = the null stream, as in qv_index_search_device) held at the call and
- * before anything `stream` runs afterwards; there is no host synchronisation for any nq at k <= 64: queries the
- * matrix-core filter hands back (nq >= 9) are listed and redone by the exact scan on the device (round 5; until then their
- * flags were read on the host, one round trip per shard and batch).  Batches with 64 < k <= 4096 that go through the filter still
- * read their hand-back flags on the host (the redo is a selection path per query) and are synchronous per shard.  Any k. */
+ * before anything `stream` runs afterwards; there is no host synchronisation for any nq: queries the matrix-core filter
+ * hands back (nq >= 9) are listed and redone by the exact scan on the device (k <= 64: round 5; 64 < k <= 4096: round 6, the
+ * listed queries in groups of 64 through shared corpus passes + radix selection; until then their flags were read on the
+ * host, one round trip per shard and batch).  The one exception: a shard of more than ~67 M rows at k > 64, where a query's
+ * keys leave room for one query at a time, still reads the flags on the host.  Any k. */
 int qv_sharded_search_device(qv_sharded* s, const float* d_queries, uint32_t nq, uint32_t k, uint32_t* d_rows_out, float* d_dist_out, void* stream);
 int qv_sharded_sync(qv_sharded* s);                            /* wait for every stream of the handle */
 /* Measurement aid: with profiling on, every search is synchronous and its phases are timed with HIP events on the first

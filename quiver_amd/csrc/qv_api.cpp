@@ -733,7 +733,7 @@ int qv_internal_search_candidates_device(qv_index* idx, const float* d_queries, 
 // qv_index_search_batched_device), enqueued on `stream` behind the batch — listed and scanned on the device, nothing read back.
 int qv_internal_redo_flagged_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k, const uint32_t* d_flags,
                                     uint32_t* d_rows_out, float* d_dist_out, void* stream) {
-    if (!idx || !d_queries || !d_flags || !d_rows_out || !d_dist_out || k == 0 || k > (uint32_t)qv::kMaxFusedK) return fail(QV_ERR_INVALID_ARG, "bad argument");
+    if (!idx || !d_queries || !d_flags || !d_rows_out || !d_dist_out || k == 0 || k > (uint32_t)qv::kMaxSelectK) return fail(QV_ERR_INVALID_ARG, "bad argument");
     if (nq == 0) return QV_OK;
     HIPCHK(hipSetDevice(idx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -741,6 +741,14 @@ int qv_internal_redo_flagged_device(qv_index* idx, const float* d_queries, uint3
     const qv::ScanPlan plan = qv::plan_scan(v.n_tiles, idx->cus);
     void* ws = nullptr;
     std::unique_lock<std::mutex> ws_hold;
+    if (k > (uint32_t)qv::kMaxFusedK) {                               // the selection path's hand-backs: QV_ERR_UNSUPPORTED = the caller reads the flags itself
+        int rc0 = stream_workspace(idx, s, qv::flat_select_redo_workspace_bytes(v.n_tiles, nq, k, v.dim, v.dim4), &ws, &ws_hold);
+        if (rc0 != QV_OK) return rc0;
+        hipError_t e0 = qv::launch_flat_select_redo(v, plan, d_queries, nq, k, k, d_flags, ws, d_rows_out, d_dist_out, s);
+        if (e0 == hipErrorNotSupported) return QV_ERR_UNSUPPORTED;
+        if (e0 != hipSuccess) return fail(QV_ERR_DEVICE, "redo launch failed: %s", hipGetErrorString(e0));
+        return QV_OK;
+    }
     int rc = stream_workspace(idx, s, qv::redo_workspace_bytes(plan, nq, k), &ws, &ws_hold);
     if (rc != QV_OK) return rc;
     hipError_t e = qv::launch_flat_redo_flagged(v, plan, d_queries, nq, k, k, d_flags, ws, d_rows_out, d_dist_out, s);

@@ -212,7 +212,8 @@ uint32_t select_cap(uint32_t kk);
 size_t select_workspace_bytes(uint32_t nq, uint32_t kk);
 hipError_t select_prepare(void* d_ws, uint32_t nq, uint32_t kk, SelState** st_out, uint32_t** hist_out, hipStream_t s);
 hipError_t launch_select_topk(const uint64_t* d_keys, size_t stride, uint32_t n, uint32_t nq, uint32_t kk, uint32_t k_stride, void* d_ws,
-                              uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, bool window0_counted = false, bool ordered = true);
+                              uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, bool window0_counted = false, bool ordered = true,
+                              const uint32_t* d_active = nullptr /* device word: queries from *d_active on are left alone */);
 // 64 < kk <= kMaxWideK: the scan with a list of 2 keys per lane (same stream as launch_flat_topk, no key per row written),
 // then the selection over the waves' lists.  ev0 / ev1 as launch_flat_topk.
 size_t flat_wide_workspace_bytes(const ScanPlan& p, uint32_t nq, uint32_t kk);
@@ -220,12 +221,18 @@ hipError_t launch_flat_wide(const IndexView& v, const ScanPlan& p, const float* 
                             void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // keys [nq][n_tiles * 64] of nq >= 2 queries, QB (4 or 8) queries per corpus pass (k_flat_keys_mq); d_qws: flat_keys_mq_workspace_bytes
 size_t flat_keys_mq_workspace_bytes(uint32_t nq, uint32_t dim4);
-hipError_t launch_flat_keys_mq(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint64_t* d_keys, void* d_qws, hipStream_t s);
+hipError_t launch_flat_keys_mq(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint64_t* d_keys, void* d_qws, hipStream_t s,
+                               const uint32_t* d_active = nullptr /* device word: only the first *d_active queries are worked on */);
 // scan + selection for nq queries at list length kk <= kMaxSelectK: every query's keys (one 8-byte key per row, k_flat_keys), then
 // launch_select_topk; queries go in groups so that the keys of a group stay under flat_select_group_bytes
 size_t flat_select_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk, uint32_t dim4);
 hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
                               void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
+// The same for the queries whose flags are set (64 < kk <= kMaxSelectK: the batched filter's hand-backs above the wave lists' range), decided
+// and listed on the device: nothing is read back.  Results replace rows / distances [q][k_stride] of those queries.
+size_t flat_select_redo_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk, uint32_t dim, uint32_t dim4);
+hipError_t launch_flat_select_redo(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride, const uint32_t* d_flags,
+                                   void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s);
 
 // Full ranking path (any k): all distances -> 64-bit keys -> stable radix sort -> first k.
 // d_keys_a/d_keys_b: two buffers of n_tiles*64 u64; d_hist: radix histogram workspace.

@@ -318,8 +318,16 @@ size_t flat_select_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk, u
     const uint32_t g = flat_select_group(n_tiles, nq);
     return (size_t)g * n_tiles * 64 * sizeof(uint64_t) + 256 + select_workspace_bytes(g, kk) + 256 + (g >= 2 ? flat_keys_mq_workspace_bytes(g, dim4) : 0);
 }
+static hipError_t flat_select_impl(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                                   void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, const uint32_t* d_active);
 hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
                               void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    return flat_select_impl(v, p, d_queries, nq, kk, k_stride, d_ws, d_rows_out, d_dist_out, s, nullptr);
+}
+// d_active (a device word, or null): only the first *d_active queries are worked on — every kernel's other workgroups leave at once
+// (launch_flat_select_redo: the count is decided on the device).  With it the queries go through the shared passes (nq >= 2, one group).
+static hipError_t flat_select_impl(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride,
+                                   void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, const uint32_t* d_active) {
     const uint32_t n = v.n_tiles * 64;
     const uint32_t g = flat_select_group(v.n_tiles, nq);
     uint64_t* keys = static_cast<uint64_t*>(d_ws);
@@ -332,12 +340,13 @@ hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float
         if (m >= 2) {
             // several queries: they share corpus passes (4 or 8 per pass) instead of reading the corpus once each — 8 queries at
             // k = 100 over 1M x 768: one ~0.6 ms pass instead of eight 0.46 ms ones; the selection counts its first window itself
-            hipError_t e2 = launch_flat_keys_mq(v, p, d_queries + (size_t)q0 * v.dim, m, keys, qws, s);
+            hipError_t e2 = launch_flat_keys_mq(v, p, d_queries + (size_t)q0 * v.dim, m, keys, qws, s, d_active);
             if (e2 != hipSuccess) return e2;
-            e2 = launch_select_topk(keys, n, n, m, kk, k_stride, sel_ws, d_rows_out + (size_t)q0 * k_stride, d_dist_out + (size_t)q0 * k_stride, s, false);
+            e2 = launch_select_topk(keys, n, n, m, kk, k_stride, sel_ws, d_rows_out + (size_t)q0 * k_stride, d_dist_out + (size_t)q0 * k_stride, s, false, true, d_active);
             if (e2 != hipSuccess) return e2;
             continue;
         }
+        if (d_active != nullptr) return hipErrorInvalidValue;             // (the lone-query kernel takes no device-side count)
         SelState* st = nullptr; uint32_t* hist = nullptr;
         hipError_t e = select_prepare(sel_ws, m, kk, &st, &hist, s);     // states and histograms zeroed: the keys kernel counts window 0
         if (e != hipSuccess) return e;
@@ -352,6 +361,84 @@ hipError_t launch_flat_select(const IndexView& v, const ScanPlan& p, const float
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// ---------------------------------------------------------------- hand-backs above 64 results per query, redone WITHOUT the host -----
+// The k <= 64 scheme (qv_scan.hip: k_redo_compact + k_flat_scan_redo) for the selection path: the flagged queries are listed on the device,
+// and for every kLkRedoSlots list entries the exact path runs on a gathered copy of their vectors — shared corpus passes writing a key per
+// row (k_flat_keys_mq), the radix selection, the results scattered back to the queries' own slots — with every kernel's workgroups
+// leaving at once where the list has no entry for them.  ceil(nq / slots) rounds of ten launches are issued whatever the flags say: ~0.1 ms
+// of empty launches per 256 queries, the price of a call that never waits for its own filter.
+constexpr uint32_t kLkRedoSlots = 64;
+static uint32_t lk_redo_slots(uint32_t n_tiles, uint32_t nq) { return flat_select_group(n_tiles, std::min(nq, kLkRedoSlots)); }
+__global__ void __launch_bounds__(1024)
+k_lk_redo_list(const uint32_t* __restrict__ flags, uint32_t nq, uint32_t slots, uint32_t* __restrict__ list, uint32_t* __restrict__ count /* [0] flagged, [1 + r] entries of round r */) {
+    __shared__ uint32_t s_n;
+    __shared__ uint32_t w_off[16];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nq; base += blockDim.x) {             // in query order (a wave at a time: ballot + prefix popcount)
+        const uint32_t q = base + threadIdx.x;
+        const bool f = q < nq && flags[q] != 0;
+        const uint64_t m = __ballot(f);
+        if (lane == 0) w_off[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        uint32_t before = s_n;
+        for (uint32_t w = 0; w < wave; w++) before += w_off[w];
+        if (f) list[before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < (blockDim.x >> 6); w++) t += w_off[w]; s_n += t; }
+        __syncthreads();
+    }
+    const uint32_t total = s_n, rounds = (nq + slots - 1) / slots;
+    if (threadIdx.x == 0) count[0] = total;
+    for (uint32_t r = threadIdx.x; r < rounds; r += blockDim.x) count[1 + r] = total > r * slots ? (total - r * slots < slots ? total - r * slots : slots) : 0u;
+}
+// slot j of the round takes the vector of the list's entry first + j (zeros where the list has none: the query blocks are laid out for every slot)
+__global__ void __launch_bounds__(256)
+k_lk_redo_gather(const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t first, float* __restrict__ rq) {
+    const uint32_t j = blockIdx.x;
+    const bool on = first + j < count[0];
+    const float* src = queries + (size_t)(on ? list[first + j] : 0u) * dim;
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) rq[(size_t)j * dim + i] = on ? src[i] : 0.0f;
+}
+__global__ void __launch_bounds__(256)
+k_lk_redo_scatter(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t first, const uint32_t* __restrict__ t_rows, const float* __restrict__ t_dist,
+                  uint32_t k_stride, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out) {
+    const uint32_t j = blockIdx.x;
+    if (first + j >= count[0]) return;
+    const uint32_t q = list[first + j];
+    for (uint32_t i = threadIdx.x; i < k_stride; i += blockDim.x) {
+        rows_out[(size_t)q * k_stride + i] = t_rows[(size_t)j * k_stride + i];
+        dist_out[(size_t)q * k_stride + i] = t_dist[(size_t)j * k_stride + i];
+    }
+}
+static size_t up256(size_t b) { return (b + 255) / 256 * 256; }
+size_t flat_select_redo_workspace_bytes(uint32_t n_tiles, uint32_t nq, uint32_t kk, uint32_t dim, uint32_t dim4) {
+    const uint32_t slots = lk_redo_slots(n_tiles, nq);
+    return up256((size_t)nq * 4) + up256((size_t)(nq + 2) * 4) + up256((size_t)slots * dim * 4) + 2 * up256((size_t)slots * kk * 4) + flat_select_workspace_bytes(n_tiles, slots, kk, dim4) + 256;
+}
+hipError_t launch_flat_select_redo(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint32_t kk, uint32_t k_stride, const uint32_t* d_flags,
+                                   void* d_ws, uint32_t* d_rows_out, float* d_dist_out, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    const uint32_t slots = lk_redo_slots(v.n_tiles, nq);
+    if (kk <= (uint32_t)kMaxFusedK || kk > (uint32_t)kMaxSelectK || kk != k_stride || slots < 2) return hipErrorNotSupported;   // (a corpus whose keys leave room for one query at a time: the caller's host path)
+    char* w = static_cast<char*>(d_ws);
+    uint32_t* list = reinterpret_cast<uint32_t*>(w); w += up256((size_t)nq * 4);
+    uint32_t* count = reinterpret_cast<uint32_t*>(w); w += up256((size_t)(nq + 2) * 4);
+    float* rq = reinterpret_cast<float*>(w); w += up256((size_t)slots * v.dim * 4);
+    uint32_t* t_rows = reinterpret_cast<uint32_t*>(w); w += up256((size_t)slots * kk * 4);
+    float* t_dist = reinterpret_cast<float*>(w); w += up256((size_t)slots * kk * 4);
+    hipLaunchKernelGGL(k_lk_redo_list, dim3(1), dim3(1024), 0, s, d_flags, nq, slots, list, count);
+    uint32_t round = 0;
+    for (uint32_t first = 0; first < nq; first += slots, round++) {
+        hipLaunchKernelGGL(k_lk_redo_gather, dim3(slots), dim3(256), 0, s, d_queries, v.dim, list, count, first, rq);
+        hipError_t e = flat_select_impl(v, p, rq, slots, kk, k_stride, w, t_rows, t_dist, s, count + 1 + round);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_lk_redo_scatter, dim3(slots), dim3(256), 0, s, list, count, first, t_rows, t_dist, k_stride, d_rows_out, d_dist_out);
+    }
+    return hipGetLastError();
 }
 
 size_t full_sort_workspace_bytes(uint32_t n_tiles) {

@@ -725,12 +725,14 @@ k_flat_scan_mq(IndexView v, const float* __restrict__ queries, const typename MT
 // (k_flat_scan_mq's SQ form); keys_all [nq][n_tiles * 64].  grid = (workgroups, ceil(nq / QB)).
 template <int M, int U, int QB>
 __global__ void __launch_bounds__(kScanBlock, 2)
-k_flat_keys_mq(IndexView v, const typename MT<M>::Q* __restrict__ qblk, uint32_t nq, uint64_t* __restrict__ keys_all) {
+k_flat_keys_mq(IndexView v, const typename MT<M>::Q* __restrict__ qblk, uint32_t nq, uint64_t* __restrict__ keys_all,
+               const uint32_t* __restrict__ active /* null, or a device word: query groups from *active on leave at once (launch_flat_select_redo) */) {
     using Q = typename MT<M>::Q;
     using A = typename MT<M>::A;
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t q0 = blockIdx.y * QB;
+    if (active != nullptr && q0 >= *active) return;
     const Q* q_lds = qblk + (size_t)blockIdx.y * v.dim4 * 4 * QB;                // global, uniform -> scalar loads
     const uint32_t tw = gridDim.x * kScanWaves;
     const size_t n = (size_t)v.n_tiles * 64;
@@ -761,7 +763,7 @@ k_flat_keys_mq(IndexView v, const typename MT<M>::Q* __restrict__ qblk, uint32_t
 
 size_t flat_keys_mq_workspace_bytes(uint32_t nq, uint32_t dim4) { return ((size_t)(nq + 8) * dim4 * 4 * sizeof(double) + 255) / 256 * 256; }
 // keys of nq >= 2 queries in shared corpus passes; d_qws: flat_keys_mq_workspace_bytes
-hipError_t launch_flat_keys_mq(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint64_t* d_keys, void* d_qws, hipStream_t s) {
+hipError_t launch_flat_keys_mq(const IndexView& v, const ScanPlan& p, const float* d_queries, uint32_t nq, uint64_t* d_keys, void* d_qws, hipStream_t s, const uint32_t* d_active) {
     const uint32_t want = (v.n_tiles + kScanWaves - 1) / kScanWaves;
     const uint32_t grid = std::max(1u, std::min(want, p.grid));
 #define QV_KMQ(MMM, QQ)                                                                                                   \
@@ -770,7 +772,7 @@ hipError_t launch_flat_keys_mq(const IndexView& v, const ScanPlan& p, const floa
         const uint32_t groups = (nq + QQ - 1) / QQ;                                                                       \
         const uint32_t per = v.dim4 * 4 * QQ;                                                                             \
         hipLaunchKernelGGL((k_prep_qblk<MMM, QQ>), dim3((per + 255) / 256, groups), dim3(256), 0, s, d_queries, nq, v.dim, v.dim4, static_cast<QT*>(d_qws)); \
-        hipLaunchKernelGGL((k_flat_keys_mq<MMM, 4, QQ>), dim3(grid, groups), dim3(p.block), 0, s, v, static_cast<const QT*>(d_qws), nq, d_keys); \
+        hipLaunchKernelGGL((k_flat_keys_mq<MMM, 4, QQ>), dim3(grid, groups), dim3(p.block), 0, s, v, static_cast<const QT*>(d_qws), nq, d_keys, d_active); \
     }
     if (nq >= 5) { QV_DISPATCH_METRIC(v.metric, { QV_KMQ(MM, 8) }); }
     else { QV_DISPATCH_METRIC(v.metric, { QV_KMQ(MM, 4) }); }

@@ -26,12 +26,14 @@ namespace qv {
 // One window of the selection.  grid = (workgroups, nq); keys of query q at keys + q * stride, n of them (n even).
 template <int W>
 __global__ void __launch_bounds__(kSelBlock)
-k_select_hist(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint32_t k, uint32_t cap, SelState* __restrict__ st, uint32_t* __restrict__ hist) {
+k_select_hist(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint32_t k, uint32_t cap, SelState* __restrict__ st, uint32_t* __restrict__ hist,
+              const uint32_t* __restrict__ active = nullptr /* a device word: queries from *active on are left alone */) {
     constexpr int shift = SelWindow<W>::shift;
     constexpr int wbits = SelWindow<W>::wbits;
     constexpr uint32_t nb = SelWindow<W>::nb;
     __shared__ uint32_t h[kSelBins];
     const uint32_t q = blockIdx.y;
+    if (active != nullptr && q >= *active) return;
     SelState* s = st + q;
     if (s->done || s->bits != 64 - shift - wbits) return;              // decided already (uniform over the query's workgroups), or this window was
                                                                       // taken by the kernel that made the keys (k_flat_keys counts window 0 itself)
@@ -67,8 +69,10 @@ k_select_hist(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
 // keys up to the decided prefix (inclusive) -> cand[q][...]; when even 32 decided bits leave more ties than the sort holds
 // (done == 0), only the keys strictly below the tied distance: the sort kernel adds the first k_rem ties in row order
 __global__ void __launch_bounds__(kSelBlock)
-k_select_compact(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint32_t cap, SelState* __restrict__ st, uint64_t* __restrict__ cand) {
+k_select_compact(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint32_t cap, SelState* __restrict__ st, uint64_t* __restrict__ cand,
+                 const uint32_t* __restrict__ active = nullptr) {
     const uint32_t q = blockIdx.y;
+    if (active != nullptr && q >= *active) return;
     SelState* s = st + q;
     const uint32_t sh = 64 - s->bits;
     const unsigned long long top = s->prefix >> sh;
@@ -115,7 +119,8 @@ k_select_compact(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, u
 __global__ void __launch_bounds__(kSelSortBlock)
 k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint32_t kk, uint32_t k_stride, uint32_t cap,
               SelState* __restrict__ st, const uint64_t* __restrict__ cand, uint32_t* __restrict__ rows_out, float* __restrict__ dist_out, int ordered,
-              const uint32_t* __restrict__ counts = nullptr /* direct form: live keys of query q are keys[q][0 .. counts[q]) */) {
+              const uint32_t* __restrict__ counts = nullptr /* direct form: live keys of query q are keys[q][0 .. counts[q]) */,
+              const uint32_t* __restrict__ active = nullptr) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint64_t* a = reinterpret_cast<uint64_t*>(smem);                   // [cap]
     __shared__ uint32_t wcnt[kSelSortBlock / 64];
@@ -123,6 +128,7 @@ k_select_sort(const uint64_t* __restrict__ keys, size_t stride, uint32_t n, uint
     __shared__ uint32_t hh[kSelBins];                                  // histogram of the in-LDS radix passes
     __shared__ uint32_t r_d, r_cum, r_bucket, r_cnt;
     const uint32_t q = blockIdx.x;
+    if (active != nullptr && q >= *active) return;
     SelState* s = st + q;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
 #ifdef QV_SEL_PROF
@@ -371,7 +377,7 @@ hipError_t select_prepare(void* d_ws, uint32_t nq, uint32_t kk, SelState** st_ou
 }
 
 hipError_t launch_select_topk(const uint64_t* d_keys, size_t stride, uint32_t n, uint32_t nq, uint32_t kk, uint32_t k_stride, void* d_ws,
-                              uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, bool window0_counted, bool ordered) {
+                              uint32_t* d_rows_out, float* d_dist_out, hipStream_t s, bool window0_counted, bool ordered, const uint32_t* d_active) {
     if (nq == 0 || kk == 0 || kk > (uint32_t)kMaxSelectK || kk > k_stride || (n & 1u) || (stride & 1u) || n == 0 || kk > n) return hipErrorInvalidValue;
     const uint32_t cap = select_cap(kk);
     char* w = static_cast<char*>(d_ws);
@@ -388,21 +394,21 @@ hipError_t launch_select_topk(const uint64_t* d_keys, size_t stride, uint32_t n,
         const size_t lds_d = (size_t)std::max<uint32_t>(n, m_sort) * sizeof(uint64_t);
         e = set_lds(k_select_sort, lds_d);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_select_sort, dim3(nq), dim3(kSelSortBlock), lds_d, s, d_keys, stride, n, kk, k_stride, n, (SelState*)nullptr, (const uint64_t*)nullptr, d_rows_out, d_dist_out, 0);
+        hipLaunchKernelGGL(k_select_sort, dim3(nq), dim3(kSelSortBlock), lds_d, s, d_keys, stride, n, kk, k_stride, n, (SelState*)nullptr, (const uint64_t*)nullptr, d_rows_out, d_dist_out, 0, (const uint32_t*)nullptr, d_active);
         return hipGetLastError();
     }
     if (!window0_counted) {
         e = select_prepare(d_ws, nq, kk, &st, &hist, s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_select_hist<0>, dim3(grid, nq), dim3(kSelBlock), 0, s, d_keys, stride, n, kk, cap, st, hist);
+        hipLaunchKernelGGL(k_select_hist<0>, dim3(grid, nq), dim3(kSelBlock), 0, s, d_keys, stride, n, kk, cap, st, hist, d_active);
     }
-    hipLaunchKernelGGL(k_select_hist<1>, dim3(grid, nq), dim3(kSelBlock), 0, s, d_keys, stride, n, kk, cap, st, hist);
-    hipLaunchKernelGGL(k_select_hist<2>, dim3(grid, nq), dim3(kSelBlock), 0, s, d_keys, stride, n, kk, cap, st, hist);
-    hipLaunchKernelGGL(k_select_compact, dim3(grid, nq), dim3(kSelBlock), 0, s, d_keys, stride, n, cap, st, cand);
+    hipLaunchKernelGGL(k_select_hist<1>, dim3(grid, nq), dim3(kSelBlock), 0, s, d_keys, stride, n, kk, cap, st, hist, d_active);
+    hipLaunchKernelGGL(k_select_hist<2>, dim3(grid, nq), dim3(kSelBlock), 0, s, d_keys, stride, n, kk, cap, st, hist, d_active);
+    hipLaunchKernelGGL(k_select_compact, dim3(grid, nq), dim3(kSelBlock), 0, s, d_keys, stride, n, cap, st, cand, d_active);
     const size_t lds = (size_t)cap * sizeof(uint64_t);
     e = set_lds(k_select_sort, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_select_sort, dim3(nq), dim3(kSelSortBlock), lds, s, d_keys, stride, n, kk, k_stride, cap, st, cand, d_rows_out, d_dist_out, ordered ? 1 : 0);
+    hipLaunchKernelGGL(k_select_sort, dim3(nq), dim3(kSelSortBlock), lds, s, d_keys, stride, n, kk, k_stride, cap, st, cand, d_rows_out, d_dist_out, ordered ? 1 : 0, (const uint32_t*)nullptr, d_active);
     return hipGetLastError();
 }
 

@@ -415,11 +415,16 @@ int search_ctx(qv_sharded* s, CallCtx* c, const float* queries_host, const float
             else if (rcb != QV_ERR_UNSUPPORTED) return rcb;
             else if ((rc2 = qv_index_search_device(x.idx, dq, nq, kcap, pack, pack_dist, b.stream))) return rc2;
         }
-        if (filtered && kcap <= (uint32_t)qv::kMaxFusedK) {
-            // queries whose candidate buffer overflowed (rare): the exact scan for those, listed and scanned ON THE DEVICE behind the batch —
-            // until round 5 their flags were read on the host here, one synchronisation per shard and batch
-            if ((rc2 = qv_internal_redo_flagged_device(x.idx, dq, nq, kcap, static_cast<const uint32_t*>(b.d_flags.p), pack, pack_dist, b.stream))) return rc2;
-        } else if (filtered) {                                             // more than 64 results per query: the selection paths, query by query, from the host
+        bool redone = !filtered;
+        if (filtered) {
+            // queries the filter handed back (a candidate buffer that overflowed, a guessed bound that did not hold: rare): the exact scan for those,
+            // listed and scanned ON THE DEVICE behind the batch — until round 5 their flags were read on the host here, one synchronisation per shard
+            // and batch, and until round 6 still so above 64 results per query
+            rc2 = qv_internal_redo_flagged_device(x.idx, dq, nq, kcap, static_cast<const uint32_t*>(b.d_flags.p), pack, pack_dist, b.stream);
+            if (rc2 == QV_OK) redone = true;
+            else if (rc2 != QV_ERR_UNSUPPORTED) return rc2;
+        }
+        if (!redone) {                                                     // (a corpus so large that a query's keys leave room for one query at a time: from the host)
             HIPCHK(hipMemcpyAsync(b.h_flags.p, b.d_flags.p, (size_t)nq * 4, hipMemcpyDeviceToHost, b.stream));
             HIPCHK(hipStreamSynchronize(b.stream));
             const uint32_t* fl = static_cast<const uint32_t*>(b.h_flags.p);

@@ -78,6 +78,13 @@ def test_batches_on_shards_large_enough_for_a_guessed_bound(k):
     back = np.vectorize(lambda g: pos[int(g)])(r)                                 # global row ids back to positions in `rows`
     assert (c == k).all()
     assert np.array_equal(back, er.astype(back.dtype)) and np.array_equal(d.view(np.uint32), ed.view(np.uint32))
+    # the device-pointer call: no host synchronisation at either k (the hand-backs are listed and redone on the device)
+    import torch
+    dq = torch.from_numpy(qs).cuda()
+    dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    sh.search_device(dq.data_ptr(), nq, k, dr.data_ptr(), dd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    sh.sync(); torch.cuda.synchronize()
+    assert np.array_equal(dr.cpu().numpy().view(np.uint32), r) and np.array_equal(dd.cpu().numpy().view(np.uint32), d.view(np.uint32))
     sh.close(); one.close()
 
 

@@ -1,4 +1,4 @@
-"""A batch of queries through qv_sharded_search_device with co-located shards: python tools/dev_sharded_batch.py [shards] [nq] [rows]"""
+"""A batch of queries through qv_sharded_search_device with co-located shards: python tools/dev_sharded_batch.py [shards] [nq] [rows] [k]"""
 import os
 import sys
 import time
@@ -12,7 +12,8 @@ from quiver_amd import ShardedIndex
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
-dim, k = 768, 10
+dim = 768
+k = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 sh = ShardedIndex(dim, "cosine", devices=[0] * G, peer_copy=G > 1)
 sh.add_synthetic(20260424, 0, n)
 qi = quiver_amd.DeviceIndex(dim, "cosine"); qi.add_synthetic(20260425, 0, nq)
