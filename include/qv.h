@@ -171,6 +171,9 @@ int qv_index_search(qv_index* idx, const float* queries, uint32_t nq, uint32_t k
  * callers the previous pass had just released, and the time that took in all; out[7] group_pass_ns = time inside the groups'
  * device calls.  For reports and tests. */
 int qv_index_coalesce_stats(qv_index* idx, uint64_t out[8]);
+/* One more counter of the same front (kept out of out[8] so that ABI 4 callers' arrays stay the size they are): groups whose first
+ * pass handed part of their members their results before the rest were redone (the filter's hand-backs inside a group). */
+int qv_index_coalesce_early_rounds(qv_index* idx, uint64_t* out);
 
 /* Same with device-resident queries/results; enqueues on `stream`, no sync. */
 int qv_index_search_device(qv_index* idx, const float* d_queries, uint32_t nq, uint32_t k,
@@ -294,6 +297,7 @@ int qv_graph_search(qv_graph* g, const float* queries, uint32_t nq, uint32_t k, 
  * qv_graph_insert / qv_graph_make_buildable / qv_graph_destroy need external exclusion against searches (the reference's
  * write lock).  qv_graph_coalesce_stats: as qv_index_coalesce_stats. */
 int qv_graph_coalesce_stats(qv_graph* g, uint64_t out[8]);
+int qv_graph_coalesce_early_rounds(qv_graph* g, uint64_t* out);
 /* Device-pointer form: queries, results, counts (and optional evals) live on the device; the traversal is
  * enqueued on `stream` (0 = the graph's own stream) with no synchronisation.  One pass only: a query that
  * met two equal distances or a NaN on its way (or visited more nodes than its visited table holds: ~48 x ef)

@@ -57,6 +57,8 @@ PROTOTYPES = {
     "qv_index_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_index_coalesce_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "qv_graph_coalesce_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "qv_index_coalesce_early_rounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "qv_graph_coalesce_early_rounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "qv_index_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_index_search_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qv_index_search_negative": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, _u32p]),

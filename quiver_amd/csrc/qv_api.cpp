@@ -585,6 +585,11 @@ int qv_index_coalesce_stats(qv_index* idx, uint64_t out[8]) {
     idx->front.stats.read(out);
     return QV_OK;
 }
+int qv_index_coalesce_early_rounds(qv_index* idx, uint64_t* out) {
+    if (!idx || !out) return fail(QV_ERR_INVALID_ARG, "index/out is null");
+    *out = idx->front.stats.early();
+    return QV_OK;
+}
 
 // Search with a negative example, device side of hybrid_index.go:517-570 / hnsw/adapter.go:345-437: the reference fetches
 // retrieveK = max(2k, 30) nearest results, then calls the distance function once more per result against the negative

@@ -150,6 +150,7 @@ class Front {
             out[0] = solo.load(); out[1] = led.load(); out[2] = rode.load(); out[3] = groups.load(); out[4] = group_queries.load();
             out[5] = lingers.load(); out[6] = linger_ns.load(); out[7] = group_pass_ns.load();
         }
+        uint64_t early() const { return early_rounds.load(); }        // groups whose first pass released part of their members early
     };
     Stats stats;
 

@@ -538,6 +538,11 @@ int qv_graph_coalesce_stats(qv_graph* g, uint64_t out[8]) {
     g->front.stats.read(out);
     return QV_OK;
 }
+int qv_graph_coalesce_early_rounds(qv_graph* g, uint64_t* out) {
+    if (!g || !out) return fail(QV_ERR_INVALID_ARG, "graph/out is null");
+    *out = g->front.stats.early();
+    return QV_OK;
+}
 
 int qv_graph_search_device(qv_graph* g, const float* d_queries, uint32_t nq, uint32_t k, uint32_t ef_search,
                            uint32_t* d_rows_out, float* d_dist_out, uint32_t* d_count_out, uint32_t* d_evals_out, void* stream) {
