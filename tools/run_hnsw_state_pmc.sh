@@ -1,7 +1,7 @@
 #!/bin/bash
-# Does the traversal's fast / slow process state (profiles/LAB_r06.md §1 "States") show in the instruction cache?  Identical processes, each
+# Which counter, if any, follows the traversal's per-process state (profiles/LAB_r06.md §1 "States")?  Identical processes, each
 # under rocprofv3 --kernel-trace --pmc <instruction-cache counters>: the last three k_hnsw_search_wave dispatches' duration beside their counters.
-root=${GRAFT_REPO_ROOT:-$PWD}; out=$root/gpurun_out/r06_hnsw_icache.txt; : > $out
+root=${GRAFT_REPO_ROOT:-$PWD}; out=$root/gpurun_out/r06_hnsw_state_pmc.txt; : > $out
 export TMPDIR=/tmp QV_GRAPH_CACHE=/tmp/qv_graph_1m.npz
 python3 $root/tools/dev_hnsw_r06.py 64 128 1 > /dev/null 2>&1          # builds the graph once, cached
 rocprofv3 --list-avail 2>/dev/null | grep -oE "SQC_[A-Z_0-9]*ICACHE[A-Z_0-9]*|SQ_IFETCH[A-Z_0-9]*|SQC_INST[A-Z_0-9]*|SQ_INST_LEVEL[A-Z_0-9]*|SQ_WAIT_INST_ANY|SQ_IFETCH" | sort -u | tr '\n' ' ' >> $out; echo >> $out
