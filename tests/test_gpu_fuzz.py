@@ -335,3 +335,44 @@ def test_filter_path_under_random_mutations_equals_the_exact_scan(seed, monkeypa
         assert np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes() and np.array_equal(got[2], want[2]), (seed, step)
         _compare(m, (got[0][:2], got[1][:2], got[2][:2]), qs[:2], k)
     idx.close()
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_selection_path_under_random_mutations_equals_the_exact_scan(seed):
+    """the same for batches of 16 or more results per query over 131 072 rows or more (round 6's selection path: a guessed bound checked after
+    the filter, k_cand_narrow, a wave per 32 survivors or the pass over the tiles, the in-LDS selection), with and without the row-major
+    and bfloat16 copies, on value alphabets that make exact ties, overflowing candidate lists and failing guesses routine"""
+    rng = np.random.default_rng(7000 + seed)
+    metric = ["cosine", "dot_product", "euclidean", "squared_euclidean"][seed % 4]
+    dim = int(rng.choice([32, 64, 100, 128, 256, 768]))
+    idx = quiver_amd.DeviceIndex(dim, metric, rowmajor=bool(seed & 2), bf16_rows=bool(seed & 1))
+    m = Model(metric, dim)
+    style = seed % 3
+    x = _vectors(rng, 140_000, dim, style)
+    assert idx.add(x) == m.add(x)
+    for step in range(4):
+        n = m.rows.shape[0]
+        op = rng.choice(["add", "remove", "update"])
+        if op == "add":
+            x = _vectors(rng, int(rng.choice([1, 64, 9000, 30000])), dim, style)
+            assert idx.add(x) == m.add(x)
+        elif op == "remove":
+            lo = int(rng.integers(0, n - 6000))
+            who = np.arange(lo, lo + int(rng.integers(1, 6000)), dtype=np.uint32)
+            idx.remove(who); m.alive[who] = 0
+        else:
+            for row in rng.integers(0, n, size=20):
+                v = _vectors(rng, 1, dim, style)[0]
+                idx.update(int(row), v); m.rows[row] = v; m.alive[row] = 1
+        n = m.rows.shape[0]
+        nq = int(rng.choice([9, 40, 100, 256, 300]))
+        k = int(rng.choice([16, 40, 64, 100, 300, 1000]))
+        qs = _vectors(rng, nq, dim, style)
+        qs[0] = m.rows[rng.integers(n)]
+        got = idx.search(qs, k)
+        idx.set_filter("off")
+        want = idx.search(qs, k)
+        idx.set_filter(quiver_amd.DeviceIndex.default_filter)
+        assert np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes() and np.array_equal(got[2], want[2]), (seed, step)
+        _compare(m, (got[0][:2], got[1][:2], got[2][:2]), qs[:2], k)
+    idx.close()
