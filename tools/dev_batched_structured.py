@@ -1,5 +1,5 @@
 """The batched filter path on structured corpora (unit vectors on an r-dimensional subspace of R^768, optionally with near-duplicate
-clusters): time, flagged queries and identity with the exact scan, per filter mode.  python tools/dev_batched_structured.py [r] [rows] [nq]"""
+clusters): time, flagged queries and identity with the exact scan, per filter mode.  python tools/dev_batched_structured.py [r] [rows] [nq] [k] [modes, e.g. 3 or 3,2,1]"""
 import os
 import sys
 import time
@@ -12,7 +12,9 @@ import quiver_amd
 r = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-D, k = 768, 10
+D = 768
+k = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+modes = (sys.argv[5] if len(sys.argv) > 5 else "3,2,1").split(",")
 gen = torch.Generator(device="cuda"); gen.manual_seed(20260424)
 basis = torch.linalg.qr(torch.randn((D, r), generator=gen, device="cuda", dtype=torch.float64))[0].T.contiguous()
 
@@ -38,7 +40,7 @@ for label, centers, spread in (("subspace r=%d" % r, None, 0.0),
     er = torch.empty((nq, k), dtype=torch.int32, device="cuda"); ed = torch.empty((nq, k), dtype=torch.float32, device="cuda")
     idx.search_device(dq.data_ptr(), nq, k, er.data_ptr(), ed.data_ptr(), sp)
     torch.cuda.synchronize()
-    for mode in ("3", "2", "1"):
+    for mode in modes:
         idx.set_filter(int(mode))
         dr = torch.empty((nq, k), dtype=torch.int32, device="cuda"); dd = torch.empty((nq, k), dtype=torch.float32, device="cuda")
         fl = torch.zeros((nq,), dtype=torch.int32, device="cuda")
