@@ -1805,18 +1805,18 @@ k_rescore_select(IndexView v, const float* __restrict__ queries, const uint32_t*
 #undef RSTK
 }
 
-// ---------------------------------------------------------------- batches with 64 < k <= kMaxBatchedK --
+// ---------------------------------------------------------------- the selection path: 16 <= k <= kMaxBatchedK --
 // HybridIndex.BatchSearch takes any k (hybrid_index.go:677-811), and the negative-example branches ask for max(2k, 30)
-// (:516-522).  Up to 64 results per query the wave lists above do every selection; beyond, the same three steps — the sample's
-// bound, the candidates' narrowing, the exact top-k — are radix selections over arrays of keys (qv_select.hip), and the per-query
-// workgroup of k_rescore_select becomes grids over (candidate, query):
-//   k_sample_hist<0>, <1>        the k-th smallest of the sample's upper bounds, to 24 bits (rounded UP to its bucket's edge: a
-//                                 valid bound, 2^-15 looser at most) — two histogram windows straight over the float32 bounds
-//   k_cand_bounds                 every candidate's interval [lo, hi] from its score; keys (hi, slot)
-//   selection                     H = the k-th smallest hi: the true k-th distance is at most H
-//   k_cand_survive                candidates with lo <= H, compacted (typically k + a few dozen of thousands)
-//   k_cand_exact                  their exact distances, the scan's own arithmetic, a lane per row; keys (distance, row)
-//   selection                     the k best of those, in (distance, row) order
+// (:516-522).  The wave lists above hold 64 keys; beyond — and, since round 6, from 16 results per query wherever the bound can be a guess
+// (batched_large_k) — the same three steps, the sample's bound, the candidates' narrowing, the exact top-k, work on arrays of keys:
+//   the bound                     a guess from a small sample, rank k S / N + 4 sigma (batched_guess; k_sample_select), or — fewer than
+//                                 131 072 rows — the k-th smallest bound of half the corpus: k_sample_select, or k_sample_hist<0>, <1> (to 24
+//                                 bits, rounded UP to its bucket's edge: a valid bound, 2^-15 looser at most) where k chunks outgrow its LDS
+//   k_cand_narrow                 per query: every candidate's interval [lo, hi] from its score, H = the k-th smallest hi (the true k-th
+//                                 distance is at most H), the guess's check H <= U, the candidates with lo <= H compacted (~2.1 k of them);
+//                                 above 2 048 results as k_cand_qnorms, k_cand_bounds, a selection over (hi, slot) keys, k_cand_survive
+//   k_cand_exact_wave / k_tp_*    their exact distances, the scan's own arithmetic: a wave per 32 survivors, or one pass over the tiles
+//   k_select_sort                 the k best of those, in (distance, row) order, a workgroup per query over the counted prefix
 template <int W>
 __global__ void __launch_bounds__(kSelBlock)
 k_sample_hist(const float* __restrict__ bounds, uint32_t srows, uint32_t k, SelState* __restrict__ st, uint32_t* __restrict__ hist) {
@@ -2349,8 +2349,8 @@ bool batched_supported(const IndexView& v, uint32_t nq, uint32_t k) {
     return (v.metric == QV_COSINE || v.metric == QV_DOT || v.metric == QV_L2 || v.metric == QV_L2SQ) && k <= (uint32_t)kMaxBatchedK && nq >= (uint32_t)min_q &&
            v.n_rows >= (uint32_t)min_rows && (uint64_t)nq * v.n_rows >= (uint64_t)min_work_m * 1000000ull;
 }
-// candidate slots per query: kMfmaCandCap up to 64 results; beyond, 16 k rounded up to a power of two (the sample is capped at
-// half the corpus there, so the expected candidates grow with k: about 2 f k with f ~ 4.6 for the one-term filter)
+// candidate slots per query: kMfmaCandCap up to 256 results; beyond, 16 k rounded up to a power of two (the expected candidates grow
+// with k: about (1 + 4 / sqrt(rank)) f k under a guessed bound, 2 f k under half the corpus's, f ~ 4.6 for the one-term filter)
 uint32_t batched_cand_cap(uint32_t k) {
     uint32_t c = (uint32_t)kMfmaCandCap;
     while (c < 16u * k) c <<= 1;
