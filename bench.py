@@ -144,6 +144,7 @@ def compact_also(also, budget):
                 g, sc = pick.get("graph_traversal", {}), pick.get("search_complete", {})
                 o.update({"corpus": "16-d subspace of R^768" if key.endswith("_structured") else "iid random (BASELINE)",
                           "ef": pick.get("ef_search"), "qps": _r(g.get("qps_device_resident"), 4),
+                          **({"qps_4x_per_call": _r(g["qps_device_resident_4x_queries_per_call"], 4)} if g.get("qps_device_resident_4x_queries_per_call") else {}),
                           # recall of the graph results alone, and of HNSW.Search as the reference defines it (with its exact top-up of under-filled queries)
                           "recall10_vs_exact": _r(g.get("recall_at_10_graph_results_only"), 4), "recall10_with_topup": _r(sc.get("recall_at_10_vs_exact"), 4),
                           "gather_frac": _r(g.get("gathered_GBps", 0.0) / HBM_PEAK_GBS, 3),
