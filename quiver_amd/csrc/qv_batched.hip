@@ -207,12 +207,14 @@ __global__ void k_mfma_prep(const float* __restrict__ queries, uint32_t nq, uint
 }
 
 
-// grid: persistent waves; wave g -> query 64-block (g % nqb64), row groups (g / nqb64) + i*stride; a row group = 2 tiles = 128 rows
-#ifndef QV_MFMA_F32_WPS
-#define QV_MFMA_F32_WPS 1                  // waves per SIMD of the fp32-MFMA filter (measurement: 2 = two workgroups per CU, operands two steps deep)
-#endif
-template <int METRIC>
-__global__ void __launch_bounds__(256, QV_MFMA_F32_WPS)
+// grid: persistent waves; wave g -> query 64-block (g % nqb64), row groups (g / nqb64) + i*stride; a row group = NJ / 2 tiles.
+// NJ = 4: 128 rows per group, 8 accumulator tiles, ONE wave per SIMD (rounds 1-5).  NJ = 2: 64 rows, 4 tiles, 128 accumulator
+// registers less — TWO waves per SIMD fit (two workgroups per CU), and one wave's epilogue (6 % of the kernel: 3.10 against 2.91 ms
+// with the epilogue compiled out, -DQV_MFMA_F32_NOEPI) runs under the other's matrix instructions; the price is the query operand
+// read once per 64 rows instead of once per 128 by twice the waves: 16 bytes per cycle and CU from L2, ~10 TB/s over the chip —
+// measured 4.25 against 3.06 ms, same results.  Round 6 built it, measured it and ships NJ = 4 alone (NJ = 2: measurement build).
+template <int METRIC, int NJ>
+__global__ void __launch_bounds__(256, NJ == 2 ? 2 : 1)
 k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict__ cq, const float* __restrict__ mq, uint32_t nq_pad,
               uint32_t* __restrict__ cand_rows, float* __restrict__ cand_score, uint32_t* __restrict__ cand_cnt) {
     __shared__ __align__(16) float s_c[4][64], s_m[8][64];                        // this wave's 64 queries' filter constants
@@ -223,7 +225,7 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
     const uint32_t nqb64 = nq_pad >> 6;
     const uint32_t gw = filter_logical_block((nqb64 & 3u) == 0 ? nqb64 >> 2 : 1u) * 4 + wave, tw = gridDim.x * 4;
     const uint32_t qb64 = gw % nqb64;
-    const uint32_t n_groups = (v.n_tiles + 1) / 2;
+    const uint32_t n_groups = NJ == 4 ? (v.n_tiles + 1) / 2 : v.n_tiles;
     const uint32_t stride = tw / nqb64;
     {   // cosine: one constant t_q = c_q - m_q (test S~ >= t_q |r|); dot: c_q and m_q (test S~ >= c_q - m_q |r|)
         const float c = cq[64 * qb64 + lane], m = mq[64 * qb64 + lane];
@@ -243,23 +245,23 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
     const f4* a_base1 = qt + ((size_t)(2 * qb64 + 1) * dim4p) * 32 + l31;
 
     for (uint32_t g = gw / nqb64; g < n_groups; g += stride) {
-        const uint32_t t0 = 2 * g, t1 = (2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0;     // odd tail: tile duplicated, masked below
+        const uint32_t t0 = NJ == 4 ? 2 * g : g, t1 = NJ == 4 ? ((2 * g + 1 < v.n_tiles) ? 2 * g + 1 : t0) : t0;     // odd tail: tile duplicated, masked below
         const f4* b0 = tiles + (size_t)t0 * v.dim4 * 64 + l31;
         const f4* b1 = tiles + (size_t)t1 * v.dim4 * 64 + l31;
-        f16v acc[2][4];
-        double rnd[4]; float rho[4]; uint64_t alv[2];
-        filter_row_consts(v, t0, t1, l31, rnd, rho, alv);
+        f16v acc[2][NJ];
+        double rnd[NJ]; float rho[NJ]; uint64_t alv[NJ / 2];
+        filter_row_consts<NJ>(v, t0, t1, l31, rnd, rho, alv);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < NJ; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
         // branch-free operand fetch: a step index past the end re-reads the last step (never used).
         // For an odd dim4 the upper lane half of the last step reads Qt's zero padding on the A side
         // and re-reads the last real chunk on the B side (0 * finite = 0).
-        auto load = [&](uint32_t st, f4 (&A)[2], f4 (&B)[4]) {
+        auto load = [&](uint32_t st, f4 (&A)[2], f4 (&B)[NJ]) {
             const uint32_t sc = st < steps ? st : steps - 1;
             const uint32_t ca = 2 * sc + half;
             const uint32_t cb = ca < v.dim4 ? ca : v.dim4 - 1;
@@ -267,33 +269,22 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
             A[1] = a_base1[(size_t)ca * 32];
             B[0] = __builtin_nontemporal_load(&b0[(size_t)cb * 64]);
             B[1] = __builtin_nontemporal_load(&b0[(size_t)cb * 64 + 32]);
-            B[2] = __builtin_nontemporal_load(&b1[(size_t)cb * 64]);
-            B[3] = __builtin_nontemporal_load(&b1[(size_t)cb * 64 + 32]);
+            if constexpr (NJ == 4) {
+                B[2] = __builtin_nontemporal_load(&b1[(size_t)cb * 64]);
+                B[3] = __builtin_nontemporal_load(&b1[(size_t)cb * 64 + 32]);
+            }
         };
-        auto mma = [&](const f4 (&A)[2], const f4 (&B)[4]) {
+        auto mma = [&](const f4 (&A)[2], const f4 (&B)[NJ]) {
 #pragma unroll
             for (int d = 0; d < 4; d++)
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < NJ; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][d], B[j][d], acc[i][j], 0, 0, 0);
         };
-#if QV_MFMA_F32_WPS == 2
-        // two waves per SIMD cover each other's waits: operands one step ahead (24 registers less: no spill at 256 per wave)
-        f4 A0[2], B0[4], A1[2], B1[4];
-        load(0, A0, B0);
-        uint32_t st = 0;
-        for (; st + 2 <= steps; st += 2) {
-            load(st + 1, A1, B1); __builtin_amdgcn_sched_barrier(0);
-            mma(A0, B0);          __builtin_amdgcn_sched_barrier(0);
-            load(st + 2, A0, B0); __builtin_amdgcn_sched_barrier(0);
-            mma(A1, B1);          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (st < steps) { mma(A0, B0); st++; }
-#else
         // 3-deep software pipeline over the K steps (operands for steps s+1, s+2 in flight while s computes)
-        f4 A0[2], B0[4], A1[2], B1[4], A2[2], B2[4];
+        f4 A0[2], B0[NJ], A1[2], B1[NJ], A2[2], B2[NJ];
         load(0, A0, B0);
         load(1, A1, B1);
         uint32_t st = 0;
@@ -307,9 +298,18 @@ k_mfma_filter(IndexView v, const float* __restrict__ Qt, const float* __restrict
         }
         if (st < steps) { mma(A0, B0); st++; }
         if (st < steps) { mma(A1, B1); st++; }
-#endif
 
+#ifdef QV_MFMA_F32_NOEPI
+        // TIMING ONLY (tools/build_variant.sh): what the epilogue costs — one value of every accumulator tile kept alive, no test, no candidates
+        { float keep = 0.f;
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+              for (int j = 0; j < NJ; j++) keep += acc[i][j][0];
+          if (keep == 1.2345e-30f) cand_cnt[0] = 1; }
+#else
         filter_epilogue<METRIC>(v, acc, t0, t1, &s_c[0][0], &s_m[0][0], 64 * wave, half, l31, 64 * qb64, filter_tiny_norm(v.dim), ec, rnd, rho, alv, cqu, cqu_n, cqu_out, du);
+#endif
     }
     cand_flush(cqu, cqu_n, cqu_out);
 }
@@ -2516,7 +2516,8 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
     // 3. MFMA filter
     const uint32_t nqb64 = nq_pad / 64;
     // one 4-wave workgroup per CU (512-register waves); every query block gets the same number of waves
-    const uint32_t grid = grid_multiple((uint32_t)cus * (!bf && !q64 ? QV_MFMA_F32_WPS : 1), nqb64 / std::gcd(nqb64, 4u));
+    static const int f32_nj = dev_env_int("QV_MFMA_F32_NJ", 4);             // 2 (measurement build): 64 rows per group, two waves per SIMD — 4.25 against 3.06 ms
+    const uint32_t grid = grid_multiple((uint32_t)cus * (!bf && !q64 && f32_nj == 2 ? 2 : 1), nqb64 / std::gcd(nqb64, 4u));
     if (ev0) (void)hipEventRecord(ev0, s);
     if (q64) {
         const uint4* Qbf = reinterpret_cast<const uint4*>(Qt);
@@ -2585,9 +2586,15 @@ hipError_t launch_batched(const IndexView& v, const ScanPlan& p, const float* d_
         if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_bf16x3_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u, 1u);
         else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_bf16x3_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u, 1u);
         else hipLaunchKernelGGL(k_bf16x3_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qbf, cq, mq, nq_pad, cand, cscore, cnt, (float*)nullptr, 0u, 1u);
-    } else if (v.metric == QV_COSINE) hipLaunchKernelGGL(k_mfma_filter<QV_COSINE>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
-    else if (v.metric == QV_DOT) hipLaunchKernelGGL(k_mfma_filter<QV_DOT>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
-    else hipLaunchKernelGGL(k_mfma_filter<QV_L2>, dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter
+#ifdef QV_VARIANTS
+    } else if (f32_nj == 2) {
+        if (v.metric == QV_COSINE) hipLaunchKernelGGL((k_mfma_filter<QV_COSINE, 2>), dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+        else if (v.metric == QV_DOT) hipLaunchKernelGGL((k_mfma_filter<QV_DOT, 2>), dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+        else hipLaunchKernelGGL((k_mfma_filter<QV_L2, 2>), dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+#endif
+    } else if (v.metric == QV_COSINE) hipLaunchKernelGGL((k_mfma_filter<QV_COSINE, 4>), dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+    else if (v.metric == QV_DOT) hipLaunchKernelGGL((k_mfma_filter<QV_DOT, 4>), dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);
+    else hipLaunchKernelGGL((k_mfma_filter<QV_L2, 4>), dim3(grid), dim3(256), 0, s, v, Qt, cq, mq, nq_pad, cand, cscore, cnt);   // L2 and L2SQ share the filter
     if (ev1) (void)hipEventRecord(ev1, s);
     // 4. exact re-scoring + selection
     const size_t lds = query_lds_bytes(v.metric, v.dim4) + 4 * 64 * sizeof(uint64_t) + (size_t)kMfmaCandCap * (sizeof(uint32_t) + sizeof(float) + sizeof(uint32_t));   // query, wave lists, survivors, lower bounds, upper bounds' keys
