@@ -415,7 +415,8 @@ int qv_sharded_distance_rows(qv_sharded* s, const float* query, const uint32_t* 
  * before anything `stream` runs afterwards; there is no host synchronisation for any nq: queries the matrix-core filter
  * hands back (nq >= 9) are listed and redone by the exact scan on the device (k <= 64: round 5; 64 < k <= 4096: round 6, the
  * listed queries in groups of 64 through shared corpus passes + radix selection; until then their flags were read on the
- * host, one round trip per shard and batch).  The one exception: a shard of more than ~67 M rows at k > 64, where a query's
+ * host, one round trip per shard and batch; the first batch with k > 64 allocates that redo's keys per shard: 64 queries x
+ * rows x 8 bytes, 1 GiB at most).  The one exception: a shard of more than ~67 M rows at k > 64, where a query's
  * keys leave room for one query at a time, still reads the flags on the host.  Any k. */
 int qv_sharded_search_device(qv_sharded* s, const float* d_queries, uint32_t nq, uint32_t k, uint32_t* d_rows_out, float* d_dist_out, void* stream);
 int qv_sharded_sync(qv_sharded* s);                            /* wait for every stream of the handle */
