@@ -230,3 +230,31 @@ def test_concurrent_callers_on_a_sharded_handle_share_passes_and_equal_the_oracl
             loc.append(x - base[gi] + gi * (n // 3))
         assert loc == er.tolist(), i
         assert np.array_equal(res["dist"][i].view(np.uint32), ed.view(np.uint32)), i
+
+
+def test_concurrent_batches_on_the_selection_path_equal_the_exact_scan():
+    """eight threads, each sending batches of 16 to 1000 results per query to ONE index at the same time (every call its own context, stream and
+    workspace: the candidate lists, the pairs of the tile pass, the selection's keys); every batch equals the exact scan of the same index"""
+    n, dim = 200_000, 128
+    idx = quiver_amd.DeviceIndex(dim, "cosine")
+    idx.add_synthetic(20260424, 0, n)
+    shapes = [(64, 16), (256, 100), (40, 1000), (300, 300), (9, 64), (128, 40), (256, 1000), (100, 129)]
+    qsets = [O.gen_rows(20260500 + i, 0, nq, dim) for i, (nq, _) in enumerate(shapes)]
+    got = [None] * len(shapes); errs = []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                got[i] = idx.search(qsets[i], shapes[i][1], batched=True)
+        except Exception as ex:                                            # noqa: BLE001
+            errs.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(shapes))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs
+    idx.set_filter("off")
+    for i, (nq, k) in enumerate(shapes):
+        want = idx.search(qsets[i], k)
+        assert np.array_equal(got[i][0], want[0]) and got[i][1].tobytes() == want[1].tobytes() and np.array_equal(got[i][2], want[2]), shapes[i]
+    idx.close()
