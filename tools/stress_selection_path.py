@@ -38,13 +38,15 @@ while time.time() < t_end:
         k = int(rng.choice([1, 10, 15, 16, 17, 40, 64, 65, 100, 129, 300, 1000, 2048, 2049, 4096]))
         qrow = rng.integers(0, n, size=nq)
         qs = np.stack([idx.get_row(int(r)) for r in qrow[:8]] + [rng.standard_normal(dim).astype(np.float32) for _ in range(nq - min(nq, 8))])[:nq].astype(np.float32)
+        flt = str(rng.choice(["auto", "auto", "fp32", "bf16x3", "bf16x1"]))   # the index's choice of filter kernel (qv_index_set_filter)
+        idx.set_filter(flt)
         got = idx.search(qs, k, batched=True)
         idx.set_filter("off"); want = idx.search(qs, k); idx.set_filter(quiver_amd.DeviceIndex.default_filter)
         ok = np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes() and np.array_equal(got[2], want[2])
         runs += 1
         if not ok:
             bad += 1
-            print("MISMATCH metric=%s dim=%d n=%d rowmajor=%s bf16=%s style=%d dead=%d nq=%d k=%d" % (metric, dim, n, rowmajor, bf16, style, dead, nq, k), flush=True)
+            print("MISMATCH metric=%s dim=%d n=%d rowmajor=%s bf16=%s style=%d dead=%d nq=%d k=%d filter=%s" % (metric, dim, n, rowmajor, bf16, style, dead, nq, k, flt), flush=True)
     idx.close()
 print("%d batches, %d mismatches" % (runs, bad))
 sys.exit(1 if bad else 0)
